@@ -1,0 +1,14 @@
+"""qgd-hip: MI355X-native Hermite time stepper and discrete-adjoint gradient
+behind the reference's SchrodingerProb / eval_forward / discrete_adjoint /
+optimize_gate interface (leespen1/QuantumGateDesign.jl).
+
+The directory name contains a dot, so the package is loaded through
+``__graft_entry__.import_package()`` (registers it as ``qgd_amd``).
+"""
+from .schrodinger_prob import SchrodingerProb
+from .controls import (AbstractControl, GRAPEControl, FortranBSplineControl, GeneralBSplineControl,
+                       CarrierControl, get_number_of_control_parameters, get_control_vector_slice,
+                       fill_p_mat, fill_q_mat, control_basis, bspline_basis_derivatives)
+from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_prob, guard_projector,
+                       create_initial_conditions, create_gate, basis_state, lowering_operators_system,
+                       control_ops, multi_qudit_hamiltonian_dispersive, cnot2_problem, cnot3_problem)
