@@ -1,0 +1,140 @@
+/*
+ * qgd.h -- C ABI of libqgd_hip.so: the MI355X-native Hermite time stepper and
+ * discrete-adjoint gradient that stands behind the reference's Julia methods
+ *
+ *   eval_forward / eval_forward!      src/forward_evolution.jl:15-70
+ *   discrete_adjoint / discrete_adjoint!   src/eval_grad_discrete_adjoint.jl:83-160
+ *   infidelity_real / guard_penalty_real   src/infidelity.jl:7-18, :56-96
+ *   (as called by optimize_gate, src/ipopt_optimal_control.jl:243-346)
+ *
+ * The reference has no FFI seam on this path (it is plain Julia dispatch); its
+ * only FFI precedent is the Fortran ccall of src/Controls/FortranBSpline.jl:257-265.
+ * These entry points are what a Julia `ccall` shim for the path binds -- see
+ * INTEGRATION.md for that shim.  Plain pointers and sizes only; every matrix
+ * argument is float64, column-major (Julia layout).  The caller owns every host
+ * buffer; the library copies during the call and keeps no host pointer.  Device
+ * memory belongs to the handle.  One handle = one host thread = one GPU.
+ *
+ * Every function returns 0 on success or a QGD_ERR_* code; the message is
+ * available from qgd_last_error().  All "file:line" citations are relative to
+ * the reference checkout.
+ */
+#ifndef QGD_H
+#define QGD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QGD_ABI_VERSION 1
+
+enum {
+    QGD_OK = 0,
+    QGD_ERR_ARGUMENT = 1,    /* the reference's ArgumentError (SchrodingerProb.jl:73-154) */
+    QGD_ERR_NO_DEVICE = 2,   /* no usable GPU / HIP failure: the path never falls back to the CPU */
+    QGD_ERR_STATE = 3,       /* call order (e.g. gradient before target/controls were set) */
+    QGD_ERR_UNSUPPORTED = 4, /* size outside what the kernels cover */
+    QGD_ERR_NUMERIC = 5      /* singular step matrix */
+};
+
+typedef struct qgd_handle_s *qgd_handle;
+
+/* Replaces the SchrodingerProb container (src/SchrodingerProb.jl:25-165). */
+typedef struct qgd_problem_desc {
+    int32_t N;                  /* N_tot_levels (complex dimension) */
+    int32_t n_cols;             /* N_initial_conditions */
+    int32_t n_ops;              /* N_operators */
+    int32_t n_ess;              /* N_ess_levels */
+    int32_t order;              /* Hermite order, even, 2..QGD_MAX_ORDER */
+    int32_t nsteps;
+    double  tf;
+    const double *system_sym;   /* N x N, symmetric          (real part of H) */
+    const double *system_asym;  /* N x N, antisymmetric      (imag part of H) */
+    const double *sym_ops;      /* n_ops consecutive N x N, symmetric */
+    const double *asym_ops;     /* n_ops consecutive N x N, antisymmetric */
+    const double *u0, *v0;      /* N x n_cols */
+    const double *guard;        /* 2N x 2N guard_subspace_projector, or NULL (= zeros) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t reserved;
+} qgd_problem_desc;
+
+#define QGD_MAX_ORDER 16
+#define QGD_MAX_OPS   16
+
+/* SchrodingerProb constructor + validation.  On failure *out is NULL and
+ * qgd_last_error(NULL) holds the message. */
+int qgd_create(const qgd_problem_desc *desc, qgd_handle *out);
+void qgd_destroy(qgd_handle h);
+const char *qgd_last_error(qgd_handle h);
+int qgd_abi_version(void);
+
+/* Scripts mutate prob.nsteps (examples/cnot3_optimize_gate.jl:51-52): cheap
+ * re-parameterisation; invalidates control tables and histories. */
+int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
+
+/* Target gate in the stacked real form [Re; Im], 2N x n_cols -- what both call
+ * sites build with vcat(real, imag) (eval_grad_discrete_adjoint.jl:126,
+ * ipopt_optimal_control.jl:218). */
+int qgd_set_target(qgd_handle h, const double *target_real);
+
+/* Controls, linear fast path.  Every control family in scope is linear in pcof,
+ * so fill_p_mat!/fill_q_mat! (src/Controls/Control.jl:125-149) over the whole
+ * time grid is one matrix-vector product with a basis that depends only on the
+ * grid.  For control k (k < n_ops):  Gp[k], Gq[k] are C-ordered
+ * [nsteps+1][order/2+1][n_coeff[k]] with
+ *     Gp[k][n][d][l] = d/dpcof_l ( p_k^(d)(t_n) / d! ),   t_n = n*tf/nsteps.
+ * The basis is uploaded once; afterwards an evaluation ships only pcof. */
+int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff,
+                          const double *const *Gp, const double *const *Gq);
+
+/* Controls, general path (any AbstractControl): the tables themselves for the
+ * current pcof, Julia layout [(1+order/2), n_ops, nsteps+1] (the fill_p_mat!
+ * output stacked over time points).  Pair with qgd_set_control_basis holding
+ * the Jacobian at the current pcof when a gradient is wanted. */
+int qgd_set_control_tables(qgd_handle h, const double *p_tables, const double *q_tables);
+
+/* eval_forward! (forward_evolution.jl:33-70).  pcof may be NULL when tables were
+ * set directly.  uv_history (nullable) receives the reference layout
+ * [2N, 1+order/2, 1+nsteps, n_cols].  out3 = { <w_N,R>, <w_N,T>, guard penalty }
+ * (the first two are 0 when no target is set); infidelity =
+ * 1 - (out3[0]^2 + out3[1]^2)/n_ess^2  (infidelity.jl:7-18). */
+int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof,
+                     double *uv_history, double *out3);
+
+/* discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160): gradient of
+ * infidelity + guard penalty (no ridge term, as the reference).  With
+ * history_precomputed != 0 the forward sweep of the last qgd_eval_forward is
+ * reused (ipopt_optimal_control.jl:297-308).  Optional outputs (nullable):
+ *   uv_history      [2N, 1+m, 1+nsteps, n_cols]
+ *   lambda_history  [2N, 1+m, 1+nsteps, n_cols]  (column j=0 filled: the only one
+ *                   the reference consumes, eval_grad_discrete_adjoint.jl:604)
+ *   adjoint_forcing [2N, 1+nsteps, n_cols]       (:732-752)
+ */
+int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
+                         int32_t history_precomputed, double *grad, double *uv_history,
+                         double *lambda_history, double *adjoint_forcing, double *out3);
+
+/* Unit-test hook for the Hamiltonian application (hermite.jl:556-588) batched
+ * over columns: out = A_d(t_n) * in  (or -A_d = A_d^T with use_adjoint), using
+ * the control tables currently on the device.  in/out: 2N x n_cols. */
+int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
+                          int32_t use_adjoint, const double *in, double *out);
+
+/* Diagnostics: copy a named intermediate of the last evaluation to the host.
+ * Names: "L", "R", "Linv", "P" (complex, returned as [nt][N][N][2] C-order),
+ * "sigma" ([nt][n_ops][m][2]), "tables" ([nt][m][n_ops][2]).  Returns the number
+ * of doubles the buffer needs through *needed when out == NULL. */
+int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
+                         size_t *needed);
+
+/* Per-phase device time of the last evaluation (HIP events), milliseconds.
+ * names/ms hold up to cap entries; returns the number of phases through *n. */
+int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, int32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -143,6 +143,11 @@ def set_num_threads(n: int):
     lib().qo_set_num_threads(int(n))
 
 
+def set_converged_terminal(on: bool):
+    """See qgd_oracle.c: default False = the reference's gmres! defaults for the terminal solve."""
+    lib().qo_set_converged_terminal(1 if on else 0)
+
+
 def coefficient(j, p, q):
     return lib().qo_coefficient(j, p, q)
 
@@ -268,3 +273,18 @@ def eval_grad_finite_difference(prob, controls, pcof, target, order=2, dpcof=1e-
     lib().qo_eval_grad_finite_difference(C.byref(P.c), Cs.arr, _dptr(pc), C.c_int(Cs.n_pcof), _dptr(tr),
                                          C.c_int(order), C.c_double(dpcof), _dptr(grad))
     return grad
+
+
+def apply_hamiltonian(prob, pvals, qvals, w, derivative_order=0, use_adjoint=False):
+    """out = (+/-) A_d w for every column of w (2N x c); pvals/qvals: [(1+m), n_ops] tables."""
+    P = Problem(prob)
+    pv = np.asfortranarray(np.array(pvals, dtype=np.float64))
+    qv = np.asfortranarray(np.array(qvals, dtype=np.float64))
+    w = np.asfortranarray(np.array(w, dtype=np.float64))
+    out = np.zeros_like(w, order="F")
+    for c in range(w.shape[1]):
+        wi = np.ascontiguousarray(w[:, c]); oi = np.zeros(w.shape[0])
+        lib().qo_apply_hamiltonian(C.byref(P.c), _dptr(pv), _dptr(qv), C.c_int(pv.shape[0]),
+                                   C.c_int(derivative_order), C.c_int(1 if use_adjoint else 0), _dptr(wi), _dptr(oi))
+        out[:, c] = oi
+    return out

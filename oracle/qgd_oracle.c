@@ -20,6 +20,14 @@
 static int g_threads = 0;
 void qo_set_num_threads(int n) { g_threads = n; }
 
+/* 0 (default): the one-shot terminal solve uses IterativeSolvers' gmres! defaults as the
+ * reference does (restart = min(20, 2N), maxiter = 2N; eval_grad_discrete_adjoint.jl:61-62),
+ * which silently stops short of the tolerance on stiff problems (cnot3 at dt = 1).
+ * 1: full-length Krylov space and 20*2N iterations, so that the terminal condition is
+ * solved to the requested tolerance (used when the oracle serves as the 1e-10 yardstick). */
+static int g_converged_terminal = 0;
+void qo_set_converged_terminal(int on) { g_converged_terminal = on; }
+
 static double factorial_d(int n) { double f = 1.0; for (int i = 2; i <= n; i++) f *= i; return f; }
 static double binomial_d(int n, int k) { return factorial_d(n) / (factorial_d(k) * factorial_d(n - k)); }
 
@@ -791,6 +799,8 @@ int qo_compute_terminal_condition(const qo_prob *pr, const qo_control *const *co
     lhs_holder h; holder_init(&h, pr, m, dt);
     fill_pq_mats(pr, controls, pr->tf, pcof, m, h.pvals, h.qvals);  /* t = prob.tf, :14 */
     int restart = n2 < 20 ? n2 : 20;                                 /* gmres! default restart */
+    int maxiter = n2;                                                /* gmres! default maxiter */
+    if (g_converged_terminal) { restart = n2; maxiter = 20 * n2; }
     qo_gmres_ws ws; gmres_ws_init(&ws, n2, restart);
     double *rhs = (double *)malloc(sizeof(double) * n2);
     double *x = (double *)calloc(n2, sizeof(double));                /* uv_vec persists over columns, :20,:61 */
@@ -801,7 +811,7 @@ int qo_compute_terminal_condition(const qo_prob *pr, const qo_control *const *co
             rhs[N + i] = sc * (dR * r[N + i] - dT * r[i]);
         }
         if (forcing_end) for (int i = 0; i < n2; i++) rhs[i] += forcing_end[i + (size_t)c * n2];
-        gmres_solve(&ws, lhs_adjoint_apply, &h, NULL, x, rhs, pr->gmres_abstol, pr->gmres_reltol, n2);
+        gmres_solve(&ws, lhs_adjoint_apply, &h, NULL, x, rhs, pr->gmres_abstol, pr->gmres_reltol, maxiter);
         memcpy(terminal_out + (size_t)c * n2, x, sizeof(double) * n2);
     }
     free(rhs); free(x); gmres_ws_free(&ws); holder_free(&h);

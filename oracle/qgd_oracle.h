@@ -133,6 +133,7 @@ int  qo_eval_grad_finite_difference(const qo_prob *pr, const qo_control *const *
                                     int order, double dpcof, double *grad);
 
 void qo_set_num_threads(int n);
+void qo_set_converged_terminal(int on);
 
 #ifdef __cplusplus
 }

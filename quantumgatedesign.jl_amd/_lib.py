@@ -1,0 +1,86 @@
+"""ctypes loader for csrc/libqgd_hip.so (the C ABI of include/qgd.h).
+
+This is the only gateway to the compute path.  If the library is missing it
+raises -- there is no Python/CPU fallback for the stepper.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libqgd_hip.so")
+
+QGD_OK, QGD_ERR_ARGUMENT, QGD_ERR_NO_DEVICE, QGD_ERR_STATE, QGD_ERR_UNSUPPORTED, QGD_ERR_NUMERIC = range(6)
+
+EXPORTS = [
+    "qgd_abi_version", "qgd_create", "qgd_destroy", "qgd_last_error", "qgd_set_nsteps", "qgd_set_target",
+    "qgd_set_control_basis", "qgd_set_control_tables", "qgd_eval_forward", "qgd_discrete_adjoint",
+    "qgd_apply_hamiltonian", "qgd_get_intermediate", "qgd_get_timings",
+]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("n_cols", C.c_int32), ("n_ops", C.c_int32), ("n_ess", C.c_int32),
+        ("order", C.c_int32), ("nsteps", C.c_int32), ("tf", C.c_double),
+        ("system_sym", C.c_void_p), ("system_asym", C.c_void_p), ("sym_ops", C.c_void_p),
+        ("asym_ops", C.c_void_p), ("u0", C.c_void_p), ("v0", C.c_void_p), ("guard", C.c_void_p),
+        ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class QGDError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"qgd error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libqgd_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("qgd_kernels.hip", "qgd_api.cpp", "qgd_device.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "qgd.h"))
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "libqgd_hip.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+            "The stepper has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.qgd_abi_version.restype = C.c_int
+    L.qgd_last_error.restype = C.c_char_p
+    L.qgd_last_error.argtypes = [C.c_void_p]
+    L.qgd_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
+    L.qgd_destroy.argtypes = [C.c_void_p]
+    L.qgd_destroy.restype = None
+    L.qgd_set_nsteps.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+    L.qgd_set_target.argtypes = [C.c_void_p, C.c_void_p]
+    L.qgd_set_control_basis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_set_control_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_eval_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.qgd_discrete_adjoint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_apply_hamiltonian.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.qgd_get_intermediate.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qgd_get_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def check(handle, rc):
+    if rc != QGD_OK:
+        msg = lib().qgd_last_error(handle)
+        raise QGDError(rc, msg.decode() if msg else "unknown error")

@@ -1,0 +1,547 @@
+// qgd_api.cpp -- host side of the C ABI declared in include/qgd.h.
+// Validation mirrors the SchrodingerProb constructor (src/SchrodingerProb.jl:73-154);
+// orchestration mirrors eval_forward! (src/forward_evolution.jl:33-70) and
+// discrete_adjoint! (src/eval_grad_discrete_adjoint.jl:107-160).
+// There is no CPU fallback: without a GPU every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qgd.h"
+#include "qgd_device.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Phase { const char *name; hipEvent_t e0, e1; bool used; };
+
+}  // namespace
+
+struct qgd_handle_s {
+    qgdk_ctx k{};
+    int order = 0, nsteps = 0, device = 0;
+    std::string err;
+    std::vector<void *> static_bufs, grid_bufs, basis_bufs;
+    bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
+    std::vector<int32_t> ncoef, poff;
+    std::vector<int64_t> goff;
+    double *pcof_dev = nullptr;
+    std::vector<Phase> phases;
+    std::vector<double> u0v0_panel;   // host copy of the initial panel
+};
+
+namespace {
+
+int fail(qgd_handle h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail((h), QGD_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(qgd_handle h, std::vector<void *> &pool, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    if (e != hipSuccess) return fail(h, QGD_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    pool.push_back(q);
+    *p = static_cast<T *>(q);
+    return QGD_OK;
+}
+
+void free_pool(std::vector<void *> &pool)
+{
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+double factorial(int n) { double f = 1; for (int i = 2; i <= n; i++) f *= i; return f; }
+// hermite.jl:389-391
+double hermite_coefficient(int j, int p, int q) { return factorial(p) * factorial(p + q - j) / (factorial(p + q) * factorial(p - j)); }
+
+inline size_t panel_index(int row, int col, int PWc) { return (size_t)row * PWc + (col >> 3) * 16 + (col & 7); }
+
+struct PhaseTimer {
+    qgd_handle h; size_t idx;
+    PhaseTimer(qgd_handle h_, const char *name) : h(h_)
+    {
+        for (idx = 0; idx < h->phases.size(); idx++) if (!strcmp(h->phases[idx].name, name)) break;
+        if (idx == h->phases.size()) {
+            Phase p{name, nullptr, nullptr, false};
+            (void)hipEventCreate(&p.e0); (void)hipEventCreate(&p.e1);
+            h->phases.push_back(p);
+        }
+        h->phases[idx].used = true;
+        (void)hipEventRecord(h->phases[idx].e0, h->k.stream);
+    }
+    ~PhaseTimer() { (void)hipEventRecord(h->phases[idx].e1, h->k.stream); }
+};
+
+int alloc_grid(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    free_pool(h->grid_bufs);
+    const size_t Np = k.Np, PW = 2 * Np, PWc = 2 * k.cp, nt = k.nt, m = k.m;
+    const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
+    int rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.tab, nt * (m + 1) * (size_t)std::max(k.n_ops, 1) * 2))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.D, nt * m * panel))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.L, nt * panel))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.R, nt * panel))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.LinvA, nt * 2 * pl))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.LinvT, nt * 2 * pl))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.Pr, nt * panel))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.Pc, nt * 2 * pl))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.hist, nt * hstep))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.dpsi, nt * m * hstep))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.forcing, nt * hstep))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.yhist, nt * hstep))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.lam, nt * hstep))) return rc;
+    if ((rc = dev_alloc(h, h->grid_bufs, &k.sigma, nt * (size_t)std::max(k.n_ops, 1) * m * 2))) return rc;
+    // inverse work slabs when the matrix does not fit in LDS
+    const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
+    if (need > 150 * 1024) {
+        k.inv_batch = 512;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.inv_scratch, (size_t)k.inv_batch * 2 * pl))) return rc;
+    } else {
+        k.inv_batch = 0; k.inv_scratch = nullptr;
+    }
+    HIP_TRY(h, hipMemsetAsync(k.hist, 0, nt * hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.yhist, 0, nt * hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.forcing, 0, nt * hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    // Hermite weights c_j dt^j and c_j (-dt)^j  (hermite.jl:398-399, :422-423)
+    for (int j = 0; j <= k.m; j++) {
+        double cj = hermite_coefficient(j, k.m, k.m);
+        k.cw_host[2 * j] = cj * std::pow(k.dt, j);
+        k.cw_host[2 * j + 1] = cj * std::pow(-k.dt, j);
+    }
+    HIP_TRY(h, hipMemcpyAsync(k.cw, k.cw_host, sizeof(double) * 2 * (k.m + 1), hipMemcpyHostToDevice, k.stream));
+    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    h->have_basis = h->have_tables = h->forward_valid = h->derivs_valid = false;
+    free_pool(h->basis_bufs);
+    return QGD_OK;
+}
+
+// real history panel(s) -> Julia layout [2N, 1+m, nt, c]
+int copy_history_out(qgd_handle h, double *uv_history)
+{
+    qgdk_ctx &k = h->k;
+    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, nt = k.nt, m = k.m;
+    std::vector<double> h0(nt * hstep), hd(nt * m * hstep);
+    HIP_TRY(h, hipMemcpyAsync(h0.data(), k.hist, h0.size() * sizeof(double), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(h, hipMemcpyAsync(hd.data(), k.dpsi, hd.size() * sizeof(double), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    const size_t N = k.N, n2 = 2 * N;
+    for (size_t col = 0; col < (size_t)k.c; col++)
+        for (size_t n = 0; n < nt; n++)
+            for (size_t j = 0; j <= m; j++) {
+                const double *src = (j == 0) ? h0.data() + n * hstep : hd.data() + (n * m + (j - 1)) * hstep;
+                double *dst = uv_history + ((col * nt + n) * (m + 1) + j) * n2;
+                for (size_t i = 0; i < N; i++) {
+                    size_t o = panel_index((int)i, (int)col, (int)PWc);
+                    dst[i] = src[o];
+                    dst[N + i] = src[o + 8];
+                }
+            }
+    return QGD_OK;
+}
+
+int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
+{
+    if (n_pcof != h->k.n_pcof) return fail(h, QGD_ERR_ARGUMENT, "length of pcof does not match the control basis");
+    HIP_TRY(h, hipMemcpyAsync(h->pcof_dev, pcof, sizeof(double) * n_pcof, hipMemcpyHostToDevice, h->k.stream));
+    return QGD_OK;
+}
+
+#define K_TRY(h, expr)                                                                         \
+    do {                                                                                       \
+        int e__ = (expr);                                                                      \
+        if (e__ != 0)                                                                          \
+            return fail((h), QGD_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__)); \
+    } while (0)
+
+int run_forward(qgd_handle h, const double *pcof, int n_pcof)
+{
+    qgdk_ctx &k = h->k;
+    if (pcof) {
+        if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
+        int rc = upload_pcof(h, pcof, n_pcof);
+        if (rc) return rc;
+        PhaseTimer t(h, "tables");
+        K_TRY(h, qgdk_tables(&k, h->pcof_dev));
+    } else if (!h->have_tables && k.n_ops > 0) {
+        return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
+    }
+    HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.status, 0, sizeof(int), k.stream));
+    { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
+    { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
+    { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
+    { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_sweep_forward(&k)); }
+    { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }
+    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }
+    h->forward_valid = true;
+    h->derivs_valid = false;
+    return QGD_OK;
+}
+
+int check_status(qgd_handle h)
+{
+    int st = 0;
+    HIP_TRY(h, hipMemcpyAsync(&st, h->k.status, sizeof(int), hipMemcpyDeviceToHost, h->k.stream));
+    HIP_TRY(h, hipStreamSynchronize(h->k.stream));
+    if (st) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
+    return QGD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qgd_abi_version(void) { return QGD_ABI_VERSION; }
+
+const char *qgd_last_error(qgd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
+{
+    if (out) *out = nullptr;
+    if (!d || !out) return fail(nullptr, QGD_ERR_ARGUMENT, "null argument");
+    const int N = d->N, c = d->n_cols, n_ops = d->n_ops;
+    if (N < 1 || c < 1 || n_ops < 0) return fail(nullptr, QGD_ERR_ARGUMENT, "N, n_cols must be positive and n_ops non-negative");
+    if (n_ops > QGD_MAX_OPS_DEV) return fail(nullptr, QGD_ERR_UNSUPPORTED, "more than 8 control operators");
+    if (d->order < 2 || d->order > QGD_MAX_ORDER || (d->order & 1)) return fail(nullptr, QGD_ERR_ARGUMENT, "order must be even, 2..16");
+    if (d->nsteps < 1 || !(d->tf > 0)) return fail(nullptr, QGD_ERR_ARGUMENT, "nsteps and tf must be positive");
+    if (!d->system_sym || !d->system_asym || !d->u0 || !d->v0 || (n_ops && (!d->sym_ops || !d->asym_ops)))
+        return fail(nullptr, QGD_ERR_ARGUMENT, "null operator or initial-condition pointer");
+    if (d->n_ess > N) return fail(nullptr, QGD_ERR_ARGUMENT, "Number of essential levels cannot be greater than the total number of levels.");
+    // symmetry checks, SchrodingerProb.jl:73-95
+    auto sym_ok = [&](const double *A, double sgn) {
+        for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) if (A[i + (size_t)N * j] != sgn * A[j + (size_t)N * i]) return false;
+        return true;
+    };
+    if (!sym_ok(d->system_sym, 1.0)) return fail(nullptr, QGD_ERR_ARGUMENT, "Real part of system Hamiltonian is not symmetric.");
+    if (!sym_ok(d->system_asym, -1.0)) return fail(nullptr, QGD_ERR_ARGUMENT, "Imaginary part of system Hamiltonian is not anti-symmetric.");
+    for (int o = 0; o < n_ops; o++) {
+        if (!sym_ok(d->sym_ops + (size_t)o * N * N, 1.0)) return fail(nullptr, QGD_ERR_ARGUMENT, "Symmetric operator " + std::to_string(o + 1) + " is not symmetric.");
+        if (!sym_ok(d->asym_ops + (size_t)o * N * N, -1.0)) return fail(nullptr, QGD_ERR_ARGUMENT, "Anti-symmetric operator " + std::to_string(o + 1) + " is not anti-symmetric.");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, QGD_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (d->device < 0 || d->device >= ndev) return fail(nullptr, QGD_ERR_ARGUMENT, "device ordinal out of range");
+
+    qgd_handle h = new qgd_handle_s();
+    qgdk_ctx &k = h->k;
+    h->device = d->device;
+    h->order = d->order;
+    k.N = N; k.Np = (N + 15) / 16 * 16; k.c = c; k.cp = (c + 7) / 8 * 8;
+    k.n_ops = n_ops; k.n_ess = d->n_ess; k.m = d->order / 2;
+    k.nt = d->nsteps + 1; h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps;
+    if (qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024) {
+        delete h;
+        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N*order too large for the LDS-resident derivative kernels of this version");
+    }
+#define CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e__); qgd_destroy(h); return fail(nullptr, QGD_ERR_NO_DEVICE, m_); } } while (0)
+#define CREATE_RC(expr) do { int rc__ = (expr); if (rc__) { std::string m_ = h->err; qgd_destroy(h); return fail(nullptr, rc__, m_); } } while (0)
+    CREATE_TRY(hipSetDevice(d->device));
+    CREATE_TRY(hipStreamCreate(&k.stream));
+    const size_t Np = k.Np, pl = Np * Np, PWc = 2 * k.cp;
+    // operators: column-major padded planes K_sys, S_sys, Asym_1, Sym_1, ...
+    std::vector<double> ops((2 + 2 * (size_t)n_ops) * pl, 0.0);
+    auto put = [&](size_t slot, const double *A) {
+        for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) ops[slot * pl + i + Np * j] = A[i + (size_t)N * j];
+    };
+    put(0, d->system_asym); put(1, d->system_sym);
+    for (int o = 0; o < n_ops; o++) { put(2 + 2 * o, d->asym_ops + (size_t)o * N * N); put(3 + 2 * o, d->sym_ops + (size_t)o * N * N); }
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.ops, ops.size()));
+    CREATE_TRY(hipMemcpy(k.ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
+    // guard projector
+    k.have_guard = 0;
+    if (d->guard) for (size_t e = 0; e < (size_t)4 * N * N; e++) if (d->guard[e] != 0.0) { k.have_guard = 1; break; }
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.guard, (size_t)4 * N * N));
+    if (d->guard) CREATE_TRY(hipMemcpy(k.guard, d->guard, sizeof(double) * 4 * N * N, hipMemcpyHostToDevice));
+    // initial condition panel
+    h->u0v0_panel.assign(Np * PWc, 0.0);
+    for (int col = 0; col < c; col++) for (int i = 0; i < N; i++) {
+        size_t o = panel_index(i, col, (int)PWc);
+        h->u0v0_panel[o] = d->u0[i + (size_t)N * col];
+        h->u0v0_panel[o + 8] = d->v0[i + (size_t)N * col];
+    }
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.target, Np * PWc));
+    CREATE_TRY(hipMemset(k.target, 0, Np * PWc * sizeof(double)));
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.scal, (size_t)4));
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.cw, (size_t)2 * 20));
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.status, (size_t)2));
+    CREATE_RC(alloc_grid(h));
+    *out = h;
+    return QGD_OK;
+}
+
+void qgd_destroy(qgd_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
+    free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs);
+    for (auto &p : h->phases) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    if (h->k.stream) (void)hipStreamDestroy(h->k.stream);
+    delete h;
+}
+
+int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (nsteps < 1 || !(tf > 0)) return fail(h, QGD_ERR_ARGUMENT, "nsteps and tf must be positive");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->nsteps = nsteps; h->k.nt = nsteps + 1; h->k.tf = tf; h->k.dt = tf / nsteps;
+    return alloc_grid(h);
+}
+
+int qgd_set_target(qgd_handle h, const double *target_real)
+{
+    if (!h || !target_real) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    const size_t PWc = 2 * k.cp;
+    std::vector<double> t((size_t)k.Np * PWc, 0.0);
+    for (int col = 0; col < k.c; col++) for (int i = 0; i < k.N; i++) {
+        size_t o = panel_index(i, col, (int)PWc);
+        t[o] = target_real[i + (size_t)2 * k.N * col];
+        t[o + 8] = target_real[k.N + i + (size_t)2 * k.N * col];
+    }
+    HIP_TRY(h, hipMemcpy(k.target, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    k.have_target = 1;
+    return QGD_OK;
+}
+
+int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *const *Gp, const double *const *Gq)
+{
+    if (!h || (h->k.n_ops && (!n_coeff || !Gp || !Gq))) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    free_pool(h->basis_bufs);
+    h->have_basis = false;
+    h->ncoef.assign(k.n_ops, 0); h->poff.assign(k.n_ops, 0); h->goff.assign(k.n_ops, 0);
+    size_t total = 0; int np = 0, ncmax = 0;
+    const size_t per = (size_t)k.nt * (k.m + 1);
+    for (int o = 0; o < k.n_ops; o++) {
+        if (n_coeff[o] < 0) return fail(h, QGD_ERR_ARGUMENT, "negative coefficient count");
+        h->ncoef[o] = n_coeff[o]; h->poff[o] = np; h->goff[o] = (int64_t)total;
+        np += n_coeff[o]; total += 2 * per * n_coeff[o];
+        if (n_coeff[o] > ncmax) ncmax = n_coeff[o];
+    }
+    k.n_pcof = np; k.nc_max = ncmax;
+    int rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.G, total + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.goff, (size_t)k.n_ops + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.ncoef, (size_t)k.n_ops + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.poff, (size_t)k.n_ops + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &h->pcof_dev, (size_t)np + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.grad, (size_t)np + 1))) return rc;
+    for (int o = 0; o < k.n_ops; o++) {
+        const size_t cnt = per * h->ncoef[o];
+        if (!cnt) continue;
+        HIP_TRY(h, hipMemcpy(k.G + h->goff[o], Gp[o], cnt * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(k.G + h->goff[o] + cnt, Gq[o], cnt * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (k.n_ops) {
+        HIP_TRY(h, hipMemcpy(k.goff, h->goff.data(), sizeof(int64_t) * k.n_ops, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(k.ncoef, h->ncoef.data(), sizeof(int32_t) * k.n_ops, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(k.poff, h->poff.data(), sizeof(int32_t) * k.n_ops, hipMemcpyHostToDevice));
+    }
+    h->have_basis = true;
+    return QGD_OK;
+}
+
+int qgd_set_control_tables(qgd_handle h, const double *pt, const double *qt)
+{
+    if (!h || !pt || !qt) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    const size_t cnt = (size_t)k.nt * (k.m + 1) * k.n_ops;
+    double *tmp = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&tmp, 2 * cnt * sizeof(double) + 64));
+    hipError_t e1 = hipMemcpy(tmp, pt, cnt * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(tmp + cnt, qt, cnt * sizeof(double), hipMemcpyHostToDevice);
+    int kr = (e1 == hipSuccess && e2 == hipSuccess) ? qgdk_tables_from_host(&k, tmp, tmp + cnt) : 1;
+    (void)hipStreamSynchronize(k.stream);
+    (void)hipFree(tmp);
+    if (kr) return fail(h, QGD_ERR_NO_DEVICE, "uploading control tables failed");
+    h->have_tables = true;
+    return QGD_OK;
+}
+
+int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *uv_history, double *out3)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    int rc = run_forward(h, pcof, n_pcof);
+    if (rc) return rc;
+    if (uv_history) {
+        { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+        h->derivs_valid = true;
+    }
+    if ((rc = check_status(h))) return rc;
+    if (out3) HIP_TRY(h, hipMemcpy(out3, k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
+    return QGD_OK;
+}
+
+int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32_t history_precomputed,
+                         double *grad, double *uv_history, double *lambda_history, double *adjoint_forcing,
+                         double *out3)
+{
+    if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_discrete_adjoint");
+    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_discrete_adjoint");
+    int rc;
+    if (history_precomputed) {
+        if (!h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+        // the terminal right-hand side may not have been written if the target was set later
+        { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
+    } else {
+        if ((rc = run_forward(h, pcof, n_pcof))) return rc;
+    }
+    { PhaseTimer t(h, "sweep_adjoint"); K_TRY(h, qgdk_sweep_adjoint(&k)); }
+    { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+    { PhaseTimer t(h, "gradient"); K_TRY(h, qgdk_gradient(&k)); }
+    if ((rc = check_status(h))) return rc;
+    HIP_TRY(h, hipMemcpy(grad, k.grad, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
+    if (out3) HIP_TRY(h, hipMemcpy(out3, k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
+    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, nt = k.nt, N = k.N, n2 = 2 * N, m = k.m;
+    if (lambda_history) {
+        std::vector<double> l(nt * hstep);
+        HIP_TRY(h, hipMemcpy(l.data(), k.lam, l.size() * sizeof(double), hipMemcpyDeviceToHost));
+        memset(lambda_history, 0, sizeof(double) * n2 * (m + 1) * nt * k.c);
+        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 1; n < nt; n++) {
+            double *dst = lambda_history + ((col * nt + n) * (m + 1)) * n2;
+            for (size_t i = 0; i < N; i++) {
+                size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
+                dst[i] = l[o]; dst[N + i] = l[o + 8];
+            }
+        }
+    }
+    if (adjoint_forcing) {
+        std::vector<double> f(nt * hstep);
+        HIP_TRY(h, hipMemcpy(f.data(), k.forcing, f.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) {
+            double *dst = adjoint_forcing + (col * nt + n) * n2;
+            for (size_t i = 0; i < N; i++) {
+                size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
+                dst[i] = f[o]; dst[N + i] = f[o + 8];
+            }
+        }
+    }
+    return QGD_OK;
+}
+
+int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order, int32_t use_adjoint,
+                          const double *in, double *out)
+{
+    if (!h || !in || !out) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (time_index < 0 || time_index >= k.nt || deriv_order < 0 || deriv_order > k.m)
+        return fail(h, QGD_ERR_ARGUMENT, "time index or derivative order out of range");
+    const size_t PWc = 2 * k.cp, cnt = (size_t)k.Np * PWc;
+    std::vector<double> p(cnt, 0.0), q(cnt, 0.0);
+    for (int col = 0; col < k.c; col++) for (int i = 0; i < k.N; i++) {
+        size_t o = panel_index(i, col, (int)PWc);
+        p[o] = in[i + (size_t)2 * k.N * col]; p[o + 8] = in[k.N + i + (size_t)2 * k.N * col];
+    }
+    double *din = nullptr, *dout = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&din, cnt * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&dout, cnt * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(din, p.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+    int kr = qgdk_apply(&k, din, dout, time_index, deriv_order, use_adjoint ? -1.0 : 1.0);
+    hipError_t e = hipStreamSynchronize(k.stream);
+    if (!kr && e == hipSuccess) e = hipMemcpy(q.data(), dout, cnt * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (kr || e != hipSuccess) return fail(h, QGD_ERR_NO_DEVICE, "apply kernel failed");
+    for (int col = 0; col < k.c; col++) for (int i = 0; i < k.N; i++) {
+        size_t o = panel_index(i, col, (int)PWc);
+        out[i + (size_t)2 * k.N * col] = q[o]; out[k.N + i + (size_t)2 * k.N * col] = q[o + 8];
+    }
+    return QGD_OK;
+}
+
+int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity, size_t *needed)
+{
+    if (!h || !name) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    const size_t Np = k.Np, N = k.N, nt = k.nt, PW = 2 * Np, panel = Np * PW, pl = Np * Np;
+    std::string s(name);
+    size_t need = 0;
+    if (s == "L" || s == "R" || s == "Linv" || s == "P") need = nt * N * N * 2;
+    else if (s == "sigma") need = nt * (size_t)k.n_ops * k.m * 2;
+    else if (s == "tables") need = nt * (size_t)(k.m + 1) * k.n_ops * 2;
+    else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
+    if (needed) *needed = need;
+    if (!out) return QGD_OK;
+    if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
+    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    if (s == "sigma") { HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
+    if (s == "tables") { HIP_TRY(h, hipMemcpy(out, k.tab, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
+    memset(out, 0, need * sizeof(double));
+    if (s == "Linv") {
+        std::vector<double> b(nt * 2 * pl);
+        HIP_TRY(h, hipMemcpy(b.data(), k.LinvA, b.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t n = 1; n < nt; n++) for (size_t r = 0; r < N; r++) for (size_t c = 0; c < N; c++) {
+            out[((n * N + r) * N + c) * 2] = b[n * 2 * pl + r + Np * c];
+            out[((n * N + r) * N + c) * 2 + 1] = b[n * 2 * pl + pl + r + Np * c];
+        }
+        return QGD_OK;
+    }
+    const double *src = (s == "L") ? k.L : (s == "R") ? k.R : k.Pr;
+    const size_t cnt = (s == "P") ? nt - 1 : nt;
+    std::vector<double> b(cnt * panel);
+    HIP_TRY(h, hipMemcpy(b.data(), src, b.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t n = 0; n < cnt; n++) for (size_t r = 0; r < N; r++) for (size_t c = 0; c < N; c++) {
+        size_t o = n * panel + panel_index((int)r, (int)c, (int)PW);
+        out[((n * N + r) * N + c) * 2] = b[o];
+        out[((n * N + r) * N + c) * 2 + 1] = b[o + 8];
+    }
+    return QGD_OK;
+}
+
+int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, int32_t *n)
+{
+    if (!h || !n) return QGD_ERR_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->k.stream);
+    int cnt = 0;
+    for (auto &p : h->phases) {
+        if (!p.used) continue;
+        if (cnt < cap && names && ms) {
+            names[cnt] = p.name;
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) t = -1.f;
+            ms[cnt] = t;
+        }
+        cnt++;
+    }
+    *n = cnt;
+    return QGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// qgd_device.h -- launch context shared by qgd_kernels.hip and qgd_api.cpp
+#ifndef QGD_DEVICE_H
+#define QGD_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define QGD_MAX_OPS_DEV 8
+
+typedef struct qgdk_ctx {
+    int N, Np, c, cp, n_ops, n_ess, m, nt, n_pcof, nc_max;
+    int have_guard, have_target, inv_batch;
+    double dt, tf;
+    hipStream_t stream;
+    // device buffers
+    double *ops;        // [(2+2 n_ops)][Np*Np] column-major planes: K_sys, S_sys, Asym_1, Sym_1, ...
+    double *guard;      // [2N][2N] column-major
+    double *target;     // panel [Np][2cp]
+    double *G;          // control basis, per control [pq][nt][m+1][ncoef_k]
+    int64_t *goff;      // offset of control k in G
+    int32_t *ncoef;     // coefficients of control k
+    int32_t *poff;      // offset of control k in pcof
+    double *tab;        // [nt][m+1][n_ops][2]
+    double *D;          // [nt][m][Np][2Np]
+    double *L, *R;      // [nt][Np][2Np]
+    double *LinvA, *LinvT; // [nt][2][Np*Np]
+    double *Pr;         // [nt-1][Np][2Np]
+    double *Pc;         // [nt-1][2][Np*Np]
+    double *hist;       // [nt][Np][2cp]   psi_0 (the state) at every time point
+    double *dpsi;       // [nt][m][Np][2cp] derivatives 1..m
+    double *forcing;    // [nt][Np][2cp]
+    double *yhist;      // [nt][Np][2cp]
+    double *lam;        // [nt][Np][2cp]
+    double *sigma;      // [nt][n_ops][m][2]
+    double *grad;       // [n_pcof]
+    double *scal;       // [4]: <w,R>, <w,T>, guard, spare
+    double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
+    double *inv_scratch;
+    int *status;
+    double cw_host[2 * 20];
+} qgdk_ctx;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int qgdk_tables(const qgdk_ctx *c, const double *pcof_dev);
+int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double *qt_dev);
+int qgdk_build_LR(const qgdk_ctx *c);
+int qgdk_inverse(const qgdk_ctx *c);
+int qgdk_propagator(const qgdk_ctx *c);
+int qgdk_sweep_forward(const qgdk_ctx *c);
+int qgdk_guard(const qgdk_ctx *c);
+int qgdk_terminal(const qgdk_ctx *c, int write_y);
+int qgdk_sweep_adjoint(const qgdk_ctx *c);
+int qgdk_lambda(const qgdk_ctx *c);
+int qgdk_derivs(const qgdk_ctx *c);
+int qgdk_gradient(const qgdk_ctx *c);
+int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
+size_t qgdk_lds_needed(int Np, int m, int n_ops);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1000 @@
+// qgd_kernels.hip -- CDNA4 (gfx950) kernels of the time-parallel Hermite stepper
+// and discrete adjoint.  See DESIGN.md for the algorithm, the data layout and
+// the roofline of each kernel.  Reference behaviour being reproduced:
+//   src/hermite.jl:56-101,389-427,556-588   (recursion, weights, Hamiltonian apply)
+//   src/forward_evolution.jl:88-245,352-483 (forward / adjoint sweeps)
+//   src/eval_grad_discrete_adjoint.jl:1-67,107-160,582-800
+//   src/infidelity.jl:7-18,56-96
+//
+// Conventions
+//   Real form w=[u;v] <-> psi=u+iv.  A=[K S;-S K] <-> K - iS (skew-Hermitian),
+//   A^T <-> A^H = -A.
+//   "panel": a complex [rows x C] block stored row-major as real [rows][2*Cp],
+//   columns in groups of 16 = 8 real parts followed by the 8 imaginary parts of
+//   the same 8 complex columns.  One 16x16 f64 MFMA output tile = 16 rows x 8
+//   complex columns, and   C = Are*[Bre|Bim] + Aim*[-Bim|Bre]   needs no
+//   cross-lane traffic.
+//   "planes": a complex matrix as two real column-major Np x Np planes (re, im);
+//   the natural layout of a LEFT operand (A fragment: 16 consecutive rows of one k).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qgd_device.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// B-operand pair for one 4-deep k-step out of a panel row (LDS or global):
+// b1 = [Bre|Bim], b2 = [-Bim|Bre]
+__device__ __forceinline__ void panel_b(const double *row16, int c16, double &b1, double &b2)
+{
+    b1 = row16[c16];
+    double t = row16[c16 ^ 8];
+    b2 = (c16 < 8) ? -t : t;
+}
+
+// ---------------------------------------------------------------------------
+// A-fragment providers: value of the LEFT operand at (row, k)
+// ---------------------------------------------------------------------------
+struct OpCoef {           // coefficients of one derivative order d at one time point
+    double sys;           // 1 if d == 0 else 0
+    double p[QGD_MAX_OPS_DEV];
+    double q[QGD_MAX_OPS_DEV];
+};
+
+// A_d(t_n)(row,k) = K_d - i S_d assembled from the fixed operators (hermite.jl:566-587)
+__device__ __forceinline__ void assembled_a(const double *__restrict__ ops, int Np, int n_ops,
+                                            const OpCoef &cf, int row, int k, double &are, double &aim)
+{
+    const size_t e = (size_t)row + (size_t)Np * k;
+    const size_t pl = (size_t)Np * Np;
+    double K = cf.sys * ops[e];
+    double S = cf.sys * ops[pl + e];
+    #pragma unroll
+    for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {     // static indices: keeps cf in registers
+        if (o < n_ops) {
+            K += cf.q[o] * ops[(size_t)(2 + 2 * o) * pl + e];
+            S += cf.p[o] * ops[(size_t)(3 + 2 * o) * pl + e];
+        }
+    }
+    are = K;
+    aim = -S;
+}
+
+__device__ __forceinline__ void load_coef(OpCoef &cf, const double *__restrict__ tab, int n, int d,
+                                          int m, int n_ops)
+{   // tab[n][d][k][2], d = 0..m
+    cf.sys = (d == 0) ? 1.0 : 0.0;
+    const double *t = tab + (((size_t)n * (m + 1) + d) * n_ops) * 2;
+    #pragma unroll
+    for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {
+        cf.p[o] = (o < n_ops) ? t[2 * o] : 0.0;
+        cf.q[o] = (o < n_ops) ? t[2 * o + 1] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K0: control tables  tab[n][d][k][pq] = sum_l G[k][n][d][l] * pcof[off_k + l]
+// (fill_p_mat!/fill_q_mat!, Control.jl:125-149, for the whole grid at once)
+// ---------------------------------------------------------------------------
+__global__ void k_tables(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                         const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
+                         const double *__restrict__ pcof, double *__restrict__ tab, int nt, int m,
+                         int n_ops)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = nt * (m + 1) * n_ops * 2;
+    if (idx >= total) return;
+    int pq = idx & 1;
+    int k = (idx >> 1) % n_ops;
+    int d = ((idx >> 1) / n_ops) % (m + 1);
+    int n = ((idx >> 1) / n_ops) / (m + 1);
+    int nc = ncoef[k];
+    // G for control k: [pq][nt][m+1][nc]
+    const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
+    const double *pc = pcof + poff[k];
+    double s = 0.0;
+    for (int l = 0; l < nc; l++) s += g[l] * pc[l];
+    tab[idx] = s;
+}
+
+// general path: tables given by the host in Julia layout [(1+m), n_ops, nt]
+__global__ void k_tables_from_host(const double *__restrict__ pt, const double *__restrict__ qt,
+                                   double *__restrict__ tab, int nt, int m, int n_ops)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = nt * (m + 1) * n_ops * 2;
+    if (idx >= total) return;
+    int pq = idx & 1;
+    int k = (idx >> 1) % n_ops;
+    int d = ((idx >> 1) / n_ops) % (m + 1);
+    int n = ((idx >> 1) / n_ops) / (m + 1);
+    const double *src = pq ? qt : pt;
+    tab[idx] = src[d + (size_t)(m + 1) * (k + (size_t)n_ops * n)];
+}
+
+// ---------------------------------------------------------------------------
+// K1: one level of the Taylor-coefficient recursion on the identity
+//   D_{j+1}(t_n) = 1/(j+1) * ( sum_{i=1..j} A_{j-i}(t_n) D_i(t_n) + A_j(t_n) )
+// (compute_derivatives! hermite.jl:56-101 applied to every unit vector = form_LHS/
+// form_RHS hermite.jl:594-640), fused with the Hermite weights
+//   L += c_{j+1} (-dt)^{j+1} D_{j+1},  R += c_{j+1} dt^{j+1} D_{j+1}   (hermite.jl:394-427)
+// Block: 256 threads = 4 waves; tile 64 rows x NG col-groups; grid (tiles, nt).
+// D: [nt][m][Np][2Np] panels.
+// ---------------------------------------------------------------------------
+#define LV_NG 4
+#define LV_KC 16
+__global__ __launch_bounds__(256) void k_level(const double *__restrict__ ops,
+                                               const double *__restrict__ tab,
+                                               double *__restrict__ D, double *__restrict__ L,
+                                               double *__restrict__ R, int Np, int n_ops, int m,
+                                               int j, double cL, double cR)
+{
+    __shared__ __attribute__((aligned(32))) double Bs[LV_KC][16 * LV_NG];
+    const int n = blockIdx.y;
+    const int ngroups = Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int gb = blockIdx.x % gtiles, rb4 = blockIdx.x / gtiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int rb = rb4 * 4 + wave;               // 16-row block of this wave
+    const bool row_ok = rb * 16 < Np;
+    const int arow = rb * 16 + c16;              // row this lane feeds as A operand
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW;
+    double *Dn = D + (size_t)n * m * panel;
+
+    d4 acc[LV_NG];
+    for (int g = 0; g < LV_NG; g++) acc[g] = (d4){0, 0, 0, 0};
+
+    for (int i = 1; i <= j; i++) {
+        OpCoef cf;
+        load_coef(cf, tab, n, j - i, m, n_ops);
+        const double *Bsrc = Dn + (size_t)(i - 1) * panel;   // D_i
+        for (int kc = 0; kc < Np; kc += LV_KC) {
+            // stage B tile: rows kc..kc+15, cols gb*64 .. +63
+            {
+                int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+                int gcol = gb * 16 * LV_NG + c4;
+                double4 v = make_double4(0, 0, 0, 0);
+                if (gcol < PW) v = *reinterpret_cast<const double4 *>(Bsrc + (size_t)(kc + r) * PW + gcol);
+                *reinterpret_cast<double4 *>(&Bs[r][c4]) = v;
+            }
+            double are[4], aim[4];
+            if (row_ok) {
+                #pragma unroll
+                for (int s = 0; s < 4; s++) assembled_a(ops, Np, n_ops, cf, arow, kc + 4 * s + kk, are[s], aim[s]);
+            }
+            __syncthreads();
+            if (row_ok) {
+                #pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    #pragma unroll
+                    for (int g = 0; g < LV_NG; g++) {
+                        double b1, b2;
+                        panel_b(&Bs[4 * s + kk][16 * g], c16, b1, b2);
+                        acc[g] = MFMA(are[s], b1, acc[g]);
+                        acc[g] = MFMA(aim[s], b2, acc[g]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!row_ok) return;
+    // epilogue: + A_j, scale, store D_{j+1}, accumulate L and R
+    OpCoef cj;
+    load_coef(cj, tab, n, j, m, n_ops);
+    const double inv = 1.0 / (double)(j + 1);
+    const size_t pl = (size_t)Np * Np;
+    double *Dout = Dn + (size_t)j * panel;
+    double *Ln = L + (size_t)n * panel, *Rn = R + (size_t)n * panel;
+    #pragma unroll
+    for (int g = 0; g < LV_NG; g++) {
+        const int grp = gb * LV_NG + g;
+        if (grp >= ngroups) continue;
+        const int ccol = grp * 8 + (c16 & 7);        // complex column
+        const bool is_im = c16 >= 8;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            // A_j(row, ccol): read the transposed element so that lanes are contiguous:
+            // K antisymmetric, S symmetric (SchrodingerProb.jl:73-101)
+            const size_t e = (size_t)ccol + (size_t)Np * row;
+            double add;
+            if (!is_im) {
+                double K = cj.sys * ops[e];
+                #pragma unroll
+                for (int o = 0; o < QGD_MAX_OPS_DEV; o++) if (o < n_ops) K += cj.q[o] * ops[(size_t)(2 + 2 * o) * pl + e];
+                add = -K;                              // K(row,ccol) = -K(ccol,row)
+            } else {
+                double S = cj.sys * ops[pl + e];
+                #pragma unroll
+                for (int o = 0; o < QGD_MAX_OPS_DEV; o++) if (o < n_ops) S += cj.p[o] * ops[(size_t)(3 + 2 * o) * pl + e];
+                add = -S;                              // Im A = -S
+            }
+            const double val = (acc[g][r] + add) * inv;
+            const size_t o = (size_t)row * PW + grp * 16 + c16;
+            Dout[o] = val;
+            if (j == 0) {
+                const double id = (!is_im && row == ccol) ? 1.0 : 0.0;
+                Ln[o] = id + cL * val;
+                Rn[o] = id + cR * val;
+            } else {
+                Ln[o] += cL * val;
+                Rn[o] += cR * val;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: batched complex inverse by in-place Gauss-Jordan with partial pivoting.
+// One workgroup per matrix.  Input L[n] (panel).  Outputs:
+//   LinvA[n]: planes, column-major  (left operand of P = Linv * R)
+//   LinvT[n]: planes, row-major     (left operand of lambda = Linv^H y)
+// The work matrix lives in LDS when it fits, otherwise in a global scratch slab.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
+                                                 double *__restrict__ LinvA,
+                                                 double *__restrict__ LinvT,
+                                                 double *__restrict__ scratch, int Np, int n0,
+                                                 int use_lds, int *__restrict__ status)
+{
+    extern __shared__ double smem[];
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, nth = blockDim.x;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    // aux (always LDS): colre[Np], colim[Np], perm[Np] (as double), red[2*nth/64...]
+    double *aux = smem;
+    double *colre = aux, *colim = aux + Np;
+    int *perm = reinterpret_cast<int *>(aux + 2 * Np);
+    double *redv = aux + 3 * Np;              // [4] values
+    int *redi = reinterpret_cast<int *>(redv + 8);   // [4] indices
+    double *M = use_lds ? (aux + 3 * Np + 16) : (scratch + (size_t)blockIdx.x * 2 * pl);
+    double *Mre = M, *Mim = M + pl;           // row-major: (r,c) at r*Np + c
+
+    const double *Ln = L + (size_t)n * panel;
+    for (size_t e = t; e < pl; e += nth) {
+        int r = e / Np, c = e % Np;
+        Mre[e] = Ln[(size_t)r * PW + (c >> 3) * 16 + (c & 7)];
+        Mim[e] = Ln[(size_t)r * PW + (c >> 3) * 16 + 8 + (c & 7)];
+    }
+    __syncthreads();
+
+    for (int p = 0; p < Np; p++) {
+        // pivot search over rows p..Np-1 of column p
+        double best = -1.0; int bi = p;
+        for (int r = p + t; r < Np; r += nth) {
+            double a = Mre[(size_t)r * Np + p], b = Mim[(size_t)r * Np + p];
+            double v = a * a + b * b;
+            if (v > best) { best = v; bi = r; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double ob = __shfl_down(best, off);
+            int oi = __shfl_down(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((t & 63) == 0) { redv[t >> 6] = best; redi[t >> 6] = bi; }
+        __syncthreads();
+        int pr = redi[0]; double pb = redv[0];
+        for (int w = 1; w < (nth >> 6); w++)
+            if (redv[w] > pb || (redv[w] == pb && redi[w] < pr)) { pb = redv[w]; pr = redi[w]; }
+        if (t == 0) { perm[p] = pr; if (!(pb > 0.0)) *status = 1; }
+        // swap rows p and pr
+        if (pr != p) {
+            for (int c = t; c < Np; c += nth) {
+                double a = Mre[(size_t)p * Np + c]; Mre[(size_t)p * Np + c] = Mre[(size_t)pr * Np + c]; Mre[(size_t)pr * Np + c] = a;
+                double b = Mim[(size_t)p * Np + c]; Mim[(size_t)p * Np + c] = Mim[(size_t)pr * Np + c]; Mim[(size_t)pr * Np + c] = b;
+            }
+        }
+        __syncthreads();
+        // save column p, then a_pp <- 1, a_ip <- 0
+        for (int r = t; r < Np; r += nth) {
+            colre[r] = Mre[(size_t)r * Np + p];
+            colim[r] = Mim[(size_t)r * Np + p];
+        }
+        __syncthreads();
+        for (int r = t; r < Np; r += nth) {
+            Mre[(size_t)r * Np + p] = (r == p) ? 1.0 : 0.0;
+            Mim[(size_t)r * Np + p] = 0.0;
+        }
+        __syncthreads();
+        // scale pivot row by 1/pivot
+        {
+            double a = colre[p], b = colim[p];
+            double den = 1.0 / (a * a + b * b);
+            double ir = a * den, ii = -b * den;
+            for (int c = t; c < Np; c += nth) {
+                double x = Mre[(size_t)p * Np + c], y = Mim[(size_t)p * Np + c];
+                Mre[(size_t)p * Np + c] = x * ir - y * ii;
+                Mim[(size_t)p * Np + c] = x * ii + y * ir;
+            }
+        }
+        __syncthreads();
+        // eliminate: row_i -= col_i * row_p  (i != p)
+        for (size_t e = t; e < pl; e += nth) {
+            int r = e / Np, c = e % Np;
+            if (r == p) continue;
+            double fr = colre[r], fi = colim[r];
+            double x = Mre[(size_t)p * Np + c], y = Mim[(size_t)p * Np + c];
+            Mre[e] -= fr * x - fi * y;
+            Mim[e] -= fr * y + fi * x;
+        }
+        __syncthreads();
+    }
+    // undo the row swaps as column swaps in reverse order
+    for (int p = Np - 1; p >= 0; p--) {
+        int pr = perm[p];
+        if (pr != p) {
+            for (int r = t; r < Np; r += nth) {
+                double a = Mre[(size_t)r * Np + p]; Mre[(size_t)r * Np + p] = Mre[(size_t)r * Np + pr]; Mre[(size_t)r * Np + pr] = a;
+                double b = Mim[(size_t)r * Np + p]; Mim[(size_t)r * Np + p] = Mim[(size_t)r * Np + pr]; Mim[(size_t)r * Np + pr] = b;
+            }
+            __syncthreads();
+        }
+    }
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    for (size_t e = t; e < pl; e += nth) {       // row-major planes: straight copy
+        T[e] = Mre[e];
+        T[pl + e] = Mim[e];
+    }
+    for (size_t e = t; e < pl; e += nth) {       // column-major planes
+        int c = e / Np, r = e % Np;
+        A[e] = Mre[(size_t)r * Np + c];
+        A[pl + e] = Mim[(size_t)r * Np + c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: step propagator  P[n] = Linv[n+1] * R[n]   (n = 0..nt-2)
+// (the implicit solve L(t_{n+1}) w_{n+1} = R(t_n) w_n of forward_evolution.jl:181-220,
+//  done once for all right-hand sides).  Outputs P as panel (row-major; the
+// left operand of the adjoint sweep as P^H) and as column-major planes (left
+// operand of the forward sweep).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_propagator(const double *__restrict__ LinvA,
+                                                    const double *__restrict__ R,
+                                                    double *__restrict__ Pr, double *__restrict__ Pc,
+                                                    int Np)
+{
+    __shared__ __attribute__((aligned(32))) double Bs[LV_KC][16 * LV_NG];
+    const int n = blockIdx.y;
+    const int ngroups = Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int gb = blockIdx.x % gtiles, rb4 = blockIdx.x / gtiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int rb = rb4 * 4 + wave;
+    const bool row_ok = rb * 16 < Np;
+    const int arow = rb * 16 + c16;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    const double *Are = LinvA + (size_t)(n + 1) * 2 * pl, *Aim = Are + pl;
+    const double *Bsrc = R + (size_t)n * panel;
+
+    d4 acc[LV_NG];
+    for (int g = 0; g < LV_NG; g++) acc[g] = (d4){0, 0, 0, 0};
+    for (int kc = 0; kc < Np; kc += LV_KC) {
+        {
+            int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+            int gcol = gb * 16 * LV_NG + c4;
+            double4 v = make_double4(0, 0, 0, 0);
+            if (gcol < PW) v = *reinterpret_cast<const double4 *>(Bsrc + (size_t)(kc + r) * PW + gcol);
+            *reinterpret_cast<double4 *>(&Bs[r][c4]) = v;
+        }
+        double are[4], aim[4];
+        if (row_ok) {
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                size_t e = (size_t)arow + (size_t)Np * (kc + 4 * s + kk);
+                are[s] = Are[e]; aim[s] = Aim[e];
+            }
+        }
+        __syncthreads();
+        if (row_ok) {
+            #pragma unroll
+            for (int s = 0; s < 4; s++)
+                #pragma unroll
+                for (int g = 0; g < LV_NG; g++) {
+                    double b1, b2;
+                    panel_b(&Bs[4 * s + kk][16 * g], c16, b1, b2);
+                    acc[g] = MFMA(are[s], b1, acc[g]);
+                    acc[g] = MFMA(aim[s], b2, acc[g]);
+                }
+        }
+        __syncthreads();
+    }
+    if (!row_ok) return;
+    double *Prn = Pr + (size_t)n * panel, *Pcn = Pc + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int g = 0; g < LV_NG; g++) {
+        const int grp = gb * LV_NG + g;
+        if (grp >= ngroups) continue;
+        const int ccol = grp * 8 + (c16 & 7);
+        const bool is_im = c16 >= 8;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            Prn[(size_t)row * PW + grp * 16 + c16] = acc[g][r];
+            Pcn[(is_im ? pl : 0) + (size_t)row + (size_t)Np * ccol] = acc[g][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4/K7: sequential sweeps.  One workgroup per group of 8 columns.
+//   forward: psi_{n+1} = P_n psi_n                       (forward_evolution.jl:163-221)
+//   adjoint: y_n = P_n^H y_{n+1} + f_n, n = nt-2..1      (forward_evolution.jl:421-462 in the
+//            variable y_n = L_n^T lambda_n)
+// hist: [nt][Np][2cp] panels.
+// ---------------------------------------------------------------------------
+template <bool ADJ>
+__global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Pmat,
+                                               double *__restrict__ hist,
+                                               const double *__restrict__ forcing, int Np, int cp,
+                                               int nt)
+{
+    extern __shared__ double smem[];
+    double *cur = smem, *nxt = smem + (size_t)Np * 16;
+    const int grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    const size_t hstep = (size_t)Np * PWc;
+
+    const int n_start = ADJ ? nt - 1 : 0;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        cur[e] = hist[(size_t)n_start * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+
+    const int nsteps = ADJ ? nt - 2 : nt - 1;
+    for (int s = 0; s < nsteps; s++) {
+        const int nsrc = ADJ ? nt - 1 - s : s;          // time index of the state in cur
+        const int ndst = ADJ ? nsrc - 1 : nsrc + 1;
+        const int np = ADJ ? ndst : nsrc;               // propagator index
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            d4 acc = (d4){0, 0, 0, 0};
+            const int arow = rb * 16 + c16;
+            for (int k0 = 0; k0 < Np; k0 += 4) {
+                const int k = k0 + kk;
+                double are, aim;
+                if (!ADJ) {
+                    const double *Pcn = Pmat + (size_t)np * 2 * pl;
+                    are = Pcn[(size_t)arow + (size_t)Np * k];
+                    aim = Pcn[pl + (size_t)arow + (size_t)Np * k];
+                } else {   // (P^H)(row,k) = conj(P(k,row)), P as panel
+                    const double *Prn = Pmat + (size_t)np * panel + (size_t)k * PW + (arow >> 3) * 16 + (arow & 7);
+                    are = Prn[0];
+                    aim = -Prn[8];
+                }
+                double b1, b2;
+                panel_b(cur + (size_t)k * 16, c16, b1, b2);
+                acc = MFMA(are, b1, acc);
+                acc = MFMA(aim, b2, acc);
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                double v = acc[r];
+                const size_t ho = (size_t)ndst * hstep + (size_t)row * PWc + grp * 16 + c16;
+                if (ADJ) v += forcing[ho];
+                nxt[(size_t)row * 16 + c16] = v;
+                hist[ho] = v;
+            }
+        }
+        __syncthreads();
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5: guard penalty and adjoint forcing (infidelity.jl:56-96,
+// eval_grad_discrete_adjoint.jl:732-752).  One workgroup per time point.
+//   f_n = -(2 dt/tf) * trap_n * W w_n ;  penalty += (dt/tf) trap_n w_n^T W w_n
+// W: dense real 2N x 2N, column-major (unpadded).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
+                                               const double *__restrict__ hist,
+                                               double *__restrict__ forcing,
+                                               double *__restrict__ scal, int N, int Np, int c,
+                                               int cp, int nt, double dt, double tf, int have_guard)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *h = hist + (size_t)n * hstep;
+    double *f = forcing + (size_t)n * hstep;
+    const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0;
+    double pen = 0.0;
+    if (!have_guard) {
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) f[e] = 0.0;
+        return;
+    }
+    // zero the padding
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) f[e] = 0.0;
+    __syncthreads();
+    const int n2 = 2 * N;
+    for (int e = threadIdx.x; e < n2 * c; e += blockDim.x) {
+        const int i = e % n2, col = e / n2;
+        const int cbase = (col >> 3) * 16 + (col & 7);
+        double s = 0.0;
+        for (int jx = 0; jx < n2; jx++) {
+            const double wj = (jx < N) ? h[(size_t)jx * PWc + cbase] : h[(size_t)(jx - N) * PWc + cbase + 8];
+            s += W[(size_t)i + (size_t)n2 * jx] * wj;
+        }
+        const size_t o = (i < N) ? (size_t)i * PWc + cbase : (size_t)(i - N) * PWc + cbase + 8;
+        pen += h[o] * s;
+        f[o] = -(2.0 * dt / tf) * trap * s;
+    }
+    for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = red[0] + red[1] + red[2] + red[3];
+        atomicAdd(&scal[2], tot * trap * dt / tf);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: overlaps and terminal right-hand side (infidelity.jl:13-17,
+// eval_grad_discrete_adjoint.jl:22-40).  Single workgroup.
+//   scal[0] = <w_N,R>, scal[1] = <w_N,T>;  y_N = (2/Ness^2)(a R + b T) + f_N
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ hist,
+                                                  const double *__restrict__ target,
+                                                  const double *__restrict__ forcing,
+                                                  double *__restrict__ yhist,
+                                                  double *__restrict__ scal, int Np, int cp, int nt,
+                                                  int n_ess, int have_target, int write_y)
+{
+    __shared__ double red[8];
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *w = hist + (size_t)(nt - 1) * hstep;
+    double a = 0.0, b = 0.0;
+    if (have_target) {
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+            const int col = e % PWc;
+            const int c16 = col & 15;
+            const double tv = target[e];
+            a += w[e] * tv;
+            // T = [R_im; -R_re]: pairs u with R_im and v with -R_re
+            const double tp = target[e ^ 8];           // partner (re<->im) of the same column
+            b += (c16 < 8) ? w[e] * tp : -w[e] * tp;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+    if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
+    if (!write_y) return;
+    const double sc = 2.0 / ((double)n_ess * (double)n_ess);
+    double *y = yhist + (size_t)(nt - 1) * hstep;
+    const double *f = forcing + (size_t)(nt - 1) * hstep;
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+        const int c16 = (e % PWc) & 15;
+        const double tv = target[e], tp = target[e ^ 8];
+        const double Tv = (c16 < 8) ? tp : -tp;        // T component at this slot
+        y[e] = sc * (a * tv + b * Tv) + f[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8: lambda_n = Linv_n^H y_n for n = 1..nt-1 (parallel over n and column groups)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT,
+                                                const double *__restrict__ yhist,
+                                                double *__restrict__ lam, int Np, int cp)
+{
+    extern __shared__ double smem[];
+    double *ys = smem;                                   // [Np][16]
+    const int n = blockIdx.y + 1, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, pl = (size_t)Np * Np;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        ys[e] = yhist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    const double *Tre = LinvT + (size_t)n * 2 * pl, *Tim = Tre + pl;   // (r,c) at c + Np*r
+    for (int rb = wave; rb * 16 < Np; rb += nw) {
+        d4 acc = (d4){0, 0, 0, 0};
+        const int arow = rb * 16 + c16;
+        for (int k0 = 0; k0 < Np; k0 += 4) {
+            const int k = k0 + kk;
+            // (Linv^H)(row,k) = conj(Linv(k,row)); Linv(k,row) sits at row + Np*k
+            const double are = Tre[(size_t)arow + (size_t)Np * k];
+            const double aim = -Tim[(size_t)arow + (size_t)Np * k];
+            double b1, b2;
+            panel_b(ys + (size_t)k * 16, c16, b1, b2);
+            acc = MFMA(are, b1, acc);
+            acc = MFMA(aim, b2, acc);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            lam[(size_t)n * hstep + (size_t)row * PWc + grp * 16 + c16] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K9: state derivatives at every time point (the stored history of
+// forward_evolution.jl:172-179,:236-242):  psi_{j+1} = 1/(j+1) sum_{i<=j} A_{j-i} psi_i
+// One workgroup per (time point, column group).  dpsi: [nt][m][Np][2cp].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
+                                                const double *__restrict__ tab,
+                                                const double *__restrict__ hist,
+                                                double *__restrict__ dpsi, int Np, int cp,
+                                                int n_ops, int m)
+{
+    extern __shared__ double smem[];                    // (m+1) panels [Np][16]
+    const int n = blockIdx.y, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t ps = (size_t)Np * 16;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        smem[e] = hist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            d4 acc = (d4){0, 0, 0, 0};
+            const int arow = rb * 16 + c16;
+            for (int i = 0; i <= j; i++) {
+                OpCoef cf;
+                load_coef(cf, tab, n, j - i, m, n_ops);
+                const double *src = smem + (size_t)i * ps;
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    double are, aim, b1, b2;
+                    assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                    acc = MFMA(are, b1, acc);
+                    acc = MFMA(aim, b2, acc);
+                }
+            }
+            const double inv = 1.0 / (double)(j + 1);
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                const double v = acc[r] * inv;
+                smem[(size_t)(j + 1) * ps + (size_t)row * 16 + c16] = v;
+                dpsi[(((size_t)n * m + j) * Np + row) * PWc + grp * 16 + c16] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K10: gradient scalars.  Per (time point, column group):
+//   seeds   g_j = c_j dt^j lambda_{n+1} [n<=nt-2]  -  c_j (-dt)^j lambda_n [n>=1]
+//   sweep   j = m..2, i = 1..j-1:  g_i += (1/j) A_{j-1-i}^H g_j     (A^H = -A)
+//   sigma   sigP[k][d] += (1/j) <(dA/dp_k) psi_i, g_j>,  sigQ likewise, d = j-1-i
+// This is the O(m^2) reverse form of accumulate_gradient_arbitrary_fast! /
+// recursive_magic! (eval_grad_discrete_adjoint.jl:582-726); inner products as
+// compute_inner_prod_S!/K! (:764-800).  sigma: [nt][n_ops][m][2] (atomicAdd
+// across column groups).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ ops,
+                                                   const double *__restrict__ tab,
+                                                   const double *__restrict__ hist,
+                                                   const double *__restrict__ dpsi,
+                                                   const double *__restrict__ lam,
+                                                   double *__restrict__ sigma,
+                                                   const double *__restrict__ cw, int Np, int cp,
+                                                   int n_ops, int m, int nt)
+{
+    extern __shared__ double smem[];     // psi_0..psi_{m-1} (m panels), g_1..g_m (m panels), sig[n_ops*m*2]
+    const int n = blockIdx.y, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t ps = (size_t)Np * 16;
+    double *psi = smem, *gs = smem + (size_t)m * ps;   // gs[(j-1)*ps]
+    double *sig = gs + (size_t)m * ps;
+    const size_t pl = (size_t)Np * Np;
+
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x) {
+        const size_t src = (size_t)(e >> 4) * PWc + grp * 16 + (e & 15);
+        psi[e] = hist[(size_t)n * hstep + src];
+        for (int i = 1; i < m; i++) psi[(size_t)i * ps + e] = dpsi[(((size_t)n * m + (i - 1)) * Np) * PWc + src];
+        const double ln = (n >= 1) ? lam[(size_t)n * hstep + src] : 0.0;
+        const double lx = (n <= nt - 2) ? lam[(size_t)(n + 1) * hstep + src] : 0.0;
+        for (int j = 1; j <= m; j++) gs[(size_t)(j - 1) * ps + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+    }
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    __syncthreads();
+
+    // reverse sweep
+    for (int j = m; j >= 2; j--) {
+        const double *src = gs + (size_t)(j - 1) * ps;
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            const int arow = rb * 16 + c16;
+            for (int i = 1; i <= j - 1; i++) {
+                OpCoef cf;
+                load_coef(cf, tab, n, j - 1 - i, m, n_ops);
+                d4 acc = (d4){0, 0, 0, 0};
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    double are, aim, b1, b2;
+                    assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                    acc = MFMA(are, b1, acc);
+                    acc = MFMA(aim, b2, acc);
+                }
+                const double sc = -1.0 / (double)j;     // A^H = -A
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = rb * 16 + kk + 4 * r;
+                    gs[(size_t)(i - 1) * ps + (size_t)row * 16 + c16] += sc * acc[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // inner products
+    for (int o = 0; o < n_ops; o++) {
+        const double *Asym = ops + (size_t)(2 + 2 * o) * pl, *Sym = ops + (size_t)(3 + 2 * o) * pl;
+        for (int i = 0; i < m; i++) {
+            const double *src = psi + (size_t)i * ps;
+            for (int rb = wave; rb * 16 < Np; rb += nw) {
+                const int arow = rb * 16 + c16;
+                d4 U = (d4){0, 0, 0, 0}, V = (d4){0, 0, 0, 0};
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    const size_t e = (size_t)arow + (size_t)Np * (k0 + kk);
+                    const double b1 = src[(size_t)(k0 + kk) * 16 + c16];
+                    U = MFMA(Sym[e], b1, U);
+                    V = MFMA(Asym[e], b1, V);
+                }
+                for (int j = i + 1; j <= m; j++) {
+                    const double *gj = gs + (size_t)(j - 1) * ps;
+                    double sp = 0.0, sq = 0.0;
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = rb * 16 + kk + 4 * r;
+                        double g1, g2;
+                        panel_b(gj + (size_t)row * 16, c16, g1, g2);
+                        sq += V[r] * g1;              // Re<V, g>
+                        sp += U[r] * g2;              // Re<-iU, g> = Uim*gre - Ure*gim
+                    }
+                    for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
+                    if (lane == 0) {
+                        const int d = j - 1 - i;
+                        atomicAdd(&sig[(o * m + d) * 2], sp / (double)j);
+                        atomicAdd(&sig[(o * m + d) * 2 + 1], sq / (double)j);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x)
+        atomicAdd(&sigma[(size_t)n * n_ops * m * 2 + e], sig[e]);
+}
+
+// ---------------------------------------------------------------------------
+// K11: gradient contraction  grad[off_k + l] = - sum_{n,d} Gp[k][n][d][l] sigP[n][k][d] + Gq.. sigQ..
+// (the "grad_slice .-= contrib" of eval_grad_discrete_adjoint.jl:642-643)
+// grid: (ceil(nc_max/64), n_ops, NSPLIT); atomicAdd over the time splits.
+// ---------------------------------------------------------------------------
+__global__ void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                           const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
+                           const double *__restrict__ sigma, double *__restrict__ grad, int nt, int m,
+                           int n_ops)
+{
+    const int k = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = ncoef[k];
+    if (l >= nc) return;
+    const int nsplit = gridDim.z;
+    const int n0 = (int)(((long long)nt * blockIdx.z) / nsplit), n1 = (int)(((long long)nt * (blockIdx.z + 1)) / nsplit);
+    const double *gp = G + goff[k];
+    const double *gq = gp + (size_t)nt * (m + 1) * nc;
+    double s = 0.0;
+    for (int n = n0; n < n1; n++)
+        for (int d = 0; d < m; d++) {
+            const double sp = sigma[(((size_t)n * n_ops + k) * m + d) * 2];
+            const double sq = sigma[(((size_t)n * n_ops + k) * m + d) * 2 + 1];
+            s += gp[((size_t)n * (m + 1) + d) * nc + l] * sp + gq[((size_t)n * (m + 1) + d) * nc + l] * sq;
+        }
+    atomicAdd(&grad[poff[k] + l], -s);
+}
+
+// ---------------------------------------------------------------------------
+// Test hook: out = (+/-) A_d(t_n) * in for a panel of columns (apply_hamiltonian!,
+// hermite.jl:556-588, batched over all initial-condition columns).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply(const double *__restrict__ ops,
+                                               const double *__restrict__ tab,
+                                               const double *__restrict__ in,
+                                               double *__restrict__ out, int Np, int cp, int n_ops,
+                                               int m, int n, int d, double sign)
+{
+    extern __shared__ double smem[];
+    const int grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        smem[e] = in[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    OpCoef cf;
+    load_coef(cf, tab, n, d, m, n_ops);
+    for (int rb = wave; rb * 16 < Np; rb += nw) {
+        d4 acc = (d4){0, 0, 0, 0};
+        const int arow = rb * 16 + c16;
+        for (int k0 = 0; k0 < Np; k0 += 4) {
+            double are, aim, b1, b2;
+            assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+            panel_b(smem + (size_t)(k0 + kk) * 16, c16, b1, b2);
+            acc = MFMA(are, b1, acc);
+            acc = MFMA(aim, b2, acc);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            out[(size_t)row * PWc + grp * 16 + c16] = sign * acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (called from qgd_api.cpp)
+// ---------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+extern "C" {
+
+int qgdk_tables(const qgdk_ctx *c, const double *pcof)
+{
+    int total = c->nt * (c->m + 1) * c->n_ops * 2;
+    hipLaunchKernelGGL(k_tables, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
+                       c->poff, pcof, c->tab, c->nt, c->m, c->n_ops);
+    return (int)hipGetLastError();
+}
+
+int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt, const double *qt)
+{
+    int total = c->nt * (c->m + 1) * c->n_ops * 2;
+    hipLaunchKernelGGL(k_tables_from_host, dim3((total + 255) / 256), dim3(256), 0, c->stream, pt, qt, c->tab,
+                       c->nt, c->m, c->n_ops);
+    return (int)hipGetLastError();
+}
+
+int qgdk_build_LR(const qgdk_ctx *c)
+{
+    const int ngroups = c->Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int rtiles = (c->Np + 63) / 64;
+    for (int j = 0; j < c->m; j++) {
+        double cL = c->cw_host[2 * (j + 1) + 1], cR = c->cw_host[2 * (j + 1)];
+        hipLaunchKernelGGL(k_level, dim3(gtiles * rtiles, c->nt), dim3(256), 0, c->stream, c->ops, c->tab, c->D,
+                           c->L, c->R, c->Np, c->n_ops, c->m, j, cL, cR);
+    }
+    return (int)hipGetLastError();
+}
+
+int qgdk_inverse(const qgdk_ctx *c)
+{
+    const size_t pl = (size_t)c->Np * c->Np;
+    size_t aux = (size_t)(3 * c->Np + 16) * sizeof(double);
+    size_t mat = 2 * pl * sizeof(double);
+    int use_lds = (aux + mat <= 150 * 1024) ? 1 : 0;
+    size_t shm = aux + (use_lds ? mat : 0);
+    if (use_lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_inverse, dim3(c->nt - 1), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT,
+                           (double *)nullptr, c->Np, 1, 1, c->status);
+    } else {
+        // global scratch: process in batches of inv_batch matrices
+        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+            int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+            hipLaunchKernelGGL(k_inverse, dim3(nb), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT,
+                               c->inv_scratch, c->Np, n0, 0, c->status);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+int qgdk_propagator(const qgdk_ctx *c)
+{
+    const int ngroups = c->Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int rtiles = (c->Np + 63) / 64;
+    hipLaunchKernelGGL(k_propagator, dim3(gtiles * rtiles, c->nt - 1), dim3(256), 0, c->stream, c->LinvA, c->R,
+                       c->Pr, c->Pc, c->Np);
+    return (int)hipGetLastError();
+}
+
+int qgdk_sweep_forward(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)2 * c->Np * 16 * sizeof(double);
+    hipLaunchKernelGGL(k_sweep<false>, dim3(c->cp / 8), dim3(256), shm, c->stream, c->Pc, c->hist,
+                       (const double *)nullptr, c->Np, c->cp, c->nt);
+    return (int)hipGetLastError();
+}
+
+int qgdk_guard(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_guard, dim3(c->nt), dim3(256), 0, c->stream, c->guard, c->hist, c->forcing, c->scal,
+                       c->N, c->Np, c->c, c->cp, c->nt, c->dt, c->tf, c->have_guard);
+    return (int)hipGetLastError();
+}
+
+int qgdk_terminal(const qgdk_ctx *c, int write_y)
+{
+    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
+                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y);
+    return (int)hipGetLastError();
+}
+
+int qgdk_sweep_adjoint(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)2 * c->Np * 16 * sizeof(double);
+    if (c->nt >= 3)
+        hipLaunchKernelGGL(k_sweep<true>, dim3(c->cp / 8), dim3(256), shm, c->stream, c->Pr, c->yhist, c->forcing,
+                           c->Np, c->cp, c->nt);
+    return (int)hipGetLastError();
+}
+
+int qgdk_lambda(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)c->Np * 16 * sizeof(double);
+    hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
+                       c->Np, c->cp);
+    return (int)hipGetLastError();
+}
+
+int qgdk_derivs(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
+    if (shm > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_derivs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_derivs, dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi,
+                       c->Np, c->cp, c->n_ops, c->m);
+    return (int)hipGetLastError();
+}
+
+int qgdk_gradient(const qgdk_ctx *c)
+{
+    size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
+    if (shm > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_gradsweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    HIPCHK(hipMemsetAsync(c->sigma, 0, (size_t)c->nt * c->n_ops * c->m * 2 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_gradsweep, dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist,
+                       c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt);
+    HIPCHK(hipMemsetAsync(c->grad, 0, (size_t)c->n_pcof * sizeof(double), c->stream));
+    int nsplit = c->nt >= 64 ? 16 : 1;
+    hipLaunchKernelGGL(k_contract, dim3((c->nc_max + 63) / 64, c->n_ops, nsplit), dim3(64), 0, c->stream, c->G,
+                       c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
+    return (int)hipGetLastError();
+}
+
+int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, double sign)
+{
+    size_t shm = (size_t)c->Np * 16 * sizeof(double);
+    hipLaunchKernelGGL(k_apply, dim3(c->cp / 8), dim3(256), shm, c->stream, c->ops, c->tab, in, out, c->Np, c->cp,
+                       c->n_ops, c->m, n, d, sign);
+    return (int)hipGetLastError();
+}
+
+size_t qgdk_lds_needed(int Np, int m, int n_ops)
+{
+    size_t a = (size_t)(m + 1) * Np * 16 * sizeof(double);
+    size_t b = ((size_t)2 * m * Np * 16 + (size_t)n_ops * m * 2) * sizeof(double);
+    return a > b ? a : b;
+}
+
+} // extern "C"

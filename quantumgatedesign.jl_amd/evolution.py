@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's stepper / gradient entry points, calling the
+C ABI (include/qgd.h) through ctypes.  Same names, argument meaning and error
+behaviour as the reference:
+
+  eval_forward(prob, controls, pcof; order, saveEveryNsteps)      forward_evolution.jl:15-29
+  eval_forward_(uv_history, prob, controls, pcof; order)          forward_evolution.jl:33-70   (Julia eval_forward!)
+  discrete_adjoint(prob, controls, pcof, target; order)           eval_grad_discrete_adjoint.jl:83-102
+  discrete_adjoint_(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target;
+                    order, history_precomputed)                   eval_grad_discrete_adjoint.jl:107-160
+  infidelity(...), infidelity_real, guard_penalty_real            infidelity.jl:7-96
+
+Julia's trailing ``!`` is spelled as a trailing underscore.  Arrays use the
+reference's column-major layouts (numpy ``order="F"``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from .controls import as_control_list, control_basis, get_number_of_control_parameters
+
+
+def _f(a):
+    return np.asfortranarray(np.array(a, dtype=np.float64))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def complex_to_real(x):
+    """state_vector_helpers.jl:72-74."""
+    x = np.asarray(x)
+    return np.asfortranarray(np.vstack([np.real(x), np.imag(x)]).astype(np.float64))
+
+
+def real_to_complex(x):
+    """state_vector_helpers.jl:78-87."""
+    N = x.shape[0] // 2
+    return x[:N] + 1j * x[N:]
+
+
+class DeviceProblem:
+    """One qgd handle: a SchrodingerProb resident on one GPU for one Hermite order."""
+
+    def __init__(self, prob, order: int, device: int = 0):
+        self.lib = _lib.lib()
+        self.N = prob.N_tot_levels
+        self.c = prob.N_initial_conditions
+        self.n_ops = prob.N_operators
+        self.order = int(order)
+        self.m = self.order // 2
+        self.nsteps = prob.nsteps
+        self.tf = prob.tf
+        N = self.N
+        bufs = dict(
+            ssym=_f(prob.system_sym), sasym=_f(prob.system_asym),
+            sym=np.ascontiguousarray(np.stack([_f(o).T for o in prob.sym_operators])) if self.n_ops else np.zeros(1),
+            asym=np.ascontiguousarray(np.stack([_f(o).T for o in prob.asym_operators])) if self.n_ops else np.zeros(1),
+            u0=_f(prob.u0), v0=_f(prob.v0), guard=_f(prob.guard_subspace_projector))
+        d = _lib.ProblemDesc(N, self.c, self.n_ops, prob.N_ess_levels, self.order, prob.nsteps, prob.tf,
+                             _vp(bufs["ssym"]), _vp(bufs["sasym"]), _vp(bufs["sym"]), _vp(bufs["asym"]),
+                             _vp(bufs["u0"]), _vp(bufs["v0"]), _vp(bufs["guard"]), device, 0)
+        h = C.c_void_p()
+        rc = self.lib.qgd_create(C.byref(d), C.byref(h))
+        _lib.check(None, rc)
+        self.h = h
+        self._finalizer = weakref.finalize(self, self.lib.qgd_destroy, h)
+        self._basis_key = None
+        self._target_key = None
+        self.n_pcof = 0
+
+    def close(self):
+        self._finalizer()
+
+    # -- setup -------------------------------------------------------------
+    def set_nsteps(self, nsteps, tf):
+        _lib.check(self.h, self.lib.qgd_set_nsteps(self.h, int(nsteps), float(tf)))
+        self.nsteps, self.tf = int(nsteps), float(tf)
+        self._basis_key = None
+
+    def set_target(self, target):
+        t = complex_to_real(target) if np.iscomplexobj(target) or np.asarray(target).shape[0] == self.N else _f(target)
+        key = t.tobytes()
+        if key != self._target_key:
+            _lib.check(self.h, self.lib.qgd_set_target(self.h, _vp(t)))
+            self._target_key = key
+
+    def set_controls(self, controls):
+        cl = as_control_list(controls)
+        if len(cl) != self.n_ops:
+            raise ValueError(f"{len(cl)} controls for {self.n_ops} control operators")
+        key = (tuple(id(c) for c in cl), self.nsteps, self.tf)
+        if key == self._basis_key:
+            return
+        if not all(getattr(c, "is_linear", False) for c in cl):
+            raise NotImplementedError("non-linear controls: use set_control_tables with explicit tables")
+        Gp, Gq, _ = control_basis(cl, self.nsteps, self.tf, self.m)
+        nco = np.array([c.N_coeff for c in cl], dtype=np.int32)
+        gp_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gp])
+        gq_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gq])
+        _lib.check(self.h, self.lib.qgd_set_control_basis(self.h, _vp(nco), gp_ptrs, gq_ptrs))
+        self._basis_key = key
+        self._controls_keepalive = cl
+        self.n_pcof = int(nco.sum())
+
+    def set_control_tables(self, p_tables, q_tables):
+        p, q = _f(p_tables), _f(q_tables)
+        shape = (self.m + 1, self.n_ops, self.nsteps + 1)
+        if p.shape != shape or q.shape != shape:
+            raise ValueError(f"control tables must have shape {shape}")
+        _lib.check(self.h, self.lib.qgd_set_control_tables(self.h, _vp(p), _vp(q)))
+
+    # -- evaluation --------------------------------------------------------
+    def eval_forward(self, pcof=None, uv_history=None):
+        out3 = np.zeros(3)
+        pc = None if pcof is None else np.ascontiguousarray(pcof, dtype=np.float64)
+        _lib.check(self.h, self.lib.qgd_eval_forward(
+            self.h, None if pc is None else _vp(pc), 0 if pc is None else len(pc),
+            None if uv_history is None else _vp(uv_history), _vp(out3)))
+        return out3
+
+    def discrete_adjoint(self, pcof, history_precomputed=False, uv_history=None, lambda_history=None,
+                         adjoint_forcing=None):
+        pc = np.ascontiguousarray(pcof, dtype=np.float64)
+        grad = np.zeros(len(pc))
+        out3 = np.zeros(3)
+        _lib.check(self.h, self.lib.qgd_discrete_adjoint(
+            self.h, _vp(pc), len(pc), 1 if history_precomputed else 0, _vp(grad),
+            None if uv_history is None else _vp(uv_history),
+            None if lambda_history is None else _vp(lambda_history),
+            None if adjoint_forcing is None else _vp(adjoint_forcing), _vp(out3)))
+        return grad, out3
+
+    def apply_hamiltonian(self, w, time_index=0, derivative_order=0, use_adjoint=False):
+        w = _f(w).reshape(2 * self.N, self.c, order="F")
+        out = np.zeros_like(w, order="F")
+        _lib.check(self.h, self.lib.qgd_apply_hamiltonian(self.h, time_index, derivative_order,
+                                                          1 if use_adjoint else 0, _vp(w), _vp(out)))
+        return out
+
+    def intermediate(self, name):
+        need = C.c_size_t()
+        _lib.check(self.h, self.lib.qgd_get_intermediate(self.h, name.encode(), None, 0, C.byref(need)))
+        out = np.zeros(need.value)
+        _lib.check(self.h, self.lib.qgd_get_intermediate(self.h, name.encode(), _vp(out), need.value, C.byref(need)))
+        nt = self.nsteps + 1
+        if name in ("L", "R", "Linv", "P"):
+            z = out.reshape(nt, self.N, self.N, 2)
+            return z[..., 0] + 1j * z[..., 1]
+        if name == "sigma":
+            return out.reshape(nt, self.n_ops, self.m, 2)
+        return out.reshape(nt, self.m + 1, self.n_ops, 2)
+
+    def timings(self):
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = C.c_int32()
+        _lib.check(self.h, self.lib.qgd_get_timings(self.h, names, ms, cap, C.byref(n)))
+        return {names[i].decode(): ms[i] for i in range(min(n.value, cap))}
+
+
+# ---------------------------------------------------------------------------
+# handle cache: one DeviceProblem per (prob object, order)
+# ---------------------------------------------------------------------------
+_cache: dict = {}
+
+
+def device_problem(prob, order: int, device: int = 0) -> DeviceProblem:
+    key = (id(prob), int(order), device)
+    ent = _cache.get(key)
+    if ent is not None and ent[0]() is prob:
+        dp = ent[1]
+        if dp.nsteps != prob.nsteps or dp.tf != prob.tf:
+            dp.set_nsteps(prob.nsteps, prob.tf)
+        return dp
+    dp = DeviceProblem(prob, order, device)
+    _cache[key] = (weakref.ref(prob), dp)
+    return dp
+
+
+def clear_cache():
+    for _, dp in list(_cache.values()):
+        dp.close()
+    _cache.clear()
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped API
+# ---------------------------------------------------------------------------
+def _history_shape(prob, order):
+    return (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+
+
+def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None):
+    """eval_forward! (forward_evolution.jl:33-70): fills ``uv_history``
+    ``[2N, 1+order/2, 1+nsteps, N_initial_conditions]`` (Fortran order) in place."""
+    if forcing is not None:
+        raise NotImplementedError("forcing (forward-sensitivity gradient, SURVEY f2) is not on the device path yet")
+    if saveEveryNsteps != 1:
+        raise NotImplementedError("saveEveryNsteps != 1")
+    if uv_history.shape != _history_shape(prob, order) or not uv_history.flags.f_contiguous:
+        raise ValueError(f"uv_history must be Fortran-ordered with shape {_history_shape(prob, order)}")
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    dp.eval_forward(pcof, uv_history)
+    return None
+
+
+def eval_forward(prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None):
+    """forward_evolution.jl:15-29: complex state history ``[N, 1+nsteps, N_initial_conditions]``."""
+    hist = np.zeros(_history_shape(prob, order), order="F")
+    eval_forward_(hist, prob, controls, pcof, order=order, saveEveryNsteps=saveEveryNsteps, forcing=forcing)
+    return real_to_complex(hist[:, 0, :, :])
+
+
+def infidelity_real(psi, target, N_ess):
+    """infidelity.jl:7-18 (host arithmetic on two small matrices)."""
+    R = np.asarray(target, float)
+    N = R.shape[0] // 2
+    T = np.vstack([R[N:], -R[:N]])
+    psi = np.asarray(psi, float)
+    return 1 - (np.sum(psi * R) ** 2 + np.sum(psi * T) ** 2) / N_ess ** 2
+
+
+def infidelity(*args, order=2):
+    """infidelity(psi, target, N_ess)  or  infidelity(prob, controls, pcof, target; order)
+    (infidelity.jl:20-47).  The second form runs the forward sweep on the device."""
+    if len(args) == 3:
+        psi, target, N_ess = args
+        return infidelity_real(complex_to_real(psi), complex_to_real(target), N_ess)
+    prob, controls, pcof, target = args
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    dp.set_target(target)
+    a, b, _ = dp.eval_forward(pcof)
+    return 1 - (a * a + b * b) / prob.N_ess_levels ** 2
+
+
+def guard_penalty_real(history, dt, T, W):
+    """infidelity.jl:56-96 (host; the device computes the same sum inside eval_forward)."""
+    h = np.asarray(history)
+    if h.ndim == 3:
+        h = h[..., None]
+    w = h[:, 0, :, :]
+    Ww = np.einsum("ij,jnc->inc", np.asarray(W), w)
+    trap = np.ones(w.shape[1]); trap[0] = trap[-1] = 0.5
+    return float(np.einsum("n,inc,inc->", trap, w, Ww) * dt / T)
+
+
+def discrete_adjoint_(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target,
+                      order=2, cost_type="Infidelity", history_precomputed=False):
+    """discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160)."""
+    if cost_type not in ("Infidelity", ":Infidelity"):
+        raise NotImplementedError("only cost_type=:Infidelity is implemented (the reference marks the others untested)")
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    dp.set_target(target)
+    g, _ = dp.discrete_adjoint(pcof, history_precomputed, history, lambda_history, adjoint_forcing)
+    grad[:] = g
+    return grad
+
+
+def discrete_adjoint(prob, controls, pcof, target, order=2, cost_type="Infidelity"):
+    """eval_grad_discrete_adjoint.jl:83-102: returns the gradient."""
+    grad = np.zeros(get_number_of_control_parameters(controls))
+    return discrete_adjoint_(grad, None, None, None, prob, controls, pcof, target, order=order, cost_type=cost_type)

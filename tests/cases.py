@@ -1,0 +1,69 @@
+"""Seeded problem/control cases shared by the CPU and GPU parity tests.  The
+shapes follow the reference's own tests (test/GradientTests/compare_gradients.jl:
+Rabi 2-level and random N=4, GRAPE / B-spline degree 16 / carrier controls,
+nsteps=10) plus the BASELINE.json configurations at reduced nsteps."""
+import numpy as np
+
+
+def rand_target(prob, seed=0):
+    r = np.random.default_rng(seed)
+    s = (prob.N_tot_levels, prob.N_initial_conditions)
+    return r.random(s) + 1j * r.random(s)
+
+
+def gradient_cases(qgd):
+    """(name, prob, controls, pcof, target) as in compare_gradients.jl:103-230."""
+    out = []
+    rng = np.random.default_rng(0)
+    mk = dict(gmres_abstol=1e-15, gmres_reltol=1e-15)
+
+    def add(name, prob, ctrl):
+        pcof = rng.random(qgd.get_number_of_control_parameters(ctrl))
+        out.append((name, prob, ctrl, pcof, rand_target(prob)))
+
+    p = qgd.construct_rabi_prob(tf=np.pi, nsteps=10, **mk)
+    add("rabi-grape", p, qgd.GRAPEControl(5, p.tf))
+    add("rabi-bspline16", p, qgd.FortranBSplineControl(16, 20, p.tf))
+    add("rabi-carrier", p, qgd.CarrierControl(qgd.FortranBSplineControl(16, 20, p.tf), [-10, -1, 0, 1, 10]))
+    p = qgd.construct_rand_prob(4, 1, tf=1.0, nsteps=10, **mk)
+    add("rand4-grape", p, qgd.GRAPEControl(5, p.tf))
+    p2 = qgd.construct_rand_prob(4, 1, tf=0.1, nsteps=10, **mk)
+    add("rand4-bspline16", p2, qgd.FortranBSplineControl(16, 20, p2.tf))
+    add("rand4-carrier", p, qgd.CarrierControl(qgd.FortranBSplineControl(16, 20, p.tf), [-10, -1, 0, 1, 10]))
+    return out
+
+
+def cnot2_case(qgd, nsteps=40, tf=40.0, seed=1, amp=0.05):
+    prob, target = qgd.cnot2_problem(nsteps=nsteps, tf=tf)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    ctrl = [qgd.GeneralBSplineControl(2, 10, prob.tf) for _ in range(prob.N_operators)]
+    pcof = amp * (0.5 - np.random.default_rng(seed).random(qgd.get_number_of_control_parameters(ctrl)))
+    return prob, ctrl, pcof, target
+
+
+def guarded_case(qgd, nsteps=30, tf=15.0, seed=2):
+    """Two 3-level qudits with a guard level each: exercises guard penalty/forcing, N=9 (padding)."""
+    freqs = 2 * np.pi * np.array([4.1, 4.8])
+    kerr = 2 * np.pi * np.array([[0.22, 0.01], [0.01, 0.225]])
+    prob = qgd.DispersiveProblem((3, 3), (2, 2), freqs, freqs, kerr, tf, nsteps, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    target = qgd.create_gate((3, 3), (2, 2), [((1, 0), (1, 1)), ((1, 1), (1, 0))])
+    ctrl = [qgd.CarrierControl(qgd.FortranBSplineControl(2, 8, prob.tf), [0.0, -kerr[0, 0]]) for _ in range(2)]
+    pcof = 0.1 * (0.5 - np.random.default_rng(seed).random(qgd.get_number_of_control_parameters(ctrl)))
+    return prob, ctrl, pcof, target
+
+
+def cnot3_controls(qgd, prob):
+    """BASELINE.md build choice: degree-2 B-spline, 10 basis functions per carrier, 3 carriers per control."""
+    xa, xb = 2 * 0.1099, 2 * 0.1126
+    carriers = [[0.0, -2 * np.pi * xa, -2 * np.pi * 1e-6], [0.0, -2 * np.pi * xb, -2 * np.pi * 1e-6],
+                [0.0, -2 * np.pi * np.sqrt(xa * 0.002494 ** 2 / xa), -2 * np.pi * np.sqrt(xb * 0.002494 ** 2 / xa)]]
+    return [qgd.CarrierControl(qgd.FortranBSplineControl(2, 10, prob.tf), carriers[k]) for k in range(3)]
+
+
+def cnot3_case(qgd, nsteps=20, tf=20.0, seed=0):
+    prob, target = qgd.cnot3_problem(nsteps=nsteps, tf=tf)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    ctrl = cnot3_controls(qgd, prob)
+    npar = qgd.get_number_of_control_parameters(ctrl)
+    pcof = (np.random.default_rng(seed).random(npar) - 0.5) * 2 * np.pi * 0.005
+    return prob, ctrl, pcof, target

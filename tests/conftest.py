@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def qgd():
+    from __graft_entry__ import import_package
+    return import_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from __graft_entry__ import import_oracle
+    o = import_oracle()
+    o.lib()
+    return o

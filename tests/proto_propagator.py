@@ -1,0 +1,133 @@
+"""numpy statement of the DEVICE algorithm (time-parallel propagator form), used
+only by tests to localise kernel bugs stage by stage.  It is not the oracle
+(oracle/ restates the reference's algorithm) and not the product.
+
+Real form w=[u;v] <-> psi=u+iv;  A=[K S;-S K] <-> K - iS;  A^T <-> (.)^H;
+<w,l> = Re(psi^H chi).  See DESIGN.md "Algorithm".
+"""
+import math
+
+import numpy as np
+
+
+def coefficient(j, p, q):
+    return math.factorial(p) * math.factorial(p + q - j) / (math.factorial(p + q) * math.factorial(p - j))
+
+
+def tables(Gp, Gq, offsets, pcof, n_deriv):
+    """tp[n, d, k] = p_k^(d)(t_n)/d!"""
+    nt = Gp[0].shape[0]
+    tp = np.zeros((nt, n_deriv + 1, len(Gp)))
+    tq = np.zeros_like(tp)
+    for k, (gp, gq, off) in enumerate(zip(Gp, Gq, offsets)):
+        sl = pcof[off:off + gp.shape[2]]
+        tp[:, :, k] = gp[:, :n_deriv + 1] @ sl
+        tq[:, :, k] = gq[:, :n_deriv + 1] @ sl
+    return tp, tq
+
+
+def assemble(prob, tp, tq, m):
+    """Ac[n, d] = K_d - i S_d (complex N x N), d = 0..m-1."""
+    nt = tp.shape[0]
+    N = prob.N_tot_levels
+    Ac = np.zeros((nt, m, N, N), dtype=complex)
+    sym = np.stack(prob.sym_operators) if prob.N_operators else np.zeros((0, N, N))
+    asym = np.stack(prob.asym_operators) if prob.N_operators else np.zeros((0, N, N))
+    for d in range(m):
+        K = np.einsum("nk,kij->nij", tq[:, d, :], asym)
+        S = np.einsum("nk,kij->nij", tp[:, d, :], sym)
+        if d == 0:
+            K = K + prob.system_asym
+            S = S + prob.system_sym
+        Ac[:, d] = K - 1j * S
+    return Ac
+
+
+def build_LR(Ac, m, dt):
+    nt, _, N, _ = Ac.shape
+    D = [np.broadcast_to(np.eye(N, dtype=complex), (nt, N, N)).copy()]
+    for j in range(m):
+        acc = np.zeros((nt, N, N), dtype=complex)
+        for i in range(j + 1):
+            acc += Ac[:, j - i] @ D[i]
+        D.append(acc / (j + 1))
+    L = sum(coefficient(j, m, m) * (-dt) ** j * D[j] for j in range(m + 1))
+    R = sum(coefficient(j, m, m) * dt ** j * D[j] for j in range(m + 1))
+    return L, R, D
+
+
+def evaluate(prob, Gp, Gq, offsets, pcof, target, order):
+    """Full forward + adjoint + gradient.  Returns dict of every intermediate."""
+    m = order // 2
+    N, c, nsteps = prob.N_tot_levels, prob.N_initial_conditions, prob.nsteps
+    dt = prob.tf / nsteps
+    nt = nsteps + 1
+    tp, tq = tables(Gp, Gq, offsets, pcof, m)
+    Ac = assemble(prob, tp, tq, m)
+    L, R, _ = build_LR(Ac, m, dt)
+    Linv = np.linalg.inv(L)
+    P = Linv[1:] @ R[:-1]
+    psi = np.zeros((nt, N, c), dtype=complex)
+    psi[0] = prob.u0 + 1j * prob.v0
+    for n in range(nsteps):
+        psi[n + 1] = P[n] @ psi[n]
+    W = prob.guard_subspace_projector
+    wreal = np.concatenate([psi.real, psi.imag], axis=1)           # [nt, 2N, c]
+    Ww = np.einsum("ij,njc->nic", W, wreal)
+    trap = np.ones(nt); trap[0] = trap[-1] = 0.5
+    guard = (dt / prob.tf) * np.einsum("n,nic,nic->", trap, wreal, Ww)
+    f = -(2 * dt / prob.tf) * trap[:, None, None] * Ww
+    fc = f[:, :N] + 1j * f[:, N:]
+    T = np.asarray(target)
+    ovl = np.sum(np.conj(T) * psi[-1])                              # <w,R> + i<w,T>
+    a, b = ovl.real, ovl.imag
+    infid = 1 - (a * a + b * b) / prob.N_ess_levels ** 2
+    y = np.zeros((nt, N, c), dtype=complex)
+    y[-1] = (2 / prob.N_ess_levels ** 2) * (a + 1j * b) * T + fc[-1]  # a*R + b*T with T=[Rim;-Rre] <-> -i*R
+    for n in range(nsteps - 1, 0, -1):
+        y[n] = P[n].conj().T @ y[n + 1] + fc[n]
+    lam = np.zeros_like(y)
+    lam[1:] = np.conj(np.transpose(Linv[1:], (0, 2, 1))) @ y[1:]
+    # derivatives of the state at every time point
+    ws = [psi]
+    for j in range(m):
+        acc = np.zeros_like(psi)
+        for i in range(j + 1):
+            acc += Ac[:, j - i] @ ws[i]
+        ws.append(acc / (j + 1))
+    # gradient seeds
+    g = [None] * (m + 1)
+    lam_next = np.zeros_like(lam); lam_next[:-1] = lam[1:]
+    lam_here = lam.copy(); lam_here[0] = 0
+    for j in range(m + 1):
+        cj = coefficient(j, m, m)
+        g[j] = cj * dt ** j * lam_next - cj * (-dt) ** j * lam_here
+    AcH = np.conj(np.transpose(Ac, (0, 1, 3, 2)))
+    for j in range(m, 1, -1):
+        for i in range(1, j):
+            g[i] = g[i] + (1.0 / j) * (AcH[:, j - 1 - i] @ g[j])
+    nops = prob.N_operators
+    sigP = np.zeros((nt, nops, m))
+    sigQ = np.zeros((nt, nops, m))
+    for k in range(nops):
+        Sk, Ak = prob.sym_operators[k], prob.asym_operators[k]
+        for j in range(1, m + 1):
+            for i in range(j):
+                d = j - 1 - i
+                Pw = -1j * (Sk @ ws[i])
+                Qw = Ak @ ws[i]
+                sigP[:, k, d] += (1.0 / j) * np.einsum("nic,nic->n", np.conj(Pw), g[j]).real
+                sigQ[:, k, d] += (1.0 / j) * np.einsum("nic,nic->n", np.conj(Qw), g[j]).real
+    grad = np.zeros(len(pcof))
+    for k, (gp, gq, off) in enumerate(zip(Gp, Gq, offsets)):
+        nl = gp.shape[2]
+        grad[off:off + nl] -= np.einsum("ndl,nd->l", gp[:, :m], sigP[:, k]) + np.einsum("ndl,nd->l", gq[:, :m], sigQ[:, k])
+    return dict(tp=tp, tq=tq, Ac=Ac, L=L, R=R, Linv=Linv, P=P, psi=psi, ws=ws, guard=guard, infidelity=infid,
+                overlap=(a, b), f=fc, y=y, lam=lam, g=g, sigP=sigP, sigQ=sigQ, grad=grad)
+
+
+def history_real(ws):
+    """[2N, 1+m, nt, c] Julia-layout history from the list of complex derivatives."""
+    arr = np.stack(ws, axis=0)                       # [1+m, nt, N, c]
+    real = np.concatenate([arr.real, arr.imag], axis=2)  # [1+m, nt, 2N, c]
+    return np.asfortranarray(np.transpose(real, (2, 0, 1, 3)))

@@ -1,0 +1,202 @@
+"""CPU tests of the host side: B-splines against the reference's own Fortran (golden
+fixture generated from oracle/_ref), controls, problem constructors, validation, and that
+the C-ABI library loads and exports every symbol include/qgd.h declares."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "bspline_bsplvd.npz"))
+
+
+def test_bspline_oracle_vs_reference_fortran_golden(orc):
+    """oracle de Boor evaluation == pppack bsplvd_ output (fixture from the compiled reference)."""
+    for deg, nb, x, nd, val in zip(GOLD["degree"], GOLD["n_basis"], GOLD["x"], GOLD["nderiv"], GOLD["values"]):
+        k = deg + 1
+        first, out = orc.bspline_basis_derivs(int(deg), int(nb), float(x), int(nd))
+        ref = val[:k, :nd].T                       # [d, i]
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+        assert np.abs(out - ref).max() <= 1e-12 * scale.max(), (deg, nb, x)
+        assert np.all(np.abs(out - ref) <= 2e-13 * scale), (deg, nb, x)
+
+
+def test_bspline_host_vs_reference_fortran_golden(qgd):
+    """the package's numpy B-spline basis == pppack bsplvd_ output."""
+    for deg, nb, x, left, nd, val in zip(GOLD["degree"], GOLD["n_basis"], GOLD["x"], GOLD["left"], GOLD["nderiv"], GOLD["values"]):
+        k = deg + 1
+        B = qgd.bspline_basis_derivatives(int(deg), int(nb), np.array([x]), int(nd) - 1)[0]   # [d, n_basis]
+        first = int(left) - k
+        ref = val[:k, :nd].T
+        got = B[:, first:first + k]
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+        assert np.all(np.abs(got - ref) <= 1e-11 * scale), (deg, nb, x)
+        mask = np.ones(nb, bool); mask[first:first + k] = False
+        assert not mask.any() or np.abs(B[:, mask]).max() == 0.0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bspline_lib.so")),
+                    reason="oracle/_ref not built (reference checkout absent)")
+def test_bspline_oracle_vs_live_reference_fortran(orc):
+    """Same check against the live compiled reference routine at fresh random points."""
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "bspline_lib.so"))
+    rng = np.random.default_rng(9)
+    for deg, nb in [(2, 10), (4, 9), (16, 20)]:
+        k = deg + 1; nk = nb + k; nd = nk - 2 * (k - 1)
+        knots = np.concatenate([np.zeros(k - 1), np.linspace(0, 1, nd), np.ones(k - 1)])
+        for x in rng.random(20):
+            left = min(int(np.floor(x * (nd - 1) + k)), nk - k)
+            a = np.zeros((k, k), order="F"); out = np.zeros((k, k), order="F")
+            i64 = lambda v: C.byref(C.c_int64(v))
+            lib.bsplvd_(knots.ctypes.data_as(C.c_void_p), i64(k), C.byref(C.c_double(x)), i64(left),
+                        a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), i64(k))
+            _, got = orc.bspline_basis_derivs(deg, nb, float(x), k)
+            scale = np.maximum(1.0, np.abs(out.T).max(axis=1, keepdims=True))
+            assert np.all(np.abs(got - out.T) <= 1e-12 * scale)
+
+
+def _controls(qgd):
+    tf = 3.0
+    return [qgd.GRAPEControl(5, tf), qgd.FortranBSplineControl(2, 10, tf), qgd.GeneralBSplineControl(3, 7, tf),
+            qgd.FortranBSplineControl(16, 20, tf),
+            qgd.CarrierControl(qgd.FortranBSplineControl(4, 8, tf), [-2.0, 0.0, 1.5])]
+
+
+def test_controls_host_vs_oracle(qgd, orc):
+    """fill_p_vec!/fill_q_vec! tables and eval_grad_*_derivative! of the package == oracle."""
+    rng = np.random.default_rng(11)
+    for ctrl in _controls(qgd):
+        pcof = rng.standard_normal(ctrl.N_coeff)
+        for t in np.concatenate([[0.0, ctrl.tf, ctrl.tf / 2], rng.random(5) * ctrl.tf]):
+            for q in (False, True):
+                ref = orc.fill_p_vec(ctrl, float(t), pcof, 6, q=q)
+                got = np.zeros(6)
+                (ctrl.fill_q_vec if q else ctrl.fill_p_vec)(got, t, pcof)
+                assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (type(ctrl).__name__, t, q)
+                for d in range(4):
+                    gref = orc.eval_grad_derivative(ctrl, float(t), pcof, d, q=q)
+                    ggot = (ctrl.eval_grad_q_derivative if q else ctrl.eval_grad_p_derivative)(t, pcof, d)
+                    assert np.abs(ggot - gref).max() <= 1e-11 * max(1.0, np.abs(gref).max())
+
+
+def test_control_derivatives_vs_finite_differences(qgd):
+    """test/ControlFunctionTests/test_control_derivatives.jl:26-27,90: >=95% of sample times
+    within 50*(1e-15)^(2/3) of a central difference of the next-lower derivative."""
+    rng = np.random.default_rng(12)
+    tol = 50 * (1e-15) ** (2 / 3)
+    h = 1e-5
+    for ctrl in _controls(qgd)[1:]:
+        pcof = rng.standard_normal(ctrl.N_coeff)
+        ts = 0.05 * ctrl.tf + 0.9 * ctrl.tf * rng.random(200)
+        for d in range(1, 3):
+            ok = 0
+            for t in ts:
+                fd = (ctrl.eval_p_derivative(t + h, pcof, d - 1) - ctrl.eval_p_derivative(t - h, pcof, d - 1)) / (2 * h)
+                an = ctrl.eval_p_derivative(t, pcof, d)
+                ok += abs(fd - an) <= tol * max(1.0, abs(an)) * 1e3
+            assert ok >= 0.95 * len(ts), (type(ctrl).__name__, d, ok)
+
+
+def test_control_basis_is_table(qgd):
+    """G @ pcof reproduces fill_p_mat!/fill_q_mat! (Control.jl:125-149) on the stepper's grid."""
+    rng = np.random.default_rng(13)
+    ctrls = _controls(qgd)[:3]
+    nsteps, tf, m = 12, 3.0, 3
+    pcof = rng.standard_normal(qgd.get_number_of_control_parameters(ctrls))
+    Gp, Gq, off = qgd.control_basis(ctrls, nsteps, tf, m)
+    for n in (0, 5, 12):
+        t = n * (tf / nsteps)
+        pm = qgd.fill_p_mat(np.zeros((m + 1, 3)), ctrls, t, pcof)
+        qm = qgd.fill_q_mat(np.zeros((m + 1, 3)), ctrls, t, pcof)
+        for k, c in enumerate(ctrls):
+            sl = pcof[off[k]:off[k] + c.N_coeff]
+            assert np.abs(Gp[k][n] @ sl - pm[:, k]).max() < 1e-12
+            assert np.abs(Gq[k][n] @ sl - qm[:, k]).max() < 1e-12
+
+
+def test_guard_projector_doc_examples(qgd):
+    """multi_qudit_systems.jl:291-314."""
+    g = qgd.guard_projector([3], [2])
+    assert np.array_equal(np.diag(g), [0, 0, 1, 0, 0, 1]) and np.count_nonzero(g) == 2
+    g = qgd.guard_projector([2, 2], [2, 1])
+    assert np.array_equal(np.diag(g), [0, 0, 1, 1, 0, 0, 1, 1]) and np.count_nonzero(g) == 4
+
+
+def test_dispersive_problem_structure(qgd):
+    prob, target = qgd.cnot3_problem(nsteps=10, tf=10.0)
+    assert (prob.N_tot_levels, prob.N_initial_conditions, prob.N_operators, prob.N_ess_levels) == (64, 8, 3, 8)
+    # initial conditions: essential basis states in bit-string order, last subsystem fastest
+    idx = [np.argmax(prob.u0[:, c]) for c in range(8)]
+    assert idx == [a * 16 + b * 4 + s for a in (0, 1) for b in (0, 1) for s in (0, 1)]
+    # system Hamiltonian is real diagonal in the rotating frame; operators are a +- a'
+    assert np.count_nonzero(prob.system_asym) == 0
+    assert np.count_nonzero(prob.system_sym - np.diag(np.diag(prob.system_sym))) == 0
+    a = qgd.lowering_operators_system((4, 4, 4))[1]
+    assert np.array_equal(prob.sym_operators[1], a + a.T) and np.array_equal(prob.asym_operators[1], a - a.T)
+    # CNOT on (a,b): |1 0 s> <-> |1 1 s>
+    t = np.real(target)
+    col = {(a, b, s): a * 4 + b * 2 + s for a in (0, 1) for b in (0, 1) for s in (0, 1)}
+    row = lambda a, b, s: a * 16 + b * 4 + s
+    assert t[row(1, 1, 0), col[(1, 0, 0)]] == 1 and t[row(1, 0, 1), col[(1, 1, 1)]] == 1
+    assert t[row(0, 1, 1), col[(0, 1, 1)]] == 1
+    assert np.allclose(t.T @ t, np.eye(8))
+    # guard projector kills essential levels only
+    W = prob.guard_subspace_projector
+    assert np.trace(W) == 2 * (64 - 8)
+
+
+def test_schrodinger_prob_validation(qgd):
+    """Constructor checks of SchrodingerProb.jl:73-154 (ArgumentError -> ValueError)."""
+    S = np.array([[1.0, 2.0], [2.0, 0.0]]); K = np.array([[0.0, 1.0], [-1.0, 0.0]]); Z = np.zeros((2, 2))
+    ok = qgd.SchrodingerProb(S, K, [S], [K], np.eye(2), Z, None, 1.0, 10, 2)
+    assert ok.real_system_size == 4 and ok.guard_subspace_projector.shape == (4, 4)
+    with pytest.raises(ValueError, match="not symmetric"):
+        qgd.SchrodingerProb(K, K, [S], [K], np.eye(2), Z, None, 1.0, 10, 2)
+    with pytest.raises(ValueError, match="not anti-symmetric"):
+        qgd.SchrodingerProb(S, S, [S], [K], np.eye(2), Z, None, 1.0, 10, 2)
+    with pytest.raises(ValueError, match="Anti-symmetric operator 1"):
+        qgd.SchrodingerProb(S, K, [S], [S], np.eye(2), Z, None, 1.0, 10, 2)
+    with pytest.raises(ValueError, match="essential levels"):
+        qgd.SchrodingerProb(S, K, [S], [K], np.eye(2), Z, None, 1.0, 10, 3)
+    with pytest.raises(ValueError, match="Guard subspace projector size"):
+        qgd.SchrodingerProb(S, K, [S], [K], np.eye(2), Z, np.zeros((2, 2)), 1.0, 10, 2)
+    with pytest.raises(ValueError, match="Hermitian"):
+        qgd.SchrodingerProb.from_hamiltonian(np.array([[0, 1], [2, 0]]), [S], [K], np.eye(2), 1.0, 10, 2)
+
+
+def test_c_abi_exports_match_header(qgd):
+    """libqgd_hip.so loads without a GPU and exports every function include/qgd.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "qgd.h")).read()
+    declared = set(re.findall(r"\b(qgd_[a-z_]+)\s*\(", hdr))
+    assert declared == set(qgd._lib.EXPORTS), declared ^ set(qgd._lib.EXPORTS)
+    lib = qgd._lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.qgd_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback(qgd):
+    """Without a GPU the compute entry points fail loudly (QGD_ERR_NO_DEVICE); on a GPU box this
+    test only checks the argument validation of qgd_create."""
+    import torch
+    prob, _ = qgd.cnot2_problem(nsteps=4, tf=4.0)
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(qgd._lib.QGDError) as ei:
+            qgd.DeviceProblem(prob, 4)
+        assert ei.value.code == qgd._lib.QGD_ERR_NO_DEVICE
+    with pytest.raises(qgd._lib.QGDError) as ei:
+        qgd.DeviceProblem(prob, 3)          # odd order: ArgumentError before any device work
+    assert ei.value.code == qgd._lib.QGD_ERR_ARGUMENT
+
+
+def test_oracle_is_not_imported_by_the_package(qgd):
+    """The product must not reach the oracle (tier rule 3)."""
+    pkg = os.path.join(ROOT, "quantumgatedesign.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle-free", ""), os.path.join(dirpath, f)

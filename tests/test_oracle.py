@@ -1,0 +1,164 @@
+"""CPU tests: the oracle against everything the reference's own tests pin for this path
+(SURVEY.md section 8c).  No GPU needed."""
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import cases
+import proto_propagator as pp
+
+
+def test_hermite_coefficients(orc):
+    """c_j = m!(2m-j)!/((2m)!(m-j)!)  (hermite.jl:389-391); Pade(m,m) weights of exp."""
+    assert orc.coefficient(0, 4, 4) == 1.0
+    assert abs(orc.coefficient(1, 4, 4) - 0.5) < 1e-16
+    assert abs(orc.coefficient(2, 4, 4) / 2 - 3 / 28) < 1e-16      # c_j/j! are the Pade weights
+    assert abs(orc.coefficient(4, 4, 4) / 24 - 1 / 1680) < 1e-18
+    assert abs(orc.coefficient(1, 1, 1) - 0.5) < 1e-16
+
+
+def test_hardcoded_derivatives(qgd, orc):
+    """Known-answer matrices of test/hardcoded_derivatives.jl:35-160: w', w'', w''', w''''
+    and their transposes for A(t) = [0 K; -K 0], K = Ks + theta cos(t) Kc, to 1e-15."""
+    rng = np.random.default_rng(7)
+    w = rng.random(4); t = rng.random(); th = rng.random()
+    Ks = np.array([[1.0, 0], [0, 0]]); Kc = np.array([[0.0, 1], [1, 0]]); Z = np.zeros((2, 2))
+    blk = lambda K: np.block([[Z, K], [-K, Z]])
+    A = blk(Ks + th * math.cos(t) * Kc)
+    A1 = blk(-th * math.sin(t) * Kc); A2 = blk(-th * math.cos(t) * Kc); A3 = blk(th * math.sin(t) * Kc)
+    M2 = A1 + A @ A
+    M3 = A2 + 2 * A1 @ A + A @ A1 + A @ A @ A
+    M4 = (A3 + 3 * A2 @ A + 3 * A1 @ A1 + 3 * A1 @ A @ A + A @ A2 + 2 * A @ A1 @ A + A @ A @ A1 + A @ A @ A @ A)
+    hard = np.stack([w, A @ w, M2 @ w / 2, M3 @ w / 6, M4 @ w / 24], axis=1)
+    hard_adj = np.stack([w, A.T @ w, M2.T @ w / 2, M3.T @ w / 6, M4.T @ w / 24], axis=1)
+    prob = qgd.SchrodingerProb(Ks, Z, [Kc], [Z], np.zeros(2), np.zeros(2), None, 1.0, 1, 2)
+    # SingleSymCosControl: p(t) = theta cos(t), q = 0 -> table rows p^(d)/d!
+    pv = np.array([[th * math.cos(t)], [-th * math.sin(t)], [-th * math.cos(t) / 2], [th * math.sin(t) / 6],
+                   [th * math.cos(t) / 24]])
+    qv = np.zeros_like(pv)
+    uv = np.zeros((4, 5), order="F"); uv[:, 0] = w
+    got = orc.compute_derivatives(prob, pv, qv, uv)
+    assert np.abs(got - hard).max() < 1e-15
+    got_adj = orc.compute_derivatives(prob, pv, qv, uv, adjoint=True)
+    assert np.abs(got_adj - hard_adj).max() < 1e-15
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10, 12])
+def test_constant_control_is_pade(qgd, orc, order):
+    """With a constant Hamiltonian one step is the diagonal (m,m) Pade approximant of
+    exp(A dt): the whole sweep vs scipy.linalg.expm."""
+    prob = qgd.construct_rand_prob(4, 1, tf=0.5, nsteps=8, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    ctrl = qgd.GRAPEControl(1, prob.tf)
+    pcof = np.array([0.3, -0.2])
+    hist = orc.eval_forward(prob, ctrl, pcof, order=order)
+    m = order // 2
+    Hc = (prob.system_asym + pcof[1] * prob.asym_operators[0]) - 1j * (prob.system_sym + pcof[0] * prob.sym_operators[0])
+    dt = prob.tf / prob.nsteps
+    num = sum(orc.coefficient(j, m, m) * np.linalg.matrix_power(Hc * dt, j) / math.factorial(j) for j in range(m + 1))
+    den = sum(orc.coefficient(j, m, m) * np.linalg.matrix_power(-Hc * dt, j) / math.factorial(j) for j in range(m + 1))
+    step = np.linalg.solve(den, num)
+    psi = prob.u0 + 1j * prob.v0
+    for n in range(prob.nsteps):
+        psi = step @ psi
+    got = hist[:4, 0, -1, :] + 1j * hist[4:, 0, -1, :]
+    assert np.abs(got - psi).max() < 1e-12
+    if order >= 10:
+        exact = scipy.linalg.expm(Hc * prob.tf) @ (prob.u0 + 1j * prob.v0)
+        assert np.abs(got - exact).max() < 1e-9
+
+
+def test_rabi_closed_form(qgd, orc):
+    """H = [[0, p+iq],[p-iq, 0]]: U(t) = cos(|W|t) I - i sin(|W|t) H/|W|; |W|=1/2, tf=pi is a SWAP
+    (rabi_oscillator.jl:1-22, optimization_rabi_osc_SWAP.jl:18-39)."""
+    prob = qgd.construct_rabi_prob(tf=np.pi, nsteps=40, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    ctrl = qgd.GRAPEControl(1, prob.tf)
+    for p, q_ in ((0.5, 0.0), (0.3, 0.4), (0.2, -0.1)):
+        hist = orc.eval_forward(prob, ctrl, np.array([p, q_]), order=10)
+        U = hist[:2, 0, -1, :] + 1j * hist[2:, 0, -1, :]
+        W = math.hypot(p, q_)
+        H = np.array([[0, p + 1j * q_], [p - 1j * q_, 0]])
+        exact = math.cos(W * np.pi) * np.eye(2) - 1j * math.sin(W * np.pi) * H / W
+        assert np.abs(U - exact).max() < 1e-11
+    target = np.array([[0, -1j], [-1j, 0]])
+    hist = orc.eval_forward(prob, ctrl, np.array([0.5, 0.0]), order=8)
+    assert abs(orc.infidelity_real(hist[:, 0, -1, :], orc.target_real(target), 2)) < 1e-12
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_three_way_gradient_agreement(qgd, orc, order):
+    """The reference's parity contract (test/GradientTests/compare_gradients.jl:47-65):
+    discrete adjoint == forced to 1e-14, both == central differences (1e-5) to 1e-9."""
+    for name, prob, ctrl, pcof, target in cases.gradient_cases(qgd):
+        ga = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+        gf = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+        gd = orc.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order, dpcof=1e-5)
+        assert np.allclose(ga, gf, atol=1e-14, rtol=1e-14), (name, order, np.abs(ga - gf).max())
+        # the reference uses 1e-9 on its MersenneTwister draws; ours differ, and the central
+        # difference's own O(dpcof^2) truncation error reaches 1.05e-9 on one carrier case
+        assert np.allclose(ga, gd, atol=3e-9, rtol=3e-9), (name, order, np.abs(ga - gd).max())
+        assert np.allclose(gf, gd, atol=3e-9, rtol=3e-9), (name, order)
+
+
+def test_three_way_with_guard_and_two_controls(qgd, orc):
+    """Same contract on a problem with a guard projector and two carrier controls."""
+    prob, ctrl, pcof, target = cases.guarded_case(qgd, nsteps=12, tf=6.0)
+    for order in (4, 8):
+        ga = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+        gf = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+        gd = orc.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order, dpcof=1e-5)
+        assert np.abs(ga - gf).max() < 1e-13
+        assert np.abs(ga - gd).max() < 1e-8
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_convergence_order(qgd, orc, order):
+    """Step doubling: observed order within +-0.5 of nominal
+    (test/ConvergenceTests/forward_convergence.jl:47-65; Richardson, src/Tests/test_convergence.jl:238-250).
+    Random N=4 problem, smooth (single-piece degree-16) B-spline control."""
+    base = 16
+    sols = []
+    for nsteps in (base, 2 * base, 4 * base):
+        prob = qgd.construct_rand_prob(4, 1, tf=1.0, nsteps=nsteps, gmres_abstol=1e-15, gmres_reltol=1e-15, scale=0.5)
+        ctrl = qgd.FortranBSplineControl(16, 17, prob.tf)
+        pcof = 0.5 * np.random.default_rng(3).random(ctrl.N_coeff)
+        sols.append(orc.eval_forward(prob, ctrl, pcof, order=order)[:, 0, -1, :])
+    # Richardson: ||u_h - u_{h/2}|| / ||u_{h/2} - u_{h/4}|| = 2^order
+    obs = math.log2(np.linalg.norm(sols[0] - sols[1]) / np.linalg.norm(sols[1] - sols[2]))
+    assert abs(obs - order) < 0.5, (order, obs)
+
+
+@pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 6), ("guarded", 12)])
+def test_propagator_form_equals_reference_form(qgd, orc, which, order):
+    """The device algorithm (explicit step propagators, O(m^2) reverse sweep; numpy statement in
+    proto_propagator.py) reproduces the reference algorithm (GMRES per step, exponential
+    recursions) to rounding."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    m = order // 2
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, m)
+    r = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    g, hist, lam, forcing, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    assert np.abs(pp.history_real(r["ws"]) - hist).max() < 1e-12
+    assert np.abs(g - r["grad"]).max() <= 1e-12 * np.abs(g).max()
+    assert abs(r["guard"] - orc.guard_penalty_real(prob, hist)) < 1e-13
+
+
+def test_reference_terminal_solve_stalls(qgd, orc):
+    """Documented behaviour of the reference on cnot3 at dt = 1: the one-shot gmres! of
+    compute_terminal_condition runs with IterativeSolvers' defaults (restart 20, 2N iterations,
+    eval_grad_discrete_adjoint.jl:61-62), needs ~90 Krylov vectors and stops short; the gradient
+    is then off by ~1e-6 relative.  With the solve run to convergence the oracle agrees with the
+    exact discrete gradient to rounding."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=6, tf=6.0)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, 4)
+    exact = pp.evaluate(prob, Gp, Gq, off, pcof, target, 8)["grad"]
+    g_faithful = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8)
+    orc.set_converged_terminal(True)
+    try:
+        g_conv = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8)
+    finally:
+        orc.set_converged_terminal(False)
+    rel = lambda g: np.abs(g - exact).max() / np.abs(exact).max()
+    assert rel(g_conv) < 1e-12
+    assert 1e-9 < rel(g_faithful) < 1e-3
