@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+adjoint timesteps/s of the Hermite stepper on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete gradient evaluation of the workload
+(discrete_adjoint!(..., history_precomputed=false): control tables, step propagators,
+forward sweep, guard forcing, terminal condition, adjoint sweep, gradient), host to host
+(pcof in, gradient out), through the C ABI.  value = nsteps * K / elapsed.
+
+Workload (BASELINE.json configs[2]): 3-qubit dispersive CNOT,
+subsystems (4,4,4), N=64, 8 initial-condition columns, 3 control operators, Hermite order 8,
+tf=550, dt=1 (nsteps=550), fp64; 180 B-spline-with-carrier coefficients, seed 0.
+
+The JSON line also carries
+  roofline      the dominant kernel (largest share of device time): algorithmic flops or
+                bytes per launch / its mean duration measured with HIP events on the
+                library's stream, against the gfx950 peak;
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm) timed on this
+                host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP64_MATRIX_TFLOPS = 78.6   # MI355X fp64 matrix = vector peak (spec); 256 CU * 4 SIMD * 2.4 GHz * 32 flop/clk
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def workload(qgd, nsteps, tf):
+    import numpy as np
+    import cases
+    prob, target = qgd.cnot3_problem(nsteps=nsteps, tf=tf)
+    ctrl = cases.cnot3_controls(qgd, prob)
+    npar = qgd.get_number_of_control_parameters(ctrl)
+    pcof = (np.random.default_rng(0).random(npar) - 0.5) * 2 * np.pi * 0.005
+    return prob, ctrl, pcof, target
+
+
+def phase_model(N, c, m, n_ops, nt):
+    """Algorithmic work per launch of each device phase (DESIGN.md 'Kernels')."""
+    cgemm = 8.0 * N ** 3                       # complex N x N x N product, real flops
+    apply_ = 8.0 * N * N * c                   # one Hamiltonian application on all columns
+    hist_b = 16.0 * N * c                      # one complex state panel, bytes
+    return {
+        "build_LR": ("mfma", nt * (m * (m - 1) / 2) * cgemm),
+        "inverse": ("mfma", (nt - 1) * cgemm),
+        "propagator": ("mfma", (nt - 1) * cgemm),
+        "sweep_forward": ("hbm", (nt - 1) * (16.0 * N * N + 2 * hist_b)),
+        "sweep_adjoint": ("hbm", (nt - 2) * (16.0 * N * N + 3 * hist_b)),
+        "derivs": ("mfma", nt * (m * (m + 1) / 2) * apply_),
+        "gradient": ("mfma", nt * ((m * (m - 1) / 2) + n_ops * m) * apply_),
+        "lambda": ("mfma", (nt - 1) * apply_),
+        "guard": ("hbm", nt * (3 * hist_b)),
+    }
+
+
+def cpu_baseline(qgd, orc, seconds_target=12.0):
+    """Oracle ('port' of the reference CPU path) on a bounded sample: the same cnot3 problem and
+    controls at dt=1 with fewer steps, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19),
+    columns in parallel as the reference's Threads.@threads (forward_evolution.jl:48,332)."""
+    import numpy as np
+    cores = os.cpu_count() or 1
+    threads = min(8, cores)
+    orc.set_num_threads(threads)
+    nsample = 12
+    prob, ctrl, pcof, target = workload(qgd, nsample, float(nsample))
+    prob.gmres_abstol = prob.gmres_reltol = 1e-12
+    t0 = time.time()
+    orc.discrete_adjoint(prob, ctrl, pcof, target, order=8)
+    per_step = (time.time() - t0) / nsample
+    nsample = int(max(12, min(400, seconds_target / per_step)))
+    prob, ctrl, pcof, target = workload(qgd, nsample, float(nsample))
+    prob.gmres_abstol = prob.gmres_reltol = 1e-12
+    t0 = time.time()
+    _, _, _, _, st = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8, return_all=True)
+    el = time.time() - t0
+    return {
+        "value": nsample / el, "unit": "timesteps/s", "cores": threads, "kind": "port",
+        "sample": f"cnot3 order 8, dt=1, {nsample} of 550 timesteps, all 8 columns, GMRES tol 1e-12, "
+                  f"{threads} threads over columns (gradient accumulation serial as in the reference); "
+                  f"mean GMRES iterations fwd {st.fwd_gmres_iters:.1f} adj {st.adj_gmres_iters:.1f}",
+        "seconds": el,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nsteps", type=int, default=550, help="timesteps of the workload (tf = nsteps, dt = 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch   # first: so that one HIP runtime (torch's) serves both torch and libqgd_hip
+    import torch.distributed as dist
+    from __graft_entry__ import import_package, import_oracle
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+
+    qgd = import_package()
+    prob, ctrl, pcof, target = workload(qgd, args.nsteps, float(args.nsteps))
+    order = 8
+    dp = qgd.DeviceProblem(prob, order, device=local_rank if world > 1 else 0)
+    dp.set_controls(ctrl)
+    dp.set_target(target)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dp.discrete_adjoint(pcof)
+    phase_ms = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grad, out3 = dp.discrete_adjoint(pcof)
+        for k, v in dp.timings().items():
+            phase_ms[k] = phase_ms.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        for k in phase_ms:
+            phase_ms[k] /= args.steps
+        model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1)
+        timed = {k: v for k, v in phase_ms.items() if k in model and v > 0}
+        dom = max(timed, key=timed.get)
+        bound, work = model[dom]
+        if bound == "mfma":
+            achieved = work / (timed[dom] * 1e-3) / 1e12
+            peak, unit = PEAK_FP64_MATRIX_TFLOPS, "TFLOP/s"
+        else:
+            achieved = work / (timed[dom] * 1e-3) / 1e9
+            peak, unit = PEAK_HBM_GBS, "GB/s"
+        # replicas: every rank evaluates the full problem (see DESIGN.md "Multi-GPU")
+        total_timesteps = args.nsteps * args.steps * n_gpus
+        out = {
+            "metric": "forward+adjoint timesteps/sec, cnot3 order-8 fp64",
+            "value": total_timesteps / elapsed, "unit": "timesteps/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
+                                   f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
+                       "parallelism": "1 GPU" if n_gpus == 1 else f"{n_gpus} replicas"},
+            "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": None,
+                         "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
+            "phases_ms": {k: round(v, 4) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
+            "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
+            "grad_norm": float(np.linalg.norm(grad)),
+        }
+        if not args.no_cpu_baseline:
+            orc = import_oracle()
+            out["cpu_baseline"] = cpu_baseline(qgd, orc)
+        print(json.dumps(out))
+    dp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
