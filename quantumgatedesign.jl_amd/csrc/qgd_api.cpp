@@ -110,6 +110,21 @@ int alloc_grid(qgd_handle h)
     if ((rc = dev_alloc(h, h->grid_bufs, &k.yhist, nt * hstep))) return rc;
     if ((rc = dev_alloc(h, h->grid_bufs, &k.lam, nt * hstep))) return rc;
     if ((rc = dev_alloc(h, h->grid_bufs, &k.sigma, nt * (size_t)std::max(k.n_ops, 1) * m * 2))) return rc;
+    // blocked scan of the sweeps: S steps in B blocks, chain length 2*blen + B
+    {
+        const int S = k.nt - 1;
+        int B = (int)std::lround(std::sqrt(2.0 * S));
+        if (S < 24) B = 1;
+        if (B > 64) B = 64;
+        k.scan_blen = (S + B - 1) / B;
+        k.scan_blocks = (S + k.scan_blen - 1) / k.scan_blen;
+        const size_t nb = (size_t)k.scan_blocks;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiC, nb * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiR, nb * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.phi, nb * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
+    }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
     if (need > 150 * 1024) {

@@ -36,6 +36,10 @@ typedef struct qgdk_ctx {
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *inv_scratch;
+    double *PiC, *PiR;  // [B][2][Np*Np] block propagators: planes (col-major) / panel
+    double *phi;        // [B][Np][2cp] affine parts of the adjoint blocks
+    double *bnd, *bndY; // [B+1][Np][2cp] states at block boundaries
+    int scan_blocks, scan_blen;
     int *status;
     double cw_host[2 * 20];
 } qgdk_ctx;

@@ -425,55 +425,196 @@ __global__ __launch_bounds__(256) void k_propagator(const double *__restrict__ L
 }
 
 // ---------------------------------------------------------------------------
-// K4/K7: sequential sweeps.  One workgroup per group of 8 columns.
+// K4/K7: the two sweeps as a blocked scan over time.
 //   forward: psi_{n+1} = P_n psi_n                       (forward_evolution.jl:163-221)
-//   adjoint: y_n = P_n^H y_{n+1} + f_n, n = nt-2..1      (forward_evolution.jl:421-462 in the
+//   adjoint: y_n = P_n^H y_{n+1} + f_n                   (forward_evolution.jl:421-462 in the
 //            variable y_n = L_n^T lambda_n)
-// hist: [nt][Np][2cp] panels.
+// The S = nt-1 steps are cut into B blocks of `blen` steps.  Three phases:
+//   (i)   per block, in parallel: the block propagator Pi_b = P_{e-1}...P_s (forward; its
+//         conjugate transpose serves the adjoint) by chaining the identity's columns, and
+//         for the adjoint the affine part phi_b (zero start, forcing added);
+//   (ii)  one short sequential chain over the B block propagators -> states at block starts;
+//   (iii) per block, in parallel: re-run the block from its true start, writing the history.
+// Chain length drops from S to 2*blen + B matrix-panel products.
+// All three phases are the same "chain" kernel; one workgroup = one (block, group of 8
+// columns).  MODE 0: identity start, store Pi_b.  MODE 1: forward, write history.
+// MODE 2: adjoint from zero, store phi_b.  MODE 3: adjoint, write history.
 // ---------------------------------------------------------------------------
-template <bool ADJ>
-__global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Pmat,
-                                               double *__restrict__ hist,
-                                               const double *__restrict__ forcing, int Np, int cp,
-                                               int nt)
-{
-    extern __shared__ double smem[];
-    double *cur = smem, *nxt = smem + (size_t)Np * 16;
-    const int grp = blockIdx.x;
-    const int PWc = 2 * cp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    const int c16 = lane & 15, kk = lane >> 4;
-    const int PW = 2 * Np;
-    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
-    const size_t hstep = (size_t)Np * PWc;
+struct ChainArgs {
+    const double *Pmat;      // forward: planes [S][2][Np*Np] col-major; adjoint: panels [S][Np][2Np]
+    const double *start;     // start panels, block b at start + b*start_stride  (layout [Np][2cp])
+    long long start_stride;
+    double *out;             // history [.][Np][2cp] (MODE 1: out[n+1], MODE 3: out[n])
+    const double *forcing;   // [.][Np][2cp], adjoint modes
+    double *PiC, *PiR;       // MODE 0 outputs: planes / panel per block
+    double *phi;             // MODE 2 output: [B][Np][2cp]
+    int Np, cp, S, nblocks, blen, ngroups;
+};
 
-    const int n_start = ADJ ? nt - 1 : 0;
-    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
-        cur[e] = hist[(size_t)n_start * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+template <int MODE>
+__device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &grp)
+{
+    if (MODE == 0) {
+        // XCD-aware: the ngroups workgroups of one block share blockIdx%8, hence one XCD's L2,
+        // because they all stream the same P_n (speed only; MI355X_MICROARCH.md "Workgroup dispatch").
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = xcd + 8 * (slot / a.ngroups);
+        grp = slot % a.ngroups;
+    } else {
+        b = blockIdx.x / a.ngroups;
+        grp = blockIdx.x % a.ngroups;
+    }
+}
+
+// A fragment of step n at (row, k)
+template <bool ADJ>
+__device__ __forceinline__ void chain_a(const double *__restrict__ Pmat, int Np, int n, int arow, int k,
+                                        double &are, double &aim)
+{
+    const size_t pl = (size_t)Np * Np;
+    if (!ADJ) {
+        const double *P = Pmat + (size_t)n * 2 * pl + (size_t)arow + (size_t)Np * k;
+        are = P[0];
+        aim = P[pl];
+    } else {   // (P^H)(row,k) = conj(P(k,row)); P stored as panel
+        const double *P = Pmat + (size_t)n * 2 * pl + (size_t)k * 2 * Np + (arow >> 3) * 16 + (arow & 7);
+        are = P[0];
+        aim = -P[8];
+    }
+}
+
+// NP > 0: compile-time size, 8 waves = (row block, K slice), next step's fragments prefetched
+// into registers while the current step's MFMAs run.
+template <int NP, int MODE>
+__global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
+{
+    constexpr bool ADJ = (MODE >= 2);
+    constexpr int NRB = NP / 16;
+    constexpr int KSPLIT = (8 / NRB) < (NP / 4) ? (8 / NRB) : (NP / 4);
+    constexpr int NACT = NRB * KSPLIT;
+    constexpr int KS = NP / 4 / KSPLIT;
+    static_assert(NRB * 16 == NP && KS * KSPLIT * 4 == NP && NACT <= 8, "tile");
+    __shared__ __attribute__((aligned(16))) double cur[NP * 16];
+    __shared__ __attribute__((aligned(16))) double part[KSPLIT][NP * 16];
+
+    int b, grp;
+    chain_block_of<MODE>(a, b, grp);
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * NP : 2 * a.cp;
+    const size_t hstep = (size_t)NP * PWc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const bool active = wave < NACT;
+    const int rb = wave / KSPLIT, kq = wave % KSPLIT;
+    const int arow = rb * 16 + c16;
+
+    // start panel
+    for (int e = tid; e < NP * 16; e += 512) {
+        const int row = e >> 4, c = e & 15;
+        double v;
+        if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+        else if (MODE == 2) v = 0.0;
+        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+        cur[e] = v;
+    }
+    double are[KS], aim[KS], nre[KS], nim[KS];
+    const int nsteps = e0 - s0;
+    if (active && nsteps > 0) {
+        const int n = ADJ ? e0 - 1 : s0;
+        #pragma unroll
+        for (int i = 0; i < KS; i++) chain_a<ADJ>(a.Pmat, NP, n, arow, (kq * KS + i) * 4 + kk, are[i], aim[i]);
+    }
     __syncthreads();
 
-    const int nsteps = ADJ ? nt - 2 : nt - 1;
-    for (int s = 0; s < nsteps; s++) {
-        const int nsrc = ADJ ? nt - 1 - s : s;          // time index of the state in cur
-        const int ndst = ADJ ? nsrc - 1 : nsrc + 1;
-        const int np = ADJ ? ndst : nsrc;               // propagator index
+    for (int st = 0; st < nsteps; st++) {
+        const int n = ADJ ? e0 - 1 - st : s0 + st;          // propagator index of this step
+        const int nn = ADJ ? n - 1 : n + 1;                  // next step's propagator
+        const bool more = st + 1 < nsteps;
+        if (active) {
+            if (more) {
+                #pragma unroll
+                for (int i = 0; i < KS; i++) chain_a<ADJ>(a.Pmat, NP, nn, arow, (kq * KS + i) * 4 + kk, nre[i], nim[i]);
+            }
+            d4 acc = (d4){0, 0, 0, 0};
+            #pragma unroll
+            for (int i = 0; i < KS; i++) {
+                double b1, b2;
+                panel_b(cur + ((kq * KS + i) * 4 + kk) * 16, c16, b1, b2);
+                acc = MFMA(are[i], b1, acc);
+                acc = MFMA(aim[i], b2, acc);
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) part[kq][(rb * 16 + kk + 4 * r) * 16 + c16] = acc[r];
+        }
+        __syncthreads();
+        const int nout = ADJ ? n : n + 1;                    // time index of the new state
+        for (int e = tid; e < NP * 16; e += 512) {
+            double v = part[0][e];
+            #pragma unroll
+            for (int q = 1; q < KSPLIT; q++) v += part[q][e];
+            const size_t ho = (size_t)nout * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15);
+            if (ADJ) v += a.forcing[ho];
+            cur[e] = v;
+            if (MODE == 1 || MODE == 3) a.out[ho] = v;
+        }
+        if (active && more) {
+            #pragma unroll
+            for (int i = 0; i < KS; i++) { are[i] = nre[i]; aim[i] = nim[i]; }
+        }
+        __syncthreads();
+    }
+    if (MODE == 0) {
+        const size_t pl = (size_t)NP * NP;
+        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+        for (int e = tid; e < NP * 16; e += 512) {
+            const int row = e >> 4, c = e & 15;
+            const int col = grp * 8 + (c & 7);
+            pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)NP * col] = cur[e];
+            pr[(size_t)row * 2 * NP + grp * 16 + c] = cur[e];
+        }
+    }
+    if (MODE == 2) {
+        for (int e = tid; e < NP * 16; e += 512)
+            a.phi[(size_t)b * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = cur[e];
+    }
+}
+
+// any Np: runtime sizes, each wave loops over its row blocks, no K split, no prefetch
+template <int MODE>
+__global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
+{
+    constexpr bool ADJ = (MODE >= 2);
+    extern __shared__ double smem[];
+    const int Np = a.Np;
+    double *cur = smem, *nxt = smem + (size_t)Np * 16;
+    int b, grp;
+    chain_block_of<MODE>(a, b, grp);
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * Np : 2 * a.cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < Np * 16; e += blockDim.x) {
+        const int row = e >> 4, c = e & 15;
+        double v;
+        if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+        else if (MODE == 2) v = 0.0;
+        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+        cur[e] = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < e0 - s0; st++) {
+        const int n = ADJ ? e0 - 1 - st : s0 + st;
+        const int nout = ADJ ? n : n + 1;
         for (int rb = wave; rb * 16 < Np; rb += nw) {
             d4 acc = (d4){0, 0, 0, 0};
             const int arow = rb * 16 + c16;
             for (int k0 = 0; k0 < Np; k0 += 4) {
-                const int k = k0 + kk;
-                double are, aim;
-                if (!ADJ) {
-                    const double *Pcn = Pmat + (size_t)np * 2 * pl;
-                    are = Pcn[(size_t)arow + (size_t)Np * k];
-                    aim = Pcn[pl + (size_t)arow + (size_t)Np * k];
-                } else {   // (P^H)(row,k) = conj(P(k,row)), P as panel
-                    const double *Prn = Pmat + (size_t)np * panel + (size_t)k * PW + (arow >> 3) * 16 + (arow & 7);
-                    are = Prn[0];
-                    aim = -Prn[8];
-                }
-                double b1, b2;
-                panel_b(cur + (size_t)k * 16, c16, b1, b2);
+                double are, aim, b1, b2;
+                chain_a<ADJ>(a.Pmat, Np, n, arow, k0 + kk, are, aim);
+                panel_b(cur + (size_t)(k0 + kk) * 16, c16, b1, b2);
                 acc = MFMA(are, b1, acc);
                 acc = MFMA(aim, b2, acc);
             }
@@ -481,15 +622,46 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Pmat,
             for (int r = 0; r < 4; r++) {
                 const int row = rb * 16 + kk + 4 * r;
                 double v = acc[r];
-                const size_t ho = (size_t)ndst * hstep + (size_t)row * PWc + grp * 16 + c16;
-                if (ADJ) v += forcing[ho];
+                const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16;
+                if (ADJ) v += a.forcing[ho];
                 nxt[(size_t)row * 16 + c16] = v;
-                hist[ho] = v;
+                if (MODE == 1 || MODE == 3) a.out[ho] = v;
             }
         }
         __syncthreads();
         double *tmp = cur; cur = nxt; nxt = tmp;
     }
+    if (MODE == 0) {
+        const size_t pl = (size_t)Np * Np;
+        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+        for (int e = tid; e < Np * 16; e += blockDim.x) {
+            const int row = e >> 4, c = e & 15;
+            const int col = grp * 8 + (c & 7);
+            pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)Np * col] = cur[e];
+            pr[(size_t)row * 2 * Np + grp * 16 + c] = cur[e];
+        }
+    }
+    if (MODE == 2) {
+        for (int e = tid; e < Np * 16; e += blockDim.x)
+            a.phi[(size_t)b * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = cur[e];
+    }
+}
+
+template <int MODE>
+static int launch_chain(const ChainArgs &a, hipStream_t stream)
+{
+    const int nwg = (MODE == 0) ? 8 * a.ngroups * ((a.nblocks + 7) / 8) : a.nblocks * a.ngroups;
+    if (nwg <= 0) return 0;
+    switch (a.Np) {
+    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    default: {
+        size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
+        hipLaunchKernelGGL((k_chain_generic<MODE>), dim3(nwg), dim3(256), shm, stream, a);
+    }
+    }
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -920,10 +1092,30 @@ int qgdk_propagator(const qgdk_ctx *c)
 
 int qgdk_sweep_forward(const qgdk_ctx *c)
 {
-    size_t shm = (size_t)2 * c->Np * 16 * sizeof(double);
-    hipLaunchKernelGGL(k_sweep<false>, dim3(c->cp / 8), dim3(256), shm, c->stream, c->Pc, c->hist,
-                       (const double *)nullptr, c->Np, c->cp, c->nt);
-    return (int)hipGetLastError();
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1;
+    if (c->scan_blocks <= 1) {            // short grids: one plain chain
+        a.Pmat = c->Pc; a.start = c->hist; a.start_stride = 0; a.out = c->hist;
+        a.nblocks = 1; a.blen = a.S; a.ngroups = c->cp / 8;
+        return launch_chain<1>(a, c->stream);
+    }
+    const int B = c->scan_blocks, blen = c->scan_blen;
+    // (i) block propagators
+    a.Pmat = c->Pc; a.PiC = c->PiC; a.PiR = c->PiR; a.nblocks = B; a.blen = blen; a.ngroups = c->Np / 8;
+    int rc = launch_chain<0>(a, c->stream);
+    if (rc) return rc;
+    // (ii) states at block starts: bnd[b+1] = Pi_b bnd[b]
+    HIPCHK(hipMemcpyAsync(c->bnd, c->hist, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    ChainArgs s2{};
+    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiC; s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd;
+    s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+    if ((rc = launch_chain<1>(s2, c->stream))) return rc;
+    // (iii) history inside every block
+    ChainArgs s3{};
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd; s3.start_stride = (long long)hstep;
+    s3.out = c->hist; s3.nblocks = B; s3.blen = blen; s3.ngroups = c->cp / 8;
+    return launch_chain<1>(s3, c->stream);
 }
 
 int qgdk_guard(const qgdk_ctx *c)
@@ -942,11 +1134,33 @@ int qgdk_terminal(const qgdk_ctx *c, int write_y)
 
 int qgdk_sweep_adjoint(const qgdk_ctx *c)
 {
-    size_t shm = (size_t)2 * c->Np * 16 * sizeof(double);
-    if (c->nt >= 3)
-        hipLaunchKernelGGL(k_sweep<true>, dim3(c->cp / 8), dim3(256), shm, c->stream, c->Pr, c->yhist, c->forcing,
-                           c->Np, c->cp, c->nt);
-    return (int)hipGetLastError();
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const int S = c->nt - 1;
+    if (c->scan_blocks <= 1) {
+        ChainArgs a{};
+        a.Np = c->Np; a.cp = c->cp; a.S = S; a.Pmat = c->Pr; a.start = c->yhist + (size_t)S * hstep; a.start_stride = 0;
+        a.out = c->yhist; a.forcing = c->forcing; a.nblocks = 1; a.blen = S; a.ngroups = c->cp / 8;
+        return launch_chain<3>(a, c->stream);
+    }
+    const int B = c->scan_blocks, blen = c->scan_blen;
+    // (i) affine parts phi_b (block propagators Pi_b were stored by the forward sweep)
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = S; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = c->phi;
+    a.nblocks = B; a.blen = blen; a.ngroups = c->cp / 8;
+    int rc = launch_chain<2>(a, c->stream);
+    if (rc) return rc;
+    // (ii) bndY[b] = Pi_b^H bndY[b+1] + phi_b, from bndY[B] = y_{nt-1}
+    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, c->yhist + (size_t)S * hstep, hstep * sizeof(double),
+                          hipMemcpyDeviceToDevice, c->stream));
+    ChainArgs s2{};
+    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiR; s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0;
+    s2.out = c->bndY; s2.forcing = c->phi; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+    if ((rc = launch_chain<3>(s2, c->stream))) return rc;
+    // (iii) history inside every block, block b starts from bndY[b+1]
+    ChainArgs s3{};
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = S; s3.Pmat = c->Pr; s3.start = c->bndY + hstep; s3.start_stride = (long long)hstep;
+    s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = B; s3.blen = blen; s3.ngroups = c->cp / 8;
+    return launch_chain<3>(s3, c->stream);
 }
 
 int qgdk_lambda(const qgdk_ctx *c)
