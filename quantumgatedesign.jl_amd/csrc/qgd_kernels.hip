@@ -349,6 +349,154 @@ __global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
 }
 
 // ---------------------------------------------------------------------------
+// K2 (fast path, Np <= 64): the same Gauss-Jordan inverse with the matrix held in
+// registers: 256 threads as a 16x16 grid, thread (ty,tx) owns the BSxBS block of rows
+// ty*BS.. and columns tx*BS.. (BS = Np/16).  Per pivot only the pivot column, the pivot
+// row and the swapped row travel through LDS (2 barriers); the rank-1 update is local.
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void k_inverse_reg(const double *__restrict__ L,
+                                                     double *__restrict__ LinvA,
+                                                     double *__restrict__ LinvT, int n0,
+                                                     int *__restrict__ status)
+{
+    constexpr int BS = NP / 16;
+    __shared__ double colre[2][NP], colim[2][NP];
+    __shared__ double rowre[2][2][NP], rowim[2][2][NP];
+    __shared__ int perm[NP], outpos[NP], idx[NP];
+    __shared__ double pivinv[2][2];
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15, lane = t & 63;
+    constexpr int PW = 2 * NP;
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const double *Ln = L + (size_t)n * panel;
+
+    double are[BS][BS], aim[BS][BS];
+    #pragma unroll
+    for (int i = 0; i < BS; i++)
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int r = ty * BS + i, c = tx * BS + j;
+            are[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + (c & 7)];
+            aim[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + 8 + (c & 7)];
+        }
+
+    // statically indexed access to row / column `ii` of the register block (ii is uniform)
+#define INV_SEL(ii, STMT) switch (ii) { \
+    case 0: { constexpr int I = 0; STMT } break; \
+    case 1: { constexpr int I = (1 < BS) ? 1 : 0; STMT } break; \
+    case 2: { constexpr int I = (2 < BS) ? 2 : 0; STMT } break; \
+    default: { constexpr int I = (3 < BS) ? 3 : 0; STMT } break; }
+    for (int p = 0; p < NP; p++) {
+        const int buf = p & 1;
+        const int pblk = p / BS, poff = p % BS;        // uniform
+        if (tx == pblk) {                               // publish column p
+            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
+                colre[buf][ty * BS + i] = are[i][I]; colim[buf][ty * BS + i] = aim[i][I]; })
+        }
+        if (ty == pblk) {                               // publish row p (before any swap)
+            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                rowre[buf][0][tx * BS + j] = are[I][j]; rowim[buf][0][tx * BS + j] = aim[I][j]; })
+        }
+        __syncthreads();
+        // pivot search, redundantly in every wave.  One 64-bit key per lane: the bit pattern of
+        // |a|^2 (non-negative doubles order like unsigned integers) with the low 6 mantissa bits
+        // replaced by 63-row, so that one max-reduction yields the arg-max (ties -> lowest row).
+        unsigned long long key = 0;
+        if (lane < NP && lane >= p) {
+            const double a = colre[buf][lane], b = colim[buf][lane];
+            key = ((unsigned long long)__double_as_longlong(a * a + b * b) & ~63ull) | (unsigned long long)(63 - lane);
+        }
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long ok = __shfl_xor(key, off);
+            key = ok > key ? ok : key;
+        }
+        const int pr = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63ull));
+        if (t == 0) { perm[p] = pr; if (!((key >> 6) != 0)) *status = 1; }
+        const int rblk = pr / BS, roff = pr % BS;
+        if (ty == rblk) {                               // owners of row pr publish it scaled by 1/pivot
+            const double pa = colre[buf][pr], pb = colim[buf][pr];
+            const double den = 1.0 / (pa * pa + pb * pb);
+            const double ir = pa * den, ii = -pb * den;
+            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                const double x = are[I][j]; const double y = aim[I][j];
+                rowre[buf][1][tx * BS + j] = x * ir - y * ii; rowim[buf][1][tx * BS + j] = x * ii + y * ir; })
+            if (tx == 0) { pivinv[buf][0] = ir; pivinv[buf][1] = ii; }
+        }
+        const double cpr = colre[buf][p], cpi = colim[buf][p];   // old a_pp: multiplier of the swapped row
+        __syncthreads();
+        const double ir = pivinv[buf][0], ii = pivinv[buf][1];  // 1/pivot
+        if (ty == rblk && pr != p) {                    // row swap: row pr takes the old row p
+            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                are[I][j] = rowre[buf][0][tx * BS + j]; aim[I][j] = rowim[buf][0][tx * BS + j]; })
+        }
+        double rpr[BS], rpi[BS], ur[BS], ui[BS];        // scaled pivot row; the same with column p zeroed
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int c = tx * BS + j;
+            rpr[j] = rowre[buf][1][c];
+            rpi[j] = rowim[buf][1][c];
+            ur[j] = (c == p) ? 0.0 : rpr[j];
+            ui[j] = (c == p) ? 0.0 : rpi[j];
+        }
+        double fr[BS], fi[BS];                          // multipliers of my rows (0 for the pivot row)
+        #pragma unroll
+        for (int i = 0; i < BS; i++) {
+            const int r = ty * BS + i;
+            const double cr = colre[buf][r], ci = colim[buf][r];
+            fr[i] = (r == p) ? 0.0 : ((r == pr) ? cpr : cr);
+            fi[i] = (r == p) ? 0.0 : ((r == pr) ? cpi : ci);
+        }
+        #pragma unroll
+        for (int i = 0; i < BS; i++)
+            #pragma unroll
+            for (int j = 0; j < BS; j++) {
+                are[i][j] -= fr[i] * ur[j] - fi[i] * ui[j];
+                aim[i][j] -= fr[i] * ui[j] + fi[i] * ur[j];
+            }
+        if (tx == pblk) {                               // column p: -f/pivot (pivot row fixed next)
+            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
+                are[i][I] = -(fr[i] * ir - fi[i] * ii); aim[i][I] = -(fr[i] * ii + fi[i] * ir); })
+        }
+        if (ty == pblk) {                               // pivot row: scaled row, 1/pivot in column p
+            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                const bool dg = (tx * BS + j == p);
+                are[I][j] = dg ? ir : rpr[j]; aim[I][j] = dg ? ii : rpi[j]; })
+        }
+    }
+#undef INV_SEL
+    __syncthreads();
+    if (t == 0) {   // compose the column swaps that undo the row interchanges
+        for (int x = 0; x < NP; x++) idx[x] = x;
+        for (int p = NP - 1; p >= 0; p--) { const int q = perm[p]; const int tmp = idx[p]; idx[p] = idx[q]; idx[q] = tmp; }
+        for (int x = 0; x < NP; x++) outpos[idx[x]] = x;
+    }
+    __syncthreads();
+    // stage the (column-permuted) inverse through LDS so that both output layouts are
+    // written with coalesced stores; rows padded by one double against bank conflicts
+    extern __shared__ double stage[];          // one plane at a time: NP x (NP+1)
+    constexpr int LDP = NP + 1;
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int oc = outpos[tx * BS + j];
+            #pragma unroll
+            for (int i = 0; i < BS; i++) stage[(ty * BS + i) * LDP + oc] = pass ? aim[i][j] : are[i][j];
+        }
+        __syncthreads();
+        for (int e = t; e < NP * NP; e += 256) {
+            const int hi = e / NP, lo = e % NP;       // NP is a compile-time constant
+            T[pass * pl + e] = stage[hi * LDP + lo];  // row-major: (r=hi, c=lo)
+            A[pass * pl + e] = stage[lo * LDP + hi];  // column-major: (r=lo, c=hi)
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3: step propagator  P[n] = Linv[n+1] * R[n]   (n = 0..nt-2)
 // (the implicit solve L(t_{n+1}) w_{n+1} = R(t_n) w_n of forward_evolution.jl:181-220,
 //  done once for all right-hand sides).  Outputs P as panel (row-major; the
@@ -1060,6 +1208,14 @@ int qgdk_build_LR(const qgdk_ctx *c)
 
 int qgdk_inverse(const qgdk_ctx *c)
 {
+    const int nmat = c->nt - 1;
+    switch (c->Np) {
+    case 16: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2176)); hipLaunchKernelGGL((k_inverse_reg<16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 32: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8448)); hipLaunchKernelGGL((k_inverse_reg<32>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 48: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 18816)); hipLaunchKernelGGL((k_inverse_reg<48>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 64: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 33280)); hipLaunchKernelGGL((k_inverse_reg<64>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    default: break;
+    }
     const size_t pl = (size_t)c->Np * c->Np;
     size_t aux = (size_t)(3 * c->Np + 16) * sizeof(double);
     size_t mat = 2 * pl * sizeof(double);
