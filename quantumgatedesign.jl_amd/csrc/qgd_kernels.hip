@@ -43,7 +43,13 @@ struct OpCoef {           // coefficients of one derivative order d at one time 
     double q[QGD_MAX_OPS_DEV];
 };
 
+// NOPS template parameter: the number of control operators at compile time (branch-free,
+// all loads of one element issued together); NOPS = -1 keeps the count at run time.
+#define NOPS_LIM(NOPS) ((NOPS) < 0 ? QGD_MAX_OPS_DEV : (NOPS))
+#define NOPS_ON(NOPS, o, n_ops) ((NOPS) >= 0 || (o) < (n_ops))
+
 // A_d(t_n)(row,k) = K_d - i S_d assembled from the fixed operators (hermite.jl:566-587)
+template <int NOPS>
 __device__ __forceinline__ void assembled_a(const double *__restrict__ ops, int Np, int n_ops,
                                             const OpCoef &cf, int row, int k, double &are, double &aim)
 {
@@ -52,8 +58,8 @@ __device__ __forceinline__ void assembled_a(const double *__restrict__ ops, int 
     double K = cf.sys * ops[e];
     double S = cf.sys * ops[pl + e];
     #pragma unroll
-    for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {     // static indices: keeps cf in registers
-        if (o < n_ops) {
+    for (int o = 0; o < NOPS_LIM(NOPS); o++) {      // static indices: keeps cf in registers
+        if (NOPS_ON(NOPS, o, n_ops)) {
             K += cf.q[o] * ops[(size_t)(2 + 2 * o) * pl + e];
             S += cf.p[o] * ops[(size_t)(3 + 2 * o) * pl + e];
         }
@@ -125,6 +131,7 @@ __global__ void k_tables_from_host(const double *__restrict__ pt, const double *
 // ---------------------------------------------------------------------------
 #define LV_NG 4
 #define LV_KC 16
+template <int NOPS>
 __global__ __launch_bounds__(256) void k_level(const double *__restrict__ ops,
                                                const double *__restrict__ tab,
                                                double *__restrict__ D, double *__restrict__ L,
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_level(const double *__restrict__ ops,
             double are[4], aim[4];
             if (row_ok) {
                 #pragma unroll
-                for (int s = 0; s < 4; s++) assembled_a(ops, Np, n_ops, cf, arow, kc + 4 * s + kk, are[s], aim[s]);
+                for (int s = 0; s < 4; s++) assembled_a<NOPS>(ops, Np, n_ops, cf, arow, kc + 4 * s + kk, are[s], aim[s]);
             }
             __syncthreads();
             if (row_ok) {
@@ -206,12 +213,12 @@ __global__ __launch_bounds__(256) void k_level(const double *__restrict__ ops,
             if (!is_im) {
                 double K = cj.sys * ops[e];
                 #pragma unroll
-                for (int o = 0; o < QGD_MAX_OPS_DEV; o++) if (o < n_ops) K += cj.q[o] * ops[(size_t)(2 + 2 * o) * pl + e];
+                for (int o = 0; o < NOPS_LIM(NOPS); o++) if (NOPS_ON(NOPS, o, n_ops)) K += cj.q[o] * ops[(size_t)(2 + 2 * o) * pl + e];
                 add = -K;                              // K(row,ccol) = -K(ccol,row)
             } else {
                 double S = cj.sys * ops[pl + e];
                 #pragma unroll
-                for (int o = 0; o < QGD_MAX_OPS_DEV; o++) if (o < n_ops) S += cj.p[o] * ops[(size_t)(3 + 2 * o) * pl + e];
+                for (int o = 0; o < NOPS_LIM(NOPS); o++) if (NOPS_ON(NOPS, o, n_ops)) S += cj.p[o] * ops[(size_t)(3 + 2 * o) * pl + e];
                 add = -S;                              // Im A = -S
             }
             const double val = (acc[g][r] + add) * inv;
@@ -227,6 +234,174 @@ __global__ __launch_bounds__(256) void k_level(const double *__restrict__ ops,
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// K1 (fast path, Np = 64): all levels of the recursion fused into one launch.
+// One workgroup = (time point, half of the columns): 512 threads = 8 waves,
+// wave = (16-row block, pair of column groups).  D_1..D_{m-1} of the workgroup's 32
+// complex columns stay in LDS (column slabs of the recursion are independent), L and R
+// stay in registers, and the work is ordered by SOURCE: when D_i is complete its
+// contributions A_d D_i to every later level are accumulated at once, so each operator
+// element is fetched once per (source, k) and serves up to m-1 MFMA pairs.
+// No global round trips between levels, m-1 barriers per workgroup.
+// ---------------------------------------------------------------------------
+struct OpVals { double K0, S0, K[QGD_MAX_OPS_DEV], S[QGD_MAX_OPS_DEV]; };
+
+template <int NOPS>
+__device__ __forceinline__ void load_opvals(OpVals &v, const double *__restrict__ ops, int Np, int n_ops, size_t e)
+{
+    const size_t pl = (size_t)Np * Np;
+    v.K0 = ops[e];
+    v.S0 = ops[pl + e];
+    #pragma unroll
+    for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+        if (NOPS_ON(NOPS, o, n_ops)) { v.K[o] = ops[(size_t)(2 + 2 * o) * pl + e]; v.S[o] = ops[(size_t)(3 + 2 * o) * pl + e]; }
+        else { v.K[o] = 0.0; v.S[o] = 0.0; }
+    }
+}
+
+// coefficient block in LDS: cf[d][0] = sys flag, cf[d][1+2o] = p, cf[d][2+2o] = q
+#define CF_STRIDE (1 + 2 * QGD_MAX_OPS_DEV)
+template <int NOPS>
+__device__ __forceinline__ void combine_opvals(const OpVals &v, const double *cf, int n_ops, double &are, double &aim)
+{
+    double K = cf[0] * v.K0, S = cf[0] * v.S0;
+    #pragma unroll
+    for (int o = 0; o < NOPS_LIM(NOPS); o++)
+        if (NOPS_ON(NOPS, o, n_ops)) { K += cf[2 + 2 * o] * v.K[o]; S += cf[1 + 2 * o] * v.S[o]; }
+    are = K;
+    aim = -S;
+}
+
+template <int M, int NOPS>
+__global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ ops,
+                                                    const double *__restrict__ tab,
+                                                    double *__restrict__ L, double *__restrict__ R,
+                                                    int n_ops, const double *__restrict__ cw)
+{
+    constexpr int NP = 64, NGW = 4, SW = 16 * NGW;   // slab width in doubles
+    constexpr int ND = (M > 1) ? M - 1 : 1;
+    extern __shared__ double smem[];
+    double *Dbuf = smem;                               // [M-1][NP][SW]
+    double *cfs = smem + (size_t)ND * NP * SW;         // [M][CF_STRIDE]
+    const int n = blockIdx.x >> 1, h = blockIdx.x & 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int rb = wave & 3, gh = wave >> 2;           // row block, pair of groups inside the slab
+    const int arow = rb * 16 + c16;
+    constexpr int PW = 2 * NP;
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+
+    for (int e = tid; e < M * CF_STRIDE; e += 512) {
+        const int d = e / CF_STRIDE, q = e % CF_STRIDE;
+        double v = 0.0;
+        if (q == 0) v = (d == 0) ? 1.0 : 0.0;
+        else { const int o = (q - 1) >> 1; if (o < n_ops) v = tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2 + ((q - 1) & 1)]; }
+        cfs[e] = v;
+    }
+    __syncthreads();
+
+    d4 Lacc[2], Racc[2], T[M][2];                      // T[q]: accumulator of D_{q+1}
+    #pragma unroll
+    for (int g = 0; g < 2; g++) {
+        #pragma unroll
+        for (int q = 0; q < M; q++) T[q][g] = (d4){0, 0, 0, 0};
+        const int ccol = (h * NGW + gh * 2 + g) * 8 + (c16 & 7);
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double id = (c16 < 8 && rb * 16 + kk + 4 * r == ccol) ? 1.0 : 0.0;
+            Lacc[g][r] = id;
+            Racc[g][r] = id;
+        }
+    }
+
+    #pragma unroll
+    for (int i = 0; i < M; i++) {                      // source D_i (D_0 = I) feeds levels i+1 .. M
+        const double *Dsrc = Dbuf + (size_t)(i > 0 ? i - 1 : 0) * NP * SW;
+        // the identity slab is non-zero only for k inside the slab's own 32 complex columns
+        const int ks0 = (i == 0) ? h * 8 : 0, ks1 = (i == 0) ? h * 8 + 8 : NP / 4;
+        OpVals cur, nxt;
+        load_opvals<NOPS>(cur, ops, NP, n_ops, (size_t)arow + (size_t)NP * (ks0 * 4 + kk));
+        for (int ks = ks0; ks < ks1; ks++) {
+            const int k = ks * 4 + kk;
+            if (ks + 1 < ks1) load_opvals<NOPS>(nxt, ops, NP, n_ops, (size_t)arow + (size_t)NP * (k + 4));
+            double b1[2], b2[2];
+            #pragma unroll
+            for (int g = 0; g < 2; g++) {
+                if (i == 0) {
+                    const int ccol = (h * NGW + gh * 2 + g) * 8 + (c16 & 7);
+                    const double one = (k == ccol) ? 1.0 : 0.0;
+                    b1[g] = (c16 < 8) ? one : 0.0;       // [Bre|Bim] of the identity
+                    b2[g] = (c16 < 8) ? 0.0 : one;       // [-Bim|Bre]
+                } else {
+                    panel_b(Dsrc + (size_t)k * SW + (gh * 2 + g) * 16, c16, b1[g], b2[g]);
+                }
+            }
+            #pragma unroll
+            for (int d = 0; d + i < M; d++) {          // target level i+d+1
+                double are, aim;
+                combine_opvals<NOPS>(cur, cfs + d * CF_STRIDE, n_ops, are, aim);
+                #pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    T[i + d][g] = MFMA(are, b1[g], T[i + d][g]);
+                    T[i + d][g] = MFMA(aim, b2[g], T[i + d][g]);
+                }
+            }
+            cur = nxt;
+        }
+        // D_{i+1} = T[i]/(i+1)
+        const double inv = 1.0 / (double)(i + 1);
+        const double cL = cw[2 * (i + 1) + 1], cR = cw[2 * (i + 1)];
+        #pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int gl = gh * 2 + g;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                const double val = T[i][g][r] * inv;
+                if (i + 1 < M) Dbuf[(size_t)i * NP * SW + (size_t)row * SW + gl * 16 + c16] = val;
+                Lacc[g][r] += cL * val;
+                Racc[g][r] += cR * val;
+            }
+        }
+        if (i + 1 < M) __syncthreads();
+    }
+    double *Ln = L + (size_t)n * panel, *Rn = R + (size_t)n * panel;
+    #pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int grp = h * NGW + gh * 2 + g;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            Ln[(size_t)row * PW + grp * 16 + c16] = Lacc[g][r];
+            Rn[(size_t)row * PW + grp * 16 + c16] = Racc[g][r];
+        }
+    }
+}
+
+#define DISPATCH_NOPS(n_ops, CALL) \
+    switch (n_ops) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+                     default: CALL(-1); break; }
+
+template <int M, int NOPS>
+static int launch_build_LR64_n(const qgdk_ctx *c)
+{
+    const size_t shm = ((size_t)((M > 1) ? M - 1 : 1) * 64 * 64 + (size_t)M * CF_STRIDE) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void *)k_build_LR64<M, NOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_build_LR64<M, NOPS>), dim3(2 * c->nt), dim3(512), shm, c->stream, c->ops, c->tab, c->L, c->R,
+                       c->n_ops, c->cw);
+    return (int)hipGetLastError();
+}
+
+template <int M>
+static int launch_build_LR64(const qgdk_ctx *c)
+{
+#define CALL_LR(N) return launch_build_LR64_n<M, N>(c)
+    DISPATCH_NOPS(c->n_ops, CALL_LR)
+#undef CALL_LR
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -951,6 +1126,7 @@ __global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT
 // forward_evolution.jl:172-179,:236-242):  psi_{j+1} = 1/(j+1) sum_{i<=j} A_{j-i} psi_i
 // One workgroup per (time point, column group).  dpsi: [nt][m][Np][2cp].
 // ---------------------------------------------------------------------------
+template <int NOPS>
 __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
                                                 const double *__restrict__ tab,
                                                 const double *__restrict__ hist,
@@ -977,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
                 const double *src = smem + (size_t)i * ps;
                 for (int k0 = 0; k0 < Np; k0 += 4) {
                     double are, aim, b1, b2;
-                    assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
                     panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
                     acc = MFMA(are, b1, acc);
                     acc = MFMA(aim, b2, acc);
@@ -1006,6 +1182,7 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
 // compute_inner_prod_S!/K! (:764-800).  sigma: [nt][n_ops][m][2] (atomicAdd
 // across column groups).
 // ---------------------------------------------------------------------------
+template <int NOPS>
 __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ ops,
                                                    const double *__restrict__ tab,
                                                    const double *__restrict__ hist,
@@ -1048,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
                 d4 acc = (d4){0, 0, 0, 0};
                 for (int k0 = 0; k0 < Np; k0 += 4) {
                     double are, aim, b1, b2;
-                    assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
                     panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
                     acc = MFMA(are, b1, acc);
                     acc = MFMA(aim, b2, acc);
@@ -1136,6 +1313,7 @@ __global__ void k_contract(const double *__restrict__ G, const int64_t *__restri
 // Test hook: out = (+/-) A_d(t_n) * in for a panel of columns (apply_hamiltonian!,
 // hermite.jl:556-588, batched over all initial-condition columns).
 // ---------------------------------------------------------------------------
+template <int NOPS>
 __global__ __launch_bounds__(256) void k_apply(const double *__restrict__ ops,
                                                const double *__restrict__ tab,
                                                const double *__restrict__ in,
@@ -1157,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_apply(const double *__restrict__ ops,
         const int arow = rb * 16 + c16;
         for (int k0 = 0; k0 < Np; k0 += 4) {
             double are, aim, b1, b2;
-            assembled_a(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+            assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
             panel_b(smem + (size_t)(k0 + kk) * 16, c16, b1, b2);
             acc = MFMA(are, b1, acc);
             acc = MFMA(aim, b2, acc);
@@ -1195,13 +1373,25 @@ int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt, const double *qt)
 
 int qgdk_build_LR(const qgdk_ctx *c)
 {
+    if (c->Np == 64) {           // fused LDS-resident path (order <= 10: D_1..D_{m-1} slabs fit in LDS)
+        switch (c->m) {
+        case 1: return launch_build_LR64<1>(c);
+        case 2: return launch_build_LR64<2>(c);
+        case 3: return launch_build_LR64<3>(c);
+        case 4: return launch_build_LR64<4>(c);
+        case 5: return launch_build_LR64<5>(c);
+        default: break;
+        }
+    }
     const int ngroups = c->Np / 8;
     const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
     const int rtiles = (c->Np + 63) / 64;
     for (int j = 0; j < c->m; j++) {
         double cL = c->cw_host[2 * (j + 1) + 1], cR = c->cw_host[2 * (j + 1)];
-        hipLaunchKernelGGL(k_level, dim3(gtiles * rtiles, c->nt), dim3(256), 0, c->stream, c->ops, c->tab, c->D,
-                           c->L, c->R, c->Np, c->n_ops, c->m, j, cL, cR);
+#define CALL_LV(N) hipLaunchKernelGGL((k_level<N>), dim3(gtiles * rtiles, c->nt), dim3(256), 0, c->stream, c->ops, c->tab, \
+                                      c->D, c->L, c->R, c->Np, c->n_ops, c->m, j, cL, cR)
+        DISPATCH_NOPS(c->n_ops, CALL_LV)
+#undef CALL_LV
     }
     return (int)hipGetLastError();
 }
@@ -1330,21 +1520,23 @@ int qgdk_lambda(const qgdk_ctx *c)
 int qgdk_derivs(const qgdk_ctx *c)
 {
     size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
-    if (shm > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_derivs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_derivs, dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi,
-                       c->Np, c->cp, c->n_ops, c->m);
+#define CALL_DV(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_derivs<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_derivs<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi, \
+                           c->Np, c->cp, c->n_ops, c->m); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_DV)
+#undef CALL_DV
     return (int)hipGetLastError();
 }
 
 int qgdk_gradient(const qgdk_ctx *c)
 {
     size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
-    if (shm > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)k_gradsweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     HIPCHK(hipMemsetAsync(c->sigma, 0, (size_t)c->nt * c->n_ops * c->m * 2 * sizeof(double), c->stream));
-    hipLaunchKernelGGL(k_gradsweep, dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist,
-                       c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt);
+#define CALL_GS(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_gradsweep<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_gradsweep<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, \
+                           c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_GS)
+#undef CALL_GS
     HIPCHK(hipMemsetAsync(c->grad, 0, (size_t)c->n_pcof * sizeof(double), c->stream));
     int nsplit = c->nt >= 64 ? 16 : 1;
     hipLaunchKernelGGL(k_contract, dim3((c->nc_max + 63) / 64, c->n_ops, nsplit), dim3(64), 0, c->stream, c->G,
@@ -1355,8 +1547,10 @@ int qgdk_gradient(const qgdk_ctx *c)
 int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, double sign)
 {
     size_t shm = (size_t)c->Np * 16 * sizeof(double);
-    hipLaunchKernelGGL(k_apply, dim3(c->cp / 8), dim3(256), shm, c->stream, c->ops, c->tab, in, out, c->Np, c->cp,
-                       c->n_ops, c->m, n, d, sign);
+#define CALL_AP(N) hipLaunchKernelGGL((k_apply<N>), dim3(c->cp / 8), dim3(256), shm, c->stream, c->ops, c->tab, in, out, c->Np, \
+                                      c->cp, c->n_ops, c->m, n, d, sign)
+    DISPATCH_NOPS(c->n_ops, CALL_AP)
+#undef CALL_AP
     return (int)hipGetLastError();
 }
 

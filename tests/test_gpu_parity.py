@@ -52,7 +52,8 @@ def test_apply_hamiltonian(qgd, orc, which):
     dp.close()
 
 
-@pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 6), ("cnot3", 8)])
+@pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 6), ("cnot3", 2), ("cnot3", 4),
+                                         ("cnot3", 6), ("cnot3", 8), ("cnot3", 10), ("cnot3", 12)])
 def test_stage_matrices(qgd, which, order):
     """L(t_n), R(t_n), L^-1, P_n on the device vs the numpy statement of the same algorithm."""
     prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
