@@ -284,7 +284,6 @@ __global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ o
     constexpr int ND = (M > 1) ? M - 1 : 1;
     extern __shared__ double smem[];
     double *Dbuf = smem;                               // [M-1][NP][SW]
-    double *cfs = smem + (size_t)ND * NP * SW;         // [M][CF_STRIDE]
     const int n = blockIdx.x >> 1, h = blockIdx.x & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c16 = lane & 15, kk = lane >> 4;
@@ -292,15 +291,6 @@ __global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ o
     const int arow = rb * 16 + c16;
     constexpr int PW = 2 * NP;
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
-
-    for (int e = tid; e < M * CF_STRIDE; e += 512) {
-        const int d = e / CF_STRIDE, q = e % CF_STRIDE;
-        double v = 0.0;
-        if (q == 0) v = (d == 0) ? 1.0 : 0.0;
-        else { const int o = (q - 1) >> 1; if (o < n_ops) v = tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2 + ((q - 1) & 1)]; }
-        cfs[e] = v;
-    }
-    __syncthreads();
 
     d4 Lacc[2], Racc[2], T[M][2];                      // T[q]: accumulator of D_{q+1}
     #pragma unroll
@@ -320,35 +310,56 @@ __global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ o
     for (int i = 0; i < M; i++) {                      // source D_i (D_0 = I) feeds levels i+1 .. M
         const double *Dsrc = Dbuf + (size_t)(i > 0 ? i - 1 : 0) * NP * SW;
         // the identity slab is non-zero only for k inside the slab's own 32 complex columns
-        const int ks0 = (i == 0) ? h * 8 : 0, ks1 = (i == 0) ? h * 8 + 8 : NP / 4;
-        OpVals cur, nxt;
-        load_opvals<NOPS>(cur, ops, NP, n_ops, (size_t)arow + (size_t)NP * (ks0 * 4 + kk));
-        for (int ks = ks0; ks < ks1; ks++) {
-            const int k = ks * 4 + kk;
-            if (ks + 1 < ks1) load_opvals<NOPS>(nxt, ops, NP, n_ops, (size_t)arow + (size_t)NP * (k + 4));
-            double b1[2], b2[2];
+        const int ks0 = (i == 0) ? h * 8 : 0;
+        // coefficients of the derivative orders this source needs, in registers
+        // (uniform addresses: the compiler keeps them in scalar registers)
+        double cfr[M][CF_STRIDE];
+        #pragma unroll
+        for (int d = 0; d + i < M; d++) {
+            cfr[d][0] = (d == 0) ? 1.0 : 0.0;
+            #pragma unroll
+            for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+                const bool on = NOPS_ON(NOPS, o, n_ops);
+                cfr[d][1 + 2 * o] = on ? tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2] : 0.0;
+                cfr[d][2 + 2 * o] = on ? tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2 + 1] : 0.0;
+            }
+        }
+        // software pipeline: operator elements 2 k-steps ahead (ring of 3), B fragments 1 ahead
+        const int NKS = (i == 0) ? 8 : NP / 4;      // constant once the source loop is unrolled
+        OpVals ring[3];
+        #pragma unroll
+        for (int q = 0; q < 2; q++)
+            load_opvals<NOPS>(ring[q], ops, NP, n_ops, (size_t)arow + (size_t)NP * ((ks0 + q) * 4 + kk));
+        double b1[2][2], b2[2][2];                     // [buffer][group]
+        auto load_b = [&](int buf, int k) {
             #pragma unroll
             for (int g = 0; g < 2; g++) {
                 if (i == 0) {
                     const int ccol = (h * NGW + gh * 2 + g) * 8 + (c16 & 7);
                     const double one = (k == ccol) ? 1.0 : 0.0;
-                    b1[g] = (c16 < 8) ? one : 0.0;       // [Bre|Bim] of the identity
-                    b2[g] = (c16 < 8) ? 0.0 : one;       // [-Bim|Bre]
+                    b1[buf][g] = (c16 < 8) ? one : 0.0;  // [Bre|Bim] of the identity
+                    b2[buf][g] = (c16 < 8) ? 0.0 : one;  // [-Bim|Bre]
                 } else {
-                    panel_b(Dsrc + (size_t)k * SW + (gh * 2 + g) * 16, c16, b1[g], b2[g]);
+                    panel_b(Dsrc + (size_t)k * SW + (gh * 2 + g) * 16, c16, b1[buf][g], b2[buf][g]);
                 }
             }
+        };
+        load_b(0, ks0 * 4 + kk);
+        #pragma unroll
+        for (int q = 0; q < NKS; q++) {
+            const int k = (ks0 + q) * 4 + kk;
+            if (q + 2 < NKS) load_opvals<NOPS>(ring[(q + 2) % 3], ops, NP, n_ops, (size_t)arow + (size_t)NP * (k + 8));
+            if (q + 1 < NKS) load_b((q + 1) & 1, k + 4);
             #pragma unroll
             for (int d = 0; d + i < M; d++) {          // target level i+d+1
                 double are, aim;
-                combine_opvals<NOPS>(cur, cfs + d * CF_STRIDE, n_ops, are, aim);
+                combine_opvals<NOPS>(ring[q % 3], cfr[d], n_ops, are, aim);
                 #pragma unroll
                 for (int g = 0; g < 2; g++) {
-                    T[i + d][g] = MFMA(are, b1[g], T[i + d][g]);
-                    T[i + d][g] = MFMA(aim, b2[g], T[i + d][g]);
+                    T[i + d][g] = MFMA(are, b1[q & 1][g], T[i + d][g]);
+                    T[i + d][g] = MFMA(aim, b2[q & 1][g], T[i + d][g]);
                 }
             }
-            cur = nxt;
         }
         // D_{i+1} = T[i]/(i+1)
         const double inv = 1.0 / (double)(i + 1);
