@@ -289,6 +289,18 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     if (d->guard) for (size_t e = 0; e < (size_t)4 * N * N; e++) if (d->guard[e] != 0.0) { k.have_guard = 1; break; }
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.guard, (size_t)4 * N * N));
     if (d->guard) CREATE_TRY(hipMemcpy(k.guard, d->guard, sizeof(double) * 4 * N * N, hipMemcpyHostToDevice));
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.guard_diag, (size_t)2 * N));
+    if (k.have_guard) {   // diagonal projector (what guard_projector builds): elementwise fast path
+        bool diag = true;
+        const size_t n2 = 2 * (size_t)N;
+        for (size_t j = 0; j < n2 && diag; j++) for (size_t i = 0; i < n2; i++) if (i != j && d->guard[i + n2 * j] != 0.0) { diag = false; break; }
+        if (diag) {
+            std::vector<double> wd(n2);
+            for (size_t i = 0; i < n2; i++) wd[i] = d->guard[i + n2 * i];
+            CREATE_TRY(hipMemcpy(k.guard_diag, wd.data(), n2 * sizeof(double), hipMemcpyHostToDevice));
+            k.have_guard = 2;
+        }
+    }
     // initial condition panel
     h->u0v0_panel.assign(Np * PWc, 0.0);
     for (int col = 0; col < c; col++) for (int i = 0; i < N; i++) {

@@ -15,6 +15,7 @@ typedef struct qgdk_ctx {
     // device buffers
     double *ops;        // [(2+2 n_ops)][Np*Np] column-major planes: K_sys, S_sys, Asym_1, Sym_1, ...
     double *guard;      // [2N][2N] column-major
+    double *guard_diag; // [2N] when the projector is diagonal (have_guard == 2)
     double *target;     // panel [Np][2cp]
     double *G;          // control basis, per control [pq][nt][m+1][ncoef_k]
     int64_t *goff;      // offset of control k in G

@@ -1047,6 +1047,36 @@ __global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
     }
 }
 
+// K5 (fast path): W diagonal (the guard_projector of multi_qudit_systems.jl:316-349 is):
+// elementwise forcing and penalty.  wd: the 2N diagonal entries.
+__global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ wd,
+                                                    const double *__restrict__ hist,
+                                                    double *__restrict__ forcing,
+                                                    double *__restrict__ scal, int N, int Np, int cp,
+                                                    int nt, double dt, double tf)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *h = hist + (size_t)n * hstep;
+    double *f = forcing + (size_t)n * hstep;
+    const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0;
+    const double sc = -(2.0 * dt / tf) * trap;
+    double pen = 0.0;
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+        const int row = e / PWc, c16 = (e % PWc) & 15;
+        const double w = (row < N) ? wd[row + ((c16 >= 8) ? N : 0)] : 0.0;
+        const double v = h[e];
+        f[e] = sc * w * v;
+        pen += w * v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scal[2], (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf);
+}
+
 // ---------------------------------------------------------------------------
 // K6: overlaps and terminal right-hand side (infidelity.jl:13-17,
 // eval_grad_discrete_adjoint.jl:22-40).  Single workgroup.
@@ -1297,27 +1327,34 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
 // (the "grad_slice .-= contrib" of eval_grad_discrete_adjoint.jl:642-643)
 // grid: (ceil(nc_max/64), n_ops, NSPLIT); atomicAdd over the time splits.
 // ---------------------------------------------------------------------------
-__global__ void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
-                           const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
-                           const double *__restrict__ sigma, double *__restrict__ grad, int nt, int m,
-                           int n_ops)
+#define CT_CHUNK 16
+__global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                                                  const int32_t *__restrict__ ncoef,
+                                                  const int32_t *__restrict__ poff,
+                                                  const double *__restrict__ sigma,
+                                                  double *__restrict__ grad, int nt, int m, int n_ops)
 {
+    // grid (time chunks, n_ops, coefficient tiles of 64); thread = (coefficient, time sub-slot)
+    __shared__ double red[4][64];
     const int k = blockIdx.y;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int nc = ncoef[k];
-    if (l >= nc) return;
-    const int nsplit = gridDim.z;
-    const int n0 = (int)(((long long)nt * blockIdx.z) / nsplit), n1 = (int)(((long long)nt * (blockIdx.z + 1)) / nsplit);
+    const int l = blockIdx.z * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     const double *gp = G + goff[k];
     const double *gq = gp + (size_t)nt * (m + 1) * nc;
     double s = 0.0;
-    for (int n = n0; n < n1; n++)
-        for (int d = 0; d < m; d++) {
-            const double sp = sigma[(((size_t)n * n_ops + k) * m + d) * 2];
-            const double sq = sigma[(((size_t)n * n_ops + k) * m + d) * 2 + 1];
-            s += gp[((size_t)n * (m + 1) + d) * nc + l] * sp + gq[((size_t)n * (m + 1) + d) * nc + l] * sq;
-        }
-    atomicAdd(&grad[poff[k] + l], -s);
+    if (l < nc) {
+        const int n1 = min(nt, (int)(blockIdx.x + 1) * CT_CHUNK);
+        for (int n = blockIdx.x * CT_CHUNK + sub; n < n1; n += 4)
+            for (int d = 0; d < m; d++) {
+                const double sp = sigma[(((size_t)n * n_ops + k) * m + d) * 2];
+                const double sq = sigma[(((size_t)n * n_ops + k) * m + d) * 2 + 1];
+                s += gp[((size_t)n * (m + 1) + d) * nc + l] * sp + gq[((size_t)n * (m + 1) + d) * nc + l] * sq;
+            }
+    }
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && l < nc)
+        atomicAdd(&grad[poff[k] + l], -(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // ---------------------------------------------------------------------------
@@ -1477,6 +1514,11 @@ int qgdk_sweep_forward(const qgdk_ctx *c)
 
 int qgdk_guard(const qgdk_ctx *c)
 {
+    if (c->have_guard == 2) {   // diagonal projector
+        hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
+                           c->scal, c->N, c->Np, c->cp, c->nt, c->dt, c->tf);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_guard, dim3(c->nt), dim3(256), 0, c->stream, c->guard, c->hist, c->forcing, c->scal,
                        c->N, c->Np, c->c, c->cp, c->nt, c->dt, c->tf, c->have_guard);
     return (int)hipGetLastError();
@@ -1549,9 +1591,8 @@ int qgdk_gradient(const qgdk_ctx *c)
     DISPATCH_NOPS(c->n_ops, CALL_GS)
 #undef CALL_GS
     HIPCHK(hipMemsetAsync(c->grad, 0, (size_t)c->n_pcof * sizeof(double), c->stream));
-    int nsplit = c->nt >= 64 ? 16 : 1;
-    hipLaunchKernelGGL(k_contract, dim3((c->nc_max + 63) / 64, c->n_ops, nsplit), dim3(64), 0, c->stream, c->G,
-                       c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
+    hipLaunchKernelGGL(k_contract, dim3((c->nt + CT_CHUNK - 1) / CT_CHUNK, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
+                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
     return (int)hipGetLastError();
 }
 

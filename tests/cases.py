@@ -67,3 +67,12 @@ def cnot3_case(qgd, nsteps=20, tf=20.0, seed=0):
     npar = qgd.get_number_of_control_parameters(ctrl)
     pcof = (np.random.default_rng(seed).random(npar) - 0.5) * 2 * np.pi * 0.005
     return prob, ctrl, pcof, target
+
+
+def dense_guard_case(qgd, nsteps=16, tf=8.0, seed=4):
+    """guarded_case with a dense symmetric (non-diagonal) guard matrix: "the projector actually
+    doesn't need to be a projector" (SchrodingerProb.jl:137-141) -- exercises the general W kernel."""
+    prob, ctrl, pcof, target = guarded_case(qgd, nsteps=nsteps, tf=tf, seed=seed)
+    r = np.random.default_rng(seed).standard_normal((prob.real_system_size, prob.real_system_size))
+    prob.guard_subspace_projector = np.asfortranarray(0.05 * (r + r.T))
+    return prob, ctrl, pcof, target

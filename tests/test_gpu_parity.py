@@ -90,7 +90,7 @@ def test_gradient_reference_cases(qgd, orc, order):
 
 
 @pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 4), ("guarded", 8), ("guarded", 12),
-                                         ("cnot3", 8)])
+                                         ("dense_guard", 6), ("cnot3", 8)])
 def test_configs_vs_oracle(qgd, orc, which, order):
     """BASELINE.json configurations (reduced nsteps so the oracle finishes in seconds).
 
