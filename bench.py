@@ -115,9 +115,17 @@ def main():
     qgd = import_package()
     prob, ctrl, pcof, target = workload(qgd, args.nsteps, float(args.nsteps))
     order = 8
-    dp = qgd.DeviceProblem(prob, order, device=local_rank if world > 1 else 0)
-    dp.set_controls(ctrl)
-    dp.set_target(target)
+    if world > 1:
+        # time-partitioned: one problem spread over the ranks (strong scaling), DESIGN.md "Multi-GPU"
+        back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+        dp = qgd.TimePartitioned(back, qgd.TorchComm())
+        dp.timings = back.timings
+        dp.close = back.close
+    else:
+        dp = qgd.DeviceProblem(prob, order, device=0)
+        dp.set_controls(ctrl)
+        dp.set_target(target)
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,6 +152,9 @@ def main():
     if rank == 0:
         for k in phase_ms:
             phase_ms[k] /= args.steps
+        for extra, base in (("sweep_forward2", "sweep_forward"), ("sweep_adjoint2", "sweep_adjoint")):
+            if extra in phase_ms:
+                phase_ms[base] = phase_ms.get(base, 0.0) + phase_ms.pop(extra)
         model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1)
         timed = {k: v for k, v in phase_ms.items() if k in model and v > 0}
         dom = max(timed, key=timed.get)
@@ -154,18 +165,18 @@ def main():
         else:
             achieved = work / (timed[dom] * 1e-3) / 1e9
             peak, unit = PEAK_HBM_GBS, "GB/s"
-        # replicas: every rank evaluates the full problem (see DESIGN.md "Multi-GPU")
-        total_timesteps = args.nsteps * args.steps * n_gpus
+        # N > 1: ONE evaluation is spread over the ranks by time windows (strong scaling)
+        total_timesteps = args.nsteps * args.steps
         out = {
             "metric": "forward+adjoint timesteps/sec, cnot3 order-8 fp64",
             "value": total_timesteps / elapsed, "unit": "timesteps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if n_gpus == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
-                       "parallelism": "1 GPU" if n_gpus == 1 else f"{n_gpus} replicas"},
+                       "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
             "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": None,
                          "launch_ms": timed[dom], "algorithmic_work_per_launch": work},

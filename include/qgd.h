@@ -130,6 +130,32 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);
 
+/* ---- time-partitioned evaluation over several GPUs (one handle per rank) ----------------
+ * The reference's only parallel axis is the column loop (Threads.@threads,
+ * src/forward_evolution.jl:48,332); this implementation's parallel axis is time, so ranks own
+ * contiguous windows of the time grid.  The library never communicates: between the phases the
+ * caller all-gathers two exchange buffers and all-reduces one (RCCL through torch.distributed
+ * in bench.py; MPI.jl from Julia).  Sequence per evaluation, on every rank:
+ *   qgd_dist_forward_begin -> all_gather(buffer 0) -> qgd_dist_forward_end
+ *   qgd_dist_adjoint_begin -> all_gather(buffer 1) -> qgd_dist_adjoint_end
+ *   all_reduce_sum(buffer 2) -> qgd_dist_finish
+ * After qgd_set_partition the control basis must be given for the rank's own window of time
+ * points (qgd_get_partition: out8 = first, last global time point, blocks, blocks per rank,
+ * block length, rank, world, global number of time points). */
+int qgd_set_partition(qgd_handle h, int32_t rank, int32_t world);
+int qgd_get_partition(qgd_handle h, int32_t *out8);
+/* Run all device work of the handle on the caller's HIP stream (e.g. torch's current stream). */
+int qgd_set_stream(qgd_handle h, void *hip_stream);
+/* which: 0 block propagators (all-gather), 1 adjoint affine parts (all-gather),
+ * 2 gradient + {<w,R>, <w,T>, guard, 0} (all-reduce sum).  Sizes in doubles. */
+int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *total_doubles,
+                        size_t *own_offset, size_t *own_doubles);
+int qgd_dist_forward_begin(qgd_handle h, const double *pcof, int32_t n_pcof);
+int qgd_dist_forward_end(qgd_handle h);
+int qgd_dist_adjoint_begin(qgd_handle h);
+int qgd_dist_adjoint_end(qgd_handle h);
+int qgd_dist_finish(qgd_handle h, double *grad, double *out3);
+
 /* Per-phase device time of the last evaluation (HIP events), milliseconds.
  * names/ms hold up to cap entries; returns the number of phases through *n. */
 int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, int32_t *n);

@@ -15,4 +15,5 @@ from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_pr
 from .evolution import (DeviceProblem, device_problem, clear_cache, eval_forward, eval_forward_, discrete_adjoint,
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)
+from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup
 from . import _lib

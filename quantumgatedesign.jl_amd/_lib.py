@@ -19,6 +19,9 @@ EXPORTS = [
     "qgd_abi_version", "qgd_create", "qgd_destroy", "qgd_last_error", "qgd_set_nsteps", "qgd_set_target",
     "qgd_set_control_basis", "qgd_set_control_tables", "qgd_eval_forward", "qgd_discrete_adjoint",
     "qgd_apply_hamiltonian", "qgd_get_intermediate", "qgd_get_timings",
+    "qgd_set_partition", "qgd_get_partition", "qgd_set_stream", "qgd_exchange_buffer",
+    "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
+    "qgd_dist_finish",
 ]
 
 
@@ -76,6 +79,15 @@ def lib():
     L.qgd_apply_hamiltonian.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.qgd_get_intermediate.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qgd_get_timings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.qgd_set_partition.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.qgd_get_partition.argtypes = [C.c_void_p, C.c_void_p]
+    L.qgd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.qgd_exchange_buffer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.qgd_dist_forward_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    for name in ("qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end"):
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.qgd_dist_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

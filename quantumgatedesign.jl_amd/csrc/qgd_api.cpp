@@ -24,13 +24,16 @@ struct Phase { const char *name; hipEvent_t e0, e1; bool used; };
 
 struct qgd_handle_s {
     qgdk_ctx k{};
-    int order = 0, nsteps = 0, device = 0;
+    int order = 0, nsteps = 0, device = 0;      // nsteps: GLOBAL number of timesteps
+    int part_rank = 0, part_world = 1;
+    bool own_stream = true;
     std::string err;
     std::vector<void *> static_bufs, grid_bufs, basis_bufs;
     bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
     std::vector<int32_t> ncoef, poff;
     std::vector<int64_t> goff;
     double *pcof_dev = nullptr;
+    double *scal_static = nullptr;
     std::vector<Phase> phases;
     std::vector<double> u0v0_panel;   // host copy of the initial panel
 };
@@ -93,6 +96,25 @@ int alloc_grid(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     free_pool(h->grid_bufs);
+    // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
+    //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
+    {
+        const int S = h->nsteps, W = h->part_world;
+        int B0 = (int)std::lround(std::sqrt(2.0 * S));
+        if (S < 24) B0 = 1;
+        if (B0 > 64) B0 = 64;
+        if (B0 < 1) B0 = 1;
+        k.bpr = (B0 + W - 1) / W;
+        k.scan_blocks = k.bpr * W;
+        k.scan_blen = (S + k.scan_blocks - 1) / k.scan_blocks;
+        k.part_rank = h->part_rank; k.part_world = W;
+        k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr; k.blk_hi_clamped = k.blk_hi;
+        const int s_lo = k.blk_lo * k.scan_blen;
+        const int s_hi = std::min(S, k.blk_hi * k.scan_blen);
+        if (s_lo >= S) return fail(h, QGD_ERR_UNSUPPORTED, "too few timesteps for this many ranks (a rank would own no step)");
+        k.n_off = s_lo; k.nt = s_hi - s_lo + 1; k.nt_glob = S + 1;
+        k.dt = k.tf / S;
+    }
     const size_t Np = k.Np, PW = 2 * Np, PWc = 2 * k.cp, nt = k.nt, m = k.m;
     const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
     int rc;
@@ -110,20 +132,15 @@ int alloc_grid(qgd_handle h)
     if ((rc = dev_alloc(h, h->grid_bufs, &k.yhist, nt * hstep))) return rc;
     if ((rc = dev_alloc(h, h->grid_bufs, &k.lam, nt * hstep))) return rc;
     if ((rc = dev_alloc(h, h->grid_bufs, &k.sigma, nt * (size_t)std::max(k.n_ops, 1) * m * 2))) return rc;
-    // blocked scan of the sweeps: S steps in B blocks, chain length 2*blen + B
+    // blocked scan of the sweeps: chain length 2*blen + B; exchange buffers hold every rank's chunk
     {
-        const int S = k.nt - 1;
-        int B = (int)std::lround(std::sqrt(2.0 * S));
-        if (S < 24) B = 1;
-        if (B > 64) B = 64;
-        k.scan_blen = (S + B - 1) / B;
-        k.scan_blocks = (S + k.scan_blen - 1) / k.scan_blen;
-        const size_t nb = (size_t)k.scan_blocks;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiC, nb * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiR, nb * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.phi, nb * hstep))) return rc;
+        const size_t nb = (size_t)k.scan_blocks, W = (size_t)k.part_world;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiX, W * 2 * k.bpr * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiX, W * (k.bpr + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.psi0, hstep))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
@@ -137,7 +154,6 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipMemsetAsync(k.yhist, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.forcing, 0, nt * hstep * sizeof(double), k.stream));
-    HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     // Hermite weights c_j dt^j and c_j (-dt)^j  (hermite.jl:398-399, :422-423)
     for (int j = 0; j <= k.m; j++) {
         double cj = hermite_coefficient(j, k.m, k.m);
@@ -148,6 +164,7 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     h->have_basis = h->have_tables = h->forward_valid = h->derivs_valid = false;
     free_pool(h->basis_bufs);
+    k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr;
     return QGD_OK;
 }
 
@@ -189,7 +206,8 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
             return fail((h), QGD_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__)); \
     } while (0)
 
-int run_forward(qgd_handle h, const double *pcof, int n_pcof)
+// forward, part 1: everything that needs no other rank (tables .. block propagators)
+int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
 {
     qgdk_ctx &k = h->k;
     if (pcof) {
@@ -206,12 +224,48 @@ int run_forward(qgd_handle h, const double *pcof, int n_pcof)
     { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
     { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
     { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
-    { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_sweep_forward(&k)); }
-    { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }
-    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }
-    h->forward_valid = true;
+    { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
+    h->forward_valid = false;
     h->derivs_valid = false;
     return QGD_OK;
+}
+
+// forward, part 2: after the block propagators of all ranks are in PiX
+int forward_end(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
+    { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }
+    if (k.part_rank == k.part_world - 1) {   // the rank that owns the final time
+        PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target));
+    }
+    h->forward_valid = true;
+    return QGD_OK;
+}
+
+int adjoint_begin(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    { PhaseTimer t(h, "sweep_adjoint"); K_TRY(h, qgdk_adjoint_blocks(&k)); }
+    return QGD_OK;
+}
+
+int adjoint_end(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
+    { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+    { PhaseTimer t(h, "gradient"); K_TRY(h, qgdk_gradient(&k)); }
+    return QGD_OK;
+}
+
+int run_forward(qgd_handle h, const double *pcof, int n_pcof)
+{
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
+    int rc = forward_begin(h, pcof, n_pcof);
+    if (rc) return rc;
+    return forward_end(h);
 }
 
 int check_status(qgd_handle h)
@@ -265,7 +319,7 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     h->order = d->order;
     k.N = N; k.Np = (N + 15) / 16 * 16; k.c = c; k.cp = (c + 7) / 8 * 8;
     k.n_ops = n_ops; k.n_ess = d->n_ess; k.m = d->order / 2;
-    k.nt = d->nsteps + 1; h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps;
+    h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps; k.nt = d->nsteps + 1;
     if (qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024) {
         delete h;
         return fail(nullptr, QGD_ERR_UNSUPPORTED, "N*order too large for the LDS-resident derivative kernels of this version");
@@ -310,7 +364,8 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     }
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.target, Np * PWc));
     CREATE_TRY(hipMemset(k.target, 0, Np * PWc * sizeof(double)));
-    CREATE_RC(dev_alloc(h, h->static_bufs, &k.scal, (size_t)4));
+    CREATE_RC(dev_alloc(h, h->static_bufs, &h->scal_static, (size_t)8));
+    k.scal = h->scal_static;
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.cw, (size_t)2 * 20));
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.status, (size_t)2));
     CREATE_RC(alloc_grid(h));
@@ -325,7 +380,7 @@ void qgd_destroy(qgd_handle h)
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
     free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs);
     for (auto &p : h->phases) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
-    if (h->k.stream) (void)hipStreamDestroy(h->k.stream);
+    if (h->k.stream && h->own_stream) (void)hipStreamDestroy(h->k.stream);
     delete h;
 }
 
@@ -334,7 +389,7 @@ int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf)
     if (!h) return QGD_ERR_ARGUMENT;
     if (nsteps < 1 || !(tf > 0)) return fail(h, QGD_ERR_ARGUMENT, "nsteps and tf must be positive");
     HIP_TRY(h, hipSetDevice(h->device));
-    h->nsteps = nsteps; h->k.nt = nsteps + 1; h->k.tf = tf; h->k.dt = tf / nsteps;
+    h->nsteps = nsteps; h->k.tf = tf;
     return alloc_grid(h);
 }
 
@@ -362,6 +417,7 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     qgdk_ctx &k = h->k;
     free_pool(h->basis_bufs);
     h->have_basis = false;
+    k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr;
     h->ncoef.assign(k.n_ops, 0); h->poff.assign(k.n_ops, 0); h->goff.assign(k.n_ops, 0);
     size_t total = 0; int np = 0, ncmax = 0;
     const size_t per = (size_t)k.nt * (k.m + 1);
@@ -378,7 +434,9 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     if ((rc = dev_alloc(h, h->basis_bufs, &k.ncoef, (size_t)k.n_ops + 1))) return rc;
     if ((rc = dev_alloc(h, h->basis_bufs, &k.poff, (size_t)k.n_ops + 1))) return rc;
     if ((rc = dev_alloc(h, h->basis_bufs, &h->pcof_dev, (size_t)np + 1))) return rc;
-    if ((rc = dev_alloc(h, h->basis_bufs, &k.grad, (size_t)np + 1))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &k.redbuf, (size_t)np + 8))) return rc;
+    k.grad = k.redbuf; k.scal = k.redbuf + np;     // [grad | scal]: one all-reduce in the multi-GPU path
+    HIP_TRY(h, hipMemset(k.redbuf, 0, ((size_t)np + 8) * sizeof(double)));
     for (int o = 0; o < k.n_ops; o++) {
         const size_t cnt = per * h->ncoef[o];
         if (!cnt) continue;
@@ -438,6 +496,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     qgdk_ctx &k = h->k;
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_discrete_adjoint");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_discrete_adjoint");
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
     int rc;
     if (history_precomputed) {
         if (!h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
@@ -446,10 +505,8 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     } else {
         if ((rc = run_forward(h, pcof, n_pcof))) return rc;
     }
-    { PhaseTimer t(h, "sweep_adjoint"); K_TRY(h, qgdk_sweep_adjoint(&k)); }
-    { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
-    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
-    { PhaseTimer t(h, "gradient"); K_TRY(h, qgdk_gradient(&k)); }
+    if ((rc = adjoint_begin(h))) return rc;
+    if ((rc = adjoint_end(h))) return rc;
     if ((rc = check_status(h))) return rc;
     HIP_TRY(h, hipMemcpy(grad, k.grad, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
     if (out3) HIP_TRY(h, hipMemcpy(out3, k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -548,6 +605,102 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         out[((n * N + r) * N + c) * 2] = b[o];
         out[((n * N + r) * N + c) * 2 + 1] = b[o + 8];
     }
+    return QGD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Time-partitioned (multi-GPU) evaluation.  The library does no communication itself: the
+// caller moves the two exchange buffers and the reduction buffer with its own collectives
+// (torch.distributed / RCCL in bench.py, MPI from Julia) between the phases.
+// ---------------------------------------------------------------------------
+int qgd_set_partition(qgd_handle h, int32_t rank, int32_t world)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, QGD_ERR_ARGUMENT, "rank/world out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->part_rank = rank; h->part_world = world;
+    return alloc_grid(h);
+}
+
+int qgd_get_partition(qgd_handle h, int32_t *out8)
+{
+    if (!h || !out8) return QGD_ERR_ARGUMENT;
+    const qgdk_ctx &k = h->k;
+    out8[0] = k.n_off; out8[1] = k.n_off + k.nt - 1;   // first / last global time point of the window
+    out8[2] = k.scan_blocks; out8[3] = k.bpr; out8[4] = k.scan_blen; out8[5] = k.part_rank; out8[6] = k.part_world;
+    out8[7] = k.nt_glob;
+    return QGD_OK;
+}
+
+int qgd_set_stream(qgd_handle h, void *stream)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->k.stream));
+    if (h->own_stream && h->k.stream) (void)hipStreamDestroy(h->k.stream);
+    h->k.stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return QGD_OK;
+}
+
+int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *total_doubles, size_t *own_offset,
+                        size_t *own_doubles)
+{
+    if (!h || !dev_ptr || !total_doubles || !own_offset || !own_doubles) return QGD_ERR_ARGUMENT;
+    const qgdk_ctx &k = h->k;
+    const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp, W = (size_t)k.part_world;
+    if (which == 0) {          // block propagators, all-gather
+        const size_t chunk = (size_t)2 * k.bpr * 2 * pl;
+        *dev_ptr = k.PiX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
+    } else if (which == 1) {   // affine parts + y_N, all-gather
+        const size_t chunk = (size_t)(k.bpr + 1) * hstep;
+        *dev_ptr = k.phiX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
+    } else if (which == 2) {   // gradient + scalars, all-reduce(sum)
+        if (!k.redbuf) return fail(h, QGD_ERR_STATE, "no control basis set");
+        *dev_ptr = k.redbuf; *total_doubles = (size_t)k.n_pcof + 4; *own_offset = 0; *own_doubles = (size_t)k.n_pcof + 4;
+    } else return fail(h, QGD_ERR_ARGUMENT, "unknown exchange buffer");
+    return QGD_OK;
+}
+
+int qgd_dist_forward_begin(qgd_handle h, const double *pcof, int32_t n_pcof)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called first");
+    return forward_begin(h, pcof, n_pcof);
+}
+
+int qgd_dist_forward_end(qgd_handle h)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return forward_end(h);
+}
+
+int qgd_dist_adjoint_begin(qgd_handle h)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called first");
+    if (!h->forward_valid) return fail(h, QGD_ERR_STATE, "no forward evaluation to differentiate");
+    return adjoint_begin(h);
+}
+
+int qgd_dist_adjoint_end(qgd_handle h)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return adjoint_end(h);
+}
+
+int qgd_dist_finish(qgd_handle h, double *grad, double *out3)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = check_status(h);
+    if (rc) return rc;
+    if (grad) HIP_TRY(h, hipMemcpy(grad, h->k.grad, sizeof(double) * h->k.n_pcof, hipMemcpyDeviceToHost));
+    if (out3) HIP_TRY(h, hipMemcpy(out3, h->k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
     return QGD_OK;
 }
 

@@ -37,10 +37,15 @@ typedef struct qgdk_ctx {
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *inv_scratch;
-    double *PiC, *PiR;  // [B][2][Np*Np] block propagators: planes (col-major) / panel
-    double *phi;        // [B][Np][2cp] affine parts of the adjoint blocks
-    double *bnd, *bndY; // [B+1][Np][2cp] states at block boundaries
-    int scan_blocks, scan_blen;
+    // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
+    // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.
+    double *PiX;        // exchange buffer: per rank [bpr x PiC | bpr x PiR], 2*Np*Np doubles each
+    double *phiX;       // exchange buffer: per rank [bpr x phi | y_N], Np*2cp doubles each
+    double *bnd, *bndY; // [B+1][Np][2cp] states at block boundaries (every rank holds all)
+    double *psi0;       // initial panel [Np][2cp]
+    double *redbuf;     // [n_pcof + 4]: grad followed by scal (one all-reduce)
+    int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped;
+    int part_rank, part_world, n_off, nt_glob;
     int *status;
     double cw_host[2 * 20];
 } qgdk_ctx;
@@ -53,10 +58,12 @@ int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double 
 int qgdk_build_LR(const qgdk_ctx *c);
 int qgdk_inverse(const qgdk_ctx *c);
 int qgdk_propagator(const qgdk_ctx *c);
-int qgdk_sweep_forward(const qgdk_ctx *c);
+int qgdk_forward_blocks(const qgdk_ctx *c);
+int qgdk_forward_finish(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
-int qgdk_sweep_adjoint(const qgdk_ctx *c);
+int qgdk_adjoint_blocks(const qgdk_ctx *c);
+int qgdk_adjoint_finish(const qgdk_ctx *c);
 int qgdk_lambda(const qgdk_ctx *c);
 int qgdk_derivs(const qgdk_ctx *c);
 int qgdk_gradient(const qgdk_ctx *c);

@@ -783,7 +783,19 @@ struct ChainArgs {
     double *PiC, *PiR;       // MODE 0 outputs: planes / panel per block
     double *phi;             // MODE 2 output: [B][Np][2cp]
     int Np, cp, S, nblocks, blen, ngroups;
+    // exchange-buffer addressing (multi-GPU layout, one chunk per rank):
+    // matrix n lives at Pmat + (n / pm_bpr) * pm_chunk + (n % pm_bpr) * 2*Np*Np   (pm_bpr = 0: n * 2*Np*Np)
+    int pm_bpr; long long pm_chunk;
+    // forcing/history slot of time index n is n + n / f_bpr                          (f_bpr = 0: n)
+    int f_bpr;
 };
+
+__device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
+{
+    const size_t pl2 = (size_t)2 * a.Np * a.Np;
+    if (a.pm_bpr) return a.Pmat + (size_t)(n / a.pm_bpr) * a.pm_chunk + (size_t)(n % a.pm_bpr) * pl2;
+    return a.Pmat + (size_t)n * pl2;
+}
 
 template <int MODE>
 __device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &grp)
@@ -802,16 +814,16 @@ __device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &
 
 // A fragment of step n at (row, k)
 template <bool ADJ>
-__device__ __forceinline__ void chain_a(const double *__restrict__ Pmat, int Np, int n, int arow, int k,
+__device__ __forceinline__ void chain_a(const double *__restrict__ Pn, int Np, int arow, int k,
                                         double &are, double &aim)
-{
+{   // Pn: base of this step's matrix
     const size_t pl = (size_t)Np * Np;
     if (!ADJ) {
-        const double *P = Pmat + (size_t)n * 2 * pl + (size_t)arow + (size_t)Np * k;
+        const double *P = Pn + (size_t)arow + (size_t)Np * k;
         are = P[0];
         aim = P[pl];
     } else {   // (P^H)(row,k) = conj(P(k,row)); P stored as panel
-        const double *P = Pmat + (size_t)n * 2 * pl + (size_t)k * 2 * Np + (arow >> 3) * 16 + (arow & 7);
+        const double *P = Pn + (size_t)k * 2 * Np + (arow >> 3) * 16 + (arow & 7);
         are = P[0];
         aim = -P[8];
     }
@@ -855,9 +867,9 @@ __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
     double are[KS], aim[KS], nre[KS], nim[KS];
     const int nsteps = e0 - s0;
     if (active && nsteps > 0) {
-        const int n = ADJ ? e0 - 1 : s0;
+        const double *Pn = chain_matrix(a, ADJ ? e0 - 1 : s0);
         #pragma unroll
-        for (int i = 0; i < KS; i++) chain_a<ADJ>(a.Pmat, NP, n, arow, (kq * KS + i) * 4 + kk, are[i], aim[i]);
+        for (int i = 0; i < KS; i++) chain_a<ADJ>(Pn, NP, arow, (kq * KS + i) * 4 + kk, are[i], aim[i]);
     }
     __syncthreads();
 
@@ -867,8 +879,9 @@ __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
         const bool more = st + 1 < nsteps;
         if (active) {
             if (more) {
+                const double *Pnn = chain_matrix(a, nn);
                 #pragma unroll
-                for (int i = 0; i < KS; i++) chain_a<ADJ>(a.Pmat, NP, nn, arow, (kq * KS + i) * 4 + kk, nre[i], nim[i]);
+                for (int i = 0; i < KS; i++) chain_a<ADJ>(Pnn, NP, arow, (kq * KS + i) * 4 + kk, nre[i], nim[i]);
             }
             d4 acc = (d4){0, 0, 0, 0};
             #pragma unroll
@@ -888,7 +901,10 @@ __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
             #pragma unroll
             for (int q = 1; q < KSPLIT; q++) v += part[q][e];
             const size_t ho = (size_t)nout * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15);
-            if (ADJ) v += a.forcing[ho];
+            if (ADJ) {
+                const size_t fo = a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho;
+                v += a.forcing[fo];
+            }
             cur[e] = v;
             if (MODE == 1 || MODE == 3) a.out[ho] = v;
         }
@@ -942,12 +958,13 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
     for (int st = 0; st < e0 - s0; st++) {
         const int n = ADJ ? e0 - 1 - st : s0 + st;
         const int nout = ADJ ? n : n + 1;
+        const double *Pn = chain_matrix(a, n);
         for (int rb = wave; rb * 16 < Np; rb += nw) {
             d4 acc = (d4){0, 0, 0, 0};
             const int arow = rb * 16 + c16;
             for (int k0 = 0; k0 < Np; k0 += 4) {
                 double are, aim, b1, b2;
-                chain_a<ADJ>(a.Pmat, Np, n, arow, k0 + kk, are, aim);
+                chain_a<ADJ>(Pn, Np, arow, k0 + kk, are, aim);
                 panel_b(cur + (size_t)(k0 + kk) * 16, c16, b1, b2);
                 acc = MFMA(are, b1, acc);
                 acc = MFMA(aim, b2, acc);
@@ -957,7 +974,7 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
                 const int row = rb * 16 + kk + 4 * r;
                 double v = acc[r];
                 const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16;
-                if (ADJ) v += a.forcing[ho];
+                if (ADJ) v += a.forcing[a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho];
                 nxt[(size_t)row * 16 + c16] = v;
                 if (MODE == 1 || MODE == 3) a.out[ho] = v;
             }
@@ -1008,15 +1025,16 @@ __global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
                                                const double *__restrict__ hist,
                                                double *__restrict__ forcing,
                                                double *__restrict__ scal, int N, int Np, int c,
-                                               int cp, int nt, double dt, double tf, int have_guard)
+                                               int cp, int n_off, int nt_glob, int count_first, double dt, double tf,
+                                               int have_guard)
 {
     __shared__ double red[4];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, ng = n + n_off;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc;
     const double *h = hist + (size_t)n * hstep;
     double *f = forcing + (size_t)n * hstep;
-    const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0;
+    const double trap = (ng == 0 || ng == nt_glob - 1) ? 0.5 : 1.0;
     double pen = 0.0;
     if (!have_guard) {
         for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) f[e] = 0.0;
@@ -1041,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
     for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && (n > 0 || count_first)) {
         double tot = red[0] + red[1] + red[2] + red[3];
         atomicAdd(&scal[2], tot * trap * dt / tf);
     }
@@ -1053,15 +1071,15 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
                                                     const double *__restrict__ hist,
                                                     double *__restrict__ forcing,
                                                     double *__restrict__ scal, int N, int Np, int cp,
-                                                    int nt, double dt, double tf)
+                                                    int n_off, int nt_glob, int count_first, double dt, double tf)
 {
     __shared__ double red[4];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, ng = n + n_off;     // local / global time index
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc;
     const double *h = hist + (size_t)n * hstep;
     double *f = forcing + (size_t)n * hstep;
-    const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0;
+    const double trap = (ng == 0 || ng == nt_glob - 1) ? 0.5 : 1.0;
     const double sc = -(2.0 * dt / tf) * trap;
     double pen = 0.0;
     for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
@@ -1074,7 +1092,8 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
     for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&scal[2], (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf);
+    // the first point of a time window is the last point of the previous rank's window
+    if (threadIdx.x == 0 && (n > 0 || count_first)) atomicAdd(&scal[2], (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf);
 }
 
 // ---------------------------------------------------------------------------
@@ -1484,43 +1503,51 @@ int qgdk_propagator(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
-int qgdk_sweep_forward(const qgdk_ctx *c)
+// Exchange layout (DESIGN.md "Multi-GPU"): PiX = one chunk per rank, chunk = [bpr x PiC | bpr x PiR];
+// phiX = one chunk per rank, chunk = [bpr x phi | 1 x y_N (last rank only)].
+static inline size_t pix_chunk(const qgdk_ctx *c) { return (size_t)2 * c->bpr * 2 * c->Np * c->Np; }
+static inline size_t phix_chunk(const qgdk_ctx *c) { return (size_t)(c->bpr + 1) * c->Np * 2 * c->cp; }
+
+// forward, phase (i): block propagators of the owned blocks into this rank's chunk of PiX
+int qgdk_forward_blocks(const qgdk_ctx *c)
+{
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pc;
+    a.PiC = c->PiX + (size_t)c->part_rank * pix_chunk(c);
+    a.PiR = a.PiC + (size_t)c->bpr * 2 * c->Np * c->Np;
+    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    return launch_chain<0>(a, c->stream);
+}
+
+// forward, phases (ii)+(iii): boundary states over ALL blocks (every rank), then the owned blocks
+int qgdk_forward_finish(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    ChainArgs a{};
-    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1;
-    if (c->scan_blocks <= 1) {            // short grids: one plain chain
-        a.Pmat = c->Pc; a.start = c->hist; a.start_stride = 0; a.out = c->hist;
-        a.nblocks = 1; a.blen = a.S; a.ngroups = c->cp / 8;
-        return launch_chain<1>(a, c->stream);
-    }
-    const int B = c->scan_blocks, blen = c->scan_blen;
-    // (i) block propagators
-    a.Pmat = c->Pc; a.PiC = c->PiC; a.PiR = c->PiR; a.nblocks = B; a.blen = blen; a.ngroups = c->Np / 8;
-    int rc = launch_chain<0>(a, c->stream);
-    if (rc) return rc;
-    // (ii) states at block starts: bnd[b+1] = Pi_b bnd[b]
-    HIPCHK(hipMemcpyAsync(c->bnd, c->hist, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const int B = c->scan_blocks;
+    HIPCHK(hipMemcpyAsync(c->bnd, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s2{};
-    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiC; s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd;
-    s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
-    if ((rc = launch_chain<1>(s2, c->stream))) return rc;
-    // (iii) history inside every block
+    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+    s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+    int rc = launch_chain<1>(s2, c->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
-    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd; s3.start_stride = (long long)hstep;
-    s3.out = c->hist; s3.nblocks = B; s3.blen = blen; s3.ngroups = c->cp / 8;
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
+    s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = c->blk_hi - c->blk_lo; s3.blen = c->scan_blen;
+    s3.ngroups = c->cp / 8;
     return launch_chain<1>(s3, c->stream);
 }
 
 int qgdk_guard(const qgdk_ctx *c)
 {
+    const int count_first = (c->n_off == 0) ? 1 : 0;
     if (c->have_guard == 2) {   // diagonal projector
         hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
-                           c->scal, c->N, c->Np, c->cp, c->nt, c->dt, c->tf);
+                           c->scal, c->N, c->Np, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_guard, dim3(c->nt), dim3(256), 0, c->stream, c->guard, c->hist, c->forcing, c->scal,
-                       c->N, c->Np, c->c, c->cp, c->nt, c->dt, c->tf, c->have_guard);
+                       c->N, c->Np, c->c, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf, c->have_guard);
     return (int)hipGetLastError();
 }
 
@@ -1531,34 +1558,46 @@ int qgdk_terminal(const qgdk_ctx *c, int write_y)
     return (int)hipGetLastError();
 }
 
-int qgdk_sweep_adjoint(const qgdk_ctx *c)
+// adjoint, phase (i): affine parts phi_b of the owned blocks into this rank's chunk of phiX; the
+// rank that owns the final time puts y_N (written by k_terminal into yhist) in its extra slot
+int qgdk_adjoint_blocks(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    const int S = c->nt - 1;
-    if (c->scan_blocks <= 1) {
-        ChainArgs a{};
-        a.Np = c->Np; a.cp = c->cp; a.S = S; a.Pmat = c->Pr; a.start = c->yhist + (size_t)S * hstep; a.start_stride = 0;
-        a.out = c->yhist; a.forcing = c->forcing; a.nblocks = 1; a.blen = S; a.ngroups = c->cp / 8;
-        return launch_chain<3>(a, c->stream);
-    }
-    const int B = c->scan_blocks, blen = c->scan_blen;
-    // (i) affine parts phi_b (block propagators Pi_b were stored by the forward sweep)
+    double *own = c->phiX + (size_t)c->part_rank * phix_chunk(c);
     ChainArgs a{};
-    a.Np = c->Np; a.cp = c->cp; a.S = S; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = c->phi;
-    a.nblocks = B; a.blen = blen; a.ngroups = c->cp / 8;
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = own;
+    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
     int rc = launch_chain<2>(a, c->stream);
     if (rc) return rc;
-    // (ii) bndY[b] = Pi_b^H bndY[b+1] + phi_b, from bndY[B] = y_{nt-1}
-    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, c->yhist + (size_t)S * hstep, hstep * sizeof(double),
-                          hipMemcpyDeviceToDevice, c->stream));
+    if (c->part_rank == c->part_world - 1)
+        HIPCHK(hipMemcpyAsync(own + (size_t)c->bpr * hstep, c->yhist + (size_t)(c->nt - 1) * hstep, hstep * sizeof(double),
+                              hipMemcpyDeviceToDevice, c->stream));
+    else
+        HIPCHK(hipMemsetAsync(own + (size_t)c->bpr * hstep, 0, hstep * sizeof(double), c->stream));
+    return 0;
+}
+
+// adjoint, phases (ii)+(iii)
+int qgdk_adjoint_finish(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const int B = c->scan_blocks;
+    const double *yN = c->phiX + (size_t)(c->part_world - 1) * phix_chunk(c) + (size_t)c->bpr * hstep;
+    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s2{};
-    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiR; s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0;
-    s2.out = c->bndY; s2.forcing = c->phi; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
-    if ((rc = launch_chain<3>(s2, c->stream))) return rc;
-    // (iii) history inside every block, block b starts from bndY[b+1]
+    s2.Np = c->Np; s2.cp = c->cp; s2.S = B;
+    s2.Pmat = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+    s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0; s2.out = c->bndY;
+    s2.forcing = c->phiX; s2.f_bpr = c->bpr; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+    int rc = launch_chain<3>(s2, c->stream);
+    if (rc) return rc;
+    // y at the end of this rank's window
+    HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
+                          hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
-    s3.Np = c->Np; s3.cp = c->cp; s3.S = S; s3.Pmat = c->Pr; s3.start = c->bndY + hstep; s3.start_stride = (long long)hstep;
-    s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = B; s3.blen = blen; s3.ngroups = c->cp / 8;
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.start = c->bndY + (size_t)(c->blk_lo + 1) * hstep;
+    s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = c->blk_hi - c->blk_lo;
+    s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
     return launch_chain<3>(s3, c->stream);
 }
 

@@ -1,0 +1,158 @@
+"""Time-partitioned evaluation over several GPUs (one process per GPU, torch.distributed over
+RCCL/xGMI as plumbing).  See DESIGN.md "Multi-GPU" and include/qgd.h.
+
+The reference's only parallelism is a thread loop over initial-condition columns
+(src/forward_evolution.jl:48,332).  Here the parallel axis is time: rank r owns a contiguous
+window of the time grid, builds its own step propagators, and the blocked scan of the sweeps
+is completed with two all-gathers (block propagators; adjoint affine parts) and one
+all-reduce (gradient + the three objective scalars) per evaluation.
+
+``TimePartitioned`` is the orchestration; it is backend-agnostic so that the exchange pattern
+is also exercised on CPU with gloo (tests/test_distributed_cpu.py drives it with a numpy
+backend).  ``DeviceBackend`` is the product backend (C ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .controls import as_control_list, control_basis
+from .evolution import DeviceProblem, _vp
+
+
+class _DevArray:
+    """Expose raw device memory to torch through the CUDA array interface."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+class DeviceBackend:
+    """One rank's share of a SchrodingerProb on its GPU."""
+
+    def __init__(self, prob, order, controls, target, rank, world, device=0, stream=None):
+        self.dp = DeviceProblem(prob, order, device)
+        self.lib, self.h = self.dp.lib, self.dp.h
+        if stream is not None:
+            _lib.check(self.h, self.lib.qgd_set_stream(self.h, C.c_void_p(stream)))
+        _lib.check(self.h, self.lib.qgd_set_partition(self.h, rank, world))
+        part = np.zeros(8, dtype=np.int32)
+        _lib.check(self.h, self.lib.qgd_get_partition(self.h, _vp(part)))
+        self.n_lo, self.n_hi = int(part[0]), int(part[1])
+        self.partition = dict(n_lo=self.n_lo, n_hi=self.n_hi, blocks=int(part[2]), blocks_per_rank=int(part[3]),
+                              block_len=int(part[4]), rank=int(part[5]), world=int(part[6]), nt=int(part[7]))
+        cl = as_control_list(controls)
+        m = order // 2
+        Gp, Gq, _ = control_basis(cl, prob.nsteps, prob.tf, m)
+        Gp = [np.ascontiguousarray(g[self.n_lo:self.n_hi + 1]) for g in Gp]
+        Gq = [np.ascontiguousarray(g[self.n_lo:self.n_hi + 1]) for g in Gq]
+        nco = np.array([c.N_coeff for c in cl], dtype=np.int32)
+        gp = (C.c_void_p * max(len(cl), 1))(*[_vp(g) for g in Gp])
+        gq = (C.c_void_p * max(len(cl), 1))(*[_vp(g) for g in Gq])
+        _lib.check(self.h, self.lib.qgd_set_control_basis(self.h, _vp(nco), gp, gq))
+        self.n_pcof = int(nco.sum())
+        self.dp.set_target(target)
+
+    def exchange_buffer(self, which):
+        """(whole buffer, this rank's chunk) as torch CUDA tensors over the library's memory."""
+        import torch
+        ptr, tot, off, own = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _lib.check(self.h, self.lib.qgd_exchange_buffer(self.h, which, C.byref(ptr), C.byref(tot), C.byref(off), C.byref(own)))
+        whole = torch.as_tensor(_DevArray(ptr.value, tot.value), device="cuda")
+        return whole, whole[off.value:off.value + own.value]
+
+    def forward_begin(self, pcof):
+        pc = np.ascontiguousarray(pcof, dtype=np.float64)
+        _lib.check(self.h, self.lib.qgd_dist_forward_begin(self.h, _vp(pc), len(pc)))
+
+    def forward_end(self):
+        _lib.check(self.h, self.lib.qgd_dist_forward_end(self.h))
+
+    def adjoint_begin(self):
+        _lib.check(self.h, self.lib.qgd_dist_adjoint_begin(self.h))
+
+    def adjoint_end(self):
+        _lib.check(self.h, self.lib.qgd_dist_adjoint_end(self.h))
+
+    def finish(self):
+        grad, out3 = np.zeros(self.n_pcof), np.zeros(3)
+        _lib.check(self.h, self.lib.qgd_dist_finish(self.h, _vp(grad), _vp(out3)))
+        return grad, out3
+
+    def timings(self):
+        return self.dp.timings()
+
+    def close(self):
+        self.dp.close()
+
+
+class TorchComm:
+    """Collectives of one evaluation through torch.distributed (backend "nccl" = RCCL on ROCm,
+    "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def all_gather(self, whole, own):
+        self.dist.all_gather_into_tensor(whole, own.clone(), group=self.group)
+
+    def all_reduce(self, whole):
+        self.dist.all_reduce(whole, group=self.group)
+
+
+class TimePartitioned:
+    """discrete_adjoint! of one SchrodingerProb spread over the ranks of a communicator."""
+
+    def __init__(self, backend, comm):
+        self.b, self.comm = backend, comm
+
+    def discrete_adjoint(self, pcof):
+        b = self.b
+        b.forward_begin(pcof)
+        self.comm.all_gather(*b.exchange_buffer(0))
+        b.forward_end()
+        b.adjoint_begin()
+        self.comm.all_gather(*b.exchange_buffer(1))
+        b.adjoint_end()
+        self.comm.all_reduce(b.exchange_buffer(2)[0])
+        return b.finish()
+
+
+class LocalGroup:
+    """All ranks of a partition inside ONE process (every backend on the same GPU, or numpy
+    backends on the CPU): the collectives become copies.  Used to validate the partitioned
+    algorithm where only one GPU is available."""
+
+    def __init__(self, backends):
+        self.backends = backends
+
+    def _gather(self, which):
+        bufs = [b.exchange_buffer(which) for b in self.backends]
+        for _, (whole_src, own_src) in enumerate(bufs):
+            off = own_src.storage_offset() - whole_src.storage_offset()
+            for whole_dst, _ in bufs:
+                if whole_dst.data_ptr() != whole_src.data_ptr():
+                    whole_dst[off:off + own_src.numel()].copy_(own_src)
+
+    def discrete_adjoint(self, pcof):
+        bs = self.backends
+        for b in bs:
+            b.forward_begin(pcof)
+        self._gather(0)
+        for b in bs:
+            b.forward_end()
+        for b in bs:
+            b.adjoint_begin()
+        self._gather(1)
+        for b in bs:
+            b.adjoint_end()
+        wholes = [b.exchange_buffer(2)[0] for b in bs]
+        total = wholes[0].clone()
+        for w in wholes[1:]:
+            total += w
+        for w in wholes:
+            w.copy_(total)
+        return [b.finish() for b in bs]

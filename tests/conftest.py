@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch first: its bundled HIP runtime must be the one libqgd_hip.so binds to when both live in a process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -171,3 +171,30 @@ def test_full_size_properties(qgd):
     observed_order = np.log2(devs[550] / devs[1100])
     assert 7.0 <= observed_order <= 9.0, (devs, observed_order)
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("which,nsteps,world", [("cnot2", 100, 2), ("cnot2", 100, 4), ("guarded", 90, 3), ("cnot3", 64, 2),
+                                                ("cnot3", 96, 8)])
+def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
+    """The multi-GPU algorithm (time windows per rank, two all-gathers and one all-reduce per
+    evaluation) with all ranks inside this process on the one GPU: gradient and scalars must equal
+    the unpartitioned evaluation to rounding."""
+    import torch
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / 2)
+    order = 8 if which != "guarded" else 6
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_controls(ctrl)
+    dp.set_target(target)
+    g_ref, o_ref = dp.discrete_adjoint(pcof)
+    dp.close()
+    stream = torch.cuda.current_stream().cuda_stream
+    backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, world, device=0, stream=stream) for r in range(world)]
+    cover = sorted((b.n_lo, b.n_hi) for b in backs)
+    assert cover[0][0] == 0 and cover[-1][1] == nsteps
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))      # windows share their end points
+    results = qgd.LocalGroup(backs).discrete_adjoint(pcof)
+    for g, o in results:
+        assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+        assert np.abs(o - o_ref).max() <= 1e-12
+    for b in backs:
+        b.close()
