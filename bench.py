@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nsteps", type=int, default=550, help="timesteps of the workload (tf = nsteps, dt = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,15 +108,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
 
     qgd = import_package()
     prob, ctrl, pcof, target = workload(qgd, args.nsteps, float(args.nsteps))
     order = 8
-    if world > 1:
+    if use_dist:
         # time-partitioned: one problem spread over the ranks (strong scaling), DESIGN.md "Multi-GPU"
         back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
                                  stream=torch.cuda.current_stream().cuda_stream)
@@ -129,7 +134,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -144,7 +149,7 @@ def main():
             phase_ms[k] = phase_ms.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -189,7 +194,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(qgd, orc)
         print(json.dumps(out))
     dp.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
