@@ -818,6 +818,7 @@ __device__ __forceinline__ void chain_a(const double *__restrict__ Pn, int Np, i
                                         double &are, double &aim)
 {   // Pn: base of this step's matrix
     const size_t pl = (size_t)Np * Np;
+
     if (!ADJ) {
         const double *P = Pn + (size_t)arow + (size_t)Np * k;
         are = P[0];
@@ -829,8 +830,10 @@ __device__ __forceinline__ void chain_a(const double *__restrict__ Pn, int Np, i
     }
 }
 
-// NP > 0: compile-time size, 8 waves = (row block, K slice), next step's fragments prefetched
-// into registers while the current step's MFMAs run.
+// NP > 0: compile-time size, 8 waves = (row block, K slice).  The state lives in LDS as the
+// KSPLIT partial sums the waves produced (double buffered): the next step's B fragments are the
+// sums of those partials, so a step needs ONE barrier.  The A fragments (and, for the adjoint, the
+// forcing in accumulator layout) of the next PF steps are in flight in a register ring.
 template <int NP, int MODE>
 __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
 {
@@ -839,9 +842,10 @@ __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
     constexpr int KSPLIT = (8 / NRB) < (NP / 4) ? (8 / NRB) : (NP / 4);
     constexpr int NACT = NRB * KSPLIT;
     constexpr int KS = NP / 4 / KSPLIT;
+    constexpr int PF = 3;
+    constexpr int EPT = (NP * 16 + 511) / 512;           // panel elements per thread
     static_assert(NRB * 16 == NP && KS * KSPLIT * 4 == NP && NACT <= 8, "tile");
-    __shared__ __attribute__((aligned(16))) double cur[NP * 16];
-    __shared__ __attribute__((aligned(16))) double part[KSPLIT][NP * 16];
+    __shared__ __attribute__((aligned(16))) double part[2][KSPLIT][NP * 16];
 
     int b, grp;
     chain_block_of<MODE>(a, b, grp);
@@ -854,79 +858,119 @@ __global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
     const bool active = wave < NACT;
     const int rb = wave / KSPLIT, kq = wave % KSPLIT;
     const int arow = rb * 16 + c16;
-
-    // start panel
-    for (int e = tid; e < NP * 16; e += 512) {
-        const int row = e >> 4, c = e & 15;
-        double v;
-        if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
-        else if (MODE == 2) v = 0.0;
-        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
-        cur[e] = v;
-    }
-    double are[KS], aim[KS], nre[KS], nim[KS];
     const int nsteps = e0 - s0;
-    if (active && nsteps > 0) {
-        const double *Pn = chain_matrix(a, ADJ ? e0 - 1 : s0);
-        #pragma unroll
-        for (int i = 0; i < KS; i++) chain_a<ADJ>(Pn, NP, arow, (kq * KS + i) * 4 + kk, are[i], aim[i]);
+
+    // start state into part[0][0], zeros into the other partial slots
+    #pragma unroll
+    for (int t2 = 0; t2 < EPT; t2++) {
+        const int e = tid + t2 * 512;
+        if (e < NP * 16) {
+            const int row = e >> 4, c = e & 15;
+            double v;
+            if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+            else if (MODE == 2) v = 0.0;
+            else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+            part[0][0][e] = v;
+            #pragma unroll
+            for (int w2 = 1; w2 < KSPLIT; w2++) part[0][w2][e] = 0.0;
+        }
     }
+    double rre[PF][KS], rim[PF][KS], rfo[PF][4];
+    auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
+    auto issue = [&](int slot, int st) {                 // loads for step st into ring slot
+        const int n = step_index(st);
+        if (active) {
+            const double *Pn = chain_matrix(a, n);
+            #pragma unroll
+            for (int i = 0; i < KS; i++) chain_a<ADJ>(Pn, NP, arow, (kq * KS + i) * 4 + kk, rre[slot][i], rim[slot][i]);
+            if (ADJ && kq == 0) {                        // forcing f_n in accumulator layout
+                const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    rfo[slot][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16];
+            }
+        }
+    };
+    #pragma unroll
+    for (int q = 0; q < PF; q++) if (q < nsteps) issue(q, q);
     __syncthreads();
 
-    for (int st = 0; st < nsteps; st++) {
-        const int n = ADJ ? e0 - 1 - st : s0 + st;          // propagator index of this step
-        const int nn = ADJ ? n - 1 : n + 1;                  // next step's propagator
-        const bool more = st + 1 < nsteps;
+    int buf = 0;
+    // one step on ring slot q; `refill` (>= 0) is the step whose operands replace the slot
+    auto do_step = [&](int q, int st, int refill) {
+        const int n = step_index(st);
         if (active) {
-            if (more) {
-                const double *Pnn = chain_matrix(a, nn);
-                #pragma unroll
-                for (int i = 0; i < KS; i++) chain_a<ADJ>(Pnn, NP, arow, (kq * KS + i) * 4 + kk, nre[i], nim[i]);
-            }
             d4 acc = (d4){0, 0, 0, 0};
             #pragma unroll
             for (int i = 0; i < KS; i++) {
-                double b1, b2;
-                panel_b(cur + ((kq * KS + i) * 4 + kk) * 16, c16, b1, b2);
-                acc = MFMA(are[i], b1, acc);
-                acc = MFMA(aim[i], b2, acc);
+                const int ko = ((kq * KS + i) * 4 + kk) * 16;
+                double v1 = part[buf][0][ko + c16], v2 = part[buf][0][ko + (c16 ^ 8)];
+                #pragma unroll
+                for (int w2 = 1; w2 < KSPLIT; w2++) { v1 += part[buf][w2][ko + c16]; v2 += part[buf][w2][ko + (c16 ^ 8)]; }
+                acc = MFMA(rre[q][i], v1, acc);
+                acc = MFMA(rim[q][i], (c16 < 8) ? -v2 : v2, acc);
             }
             #pragma unroll
-            for (int r = 0; r < 4; r++) part[kq][(rb * 16 + kk + 4 * r) * 16 + c16] = acc[r];
-        }
-        __syncthreads();
-        const int nout = ADJ ? n : n + 1;                    // time index of the new state
-        for (int e = tid; e < NP * 16; e += 512) {
-            double v = part[0][e];
-            #pragma unroll
-            for (int q = 1; q < KSPLIT; q++) v += part[q][e];
-            const size_t ho = (size_t)nout * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15);
-            if (ADJ) {
-                const size_t fo = a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho;
-                v += a.forcing[fo];
+            for (int r = 0; r < 4; r++) {
+                double v = acc[r];
+                if (ADJ && kq == 0) v += rfo[q][r];
+                part[buf ^ 1][kq][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
             }
-            cur[e] = v;
-            if (MODE == 1 || MODE == 3) a.out[ho] = v;
         }
-        if (active && more) {
+        // history: part[buf] holds the state that the previous step produced (the start state is
+        // not an output)
+        if ((MODE == 1 || MODE == 3) && st > 0) {
+            const int ncur = ADJ ? n + 1 : n;
             #pragma unroll
-            for (int i = 0; i < KS; i++) { are[i] = nre[i]; aim[i] = nim[i]; }
+            for (int t2 = 0; t2 < EPT; t2++) {
+                const int e = tid + t2 * 512;
+                if (e < NP * 16) {
+                    double v = part[buf][0][e];
+                    #pragma unroll
+                    for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
+                    a.out[(size_t)ncur * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = v;
+                }
+            }
         }
+        if (refill >= 0) issue(q, refill);
         __syncthreads();
+        buf ^= 1;
+    };
+    // steady state: whole groups of PF steps, no conditionals (keeps the compiler's vmcnt
+    // bookkeeping exact so that PF-1 sets of loads really stay in flight); the refill index is
+    // clamped, the last groups reload the final matrix harmlessly
+    const int nfull = (nsteps / PF) * PF;
+    for (int st0 = 0; st0 < nfull; st0 += PF) {
+        #pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int nxt = st0 + q + PF;
+            do_step(q, st0 + q, nxt < nsteps ? nxt : nsteps - 1);
+        }
     }
-    if (MODE == 0) {
-        const size_t pl = (size_t)NP * NP;
-        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
-        for (int e = tid; e < NP * 16; e += 512) {
+    #pragma unroll
+    for (int q = 0; q < PF; q++)
+        if (nfull + q < nsteps) do_step(q, nfull + q, -1);
+    // final state = sum of the partials in part[buf]
+    const int nlast = ADJ ? s0 : e0;                     // its time index
+    #pragma unroll
+    for (int t2 = 0; t2 < EPT; t2++) {
+        const int e = tid + t2 * 512;
+        if (e < NP * 16) {
+            double v = part[buf][0][e];
+            #pragma unroll
+            for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
             const int row = e >> 4, c = e & 15;
-            const int col = grp * 8 + (c & 7);
-            pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)NP * col] = cur[e];
-            pr[(size_t)row * 2 * NP + grp * 16 + c] = cur[e];
+            if ((MODE == 1 || MODE == 3) && nsteps > 0)
+                a.out[(size_t)nlast * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+            if (MODE == 0) {
+                const size_t pl = (size_t)NP * NP;
+                double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+                const int col = grp * 8 + (c & 7);
+                pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)NP * col] = v;
+                pr[(size_t)row * 2 * NP + grp * 16 + c] = v;
+            }
+            if (MODE == 2) a.phi[(size_t)b * hstep + (size_t)row * PWc + grp * 16 + c] = v;
         }
-    }
-    if (MODE == 2) {
-        for (int e = tid; e < NP * 16; e += 512)
-            a.phi[(size_t)b * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = cur[e];
     }
 }
 
