@@ -125,8 +125,7 @@ def main():
         back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
                                  stream=torch.cuda.current_stream().cuda_stream)
         dp = qgd.TimePartitioned(back, qgd.TorchComm())
-        dp.timings = back.timings
-        dp.close = back.close
+        dp.timings, dp.close, dp.set_timing = back.timings, back.close, back.set_timing
     else:
         dp = qgd.DeviceProblem(prob, order, device=0)
         dp.set_controls(ctrl)
@@ -138,8 +137,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Untimed: warm-up with every phase bracketed by HIP events -> per-phase breakdown and the
+    # dominant phase.  Bracketing all 13 phases costs ~0.17 ms per evaluation (26 event records),
+    # so the timed region keeps only the pair around the dominant phase (what `roofline` needs).
+    merge = (("sweep_forward2", "sweep_forward"), ("sweep_adjoint2", "sweep_adjoint"))
+    breakdown = {}
+    dp.set_timing(1)
+    nwarm = max(args.warmup, 2)
+    for it in range(nwarm):
         dp.discrete_adjoint(pcof)
+        if it == 0:
+            continue                      # first call pays one-time launch/JIT costs
+        for k, v in dp.timings().items():
+            breakdown[k] = breakdown.get(k, 0.0) + v / (nwarm - 1)
+    known = set(phase_model(1, 1, 1, 1, 2)) | {"sweep_forward2", "sweep_adjoint2"}
+    dom_raw = max((k for k in breakdown if k in known), key=breakdown.get)
+    dp.set_timing(2, dom_raw)
+    dp.discrete_adjoint(pcof)
     phase_ms = {}
     barrier()
     t0 = time.perf_counter()
@@ -157,13 +171,17 @@ def main():
     if rank == 0:
         for k in phase_ms:
             phase_ms[k] /= args.steps
-        for extra, base in (("sweep_forward2", "sweep_forward"), ("sweep_adjoint2", "sweep_adjoint")):
-            if extra in phase_ms:
-                phase_ms[base] = phase_ms.get(base, 0.0) + phase_ms.pop(extra)
         model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1)
-        timed = {k: v for k, v in phase_ms.items() if k in model and v > 0}
-        dom = max(timed, key=timed.get)
+        # the dominant kernel, timed live in the timed region (the two halves of a sweep are separate
+        # launches of the same kernel family: the roofline object is quoted on the one bracketed)
+        dom = dict(merge).get(dom_raw, dom_raw)
+        timed = {dom: phase_ms[dom_raw]}
         bound, work = model[dom]
+        if dom_raw in dict(merge) or dom_raw in dict(merge).values():
+            work *= 0.5
+        for extra, base in merge:
+            if extra in breakdown:
+                breakdown[base] = breakdown.get(base, 0.0) + breakdown.pop(extra)
         if bound == "mfma":
             achieved = work / (timed[dom] * 1e-3) / 1e12
             peak, unit = PEAK_FP64_MATRIX_TFLOPS, "TFLOP/s"
@@ -185,7 +203,7 @@ def main():
             "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": None,
                          "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
-            "phases_ms": {k: round(v, 4) for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
+            "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),
         }

@@ -21,7 +21,7 @@ EXPORTS = [
     "qgd_apply_hamiltonian", "qgd_get_intermediate", "qgd_get_timings",
     "qgd_set_partition", "qgd_get_partition", "qgd_set_stream", "qgd_exchange_buffer",
     "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
-    "qgd_dist_finish",
+    "qgd_dist_finish", "qgd_set_timing",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
     for name in ("qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end"):
         getattr(L, name).argtypes = [C.c_void_p]
     L.qgd_dist_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_set_timing.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
     _lib = L
     return L
 

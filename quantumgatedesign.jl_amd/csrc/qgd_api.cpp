@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,8 @@ struct qgd_handle_s {
     int order = 0, nsteps = 0, device = 0;      // nsteps: GLOBAL number of timesteps
     int part_rank = 0, part_world = 1;
     bool own_stream = true;
+    bool timing = (getenv("QGD_NO_PHASE_TIMING") == nullptr);
+    std::string timing_only;            // when non-empty: only this phase is bracketed by events
     std::string err;
     std::vector<void *> static_bufs, grid_bufs, basis_bufs;
     bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
@@ -77,9 +80,11 @@ double hermite_coefficient(int j, int p, int q) { return factorial(p) * factoria
 inline size_t panel_index(int row, int col, int PWc) { return (size_t)row * PWc + (col >> 3) * 16 + (col & 7); }
 
 struct PhaseTimer {
-    qgd_handle h; size_t idx;
-    PhaseTimer(qgd_handle h_, const char *name) : h(h_)
+    qgd_handle h; size_t idx; bool on;
+    PhaseTimer(qgd_handle h_, const char *name) : h(h_), idx(0), on(h_->timing)
     {
+        if (on && !h->timing_only.empty() && h->timing_only != name) on = false;
+        if (!on) return;
         for (idx = 0; idx < h->phases.size(); idx++) if (!strcmp(h->phases[idx].name, name)) break;
         if (idx == h->phases.size()) {
             Phase p{name, nullptr, nullptr, false};
@@ -89,7 +94,7 @@ struct PhaseTimer {
         h->phases[idx].used = true;
         (void)hipEventRecord(h->phases[idx].e0, h->k.stream);
     }
-    ~PhaseTimer() { (void)hipEventRecord(h->phases[idx].e1, h->k.stream); }
+    ~PhaseTimer() { if (on) (void)hipEventRecord(h->phases[idx].e1, h->k.stream); }
 };
 
 int alloc_grid(qgd_handle h)
@@ -701,6 +706,15 @@ int qgd_dist_finish(qgd_handle h, double *grad, double *out3)
     if (rc) return rc;
     if (grad) HIP_TRY(h, hipMemcpy(grad, h->k.grad, sizeof(double) * h->k.n_pcof, hipMemcpyDeviceToHost));
     if (out3) HIP_TRY(h, hipMemcpy(out3, h->k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return QGD_OK;
+}
+
+int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    h->timing = (mode != 0);
+    h->timing_only = (mode == 2 && phase) ? phase : "";
+    for (auto &p : h->phases) p.used = false;
     return QGD_OK;
 }
 

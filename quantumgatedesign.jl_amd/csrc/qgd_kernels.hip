@@ -1463,6 +1463,8 @@ __global__ __launch_bounds__(256) void k_apply(const double *__restrict__ ops,
 // launchers (called from qgd_api.cpp)
 // ---------------------------------------------------------------------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+// hipFuncSetAttribute once per kernel instantiation (it is a host-side driver call)
+#define SET_LDS_ONCE(fn, bytes) do { static size_t done_ = 0; if ((size_t)(bytes) > done_) { HIPCHK(hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); done_ = (bytes); } } while (0)
 
 extern "C" {
 
@@ -1511,10 +1513,10 @@ int qgdk_inverse(const qgdk_ctx *c)
 {
     const int nmat = c->nt - 1;
     switch (c->Np) {
-    case 16: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2176)); hipLaunchKernelGGL((k_inverse_reg<16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 32: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8448)); hipLaunchKernelGGL((k_inverse_reg<32>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 48: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 18816)); hipLaunchKernelGGL((k_inverse_reg<48>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 64: HIPCHK(hipFuncSetAttribute((const void *)k_inverse_reg<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 33280)); hipLaunchKernelGGL((k_inverse_reg<64>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 16: SET_LDS_ONCE(k_inverse_reg<16>, 2176); hipLaunchKernelGGL((k_inverse_reg<16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 32: SET_LDS_ONCE(k_inverse_reg<32>, 8448); hipLaunchKernelGGL((k_inverse_reg<32>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 48: SET_LDS_ONCE(k_inverse_reg<48>, 18816); hipLaunchKernelGGL((k_inverse_reg<48>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 64: SET_LDS_ONCE(k_inverse_reg<64>, 33280); hipLaunchKernelGGL((k_inverse_reg<64>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
     }
     const size_t pl = (size_t)c->Np * c->Np;

@@ -84,6 +84,9 @@ class DeviceBackend:
     def timings(self):
         return self.dp.timings()
 
+    def set_timing(self, mode, phase=None):
+        self.dp.set_timing(mode, phase)
+
     def close(self):
         self.dp.close()
 

@@ -155,6 +155,10 @@ class DeviceProblem:
             return out.reshape(nt, self.n_ops, self.m, 2)
         return out.reshape(nt, self.m + 1, self.n_ops, 2)
 
+    def set_timing(self, mode, phase=None):
+        """0: no events, 1: every phase (default), 2: only ``phase``."""
+        _lib.check(self.h, self.lib.qgd_set_timing(self.h, int(mode), None if phase is None else phase.encode()))
+
     def timings(self):
         cap = 32
         names = (C.c_char_p * cap)()
