@@ -260,7 +260,7 @@ int adjoint_end(qgd_handle h)
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
     { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
-    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+    if (!h->derivs_valid && qgdk_gradient_needs_derivs(&k)) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
     { PhaseTimer t(h, "gradient"); K_TRY(h, qgdk_gradient(&k)); }
     return QGD_OK;
 }
@@ -512,6 +512,9 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     }
     if ((rc = adjoint_begin(h))) return rc;
     if ((rc = adjoint_end(h))) return rc;
+    if (uv_history && !h->derivs_valid) {   // the fused gradient kernel keeps the derivatives on chip
+        PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true;
+    }
     if ((rc = check_status(h))) return rc;
     HIP_TRY(h, hipMemcpy(grad, k.grad, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
     if (out3) HIP_TRY(h, hipMemcpy(out3, k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));

@@ -67,6 +67,8 @@ int qgdk_adjoint_finish(const qgdk_ctx *c);
 int qgdk_lambda(const qgdk_ctx *c);
 int qgdk_derivs(const qgdk_ctx *c);
 int qgdk_gradient(const qgdk_ctx *c);
+int qgdk_contract(const qgdk_ctx *c);
+int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
 #ifdef __cplusplus

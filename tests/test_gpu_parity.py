@@ -198,3 +198,22 @@ def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
         assert np.abs(o - o_ref).max() <= 1e-12
     for b in backs:
         b.close()
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 10, 12])
+def test_cnot3_gradient_all_orders(qgd, order):
+    """Every instantiation of the N=64 fast-path kernels (fused L/R build and fused gradient kernel
+    for orders 2..10, generic kernels at order 12) against the numpy statement of the algorithm,
+    which tests/test_oracle.py ties to the reference-structured oracle."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=30, tf=15.0)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    shape = (128, 1 + order // 2, 31, 8)
+    hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((128, 31, 8), order="F")
+    grad = np.zeros(len(pcof))
+    qgd.discrete_adjoint_(grad, hist, lam, forcing, prob, ctrl, pcof, target, order=order)
+    assert close(hist, pp.history_real(ref["ws"]), 1e-12)
+    assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
+    grad2 = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)       # without history copy-out
+    assert np.abs(grad2 - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
+    qgd.clear_cache()
