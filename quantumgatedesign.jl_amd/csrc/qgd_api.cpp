@@ -105,13 +105,19 @@ int alloc_grid(qgd_handle h)
     //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
     {
         const int S = h->nsteps, W = h->part_world;
-        int B0 = (int)std::lround(std::sqrt(2.0 * S));
+        // two scan levels: chain length 2*S/B + 2*B/B2 + B2, near its minimum for B ~ S^(2/3), B2 ~ sqrt(2B)
+        int B0 = (int)std::lround(std::pow((double)S, 2.0 / 3.0));
         if (S < 24) B0 = 1;
         if (B0 > 64) B0 = 64;
         if (B0 < 1) B0 = 1;
         k.bpr = (B0 + W - 1) / W;
-        k.scan_blocks = k.bpr * W;
-        k.scan_blen = (S + k.scan_blocks - 1) / k.scan_blocks;
+        for (;;) {   // every rank must own at least one non-empty block
+            k.scan_blocks = k.bpr * W;
+            k.scan_blen = (S + k.scan_blocks - 1) / k.scan_blocks;
+            const int nonempty = (S + k.scan_blen - 1) / k.scan_blen;
+            if ((W - 1) * k.bpr < nonempty || k.bpr == 1) break;
+            k.bpr--;
+        }
         k.part_rank = h->part_rank; k.part_world = W;
         k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr; k.blk_hi_clamped = k.blk_hi;
         const int s_lo = k.blk_lo * k.scan_blen;
@@ -119,6 +125,11 @@ int alloc_grid(qgd_handle h)
         if (s_lo >= S) return fail(h, QGD_ERR_UNSUPPORTED, "too few timesteps for this many ranks (a rank would own no step)");
         k.n_off = s_lo; k.nt = s_hi - s_lo + 1; k.nt_glob = S + 1;
         k.dt = k.tf / S;
+        if (k.scan_blocks > 8) {
+            int B2 = (int)std::lround(std::sqrt(2.0 * k.scan_blocks));
+            k.scan_g = (k.scan_blocks + B2 - 1) / B2;
+            k.scan_blocks2 = (k.scan_blocks + k.scan_g - 1) / k.scan_g;
+        } else { k.scan_blocks2 = 1; k.scan_g = k.scan_blocks; }
     }
     const size_t Np = k.Np, PW = 2 * Np, PWc = 2 * k.cp, nt = k.nt, m = k.m;
     const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
@@ -145,6 +156,12 @@ int alloc_grid(qgd_handle h)
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.psi0, hstep))) return rc;
+        const size_t nb2 = (size_t)k.scan_blocks2;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiC2, nb2 * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiR2, nb2 * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.phi2, nb2 * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd2, (nb2 + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY2, (nb2 + 1) * hstep))) return rc;
         HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     }
     // inverse work slabs when the matrix does not fit in LDS

@@ -45,6 +45,9 @@ typedef struct qgdk_ctx {
     double *psi0;       // initial panel [Np][2cp]
     double *redbuf;     // [n_pcof + 4]: grad followed by scal (one all-reduce)
     int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped;
+    // second scan level over the block propagators: scan_blocks2 super-blocks of scan_g blocks
+    int scan_blocks2, scan_g;
+    double *PiC2, *PiR2, *phi2, *bnd2, *bndY2;
     int part_rank, part_world, n_off, nt_glob;
     int *status;
     double cw_host[2 * 20];

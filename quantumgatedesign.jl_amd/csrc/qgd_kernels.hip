@@ -544,19 +544,20 @@ __global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
 // ty*BS.. and columns tx*BS.. (BS = Np/16).  Per pivot only the pivot column, the pivot
 // row and the swapped row travel through LDS (2 barriers); the rank-1 update is local.
 // ---------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(256) void k_inverse_reg(const double *__restrict__ L,
+template <int NP, int TG>
+__global__ __launch_bounds__(TG * TG) void k_inverse_reg(const double *__restrict__ L,
                                                      double *__restrict__ LinvA,
                                                      double *__restrict__ LinvT, int n0,
                                                      int *__restrict__ status)
 {
-    constexpr int BS = NP / 16;
+    constexpr int BS = NP / TG, NTH = TG * TG;   // TG x TG threads, BS x BS block each
+    static_assert(BS * TG == NP && BS <= 8, "block");
     __shared__ double colre[2][NP], colim[2][NP];
     __shared__ double rowre[2][2][NP], rowim[2][2][NP];
     __shared__ int perm[NP], outpos[NP], idx[NP];
     __shared__ double pivinv[2][2];
     const int n = n0 + blockIdx.x;
-    const int t = threadIdx.x, ty = t >> 4, tx = t & 15, lane = t & 63;
+    const int t = threadIdx.x, ty = t / TG, tx = t % TG, lane = t & 63;
     constexpr int PW = 2 * NP;
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
     const double *Ln = L + (size_t)n * panel;
@@ -576,7 +577,11 @@ __global__ __launch_bounds__(256) void k_inverse_reg(const double *__restrict__ 
     case 0: { constexpr int I = 0; STMT } break; \
     case 1: { constexpr int I = (1 < BS) ? 1 : 0; STMT } break; \
     case 2: { constexpr int I = (2 < BS) ? 2 : 0; STMT } break; \
-    default: { constexpr int I = (3 < BS) ? 3 : 0; STMT } break; }
+    case 3: { constexpr int I = (3 < BS) ? 3 : 0; STMT } break; \
+    case 4: { constexpr int I = (4 < BS) ? 4 : 0; STMT } break; \
+    case 5: { constexpr int I = (5 < BS) ? 5 : 0; STMT } break; \
+    case 6: { constexpr int I = (6 < BS) ? 6 : 0; STMT } break; \
+    default: { constexpr int I = (7 < BS) ? 7 : 0; STMT } break; }
     for (int p = 0; p < NP; p++) {
         const int buf = p & 1;
         const int pblk = p / BS, poff = p % BS;        // uniform
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(256) void k_inverse_reg(const double *__restrict__ 
             for (int i = 0; i < BS; i++) stage[(ty * BS + i) * LDP + oc] = pass ? aim[i][j] : are[i][j];
         }
         __syncthreads();
-        for (int e = t; e < NP * NP; e += 256) {
+        for (int e = t; e < NP * NP; e += NTH) {
             const int hi = e / NP, lo = e % NP;       // NP is a compile-time constant
             T[pass * pl + e] = stage[hi * LDP + lo];  // row-major: (r=hi, c=lo)
             A[pass * pl + e] = stage[lo * LDP + hi];  // column-major: (r=lo, c=hi)
@@ -1731,10 +1736,11 @@ int qgdk_inverse(const qgdk_ctx *c)
 {
     const int nmat = c->nt - 1;
     switch (c->Np) {
-    case 16: SET_LDS_ONCE(k_inverse_reg<16>, 2176); hipLaunchKernelGGL((k_inverse_reg<16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 32: SET_LDS_ONCE(k_inverse_reg<32>, 8448); hipLaunchKernelGGL((k_inverse_reg<32>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 48: SET_LDS_ONCE(k_inverse_reg<48>, 18816); hipLaunchKernelGGL((k_inverse_reg<48>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 64: SET_LDS_ONCE(k_inverse_reg<64>, 33280); hipLaunchKernelGGL((k_inverse_reg<64>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 16: SET_LDS_ONCE((k_inverse_reg<16, 16>), 2176); hipLaunchKernelGGL((k_inverse_reg<16, 16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 64:   // (a one-wave variant, <64, 8>, measured 0.35 ms vs 0.22 ms: latency-bound at one wave per SIMD)
+        SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
     }
     const size_t pl = (size_t)c->Np * c->Np;
@@ -1783,17 +1789,35 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
     return launch_chain<0>(a, c->stream);
 }
 
-// forward, phases (ii)+(iii): boundary states over ALL blocks (every rank), then the owned blocks
+// forward, phases (ii)+(iii): boundary states over ALL blocks (every rank), then the owned blocks.
+// Phase (ii) is itself a scan over the B block propagators when B is large (second level:
+// super-blocks of scan_g blocks): chain length g + B2 + g instead of B.
 int qgdk_forward_finish(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    const int B = c->scan_blocks;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    int rc;
     HIPCHK(hipMemcpyAsync(c->bnd, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    ChainArgs s2{};
-    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
-    s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
-    int rc = launch_chain<1>(s2, c->stream);
-    if (rc) return rc;
+    if (B2 <= 1) {
+        ChainArgs s2{};
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(s2, c->stream))) return rc;
+    } else {
+        ChainArgs a2{};   // (ii-a) super-block propagators from the block propagators
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
+        a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+        HIPCHK(hipMemcpyAsync(c->bnd2, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        ChainArgs b2{};   // (ii-b) states at super-block starts
+        b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiC2; b2.start = c->bnd2; b2.start_stride = 0; b2.out = c->bnd2;
+        b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(b2, c->stream))) return rc;
+        ChainArgs c2{};   // (ii-c) states at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = c->PiX; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
+        c2.start = c->bnd2; c2.start_stride = (long long)hstep; c2.out = c->bnd; c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(c2, c->stream))) return rc;
+    }
     HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
     s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
@@ -1841,20 +1865,37 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     return 0;
 }
 
-// adjoint, phases (ii)+(iii)
+// adjoint, phases (ii)+(iii); phase (ii) two-level like the forward one
 int qgdk_adjoint_finish(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    const int B = c->scan_blocks;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
     const double *yN = c->phiX + (size_t)(c->part_world - 1) * phix_chunk(c) + (size_t)c->bpr * hstep;
+    const double *PiRx = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np;      // panel copies inside the chunks
+    int rc;
     HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    ChainArgs s2{};
-    s2.Np = c->Np; s2.cp = c->cp; s2.S = B;
-    s2.Pmat = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
-    s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0; s2.out = c->bndY;
-    s2.forcing = c->phiX; s2.f_bpr = c->bpr; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
-    int rc = launch_chain<3>(s2, c->stream);
-    if (rc) return rc;
+    if (B2 <= 1) {
+        ChainArgs s2{};
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = PiRx; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0; s2.out = c->bndY;
+        s2.forcing = c->phiX; s2.f_bpr = c->bpr; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(s2, c->stream))) return rc;
+    } else {
+        ChainArgs a2{};   // (ii-a) affine parts of the super-blocks (their propagators PiR2 come from the forward sweep)
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
+        a2.forcing = c->phiX; a2.f_bpr = c->bpr; a2.phi = c->phi2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<2>(a2, c->stream))) return rc;
+        HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        ChainArgs b2{};   // (ii-b) y at super-block starts
+        b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiR2; b2.start = c->bndY2 + (size_t)B2 * hstep; b2.start_stride = 0;
+        b2.out = c->bndY2; b2.forcing = c->phi2; b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(b2, c->stream))) return rc;
+        ChainArgs c2{};   // (ii-c) y at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = PiRx; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
+        c2.start = c->bndY2 + hstep; c2.start_stride = (long long)hstep; c2.out = c->bndY; c2.forcing = c->phiX; c2.f_bpr = c->bpr;
+        c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(c2, c->stream))) return rc;
+    }
     // y at the end of this rank's window
     HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
                           hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

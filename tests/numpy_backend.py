@@ -12,13 +12,18 @@ import proto_propagator as pp
 
 def partition(S, world, rank):
     """Same rule as alloc_grid() in csrc/qgd_api.cpp."""
-    B0 = int(round(math.sqrt(2.0 * S)))
+    B0 = int(round(S ** (2.0 / 3.0)))
     if S < 24:
         B0 = 1
     B0 = max(1, min(64, B0))
     bpr = (B0 + world - 1) // world
-    B = bpr * world
-    blen = (S + B - 1) // B
+    while True:   # every rank must own at least one non-empty block
+        B = bpr * world
+        blen = (S + B - 1) // B
+        nonempty = (S + blen - 1) // blen
+        if (world - 1) * bpr < nonempty or bpr == 1:
+            break
+        bpr -= 1
     blk_lo, blk_hi = rank * bpr, (rank + 1) * bpr
     s_lo, s_hi = blk_lo * blen, min(S, blk_hi * blen)
     assert s_lo < S, "rank would own no step"
