@@ -162,7 +162,9 @@ int alloc_grid(qgd_handle h)
         if ((rc = dev_alloc(h, h->grid_bufs, &k.phi2, nb2 * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd2, (nb2 + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY2, (nb2 + 1) * hstep))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(k.bnd2, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
         HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+        HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
@@ -176,6 +178,8 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipMemsetAsync(k.yhist, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.forcing, 0, nt * hstep * sizeof(double), k.stream));
+    if (k.blk_lo == 0)   // the first window starts at the (constant) initial state
+        HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     // Hermite weights c_j dt^j and c_j (-dt)^j  (hermite.jl:398-399, :422-423)
     for (int j = 0; j <= k.m; j++) {
         double cj = hermite_coefficient(j, k.m, k.m);
@@ -241,8 +245,10 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
     } else if (!h->have_tables && k.n_ops > 0) {
         return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
     }
-    HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));
-    HIP_TRY(h, hipMemsetAsync(k.status, 0, sizeof(int), k.stream));
+    if (!pcof) {   // (with pcof, k_tables clears them)
+        HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));
+        HIP_TRY(h, hipMemsetAsync(k.status, 0, sizeof(int), k.stream));
+    }
     { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
     { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
     { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }

@@ -91,9 +91,11 @@ __device__ __forceinline__ void load_coef(OpCoef &cf, const double *__restrict__
 __global__ void k_tables(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
                          const double *__restrict__ pcof, double *__restrict__ tab, int nt, int m,
-                         int n_ops)
+                         int n_ops, double *__restrict__ scal, int *__restrict__ status)
 {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 4) scal[idx] = 0.0;            // objective scalars and the singularity flag start at zero
+    if (idx == 4) *status = 0;
     int total = nt * (m + 1) * n_ops * 2;
     if (idx >= total) return;
     int pq = idx & 1;
@@ -1159,7 +1161,9 @@ __global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ his
                                                   const double *__restrict__ forcing,
                                                   double *__restrict__ yhist,
                                                   double *__restrict__ scal, int Np, int cp, int nt,
-                                                  int n_ess, int have_target, int write_y)
+                                                  int n_ess, int have_target, int write_y,
+                                                  double *__restrict__ y2, double *__restrict__ y3,
+                                                  double *__restrict__ y4)
 {
     __shared__ double red[8];
     const int PWc = 2 * cp;
@@ -1191,7 +1195,8 @@ __global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ his
         const int c16 = (e % PWc) & 15;
         const double tv = target[e], tp = target[e ^ 8];
         const double Tv = (c16 < 8) ? tp : -tp;        // T component at this slot
-        y[e] = sc * (a * tv + b * Tv) + f[e];
+        const double v = sc * (a * tv + b * Tv) + f[e];
+        y[e] = v; y2[e] = v; y3[e] = v; y4[e] = v;    // history, exchange slot, boundary arrays
     }
 }
 
@@ -1200,8 +1205,16 @@ __global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ his
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT,
                                                 const double *__restrict__ yhist,
-                                                double *__restrict__ lam, int Np, int cp)
+                                                double *__restrict__ lam, int Np, int cp,
+                                                double *__restrict__ zero_a, int n_a,
+                                                double *__restrict__ zero_b, int n_b)
 {
+    {   // the gradient kernels accumulate into sigma and grad: clear them here (saves two fills)
+        const int gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const int gsz = gridDim.x * gridDim.y * blockDim.x;
+        for (int e = gid; e < n_a; e += gsz) zero_a[e] = 0.0;
+        for (int e = gid; e < n_b; e += gsz) zero_b[e] = 0.0;
+    }
     extern __shared__ double smem[];
     double *ys = smem;                                   // [Np][16]
     const int n = blockIdx.y + 1, grp = blockIdx.x;
@@ -1694,8 +1707,8 @@ extern "C" {
 int qgdk_tables(const qgdk_ctx *c, const double *pcof)
 {
     int total = c->nt * (c->m + 1) * c->n_ops * 2;
-    hipLaunchKernelGGL(k_tables, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
-                       c->poff, pcof, c->tab, c->nt, c->m, c->n_ops);
+    hipLaunchKernelGGL(k_tables, dim3((total + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
+                       c->poff, pcof, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
     return (int)hipGetLastError();
 }
 
@@ -1797,7 +1810,7 @@ int qgdk_forward_finish(const qgdk_ctx *c)
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
     int rc;
-    HIPCHK(hipMemcpyAsync(c->bnd, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    // bnd[0] = bnd2[0] = psi_0 were written when the grid was allocated (the initial state is constant)
     if (B2 <= 1) {
         ChainArgs s2{};
         s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
@@ -1808,7 +1821,6 @@ int qgdk_forward_finish(const qgdk_ctx *c)
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
         if ((rc = launch_chain<0>(a2, c->stream))) return rc;
-        HIPCHK(hipMemcpyAsync(c->bnd2, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         ChainArgs b2{};   // (ii-b) states at super-block starts
         b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiC2; b2.start = c->bnd2; b2.start_stride = 0; b2.out = c->bnd2;
         b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
@@ -1818,7 +1830,8 @@ int qgdk_forward_finish(const qgdk_ctx *c)
         c2.start = c->bnd2; c2.start_stride = (long long)hstep; c2.out = c->bnd; c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
         if ((rc = launch_chain<1>(c2, c->stream))) return rc;
     }
-    HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (c->blk_lo > 0)   // rank 0's hist[0] = psi_0 is constant
+        HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
     s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
     s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = c->blk_hi - c->blk_lo; s3.blen = c->scan_blen;
@@ -1841,8 +1854,11 @@ int qgdk_guard(const qgdk_ctx *c)
 
 int qgdk_terminal(const qgdk_ctx *c, int write_y)
 {
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
-                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y);
+                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
+                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep);
     return (int)hipGetLastError();
 }
 
@@ -1857,11 +1873,8 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
     int rc = launch_chain<2>(a, c->stream);
     if (rc) return rc;
-    if (c->part_rank == c->part_world - 1)
-        HIPCHK(hipMemcpyAsync(own + (size_t)c->bpr * hstep, c->yhist + (size_t)(c->nt - 1) * hstep, hstep * sizeof(double),
-                              hipMemcpyDeviceToDevice, c->stream));
-    else
-        HIPCHK(hipMemsetAsync(own + (size_t)c->bpr * hstep, 0, hstep * sizeof(double), c->stream));
+    // the last rank's k_terminal wrote y_N into its extra slot (and into bndY/bndY2/yhist) directly;
+    // the other ranks' extra slots are never read
     return 0;
 }
 
@@ -1873,7 +1886,8 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
     const double *yN = c->phiX + (size_t)(c->part_world - 1) * phix_chunk(c) + (size_t)c->bpr * hstep;
     const double *PiRx = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np;      // panel copies inside the chunks
     int rc;
-    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const bool last = (c->part_rank == c->part_world - 1);
+    if (!last) HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (B2 <= 1) {
         ChainArgs s2{};
         s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = PiRx; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
@@ -1885,7 +1899,7 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
         a2.forcing = c->phiX; a2.f_bpr = c->bpr; a2.phi = c->phi2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
         if ((rc = launch_chain<2>(a2, c->stream))) return rc;
-        HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (!last) HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         ChainArgs b2{};   // (ii-b) y at super-block starts
         b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiR2; b2.start = c->bndY2 + (size_t)B2 * hstep; b2.start_stride = 0;
         b2.out = c->bndY2; b2.forcing = c->phi2; b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
@@ -1897,8 +1911,9 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
         if ((rc = launch_chain<3>(c2, c->stream))) return rc;
     }
     // y at the end of this rank's window
-    HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
-                          hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (!last)
+        HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
+                              hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
     s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.start = c->bndY + (size_t)(c->blk_lo + 1) * hstep;
     s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = c->blk_hi - c->blk_lo;
@@ -1910,7 +1925,7 @@ int qgdk_lambda(const qgdk_ctx *c)
 {
     size_t shm = (size_t)c->Np * 16 * sizeof(double);
     hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
-                       c->Np, c->cp);
+                       c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof);
     return (int)hipGetLastError();
 }
 
@@ -1928,7 +1943,6 @@ int qgdk_derivs(const qgdk_ctx *c)
 int qgdk_gradient(const qgdk_ctx *c)
 {
     size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
-    HIPCHK(hipMemsetAsync(c->sigma, 0, (size_t)c->nt * c->n_ops * c->m * 2 * sizeof(double), c->stream));
     if (c->Np == 64 && c->m <= 5 && c->n_ops >= 1) {
         int rc = 0;
         switch (c->m) {
@@ -1951,7 +1965,6 @@ int qgdk_gradient(const qgdk_ctx *c)
 
 int qgdk_contract(const qgdk_ctx *c)
 {
-    HIPCHK(hipMemsetAsync(c->grad, 0, (size_t)c->n_pcof * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_contract, dim3((c->nt + CT_CHUNK - 1) / CT_CHUNK, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
                        c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
     return (int)hipGetLastError();
