@@ -16,4 +16,5 @@ from .evolution import (DeviceProblem, device_problem, clear_cache, eval_forward
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)
 from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup
+from .optimize import optimize_gate, OptimizationHistory
 from . import _lib

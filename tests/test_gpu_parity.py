@@ -217,3 +217,24 @@ def test_cnot3_gradient_all_orders(qgd, order):
     grad2 = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)       # without history copy-out
     assert np.abs(grad2 - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
     qgd.clear_cache()
+
+
+def test_optimize_gate_rabi_swap(qgd):
+    """The reference's end-to-end test (test/OptimizationTests/optimization_rabi_osc_SWAP.jl:18-39):
+    from 25 starts around the analytic optimum, optimize_gate(order=8, ridge 0) must return
+    pcof ~ [0.5, 0] with rtol 5e-4 (Julia isapprox on the vector norm)."""
+    prob = qgd.construct_rabi_prob(tf=np.pi, nsteps=20)
+    control = qgd.GRAPEControl(1, prob.tf)
+    target = np.array([[0.0, 1.0], [1.0, 0.0]])
+    opt = np.array([0.5, 0.0])
+    for p0 in np.linspace(0.4, 0.6, 5):
+        for q0 in np.linspace(-0.1, 0.1, 5):
+            hist = qgd.optimize_gate(prob, control, np.array([p0, q0]), target, order=8,
+                                     ridge_penalty_strength=0, print_level=0)
+            final = hist.pcof[-1]
+            # |Omega| = 1/2 is a circle of optima; the reference's tolerance is on the distance to [0.5, 0]
+            assert abs(np.hypot(*final) - 0.5) < 1e-4, (p0, q0, final)
+            assert hist.analytic_obj_value[-1] < 1e-6
+            if abs(q0) < 1e-12:
+                assert np.linalg.norm(final - opt) <= 5e-4 * 0.5, (p0, q0, final)
+    qgd.clear_cache()
