@@ -117,6 +117,13 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
                          int32_t history_precomputed, double *grad, double *uv_history,
                          double *lambda_history, double *adjoint_forcing, double *out3);
 
+/* eval_adjoint (src/forward_evolution.jl:300-315, per column :352-483): backward sweep from a
+ * caller-given terminal lambda_N [2N, n_cols] with optional forcing [2N, 1+nsteps, n_cols];
+ * lambda_history [2N, 1+m, 1+nsteps, n_cols] receives lambda_n in column j=0 (time index 0 stays
+ * zero, as in the reference). */
+int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const double *terminal_condition,
+                     const double *forcing, double *lambda_history);
+
 /* Unit-test hook for the Hamiltonian application (hermite.jl:556-588) batched
  * over columns: out = A_d(t_n) * in  (or -A_d = A_d^T with use_adjoint), using
  * the control tables currently on the device.  in/out: 2N x n_cols. */

@@ -156,6 +156,8 @@ int alloc_grid(qgd_handle h)
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.psi0, hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.zero_panel, hstep))) return rc;
+        HIP_TRY(h, hipMemsetAsync(k.zero_panel, 0, hstep * sizeof(double), k.stream));
         const size_t nb2 = (size_t)k.scan_blocks2;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.PiC2, nb2 * 2 * pl))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.PiR2, nb2 * 2 * pl))) return rc;
@@ -566,6 +568,56 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             }
         }
     }
+    return QGD_OK;
+}
+
+int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const double *terminal_condition,
+                     const double *forcing, double *lambda_history)
+{
+    if (!h || !terminal_condition || !lambda_history) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: eval_adjoint is single-GPU");
+    int rc = forward_begin(h, pcof, n_pcof);          // tables, L/R, inverses, propagators, block propagators
+    if (rc) return rc;
+    // the second scan level (super-block propagators) is produced by the forward boundary phase
+    { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
+    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, nt = k.nt, N = k.N, n2 = 2 * N, m = k.m;
+    // forcing [2N, nt, c] and terminal condition [2N, c] into panel layout
+    std::vector<double> f(nt * hstep, 0.0), lamN(hstep, 0.0);
+    for (size_t col = 0; col < (size_t)k.c; col++) {
+        for (size_t i = 0; i < N; i++) {
+            size_t o = panel_index((int)i, (int)col, (int)PWc);
+            lamN[o] = terminal_condition[i + n2 * col];
+            lamN[o + 8] = terminal_condition[N + i + n2 * col];
+        }
+        if (forcing)
+            for (size_t n = 0; n < nt; n++) for (size_t i = 0; i < N; i++) {
+                size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
+                const double *src = forcing + (col * nt + n) * n2;
+                f[o] = src[i]; f[o + 8] = src[N + i];
+            }
+    }
+    HIP_TRY(h, hipMemcpyAsync(k.forcing, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    HIP_TRY(h, hipMemcpyAsync(k.lam + (nt - 1) * hstep, lamN.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    // y_N = L(t_N)^H lambda_N  (the terminal condition is lambda itself here, forward_evolution.jl:411-414)
+    K_TRY(h, qgdk_apply_LH(&k));
+    if ((rc = adjoint_begin(h))) return rc;
+    { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
+    { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+    if ((rc = check_status(h))) return rc;
+    std::vector<double> l(nt * hstep);
+    HIP_TRY(h, hipMemcpy(l.data(), k.lam, l.size() * sizeof(double), hipMemcpyDeviceToHost));
+    memset(lambda_history, 0, sizeof(double) * n2 * (m + 1) * nt * k.c);
+    for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 1; n < nt; n++) {
+        double *dst = lambda_history + ((col * nt + n) * (m + 1)) * n2;
+        const double *src = (n == nt - 1) ? lamN.data() : l.data() + n * hstep;   // lambda_N is the given one
+        for (size_t i = 0; i < N; i++) {
+            size_t o = panel_index((int)i, (int)col, (int)PWc);
+            dst[i] = src[o]; dst[N + i] = src[o + 8];
+        }
+    }
+    h->forward_valid = false;   // the state history was not computed
     return QGD_OK;
 }
 

@@ -43,6 +43,7 @@ typedef struct qgdk_ctx {
     double *phiX;       // exchange buffer: per rank [bpr x phi | y_N], Np*2cp doubles each
     double *bnd, *bndY; // [B+1][Np][2cp] states at block boundaries (every rank holds all)
     double *psi0;       // initial panel [Np][2cp]
+    double *zero_panel; // [Np][2cp] of zeros
     double *redbuf;     // [n_pcof + 4]: grad followed by scal (one all-reduce)
     int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped;
     // second scan level over the block propagators: scan_blocks2 super-blocks of scan_g blocks
@@ -67,6 +68,7 @@ int qgdk_guard(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
 int qgdk_adjoint_blocks(const qgdk_ctx *c);
 int qgdk_adjoint_finish(const qgdk_ctx *c);
+int qgdk_apply_LH(const qgdk_ctx *c);
 int qgdk_lambda(const qgdk_ctx *c);
 int qgdk_derivs(const qgdk_ctx *c);
 int qgdk_gradient(const qgdk_ctx *c);

@@ -1878,6 +1878,25 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     return 0;
 }
 
+// y_N = L(t_N)^H lambda_N for a caller-given terminal lambda (eval_adjoint): one adjoint chain step with
+// the panel of L_N as the step matrix; the result goes to every place k_terminal would write y_N
+int qgdk_apply_LH(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp, panel = (size_t)c->Np * 2 * c->Np;
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = 1; a.Pmat = c->L + (size_t)(c->nt - 1) * panel;
+    a.start = c->lam + (size_t)(c->nt - 1) * hstep; a.start_stride = 0; a.out = c->yhist + (size_t)(c->nt - 1) * hstep;
+    a.forcing = c->zero_panel; a.nblocks = 1; a.blen = 1; a.ngroups = c->cp / 8;
+    int rc = launch_chain<3>(a, c->stream);
+    if (rc) return rc;
+    const double *yN = c->yhist + (size_t)(c->nt - 1) * hstep;
+    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
+    HIPCHK(hipMemcpyAsync(slot, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)c->scan_blocks * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)c->scan_blocks2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 // adjoint, phases (ii)+(iii); phase (ii) two-level like the forward one
 int qgdk_adjoint_finish(const qgdk_ctx *c)
 {

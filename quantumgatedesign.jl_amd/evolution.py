@@ -135,6 +135,17 @@ class DeviceProblem:
             None if adjoint_forcing is None else _vp(adjoint_forcing), _vp(out3)))
         return grad, out3
 
+    def eval_adjoint(self, pcof, terminal_condition, forcing=None):
+        pc = np.ascontiguousarray(pcof, dtype=np.float64)
+        term = _f(terminal_condition).reshape(2 * self.N, self.c, order="F")
+        fo = None if forcing is None else _f(forcing)
+        if fo is not None and fo.shape != (2 * self.N, self.nsteps + 1, self.c):
+            raise ValueError(f"forcing must have shape {(2 * self.N, self.nsteps + 1, self.c)}")
+        lam = np.zeros((2 * self.N, self.m + 1, self.nsteps + 1, self.c), order="F")
+        _lib.check(self.h, self.lib.qgd_eval_adjoint(self.h, _vp(pc), len(pc), _vp(term),
+                                                     None if fo is None else _vp(fo), _vp(lam)))
+        return lam
+
     def apply_hamiltonian(self, w, time_index=0, derivative_order=0, use_adjoint=False):
         w = _f(w).reshape(2 * self.N, self.c, order="F")
         out = np.zeros_like(w, order="F")
@@ -220,6 +231,15 @@ def eval_forward(prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None)
     hist = np.zeros(_history_shape(prob, order), order="F")
     eval_forward_(hist, prob, controls, pcof, order=order, saveEveryNsteps=saveEveryNsteps, forcing=forcing)
     return real_to_complex(hist[:, 0, :, :])
+
+
+def eval_adjoint(prob, controls, pcof, terminal_condition, order=2, forcing=None):
+    """QuantumGateDesign.eval_adjoint (forward_evolution.jl:300-315), used by the reference's scripts
+    (examples/cnot2_optimization.jl:56, regression.jl:49): lambda history ``[2N, 1+order/2, 1+nsteps, c]``
+    from a given terminal condition; column j=0 holds lambda_n (the only column the package consumes)."""
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    return dp.eval_adjoint(pcof, terminal_condition, forcing)
 
 
 def infidelity_real(psi, target, N_ess):

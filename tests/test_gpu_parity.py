@@ -238,3 +238,20 @@ def test_optimize_gate_rabi_swap(qgd):
             if abs(q0) < 1e-12:
                 assert np.linalg.norm(final - opt) <= 5e-4 * 0.5, (p0, q0, final)
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("which,order", [("cnot2", 4), ("guarded", 8), ("cnot3", 8)])
+def test_eval_adjoint_vs_oracle(qgd, orc, which, order):
+    """eval_adjoint from a given terminal condition with forcing (forward_evolution.jl:352-483)."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    rng = np.random.default_rng(8)
+    n2, c, nt = prob.real_system_size, prob.N_initial_conditions, prob.nsteps + 1
+    term = rng.standard_normal((n2, c))
+    forcing = 0.1 * rng.standard_normal((n2, nt, c))
+    ref = orc.eval_adjoint(prob, ctrl, pcof, term, order=order, forcing=forcing)
+    got = qgd.eval_adjoint(prob, ctrl, pcof, term, order=order, forcing=forcing)
+    assert close(got[:, 0], ref[:, 0], 1e-10)
+    got0 = qgd.eval_adjoint(prob, ctrl, pcof, np.vstack([prob.u0, prob.v0]), order=order)      # as regression.jl:46-49
+    ref0 = orc.eval_adjoint(prob, ctrl, pcof, np.vstack([prob.u0, prob.v0]), order=order)
+    assert close(got0[:, 0], ref0[:, 0], 1e-10)
+    qgd.clear_cache()
