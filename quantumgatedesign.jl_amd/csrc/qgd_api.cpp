@@ -168,6 +168,12 @@ int alloc_grid(qgd_handle h)
         HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
         HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     }
+    // derivative / gradient kernels: panels in LDS when they fit, otherwise slabs of HBM scratch
+    k.panel_scratch = nullptr;
+    if (qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS")) {
+        const size_t slabs = nt * (size_t)(k.cp / 8);
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16))) return rc;
+    }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
     if (need > 150 * 1024) {
@@ -350,9 +356,9 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     k.N = N; k.Np = (N + 15) / 16 * 16; k.c = c; k.cp = (c + 7) / 8 * 8;
     k.n_ops = n_ops; k.n_ess = d->n_ess; k.m = d->order / 2;
     h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps; k.nt = d->nsteps + 1;
-    if (qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024) {
+    if ((size_t)2 * k.Np * 16 * sizeof(double) > 150 * 1024) {
         delete h;
-        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N*order too large for the LDS-resident derivative kernels of this version");
+        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N too large for the sweep kernels of this version (N <= 4608)");
     }
 #define CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e__); qgd_destroy(h); return fail(nullptr, QGD_ERR_NO_DEVICE, m_); } } while (0)
 #define CREATE_RC(expr) do { int rc__ = (expr); if (rc__) { std::string m_ = h->err; qgd_destroy(h); return fail(nullptr, rc__, m_); } } while (0)

@@ -37,6 +37,7 @@ typedef struct qgdk_ctx {
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *inv_scratch;
+    double *panel_scratch; // large N: per-workgroup panel slabs of k_derivs/k_gradsweep in HBM instead of LDS
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.
     double *PiX;        // exchange buffer: per rank [bpr x PiC | bpr x PiR], 2*Np*Np doubles each

@@ -1257,10 +1257,12 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
                                                 const double *__restrict__ tab,
                                                 const double *__restrict__ hist,
                                                 double *__restrict__ dpsi, int Np, int cp,
-                                                int n_ops, int m)
+                                                int n_ops, int m, double *__restrict__ gpanels)
 {
-    extern __shared__ double smem[];                    // (m+1) panels [Np][16]
+    extern __shared__ double lds_panels[];              // (m+1) panels [Np][16] ...
     const int n = blockIdx.y, grp = blockIdx.x;
+    // ... or, when they do not fit in LDS (large N), a slab of global scratch per workgroup
+    double *smem = gpanels ? gpanels + ((size_t)n * gridDim.x + grp) * (size_t)(m + 1) * Np * 16 : lds_panels;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -1268,6 +1270,7 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
     const size_t ps = (size_t)Np * 16;
     for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
         smem[e] = hist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __threadfence_block();
     __syncthreads();
     for (int j = 0; j < m; j++) {
         for (int rb = wave; rb * 16 < Np; rb += nw) {
@@ -1294,6 +1297,7 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
                 dpsi[(((size_t)n * m + j) * Np + row) * PWc + grp * 16 + c16] = v;
             }
         }
+        __threadfence_block();
         __syncthreads();
     }
 }
@@ -1316,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
                                                    const double *__restrict__ lam,
                                                    double *__restrict__ sigma,
                                                    const double *__restrict__ cw, int Np, int cp,
-                                                   int n_ops, int m, int nt)
+                                                   int n_ops, int m, int nt, double *__restrict__ gpanels)
 {
     extern __shared__ double smem[];     // psi_0..psi_{m-1} (m panels), g_1..g_m (m panels), sig[n_ops*m*2]
     const int n = blockIdx.y, grp = blockIdx.x;
@@ -1325,8 +1329,10 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int c16 = lane & 15, kk = lane >> 4;
     const size_t ps = (size_t)Np * 16;
-    double *psi = smem, *gs = smem + (size_t)m * ps;   // gs[(j-1)*ps]
-    double *sig = gs + (size_t)m * ps;
+    // panels in LDS, or (large N) in a slab of global scratch per workgroup; sig always in LDS
+    double *pbase = gpanels ? gpanels + ((size_t)n * gridDim.x + grp) * (size_t)(2 * m) * Np * 16 : smem;
+    double *psi = pbase, *gs = pbase + (size_t)m * ps;   // gs[(j-1)*ps]
+    double *sig = gpanels ? smem : gs + (size_t)m * ps;
     const size_t pl = (size_t)Np * Np;
 
     for (int e = threadIdx.x; e < Np * 16; e += blockDim.x) {
@@ -1338,6 +1344,7 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
         for (int j = 1; j <= m; j++) gs[(size_t)(j - 1) * ps + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
     }
     for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    __threadfence_block();
     __syncthreads();
 
     // reverse sweep
@@ -1364,6 +1371,7 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
                 }
             }
         }
+        __threadfence_block();
         __syncthreads();
     }
 
@@ -1951,9 +1959,11 @@ int qgdk_lambda(const qgdk_ctx *c)
 int qgdk_derivs(const qgdk_ctx *c)
 {
     size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
+    double *gp = nullptr;
+    if (c->panel_scratch) { gp = c->panel_scratch; shm = 0; }
 #define CALL_DV(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_derivs<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((k_derivs<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi, \
-                           c->Np, c->cp, c->n_ops, c->m); } while (0)
+                           c->Np, c->cp, c->n_ops, c->m, gp); } while (0)
     DISPATCH_NOPS(c->n_ops, CALL_DV)
 #undef CALL_DV
     return (int)hipGetLastError();
@@ -1962,6 +1972,8 @@ int qgdk_derivs(const qgdk_ctx *c)
 int qgdk_gradient(const qgdk_ctx *c)
 {
     size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
+    double *gp = nullptr;
+    if (c->panel_scratch) { gp = c->panel_scratch; shm = (size_t)c->n_ops * c->m * 2 * sizeof(double); }
     if (c->Np == 64 && c->m <= 5 && c->n_ops >= 1) {
         int rc = 0;
         switch (c->m) {
@@ -1976,7 +1988,7 @@ int qgdk_gradient(const qgdk_ctx *c)
     }
 #define CALL_GS(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_gradsweep<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((k_gradsweep<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, \
-                           c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt); } while (0)
+                           c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt, gp); } while (0)
     DISPATCH_NOPS(c->n_ops, CALL_GS)
 #undef CALL_GS
     return qgdk_contract(c);
@@ -2001,6 +2013,7 @@ int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, d
 
 int qgdk_gradient_needs_derivs(const qgdk_ctx *c) { return !(c->Np == 64 && c->m <= 5 && c->n_ops >= 1); }
 
+// dynamic LDS of the chain/lambda kernels for any Np (they keep one or two panels only)
 size_t qgdk_lds_needed(int Np, int m, int n_ops)
 {
     size_t a = (size_t)(m + 1) * Np * 16 * sizeof(double);

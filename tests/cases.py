@@ -76,3 +76,17 @@ def dense_guard_case(qgd, nsteps=16, tf=8.0, seed=4):
     r = np.random.default_rng(seed).standard_normal((prob.real_system_size, prob.real_system_size))
     prob.guard_subspace_projector = np.asfortranarray(0.05 * (r + r.T))
     return prob, ctrl, pcof, target
+
+
+def synthetic_case(qgd, N=100, c=20, n_ops=4, nsteps=24, tf=0.5, seed=5):
+    """Shape of BASELINE.json configs[4] (random dense SchrodingerProb, entries scaled 1/N, degree-16
+    B-spline controls with 20 basis functions, order 12) at a size the tests can afford; N=100 already
+    takes every large-N fallback (HBM panel slabs, global-memory inverse, generic recursion kernels)."""
+    prob = qgd.construct_rand_prob(N, n_ops, tf=tf, nsteps=nsteps, scale=1.0 / N)
+    prob.u0 = np.asfortranarray(prob.u0[:, :c]); prob.v0 = np.asfortranarray(prob.v0[:, :c])
+    prob.N_initial_conditions = c
+    ctrl = [qgd.FortranBSplineControl(16, 20, prob.tf) for _ in range(n_ops)]
+    rng = np.random.default_rng(seed)
+    pcof = rng.random(qgd.get_number_of_control_parameters(ctrl))
+    target = rng.random((N, c)) + 1j * rng.random((N, c))
+    return prob, ctrl, pcof, target

@@ -255,3 +255,20 @@ def test_eval_adjoint_vs_oracle(qgd, orc, which, order):
     ref0 = orc.eval_adjoint(prob, ctrl, pcof, np.vstack([prob.u0, prob.v0]), order=order)
     assert close(got0[:, 0], ref0[:, 0], 1e-10)
     qgd.clear_cache()
+
+
+def test_large_n_fallback_paths(qgd):
+    """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12: generic recursion
+    kernels, global-memory Gauss-Jordan, panel slabs in HBM, three column groups -- vs the numpy
+    statement of the algorithm."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd)
+    order = 12
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    shape = (200, 7, 25, 20)
+    hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((200, 25, 20), order="F")
+    grad = np.zeros(len(pcof))
+    qgd.discrete_adjoint_(grad, hist, lam, forcing, prob, ctrl, pcof, target, order=order)
+    assert close(hist, pp.history_real(ref["ws"]), 1e-11)
+    assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
+    qgd.clear_cache()
