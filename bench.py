@@ -61,6 +61,27 @@ def phase_model(N, c, m, n_ops, nt):
     }
 
 
+KERNEL_OF_PHASE = {"build_LR": "void k_build_LR64<4, 3>", "inverse": "void k_inverse_reg<64, 16>", "propagator": "k_propagator",
+                   "gradient": "void k_gradpoint64<4, 3>", "lambda": "k_lambda", "guard": "k_guard_diag"}
+
+
+def measured_traffic(phase):
+    """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_v3_pmc_fetch_write.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this
+    same command; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so it is doubled --
+    MI355X_MICROARCH.md 'HBM').  None when no profile of that kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_fetch_write.json")
+    kern = KERNEL_OF_PHASE.get(phase)
+    if not kern or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    f = d.get("FETCH_SIZE_KB_mean_per_launch", {}).get(kern)
+    w = d.get("WRITE_SIZE_KB_mean_per_launch", {}).get(kern)
+    if f is None or w is None:
+        return None
+    return (2.0 * f + w) * 1024.0
+
+
 def cpu_baseline(qgd, orc, seconds_target=12.0):
     """Oracle ('port' of the reference CPU path) on a bounded sample: the same cnot3 problem and
     controls at dt=1 with fewer steps, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19),
@@ -201,7 +222,7 @@ def main():
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
                        "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
             "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": measured_traffic(dom),
                          "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),

@@ -272,3 +272,71 @@ def test_large_n_fallback_paths(qgd):
     assert close(hist, pp.history_real(ref["ws"]), 1e-11)
     assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
     qgd.clear_cache()
+
+
+def test_edge_no_controls_is_pade(qgd):
+    """Empty control set (N_operators = 0): the sweep is the diagonal Pade approximant of exp(A dt)
+    applied nsteps times -- closed form, no oracle needed.  Also exercises N=5 (padding), 3 columns."""
+    import math
+    rng = np.random.default_rng(21)
+    N, c, nsteps, tf = 5, 3, 7, 0.9
+    S = rng.standard_normal((N, N)); S = S + S.T
+    K = rng.standard_normal((N, N)); K = K - K.T
+    U0 = rng.standard_normal((N, c)) + 1j * rng.standard_normal((N, c))
+    prob = qgd.SchrodingerProb(S, K, [], [], U0.real, U0.imag, None, tf, nsteps, N)
+    Ac = K - 1j * S
+    dt = tf / nsteps
+    for order in (2, 6, 12, 16):
+        m = order // 2
+        cj = [math.factorial(m) * math.factorial(2 * m - j) / (math.factorial(2 * m) * math.factorial(m - j)) for j in range(m + 1)]
+        num = sum(cj[j] * np.linalg.matrix_power(Ac * dt, j) / math.factorial(j) for j in range(m + 1))
+        den = sum(cj[j] * np.linalg.matrix_power(-Ac * dt, j) / math.factorial(j) for j in range(m + 1))
+        step = np.linalg.solve(den, num)
+        psi = qgd.eval_forward(prob, [], np.zeros(0), order=order)
+        ref = U0.copy()
+        for n in range(nsteps):
+            ref = step @ ref
+            assert np.abs(psi[:, n + 1, :] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (order, n)
+    qgd.clear_cache()
+
+
+@pytest.mark.parametrize("nsteps", [1, 2, 3])
+def test_edge_tiny_grids(qgd, orc, nsteps):
+    """One, two and three timesteps (no scan blocks, adjoint loop of length 0 and 1), order 2 and 16."""
+    prob = qgd.construct_rabi_prob(tf=0.3, nsteps=nsteps, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    ctrl = qgd.FortranBSplineControl(3, 6, prob.tf)
+    pcof = np.random.default_rng(3).random(ctrl.N_coeff)
+    target = cases.rand_target(prob)
+    for order in (2, 16):
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+        hist = np.zeros(h_ref.shape, order="F")
+        grad = np.zeros_like(g_ref)
+        qgd.discrete_adjoint_(grad, hist, None, None, prob, ctrl, pcof, target, order=order)
+        assert close(hist, h_ref), (nsteps, order)
+        assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max(), (nsteps, order)
+    qgd.clear_cache()
+
+
+def test_error_behaviour_on_device(qgd):
+    """Call-order and argument errors surface as error codes with messages, never as silent fallbacks."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=8, tf=8.0)
+    dp = qgd.DeviceProblem(prob, 4)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.eval_forward(pcof)                           # pcof without a control basis
+    assert e.value.code == qgd._lib.QGD_ERR_STATE
+    dp.set_controls(ctrl)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.discrete_adjoint(pcof)                       # gradient without a target
+    assert e.value.code == qgd._lib.QGD_ERR_STATE
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.eval_forward(pcof[:-1])                      # wrong pcof length
+    assert e.value.code == qgd._lib.QGD_ERR_ARGUMENT
+    dp.set_target(target)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.discrete_adjoint(pcof, history_precomputed=True)   # nothing to reuse yet
+    assert e.value.code == qgd._lib.QGD_ERR_STATE
+    dp.close()
+    bad = prob.copy(); bad.sym_operators = [o + np.triu(np.ones_like(o), 1) for o in bad.sym_operators]
+    with pytest.raises(qgd._lib.QGDError) as e:
+        qgd.DeviceProblem(bad, 4)                       # asymmetric "symmetric" operator: ArgumentError
+    assert e.value.code == qgd._lib.QGD_ERR_ARGUMENT and "not symmetric" in str(e.value)
