@@ -43,11 +43,11 @@ class QGDError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile libqgd_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("qgd_kernels.hip", "qgd_api.cpp", "qgd_device.h")]
-    srcs.append(os.path.join(_HERE, "..", "include", "qgd.h"))
-    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "libqgd_hip.so"], stdout=subprocess.DEVNULL)
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    # make tracks the dependencies (four kernel translation units + the ABI host side)
+    subprocess.check_call(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1)), "libqgd_hip.so"],
+                          stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

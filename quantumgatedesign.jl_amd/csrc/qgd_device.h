@@ -1,4 +1,4 @@
-// qgd_device.h -- launch context shared by qgd_kernels.hip and qgd_api.cpp
+// qgd_device.h -- launch context shared by the kernel translation units (qgd_k_*.hip) and qgd_api.cpp
 #ifndef QGD_DEVICE_H
 #define QGD_DEVICE_H
 #include <hip/hip_runtime.h>

@@ -1,0 +1,651 @@
+// qgd_k_chain.hip -- the two sweeps as blocked scans, guard, terminal condition, lambda
+// (conventions and layouts: qgd_kernels_common.h; algorithm: DESIGN.md)
+#include "qgd_kernels_common.h"
+
+// ---------------------------------------------------------------------------
+// K4/K7: the two sweeps as a blocked scan over time.
+//   forward: psi_{n+1} = P_n psi_n                       (forward_evolution.jl:163-221)
+//   adjoint: y_n = P_n^H y_{n+1} + f_n                   (forward_evolution.jl:421-462 in the
+//            variable y_n = L_n^T lambda_n)
+// The S = nt-1 steps are cut into B blocks of `blen` steps.  Three phases:
+//   (i)   per block, in parallel: the block propagator Pi_b = P_{e-1}...P_s (forward; its
+//         conjugate transpose serves the adjoint) by chaining the identity's columns, and
+//         for the adjoint the affine part phi_b (zero start, forcing added);
+//   (ii)  one short sequential chain over the B block propagators -> states at block starts;
+//   (iii) per block, in parallel: re-run the block from its true start, writing the history.
+// Chain length drops from S to 2*blen + B matrix-panel products.
+// All three phases are the same "chain" kernel; one workgroup = one (block, group of 8
+// columns).  MODE 0: identity start, store Pi_b.  MODE 1: forward, write history.
+// MODE 2: adjoint from zero, store phi_b.  MODE 3: adjoint, write history.
+// ---------------------------------------------------------------------------
+struct ChainArgs {
+    const double *Pmat;      // forward: planes [S][2][Np*Np] col-major; adjoint: panels [S][Np][2Np]
+    const double *start;     // start panels, block b at start + b*start_stride  (layout [Np][2cp])
+    long long start_stride;
+    double *out;             // history [.][Np][2cp] (MODE 1: out[n+1], MODE 3: out[n])
+    const double *forcing;   // [.][Np][2cp], adjoint modes
+    double *PiC, *PiR;       // MODE 0 outputs: planes / panel per block
+    double *phi;             // MODE 2 output: [B][Np][2cp]
+    int Np, cp, S, nblocks, blen, ngroups;
+    // exchange-buffer addressing (multi-GPU layout, one chunk per rank):
+    // matrix n lives at Pmat + (n / pm_bpr) * pm_chunk + (n % pm_bpr) * 2*Np*Np   (pm_bpr = 0: n * 2*Np*Np)
+    int pm_bpr; long long pm_chunk;
+    // forcing/history slot of time index n is n + n / f_bpr                          (f_bpr = 0: n)
+    int f_bpr;
+};
+
+__device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
+{
+    const size_t pl2 = (size_t)2 * a.Np * a.Np;
+    if (a.pm_bpr) return a.Pmat + (size_t)(n / a.pm_bpr) * a.pm_chunk + (size_t)(n % a.pm_bpr) * pl2;
+    return a.Pmat + (size_t)n * pl2;
+}
+
+template <int MODE>
+__device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &grp)
+{
+    if (MODE == 0) {
+        // XCD-aware: the ngroups workgroups of one block share blockIdx%8, hence one XCD's L2,
+        // because they all stream the same P_n (speed only; MI355X_MICROARCH.md "Workgroup dispatch").
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = xcd + 8 * (slot / a.ngroups);
+        grp = slot % a.ngroups;
+    } else {
+        b = blockIdx.x / a.ngroups;
+        grp = blockIdx.x % a.ngroups;
+    }
+}
+
+// A fragment of step n at (row, k)
+template <bool ADJ>
+__device__ __forceinline__ void chain_a(const double *__restrict__ Pn, int Np, int arow, int k,
+                                        double &are, double &aim)
+{   // Pn: base of this step's matrix
+    const size_t pl = (size_t)Np * Np;
+
+    if (!ADJ) {
+        const double *P = Pn + (size_t)arow + (size_t)Np * k;
+        are = P[0];
+        aim = P[pl];
+    } else {   // (P^H)(row,k) = conj(P(k,row)); P stored as panel
+        const double *P = Pn + (size_t)k * 2 * Np + (arow >> 3) * 16 + (arow & 7);
+        are = P[0];
+        aim = -P[8];
+    }
+}
+
+// NP > 0: compile-time size, 8 waves = (row block, K slice).  The state lives in LDS as the
+// KSPLIT partial sums the waves produced (double buffered): the next step's B fragments are the
+// sums of those partials, so a step needs ONE barrier.  The A fragments (and, for the adjoint, the
+// forcing in accumulator layout) of the next PF steps are in flight in a register ring.
+template <int NP, int MODE>
+__global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
+{
+    constexpr bool ADJ = (MODE >= 2);
+    constexpr int NRB = NP / 16;
+    constexpr int KSPLIT = (8 / NRB) < (NP / 4) ? (8 / NRB) : (NP / 4);
+    constexpr int NACT = NRB * KSPLIT;
+    constexpr int KS = NP / 4 / KSPLIT;
+    constexpr int PF = 3;
+    constexpr int EPT = (NP * 16 + 511) / 512;           // panel elements per thread
+    static_assert(NRB * 16 == NP && KS * KSPLIT * 4 == NP && NACT <= 8, "tile");
+    __shared__ __attribute__((aligned(16))) double part[2][KSPLIT][NP * 16];
+
+    int b, grp;
+    chain_block_of<MODE>(a, b, grp);
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * NP : 2 * a.cp;
+    const size_t hstep = (size_t)NP * PWc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const bool active = wave < NACT;
+    const int rb = wave / KSPLIT, kq = wave % KSPLIT;
+    const int arow = rb * 16 + c16;
+    const int nsteps = e0 - s0;
+
+    // start state into part[0][0], zeros into the other partial slots
+    #pragma unroll
+    for (int t2 = 0; t2 < EPT; t2++) {
+        const int e = tid + t2 * 512;
+        if (e < NP * 16) {
+            const int row = e >> 4, c = e & 15;
+            double v;
+            if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+            else if (MODE == 2) v = 0.0;
+            else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+            part[0][0][e] = v;
+            #pragma unroll
+            for (int w2 = 1; w2 < KSPLIT; w2++) part[0][w2][e] = 0.0;
+        }
+    }
+    double rre[PF][KS], rim[PF][KS], rfo[PF][4];
+    auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
+    auto issue = [&](int slot, int st) {                 // loads for step st into ring slot
+        const int n = step_index(st);
+        if (active) {
+            const double *Pn = chain_matrix(a, n);
+            #pragma unroll
+            for (int i = 0; i < KS; i++) chain_a<ADJ>(Pn, NP, arow, (kq * KS + i) * 4 + kk, rre[slot][i], rim[slot][i]);
+            if (ADJ && kq == 0) {                        // forcing f_n in accumulator layout
+                const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    rfo[slot][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16];
+            }
+        }
+    };
+    #pragma unroll
+    for (int q = 0; q < PF; q++) if (q < nsteps) issue(q, q);
+    __syncthreads();
+
+    int buf = 0;
+    // one step on ring slot q; `refill` (>= 0) is the step whose operands replace the slot
+    auto do_step = [&](int q, int st, int refill) {
+        const int n = step_index(st);
+        if (active) {
+            d4 acc = (d4){0, 0, 0, 0};
+            #pragma unroll
+            for (int i = 0; i < KS; i++) {
+                const int ko = ((kq * KS + i) * 4 + kk) * 16;
+                double v1 = part[buf][0][ko + c16], v2 = part[buf][0][ko + (c16 ^ 8)];
+                #pragma unroll
+                for (int w2 = 1; w2 < KSPLIT; w2++) { v1 += part[buf][w2][ko + c16]; v2 += part[buf][w2][ko + (c16 ^ 8)]; }
+                acc = MFMA(rre[q][i], v1, acc);
+                acc = MFMA(rim[q][i], (c16 < 8) ? -v2 : v2, acc);
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = acc[r];
+                if (ADJ && kq == 0) v += rfo[q][r];
+                part[buf ^ 1][kq][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
+            }
+        }
+        // history: part[buf] holds the state that the previous step produced (the start state is
+        // not an output)
+        if ((MODE == 1 || MODE == 3) && st > 0) {
+            const int ncur = ADJ ? n + 1 : n;
+            #pragma unroll
+            for (int t2 = 0; t2 < EPT; t2++) {
+                const int e = tid + t2 * 512;
+                if (e < NP * 16) {
+                    double v = part[buf][0][e];
+                    #pragma unroll
+                    for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
+                    a.out[(size_t)ncur * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = v;
+                }
+            }
+        }
+        if (refill >= 0) issue(q, refill);
+        __syncthreads();
+        buf ^= 1;
+    };
+    // steady state: whole groups of PF steps, no conditionals (keeps the compiler's vmcnt
+    // bookkeeping exact so that PF-1 sets of loads really stay in flight); the refill index is
+    // clamped, the last groups reload the final matrix harmlessly
+    const int nfull = (nsteps / PF) * PF;
+    for (int st0 = 0; st0 < nfull; st0 += PF) {
+        #pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int nxt = st0 + q + PF;
+            do_step(q, st0 + q, nxt < nsteps ? nxt : nsteps - 1);
+        }
+    }
+    #pragma unroll
+    for (int q = 0; q < PF; q++)
+        if (nfull + q < nsteps) do_step(q, nfull + q, -1);
+    // final state = sum of the partials in part[buf]
+    const int nlast = ADJ ? s0 : e0;                     // its time index
+    #pragma unroll
+    for (int t2 = 0; t2 < EPT; t2++) {
+        const int e = tid + t2 * 512;
+        if (e < NP * 16) {
+            double v = part[buf][0][e];
+            #pragma unroll
+            for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
+            const int row = e >> 4, c = e & 15;
+            if ((MODE == 1 || MODE == 3) && nsteps > 0)
+                a.out[(size_t)nlast * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+            if (MODE == 0) {
+                const size_t pl = (size_t)NP * NP;
+                double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+                const int col = grp * 8 + (c & 7);
+                pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)NP * col] = v;
+                pr[(size_t)row * 2 * NP + grp * 16 + c] = v;
+            }
+            if (MODE == 2) a.phi[(size_t)b * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+        }
+    }
+}
+
+// any Np: runtime sizes, each wave loops over its row blocks, no K split, no prefetch
+template <int MODE>
+__global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
+{
+    constexpr bool ADJ = (MODE >= 2);
+    extern __shared__ double smem[];
+    const int Np = a.Np;
+    double *cur = smem, *nxt = smem + (size_t)Np * 16;
+    int b, grp;
+    chain_block_of<MODE>(a, b, grp);
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * Np : 2 * a.cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < Np * 16; e += blockDim.x) {
+        const int row = e >> 4, c = e & 15;
+        double v;
+        if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+        else if (MODE == 2) v = 0.0;
+        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+        cur[e] = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < e0 - s0; st++) {
+        const int n = ADJ ? e0 - 1 - st : s0 + st;
+        const int nout = ADJ ? n : n + 1;
+        const double *Pn = chain_matrix(a, n);
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            d4 acc = (d4){0, 0, 0, 0};
+            const int arow = rb * 16 + c16;
+            for (int k0 = 0; k0 < Np; k0 += 4) {
+                double are, aim, b1, b2;
+                chain_a<ADJ>(Pn, Np, arow, k0 + kk, are, aim);
+                panel_b(cur + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                acc = MFMA(are, b1, acc);
+                acc = MFMA(aim, b2, acc);
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                double v = acc[r];
+                const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16;
+                if (ADJ) v += a.forcing[a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho];
+                nxt[(size_t)row * 16 + c16] = v;
+                if (MODE == 1 || MODE == 3) a.out[ho] = v;
+            }
+        }
+        __syncthreads();
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (MODE == 0) {
+        const size_t pl = (size_t)Np * Np;
+        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+        for (int e = tid; e < Np * 16; e += blockDim.x) {
+            const int row = e >> 4, c = e & 15;
+            const int col = grp * 8 + (c & 7);
+            pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)Np * col] = cur[e];
+            pr[(size_t)row * 2 * Np + grp * 16 + c] = cur[e];
+        }
+    }
+    if (MODE == 2) {
+        for (int e = tid; e < Np * 16; e += blockDim.x)
+            a.phi[(size_t)b * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = cur[e];
+    }
+}
+
+template <int MODE>
+static int launch_chain(const ChainArgs &a, hipStream_t stream)
+{
+    const int nwg = (MODE == 0) ? 8 * a.ngroups * ((a.nblocks + 7) / 8) : a.nblocks * a.ngroups;
+    if (nwg <= 0) return 0;
+    switch (a.Np) {
+    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    default: {
+        size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
+        hipLaunchKernelGGL((k_chain_generic<MODE>), dim3(nwg), dim3(256), shm, stream, a);
+    }
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K5: guard penalty and adjoint forcing (infidelity.jl:56-96,
+// eval_grad_discrete_adjoint.jl:732-752).  One workgroup per time point.
+//   f_n = -(2 dt/tf) * trap_n * W w_n ;  penalty += (dt/tf) trap_n w_n^T W w_n
+// W: dense real 2N x 2N, column-major (unpadded).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
+                                               const double *__restrict__ hist,
+                                               double *__restrict__ forcing,
+                                               double *__restrict__ scal, int N, int Np, int c,
+                                               int cp, int n_off, int nt_glob, int count_first, double dt, double tf,
+                                               int have_guard)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x, ng = n + n_off;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *h = hist + (size_t)n * hstep;
+    double *f = forcing + (size_t)n * hstep;
+    const double trap = (ng == 0 || ng == nt_glob - 1) ? 0.5 : 1.0;
+    double pen = 0.0;
+    if (!have_guard) {
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) f[e] = 0.0;
+        return;
+    }
+    // zero the padding
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) f[e] = 0.0;
+    __syncthreads();
+    const int n2 = 2 * N;
+    for (int e = threadIdx.x; e < n2 * c; e += blockDim.x) {
+        const int i = e % n2, col = e / n2;
+        const int cbase = (col >> 3) * 16 + (col & 7);
+        double s = 0.0;
+        for (int jx = 0; jx < n2; jx++) {
+            const double wj = (jx < N) ? h[(size_t)jx * PWc + cbase] : h[(size_t)(jx - N) * PWc + cbase + 8];
+            s += W[(size_t)i + (size_t)n2 * jx] * wj;
+        }
+        const size_t o = (i < N) ? (size_t)i * PWc + cbase : (size_t)(i - N) * PWc + cbase + 8;
+        pen += h[o] * s;
+        f[o] = -(2.0 * dt / tf) * trap * s;
+    }
+    for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    if (threadIdx.x == 0 && (n > 0 || count_first)) {
+        double tot = red[0] + red[1] + red[2] + red[3];
+        atomicAdd(&scal[2], tot * trap * dt / tf);
+    }
+}
+
+// K5 (fast path): W diagonal (the guard_projector of multi_qudit_systems.jl:316-349 is):
+// elementwise forcing and penalty.  wd: the 2N diagonal entries.
+__global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ wd,
+                                                    const double *__restrict__ hist,
+                                                    double *__restrict__ forcing,
+                                                    double *__restrict__ scal, int N, int Np, int cp,
+                                                    int n_off, int nt_glob, int count_first, double dt, double tf)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x, ng = n + n_off;     // local / global time index
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *h = hist + (size_t)n * hstep;
+    double *f = forcing + (size_t)n * hstep;
+    const double trap = (ng == 0 || ng == nt_glob - 1) ? 0.5 : 1.0;
+    const double sc = -(2.0 * dt / tf) * trap;
+    double pen = 0.0;
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+        const int row = e / PWc, c16 = (e % PWc) & 15;
+        const double w = (row < N) ? wd[row + ((c16 >= 8) ? N : 0)] : 0.0;
+        const double v = h[e];
+        f[e] = sc * w * v;
+        pen += w * v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+    __syncthreads();
+    // the first point of a time window is the last point of the previous rank's window
+    if (threadIdx.x == 0 && (n > 0 || count_first)) atomicAdd(&scal[2], (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf);
+}
+
+// ---------------------------------------------------------------------------
+// K6: overlaps and terminal right-hand side (infidelity.jl:13-17,
+// eval_grad_discrete_adjoint.jl:22-40).  Single workgroup.
+//   scal[0] = <w_N,R>, scal[1] = <w_N,T>;  y_N = (2/Ness^2)(a R + b T) + f_N
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ hist,
+                                                  const double *__restrict__ target,
+                                                  const double *__restrict__ forcing,
+                                                  double *__restrict__ yhist,
+                                                  double *__restrict__ scal, int Np, int cp, int nt,
+                                                  int n_ess, int have_target, int write_y,
+                                                  double *__restrict__ y2, double *__restrict__ y3,
+                                                  double *__restrict__ y4)
+{
+    __shared__ double red[8];
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const double *w = hist + (size_t)(nt - 1) * hstep;
+    double a = 0.0, b = 0.0;
+    if (have_target) {
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+            const int col = e % PWc;
+            const int c16 = col & 15;
+            const double tv = target[e];
+            a += w[e] * tv;
+            // T = [R_im; -R_re]: pairs u with R_im and v with -R_re
+            const double tp = target[e ^ 8];           // partner (re<->im) of the same column
+            b += (c16 < 8) ? w[e] * tp : -w[e] * tp;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+    if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
+    if (!write_y) return;
+    const double sc = 2.0 / ((double)n_ess * (double)n_ess);
+    double *y = yhist + (size_t)(nt - 1) * hstep;
+    const double *f = forcing + (size_t)(nt - 1) * hstep;
+    for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+        const int c16 = (e % PWc) & 15;
+        const double tv = target[e], tp = target[e ^ 8];
+        const double Tv = (c16 < 8) ? tp : -tp;        // T component at this slot
+        const double v = sc * (a * tv + b * Tv) + f[e];
+        y[e] = v; y2[e] = v; y3[e] = v; y4[e] = v;    // history, exchange slot, boundary arrays
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K8: lambda_n = Linv_n^H y_n for n = 1..nt-1 (parallel over n and column groups)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT,
+                                                const double *__restrict__ yhist,
+                                                double *__restrict__ lam, int Np, int cp,
+                                                double *__restrict__ zero_a, int n_a,
+                                                double *__restrict__ zero_b, int n_b)
+{
+    {   // the gradient kernels accumulate into sigma and grad: clear them here (saves two fills)
+        const int gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const int gsz = gridDim.x * gridDim.y * blockDim.x;
+        for (int e = gid; e < n_a; e += gsz) zero_a[e] = 0.0;
+        for (int e = gid; e < n_b; e += gsz) zero_b[e] = 0.0;
+    }
+    extern __shared__ double smem[];
+    double *ys = smem;                                   // [Np][16]
+    const int n = blockIdx.y + 1, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, pl = (size_t)Np * Np;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        ys[e] = yhist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    const double *Tre = LinvT + (size_t)n * 2 * pl, *Tim = Tre + pl;   // (r,c) at c + Np*r
+    for (int rb = wave; rb * 16 < Np; rb += nw) {
+        d4 acc = (d4){0, 0, 0, 0};
+        const int arow = rb * 16 + c16;
+        for (int k0 = 0; k0 < Np; k0 += 4) {
+            const int k = k0 + kk;
+            // (Linv^H)(row,k) = conj(Linv(k,row)); Linv(k,row) sits at row + Np*k
+            const double are = Tre[(size_t)arow + (size_t)Np * k];
+            const double aim = -Tim[(size_t)arow + (size_t)Np * k];
+            double b1, b2;
+            panel_b(ys + (size_t)k * 16, c16, b1, b2);
+            acc = MFMA(are, b1, acc);
+            acc = MFMA(aim, b2, acc);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            lam[(size_t)n * hstep + (size_t)row * PWc + grp * 16 + c16] = acc[r];
+        }
+    }
+}
+
+extern "C" {
+
+// forward, phase (i): block propagators of the owned blocks into this rank's chunk of PiX
+int qgdk_forward_blocks(const qgdk_ctx *c)
+{
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pc;
+    a.PiC = c->PiX + (size_t)c->part_rank * pix_chunk(c);
+    a.PiR = a.PiC + (size_t)c->bpr * 2 * c->Np * c->Np;
+    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    return launch_chain<0>(a, c->stream);
+}
+
+// forward, phases (ii)+(iii): boundary states over ALL blocks (every rank), then the owned blocks.
+// Phase (ii) is itself a scan over the B block propagators when B is large (second level:
+// super-blocks of scan_g blocks): chain length g + B2 + g instead of B.
+int qgdk_forward_finish(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    int rc;
+    // bnd[0] = bnd2[0] = psi_0 were written when the grid was allocated (the initial state is constant)
+    if (B2 <= 1) {
+        ChainArgs s2{};
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(s2, c->stream))) return rc;
+    } else {
+        ChainArgs a2{};   // (ii-a) super-block propagators from the block propagators
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
+        a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+        ChainArgs b2{};   // (ii-b) states at super-block starts
+        b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiC2; b2.start = c->bnd2; b2.start_stride = 0; b2.out = c->bnd2;
+        b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(b2, c->stream))) return rc;
+        ChainArgs c2{};   // (ii-c) states at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = c->PiX; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
+        c2.start = c->bnd2; c2.start_stride = (long long)hstep; c2.out = c->bnd; c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(c2, c->stream))) return rc;
+    }
+    if (c->blk_lo > 0)   // rank 0's hist[0] = psi_0 is constant
+        HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    ChainArgs s3{};
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
+    s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = c->blk_hi - c->blk_lo; s3.blen = c->scan_blen;
+    s3.ngroups = c->cp / 8;
+    return launch_chain<1>(s3, c->stream);
+}
+
+int qgdk_guard(const qgdk_ctx *c)
+{
+    const int count_first = (c->n_off == 0) ? 1 : 0;
+    if (c->have_guard == 2) {   // diagonal projector
+        hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
+                           c->scal, c->N, c->Np, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_guard, dim3(c->nt), dim3(256), 0, c->stream, c->guard, c->hist, c->forcing, c->scal,
+                       c->N, c->Np, c->c, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf, c->have_guard);
+    return (int)hipGetLastError();
+}
+
+int qgdk_terminal(const qgdk_ctx *c, int write_y)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
+    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
+                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
+                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep);
+    return (int)hipGetLastError();
+}
+
+// adjoint, phase (i): affine parts phi_b of the owned blocks into this rank's chunk of phiX; the
+// rank that owns the final time puts y_N (written by k_terminal into yhist) in its extra slot
+int qgdk_adjoint_blocks(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    double *own = c->phiX + (size_t)c->part_rank * phix_chunk(c);
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = own;
+    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
+    int rc = launch_chain<2>(a, c->stream);
+    if (rc) return rc;
+    // the last rank's k_terminal wrote y_N into its extra slot (and into bndY/bndY2/yhist) directly;
+    // the other ranks' extra slots are never read
+    return 0;
+}
+
+// y_N = L(t_N)^H lambda_N for a caller-given terminal lambda (eval_adjoint): one adjoint chain step with
+// the panel of L_N as the step matrix; the result goes to every place k_terminal would write y_N
+int qgdk_apply_LH(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp, panel = (size_t)c->Np * 2 * c->Np;
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = 1; a.Pmat = c->L + (size_t)(c->nt - 1) * panel;
+    a.start = c->lam + (size_t)(c->nt - 1) * hstep; a.start_stride = 0; a.out = c->yhist + (size_t)(c->nt - 1) * hstep;
+    a.forcing = c->zero_panel; a.nblocks = 1; a.blen = 1; a.ngroups = c->cp / 8;
+    int rc = launch_chain<3>(a, c->stream);
+    if (rc) return rc;
+    const double *yN = c->yhist + (size_t)(c->nt - 1) * hstep;
+    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
+    HIPCHK(hipMemcpyAsync(slot, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bndY + (size_t)c->scan_blocks * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)c->scan_blocks2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// adjoint, phases (ii)+(iii); phase (ii) two-level like the forward one
+int qgdk_adjoint_finish(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    const double *yN = c->phiX + (size_t)(c->part_world - 1) * phix_chunk(c) + (size_t)c->bpr * hstep;
+    const double *PiRx = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np;      // panel copies inside the chunks
+    int rc;
+    const bool last = (c->part_rank == c->part_world - 1);
+    if (!last) HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (B2 <= 1) {
+        ChainArgs s2{};
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = PiRx; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0; s2.out = c->bndY;
+        s2.forcing = c->phiX; s2.f_bpr = c->bpr; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(s2, c->stream))) return rc;
+    } else {
+        ChainArgs a2{};   // (ii-a) affine parts of the super-blocks (their propagators PiR2 come from the forward sweep)
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
+        a2.forcing = c->phiX; a2.f_bpr = c->bpr; a2.phi = c->phi2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<2>(a2, c->stream))) return rc;
+        if (!last) HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        ChainArgs b2{};   // (ii-b) y at super-block starts
+        b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiR2; b2.start = c->bndY2 + (size_t)B2 * hstep; b2.start_stride = 0;
+        b2.out = c->bndY2; b2.forcing = c->phi2; b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(b2, c->stream))) return rc;
+        ChainArgs c2{};   // (ii-c) y at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = PiRx; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
+        c2.start = c->bndY2 + hstep; c2.start_stride = (long long)hstep; c2.out = c->bndY; c2.forcing = c->phiX; c2.f_bpr = c->bpr;
+        c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<3>(c2, c->stream))) return rc;
+    }
+    // y at the end of this rank's window
+    if (!last)
+        HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
+                              hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    ChainArgs s3{};
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.start = c->bndY + (size_t)(c->blk_lo + 1) * hstep;
+    s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = c->blk_hi - c->blk_lo;
+    s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
+    return launch_chain<3>(s3, c->stream);
+}
+
+int qgdk_lambda(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)c->Np * 16 * sizeof(double);
+    hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
+                       c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof);
+    return (int)hipGetLastError();
+}
+
+// dynamic LDS of the chain/lambda kernels for any Np (they keep one or two panels only)
+size_t qgdk_lds_needed(int Np, int m, int n_ops)
+{
+    size_t a = (size_t)(m + 1) * Np * 16 * sizeof(double);
+    size_t b = ((size_t)2 * m * Np * 16 + (size_t)n_ops * m * 2) * sizeof(double);
+    return a > b ? a : b;
+}
+
+
+} // extern "C"

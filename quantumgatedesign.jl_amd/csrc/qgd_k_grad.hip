@@ -1,0 +1,524 @@
+// qgd_k_grad.hip -- state derivatives, gradient scalars, contraction, Hamiltonian apply
+// (conventions and layouts: qgd_kernels_common.h; algorithm: DESIGN.md)
+#include "qgd_kernels_common.h"
+
+// ---------------------------------------------------------------------------
+// K9: state derivatives at every time point (the stored history of
+// forward_evolution.jl:172-179,:236-242):  psi_{j+1} = 1/(j+1) sum_{i<=j} A_{j-i} psi_i
+// One workgroup per (time point, column group).  dpsi: [nt][m][Np][2cp].
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
+                                                const double *__restrict__ tab,
+                                                const double *__restrict__ hist,
+                                                double *__restrict__ dpsi, int Np, int cp,
+                                                int n_ops, int m, double *__restrict__ gpanels)
+{
+    extern __shared__ double lds_panels[];              // (m+1) panels [Np][16] ...
+    const int n = blockIdx.y, grp = blockIdx.x;
+    // ... or, when they do not fit in LDS (large N), a slab of global scratch per workgroup
+    double *smem = gpanels ? gpanels + ((size_t)n * gridDim.x + grp) * (size_t)(m + 1) * Np * 16 : lds_panels;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t ps = (size_t)Np * 16;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        smem[e] = hist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __threadfence_block();
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            d4 acc = (d4){0, 0, 0, 0};
+            const int arow = rb * 16 + c16;
+            for (int i = 0; i <= j; i++) {
+                OpCoef cf;
+                load_coef(cf, tab, n, j - i, m, n_ops);
+                const double *src = smem + (size_t)i * ps;
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    double are, aim, b1, b2;
+                    assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                    acc = MFMA(are, b1, acc);
+                    acc = MFMA(aim, b2, acc);
+                }
+            }
+            const double inv = 1.0 / (double)(j + 1);
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                const double v = acc[r] * inv;
+                smem[(size_t)(j + 1) * ps + (size_t)row * 16 + c16] = v;
+                dpsi[(((size_t)n * m + j) * Np + row) * PWc + grp * 16 + c16] = v;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K10: gradient scalars.  Per (time point, column group):
+//   seeds   g_j = c_j dt^j lambda_{n+1} [n<=nt-2]  -  c_j (-dt)^j lambda_n [n>=1]
+//   sweep   j = m..2, i = 1..j-1:  g_i += (1/j) A_{j-1-i}^H g_j     (A^H = -A)
+//   sigma   sigP[k][d] += (1/j) <(dA/dp_k) psi_i, g_j>,  sigQ likewise, d = j-1-i
+// This is the O(m^2) reverse form of accumulate_gradient_arbitrary_fast! /
+// recursive_magic! (eval_grad_discrete_adjoint.jl:582-726); inner products as
+// compute_inner_prod_S!/K! (:764-800).  sigma: [nt][n_ops][m][2] (atomicAdd
+// across column groups).
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ ops,
+                                                   const double *__restrict__ tab,
+                                                   const double *__restrict__ hist,
+                                                   const double *__restrict__ dpsi,
+                                                   const double *__restrict__ lam,
+                                                   double *__restrict__ sigma,
+                                                   const double *__restrict__ cw, int Np, int cp,
+                                                   int n_ops, int m, int nt, double *__restrict__ gpanels)
+{
+    extern __shared__ double smem[];     // psi_0..psi_{m-1} (m panels), g_1..g_m (m panels), sig[n_ops*m*2]
+    const int n = blockIdx.y, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t ps = (size_t)Np * 16;
+    // panels in LDS, or (large N) in a slab of global scratch per workgroup; sig always in LDS
+    double *pbase = gpanels ? gpanels + ((size_t)n * gridDim.x + grp) * (size_t)(2 * m) * Np * 16 : smem;
+    double *psi = pbase, *gs = pbase + (size_t)m * ps;   // gs[(j-1)*ps]
+    double *sig = gpanels ? smem : gs + (size_t)m * ps;
+    const size_t pl = (size_t)Np * Np;
+
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x) {
+        const size_t src = (size_t)(e >> 4) * PWc + grp * 16 + (e & 15);
+        psi[e] = hist[(size_t)n * hstep + src];
+        for (int i = 1; i < m; i++) psi[(size_t)i * ps + e] = dpsi[(((size_t)n * m + (i - 1)) * Np) * PWc + src];
+        const double ln = (n >= 1) ? lam[(size_t)n * hstep + src] : 0.0;
+        const double lx = (n <= nt - 2) ? lam[(size_t)(n + 1) * hstep + src] : 0.0;
+        for (int j = 1; j <= m; j++) gs[(size_t)(j - 1) * ps + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+    }
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    __threadfence_block();
+    __syncthreads();
+
+    // reverse sweep
+    for (int j = m; j >= 2; j--) {
+        const double *src = gs + (size_t)(j - 1) * ps;
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            const int arow = rb * 16 + c16;
+            for (int i = 1; i <= j - 1; i++) {
+                OpCoef cf;
+                load_coef(cf, tab, n, j - 1 - i, m, n_ops);
+                d4 acc = (d4){0, 0, 0, 0};
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    double are, aim, b1, b2;
+                    assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                    panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                    acc = MFMA(are, b1, acc);
+                    acc = MFMA(aim, b2, acc);
+                }
+                const double sc = -1.0 / (double)j;     // A^H = -A
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = rb * 16 + kk + 4 * r;
+                    gs[(size_t)(i - 1) * ps + (size_t)row * 16 + c16] += sc * acc[r];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // inner products
+    for (int o = 0; o < n_ops; o++) {
+        const double *Asym = ops + (size_t)(2 + 2 * o) * pl, *Sym = ops + (size_t)(3 + 2 * o) * pl;
+        for (int i = 0; i < m; i++) {
+            const double *src = psi + (size_t)i * ps;
+            for (int rb = wave; rb * 16 < Np; rb += nw) {
+                const int arow = rb * 16 + c16;
+                d4 U = (d4){0, 0, 0, 0}, V = (d4){0, 0, 0, 0};
+                for (int k0 = 0; k0 < Np; k0 += 4) {
+                    const size_t e = (size_t)arow + (size_t)Np * (k0 + kk);
+                    const double b1 = src[(size_t)(k0 + kk) * 16 + c16];
+                    U = MFMA(Sym[e], b1, U);
+                    V = MFMA(Asym[e], b1, V);
+                }
+                for (int j = i + 1; j <= m; j++) {
+                    const double *gj = gs + (size_t)(j - 1) * ps;
+                    double sp = 0.0, sq = 0.0;
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = rb * 16 + kk + 4 * r;
+                        double g1, g2;
+                        panel_b(gj + (size_t)row * 16, c16, g1, g2);
+                        sq += V[r] * g1;              // Re<V, g>
+                        sp += U[r] * g2;              // Re<-iU, g> = Uim*gre - Ure*gim
+                    }
+                    for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
+                    if (lane == 0) {
+                        const int d = j - 1 - i;
+                        atomicAdd(&sig[(o * m + d) * 2], sp / (double)j);
+                        atomicAdd(&sig[(o * m + d) * 2 + 1], sq / (double)j);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x)
+        atomicAdd(&sigma[(size_t)n * n_ops * m * 2 + e], sig[e]);
+}
+
+// ---------------------------------------------------------------------------
+// K9+K10 fused (fast path, Np = 64): everything the gradient needs at one time point, one
+// launch, no derivative history in HBM.  Workgroup = (time point, group of 8 columns), 4 waves =
+// 4 row blocks.  psi_0..psi_{m-1} live in LDS; g_1..g_m live in REGISTERS in accumulator layout
+// (each wave owns its 16 rows) and only the g_j currently acting as right operand is staged in
+// LDS.  All passes share one register ring of operator elements that wraps around across passes
+// (the (row,k) elements are the same in every pass), so the ring never drains.
+//   D passes  psi_{j+1} = 1/(j+1) sum_{i<=j} A_{j-i} psi_i          j = 0..m-2
+//   G passes  g_i += (1/j) A_{j-1-i}^H g_j (A^H = -A), i = 1..j-1   j = m..2
+//   S passes  per operator o: U_i = Sym_o psi_i, V_i = Asym_o psi_i, then the inner products
+// ---------------------------------------------------------------------------
+template <int M, int NOPS>
+__global__ __launch_bounds__(256) void k_gradpoint64(const double *__restrict__ ops,
+                                                     const double *__restrict__ tab,
+                                                     const double *__restrict__ hist,
+                                                     const double *__restrict__ lam,
+                                                     double *__restrict__ sigma,
+                                                     const double *__restrict__ cw, int cp, int nt,
+                                                     int n_ops)
+{
+    constexpr int NP = 64, NKS = NP / 4, PS = NP * 16, RD = 4;
+    extern __shared__ double smem[];
+    double *psi = smem;                         // [M][PS]
+    double *gsrc = smem + (size_t)M * PS;       // [PS]
+    double *sig = gsrc + PS;                    // [n_ops*M*2]
+    const int n = blockIdx.y, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)NP * PWc, pl = (size_t)NP * NP;
+    const int tid = threadIdx.x, rb = tid >> 6, lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int arow = rb * 16 + c16;
+
+    for (int e = tid; e < PS; e += 256)
+        psi[e] = hist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    for (int e = tid; e < n_ops * M * 2; e += 256) sig[e] = 0.0;
+
+    // seeds in accumulator layout
+    d4 g[M];
+    {
+        double ln[4], lx[4];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t o = (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16;
+            ln[r] = (n >= 1) ? lam[(size_t)n * hstep + o] : 0.0;
+            lx[r] = (n <= nt - 2) ? lam[(size_t)(n + 1) * hstep + o] : 0.0;
+        }
+        #pragma unroll
+        for (int j = 1; j <= M; j++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) g[j - 1][r] = cw[2 * j] * lx[r] - cw[2 * j + 1] * ln[r];
+    }
+    // coefficients of derivative orders 0..M-2 (uniform -> scalar registers)
+    constexpr int ND = (M > 1) ? M - 1 : 1;
+    double cfr[ND][CF_STRIDE];
+    #pragma unroll
+    for (int d = 0; d < ND; d++) {
+        cfr[d][0] = (d == 0) ? 1.0 : 0.0;
+        #pragma unroll
+        for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+            const bool on = NOPS_ON(NOPS, o, n_ops);
+            cfr[d][1 + 2 * o] = on ? tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2] : 0.0;
+            cfr[d][2 + 2 * o] = on ? tab[(((size_t)n * (M + 1) + d) * n_ops + o) * 2 + 1] : 0.0;
+        }
+    }
+    // operator ring, wraps around over k-steps and passes
+    OpVals ring[RD];
+    auto ring_load = [&](int slot, int ks) {
+        load_opvals<NOPS>(ring[slot], ops, NP, n_ops, (size_t)arow + (size_t)NP * ((ks & (NKS - 1)) * 4 + kk));
+    };
+    if (M > 1) {
+        #pragma unroll
+        for (int q = 0; q < RD - 1; q++) ring_load(q, q);
+    }
+    __syncthreads();
+
+    // ---- D passes
+    #pragma unroll
+    for (int j = 0; j + 1 < M; j++) {
+        d4 acc = (d4){0, 0, 0, 0};
+        for (int ks4 = 0; ks4 < NKS; ks4 += RD) {
+            #pragma unroll
+            for (int q = 0; q < RD; q++) {
+                const int ks = ks4 + q, k = ks * 4 + kk;
+                ring_load((q + RD - 1) % RD, ks + RD - 1);
+                #pragma unroll
+                for (int i = 0; i <= j; i++) {
+                    double are, aim, b1, b2;
+                    combine_opvals<NOPS>(ring[q], cfr[j - i], n_ops, are, aim);
+                    panel_b(psi + (size_t)i * PS + (size_t)k * 16, c16, b1, b2);
+                    acc = MFMA(are, b1, acc);
+                    acc = MFMA(aim, b2, acc);
+                }
+            }
+        }
+        const double inv = 1.0 / (double)(j + 1);
+        #pragma unroll
+        for (int r = 0; r < 4; r++) psi[(size_t)(j + 1) * PS + (size_t)(rb * 16 + kk + 4 * r) * 16 + c16] = acc[r] * inv;
+        __syncthreads();
+    }
+
+    // ---- G passes
+    #pragma unroll
+    for (int j = M; j >= 2; j--) {
+        #pragma unroll
+        for (int r = 0; r < 4; r++) gsrc[(size_t)(rb * 16 + kk + 4 * r) * 16 + c16] = g[j - 1][r];
+        __syncthreads();
+        d4 t[M];
+        #pragma unroll
+        for (int i = 0; i < M; i++) t[i] = (d4){0, 0, 0, 0};
+        for (int ks4 = 0; ks4 < NKS; ks4 += RD) {
+            #pragma unroll
+            for (int q = 0; q < RD; q++) {
+                const int ks = ks4 + q, k = ks * 4 + kk;
+                ring_load((q + RD - 1) % RD, ks + RD - 1);
+                double b1, b2;
+                panel_b(gsrc + (size_t)k * 16, c16, b1, b2);
+                #pragma unroll
+                for (int i = 1; i <= j - 1; i++) {
+                    double are, aim;
+                    combine_opvals<NOPS>(ring[q], cfr[j - 1 - i], n_ops, are, aim);
+                    t[i] = MFMA(are, b1, t[i]);
+                    t[i] = MFMA(aim, b2, t[i]);
+                }
+            }
+        }
+        const double sc = -1.0 / (double)j;              // A^H = -A
+        #pragma unroll
+        for (int i = 1; i <= j - 1; i++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) g[i - 1][r] += sc * t[i][r];
+        __syncthreads();                                 // gsrc is rewritten by the next pass
+    }
+
+    // [-g_im | g_re] partner of every g_j, for the <(dA/dp) psi, g> products
+    d4 gs[M];
+    #pragma unroll
+    for (int j = 0; j < M; j++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double o = __shfl_xor(g[j][r], 8);
+            gs[j][r] = (c16 < 8) ? -o : o;
+        }
+
+    // ---- S passes
+    #pragma unroll
+    for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+        if (!NOPS_ON(NOPS, o, n_ops)) continue;
+        const double *Asym = ops + (size_t)(2 + 2 * o) * pl, *Sym = ops + (size_t)(3 + 2 * o) * pl;
+        d4 U[M], V[M];
+        #pragma unroll
+        for (int i = 0; i < M; i++) { U[i] = (d4){0, 0, 0, 0}; V[i] = (d4){0, 0, 0, 0}; }
+        double rs[RD], ra[RD];
+        #pragma unroll
+        for (int q = 0; q < RD - 1; q++) {
+            const size_t e = (size_t)arow + (size_t)NP * (q * 4 + kk);
+            rs[q] = Sym[e]; ra[q] = Asym[e];
+        }
+        for (int ks4 = 0; ks4 < NKS; ks4 += RD) {
+            #pragma unroll
+            for (int q = 0; q < RD; q++) {
+                const int ks = ks4 + q, k = ks * 4 + kk;
+                {
+                    const size_t e = (size_t)arow + (size_t)NP * ((((ks + RD - 1) & (NKS - 1)) * 4) + kk);
+                    rs[(q + RD - 1) % RD] = Sym[e]; ra[(q + RD - 1) % RD] = Asym[e];
+                }
+                #pragma unroll
+                for (int i = 0; i < M; i++) {
+                    const double b1 = psi[(size_t)i * PS + (size_t)k * 16 + c16];
+                    U[i] = MFMA(rs[q], b1, U[i]);
+                    V[i] = MFMA(ra[q], b1, V[i]);
+                }
+            }
+        }
+        double sp[M], sq[M];
+        #pragma unroll
+        for (int d = 0; d < M; d++) { sp[d] = 0.0; sq[d] = 0.0; }
+        #pragma unroll
+        for (int i = 0; i < M; i++)
+            #pragma unroll
+            for (int j = i + 1; j <= M; j++) {
+                double ap = 0.0, aq = 0.0;
+                #pragma unroll
+                for (int r = 0; r < 4; r++) { ap += U[i][r] * gs[j - 1][r]; aq += V[i][r] * g[j - 1][r]; }
+                sp[j - 1 - i] += ap / (double)j;
+                sq[j - 1 - i] += aq / (double)j;
+            }
+        #pragma unroll
+        for (int d = 0; d < M; d++) {
+            #pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sp[d] += __shfl_down(sp[d], off); sq[d] += __shfl_down(sq[d], off); }
+            if (lane == 0) { atomicAdd(&sig[(o * M + d) * 2], sp[d]); atomicAdd(&sig[(o * M + d) * 2 + 1], sq[d]); }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n_ops * M * 2; e += 256)
+        atomicAdd(&sigma[(size_t)n * n_ops * M * 2 + e], sig[e]);
+}
+
+template <int M, int NOPS>
+static int launch_gradpoint64(const qgdk_ctx *c)
+{
+    const size_t shm = ((size_t)(M + 1) * 64 * 16 + (size_t)c->n_ops * M * 2) * sizeof(double);
+    SET_LDS_ONCE((k_gradpoint64<M, NOPS>), shm);
+    hipLaunchKernelGGL((k_gradpoint64<M, NOPS>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab,
+                       c->hist, c->lam, c->sigma, c->cw, c->cp, c->nt, c->n_ops);
+    return (int)hipGetLastError();
+}
+
+template <int M>
+static int launch_gradpoint64_m(const qgdk_ctx *c)
+{
+#define CALL_GP(N) return launch_gradpoint64<M, N>(c)
+    DISPATCH_NOPS(c->n_ops, CALL_GP)
+#undef CALL_GP
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K11: gradient contraction  grad[off_k + l] = - sum_{n,d} Gp[k][n][d][l] sigP[n][k][d] + Gq.. sigQ..
+// (the "grad_slice .-= contrib" of eval_grad_discrete_adjoint.jl:642-643)
+// grid: (ceil(nc_max/64), n_ops, NSPLIT); atomicAdd over the time splits.
+// ---------------------------------------------------------------------------
+#define CT_CHUNK 16
+__global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                                                  const int32_t *__restrict__ ncoef,
+                                                  const int32_t *__restrict__ poff,
+                                                  const double *__restrict__ sigma,
+                                                  double *__restrict__ grad, int nt, int m, int n_ops)
+{
+    // grid (time chunks, n_ops, coefficient tiles of 64); thread = (coefficient, time sub-slot)
+    __shared__ double red[4][64];
+    const int k = blockIdx.y;
+    const int nc = ncoef[k];
+    const int l = blockIdx.z * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const double *gp = G + goff[k];
+    const double *gq = gp + (size_t)nt * (m + 1) * nc;
+    double s = 0.0;
+    if (l < nc) {
+        const int n1 = min(nt, (int)(blockIdx.x + 1) * CT_CHUNK);
+        for (int n = blockIdx.x * CT_CHUNK + sub; n < n1; n += 4)
+            for (int d = 0; d < m; d++) {
+                const double sp = sigma[(((size_t)n * n_ops + k) * m + d) * 2];
+                const double sq = sigma[(((size_t)n * n_ops + k) * m + d) * 2 + 1];
+                s += gp[((size_t)n * (m + 1) + d) * nc + l] * sp + gq[((size_t)n * (m + 1) + d) * nc + l] * sq;
+            }
+    }
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && l < nc)
+        atomicAdd(&grad[poff[k] + l], -(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// ---------------------------------------------------------------------------
+// Test hook: out = (+/-) A_d(t_n) * in for a panel of columns (apply_hamiltonian!,
+// hermite.jl:556-588, batched over all initial-condition columns).
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_apply(const double *__restrict__ ops,
+                                               const double *__restrict__ tab,
+                                               const double *__restrict__ in,
+                                               double *__restrict__ out, int Np, int cp, int n_ops,
+                                               int m, int n, int d, double sign)
+{
+    extern __shared__ double smem[];
+    const int grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+        smem[e] = in[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    OpCoef cf;
+    load_coef(cf, tab, n, d, m, n_ops);
+    for (int rb = wave; rb * 16 < Np; rb += nw) {
+        d4 acc = (d4){0, 0, 0, 0};
+        const int arow = rb * 16 + c16;
+        for (int k0 = 0; k0 < Np; k0 += 4) {
+            double are, aim, b1, b2;
+            assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+            panel_b(smem + (size_t)(k0 + kk) * 16, c16, b1, b2);
+            acc = MFMA(are, b1, acc);
+            acc = MFMA(aim, b2, acc);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            out[(size_t)row * PWc + grp * 16 + c16] = sign * acc[r];
+        }
+    }
+}
+
+extern "C" {
+
+int qgdk_derivs(const qgdk_ctx *c)
+{
+    size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
+    double *gp = nullptr;
+    if (c->panel_scratch) { gp = c->panel_scratch; shm = 0; }
+#define CALL_DV(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_derivs<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_derivs<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi, \
+                           c->Np, c->cp, c->n_ops, c->m, gp); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_DV)
+#undef CALL_DV
+    return (int)hipGetLastError();
+}
+
+int qgdk_gradient(const qgdk_ctx *c)
+{
+    size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
+    double *gp = nullptr;
+    if (c->panel_scratch) { gp = c->panel_scratch; shm = (size_t)c->n_ops * c->m * 2 * sizeof(double); }
+    if (c->Np == 64 && c->m <= 5 && c->n_ops >= 1) {
+        int rc = 0;
+        switch (c->m) {
+        case 1: rc = launch_gradpoint64_m<1>(c); break;
+        case 2: rc = launch_gradpoint64_m<2>(c); break;
+        case 3: rc = launch_gradpoint64_m<3>(c); break;
+        case 4: rc = launch_gradpoint64_m<4>(c); break;
+        default: rc = launch_gradpoint64_m<5>(c); break;
+        }
+        if (rc) return rc;
+        return qgdk_contract(c);
+    }
+#define CALL_GS(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_gradsweep<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_gradsweep<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, \
+                           c->dpsi, c->lam, c->sigma, c->cw, c->Np, c->cp, c->n_ops, c->m, c->nt, gp); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_GS)
+#undef CALL_GS
+    return qgdk_contract(c);
+}
+
+int qgdk_contract(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_contract, dim3((c->nt + CT_CHUNK - 1) / CT_CHUNK, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
+                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
+    return (int)hipGetLastError();
+}
+
+int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, double sign)
+{
+    size_t shm = (size_t)c->Np * 16 * sizeof(double);
+#define CALL_AP(N) hipLaunchKernelGGL((k_apply<N>), dim3(c->cp / 8), dim3(256), shm, c->stream, c->ops, c->tab, in, out, c->Np, \
+                                      c->cp, c->n_ops, c->m, n, d, sign)
+    DISPATCH_NOPS(c->n_ops, CALL_AP)
+#undef CALL_AP
+    return (int)hipGetLastError();
+}
+
+int qgdk_gradient_needs_derivs(const qgdk_ctx *c) { return !(c->Np == 64 && c->m <= 5 && c->n_ops >= 1); }
+
+
+} // extern "C"

@@ -1,0 +1,627 @@
+// qgd_k_inverse.hip -- batched inverses of L_n and the step propagators
+// (conventions and layouts: qgd_kernels_common.h; algorithm: DESIGN.md)
+#include "qgd_kernels_common.h"
+
+// ---------------------------------------------------------------------------
+// K2: batched complex inverse by in-place Gauss-Jordan with partial pivoting.
+// One workgroup per matrix.  Input L[n] (panel).  Outputs:
+//   LinvA[n]: planes, column-major  (left operand of P = Linv * R)
+//   LinvT[n]: planes, row-major     (left operand of lambda = Linv^H y)
+// The work matrix lives in LDS when it fits, otherwise in a global scratch slab.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
+                                                 double *__restrict__ LinvA,
+                                                 double *__restrict__ LinvT,
+                                                 double *__restrict__ scratch, int Np, int n0,
+                                                 int use_lds, int *__restrict__ status)
+{
+    extern __shared__ double smem[];
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, nth = blockDim.x;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    // aux (always LDS): colre[Np], colim[Np], perm[Np] (as double), red[2*nth/64...]
+    double *aux = smem;
+    double *colre = aux, *colim = aux + Np;
+    int *perm = reinterpret_cast<int *>(aux + 2 * Np);
+    double *redv = aux + 3 * Np;              // [4] values
+    int *redi = reinterpret_cast<int *>(redv + 8);   // [4] indices
+    double *M = use_lds ? (aux + 3 * Np + 16) : (scratch + (size_t)blockIdx.x * 2 * pl);
+    double *Mre = M, *Mim = M + pl;           // row-major: (r,c) at r*Np + c
+
+    const double *Ln = L + (size_t)n * panel;
+    for (size_t e = t; e < pl; e += nth) {
+        int r = e / Np, c = e % Np;
+        Mre[e] = Ln[(size_t)r * PW + (c >> 3) * 16 + (c & 7)];
+        Mim[e] = Ln[(size_t)r * PW + (c >> 3) * 16 + 8 + (c & 7)];
+    }
+    __syncthreads();
+
+    for (int p = 0; p < Np; p++) {
+        // pivot search over rows p..Np-1 of column p
+        double best = -1.0; int bi = p;
+        for (int r = p + t; r < Np; r += nth) {
+            double a = Mre[(size_t)r * Np + p], b = Mim[(size_t)r * Np + p];
+            double v = a * a + b * b;
+            if (v > best) { best = v; bi = r; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double ob = __shfl_down(best, off);
+            int oi = __shfl_down(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((t & 63) == 0) { redv[t >> 6] = best; redi[t >> 6] = bi; }
+        __syncthreads();
+        int pr = redi[0]; double pb = redv[0];
+        for (int w = 1; w < (nth >> 6); w++)
+            if (redv[w] > pb || (redv[w] == pb && redi[w] < pr)) { pb = redv[w]; pr = redi[w]; }
+        if (t == 0) { perm[p] = pr; if (!(pb > 0.0)) *status = 1; }
+        // swap rows p and pr
+        if (pr != p) {
+            for (int c = t; c < Np; c += nth) {
+                double a = Mre[(size_t)p * Np + c]; Mre[(size_t)p * Np + c] = Mre[(size_t)pr * Np + c]; Mre[(size_t)pr * Np + c] = a;
+                double b = Mim[(size_t)p * Np + c]; Mim[(size_t)p * Np + c] = Mim[(size_t)pr * Np + c]; Mim[(size_t)pr * Np + c] = b;
+            }
+        }
+        __syncthreads();
+        // save column p, then a_pp <- 1, a_ip <- 0
+        for (int r = t; r < Np; r += nth) {
+            colre[r] = Mre[(size_t)r * Np + p];
+            colim[r] = Mim[(size_t)r * Np + p];
+        }
+        __syncthreads();
+        for (int r = t; r < Np; r += nth) {
+            Mre[(size_t)r * Np + p] = (r == p) ? 1.0 : 0.0;
+            Mim[(size_t)r * Np + p] = 0.0;
+        }
+        __syncthreads();
+        // scale pivot row by 1/pivot
+        {
+            double a = colre[p], b = colim[p];
+            double den = 1.0 / (a * a + b * b);
+            double ir = a * den, ii = -b * den;
+            for (int c = t; c < Np; c += nth) {
+                double x = Mre[(size_t)p * Np + c], y = Mim[(size_t)p * Np + c];
+                Mre[(size_t)p * Np + c] = x * ir - y * ii;
+                Mim[(size_t)p * Np + c] = x * ii + y * ir;
+            }
+        }
+        __syncthreads();
+        // eliminate: row_i -= col_i * row_p  (i != p)
+        for (size_t e = t; e < pl; e += nth) {
+            int r = e / Np, c = e % Np;
+            if (r == p) continue;
+            double fr = colre[r], fi = colim[r];
+            double x = Mre[(size_t)p * Np + c], y = Mim[(size_t)p * Np + c];
+            Mre[e] -= fr * x - fi * y;
+            Mim[e] -= fr * y + fi * x;
+        }
+        __syncthreads();
+    }
+    // undo the row swaps as column swaps in reverse order
+    for (int p = Np - 1; p >= 0; p--) {
+        int pr = perm[p];
+        if (pr != p) {
+            for (int r = t; r < Np; r += nth) {
+                double a = Mre[(size_t)r * Np + p]; Mre[(size_t)r * Np + p] = Mre[(size_t)r * Np + pr]; Mre[(size_t)r * Np + pr] = a;
+                double b = Mim[(size_t)r * Np + p]; Mim[(size_t)r * Np + p] = Mim[(size_t)r * Np + pr]; Mim[(size_t)r * Np + pr] = b;
+            }
+            __syncthreads();
+        }
+    }
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    for (size_t e = t; e < pl; e += nth) {       // row-major planes: straight copy
+        T[e] = Mre[e];
+        T[pl + e] = Mim[e];
+    }
+    for (size_t e = t; e < pl; e += nth) {       // column-major planes
+        int c = e / Np, r = e % Np;
+        A[e] = Mre[(size_t)r * Np + c];
+        A[pl + e] = Mim[(size_t)r * Np + c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (fast path, Np <= 64): the same Gauss-Jordan inverse with the matrix held in
+// registers: 256 threads as a 16x16 grid, thread (ty,tx) owns the BSxBS block of rows
+// ty*BS.. and columns tx*BS.. (BS = Np/16).  Per pivot only the pivot column, the pivot
+// row and the swapped row travel through LDS (2 barriers); the rank-1 update is local.
+// ---------------------------------------------------------------------------
+template <int NP, int TG>
+__global__ __launch_bounds__(TG * TG) void k_inverse_reg(const double *__restrict__ L,
+                                                     double *__restrict__ LinvA,
+                                                     double *__restrict__ LinvT, int n0,
+                                                     int *__restrict__ status)
+{
+    constexpr int BS = NP / TG, NTH = TG * TG;   // TG x TG threads, BS x BS block each
+    static_assert(BS * TG == NP && BS <= 8, "block");
+    __shared__ double colre[2][NP], colim[2][NP];
+    __shared__ double rowre[2][2][NP], rowim[2][2][NP];
+    __shared__ int perm[NP], outpos[NP], idx[NP];
+    __shared__ double pivinv[2][2];
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, ty = t / TG, tx = t % TG, lane = t & 63;
+    constexpr int PW = 2 * NP;
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const double *Ln = L + (size_t)n * panel;
+
+    double are[BS][BS], aim[BS][BS];
+    #pragma unroll
+    for (int i = 0; i < BS; i++)
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int r = ty * BS + i, c = tx * BS + j;
+            are[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + (c & 7)];
+            aim[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + 8 + (c & 7)];
+        }
+
+    // statically indexed access to row / column `ii` of the register block (ii is uniform)
+#define INV_SEL(ii, STMT) switch (ii) { \
+    case 0: { constexpr int I = 0; STMT } break; \
+    case 1: { constexpr int I = (1 < BS) ? 1 : 0; STMT } break; \
+    case 2: { constexpr int I = (2 < BS) ? 2 : 0; STMT } break; \
+    case 3: { constexpr int I = (3 < BS) ? 3 : 0; STMT } break; \
+    case 4: { constexpr int I = (4 < BS) ? 4 : 0; STMT } break; \
+    case 5: { constexpr int I = (5 < BS) ? 5 : 0; STMT } break; \
+    case 6: { constexpr int I = (6 < BS) ? 6 : 0; STMT } break; \
+    default: { constexpr int I = (7 < BS) ? 7 : 0; STMT } break; }
+    for (int p = 0; p < NP; p++) {
+        const int buf = p & 1;
+        const int pblk = p / BS, poff = p % BS;        // uniform
+        if (tx == pblk) {                               // publish column p
+            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
+                colre[buf][ty * BS + i] = are[i][I]; colim[buf][ty * BS + i] = aim[i][I]; })
+        }
+        if (ty == pblk) {                               // publish row p (before any swap)
+            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                rowre[buf][0][tx * BS + j] = are[I][j]; rowim[buf][0][tx * BS + j] = aim[I][j]; })
+        }
+        __syncthreads();
+        // pivot search, redundantly in every wave.  One 64-bit key per lane: the bit pattern of
+        // |a|^2 (non-negative doubles order like unsigned integers) with the low 6 mantissa bits
+        // replaced by 63-row, so that one max-reduction yields the arg-max (ties -> lowest row).
+        unsigned long long key = 0;
+        if (lane < NP && lane >= p) {
+            const double a = colre[buf][lane], b = colim[buf][lane];
+            key = ((unsigned long long)__double_as_longlong(a * a + b * b) & ~63ull) | (unsigned long long)(63 - lane);
+        }
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long ok = __shfl_xor(key, off);
+            key = ok > key ? ok : key;
+        }
+        const int pr = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63ull));
+        if (t == 0) { perm[p] = pr; if (!((key >> 6) != 0)) *status = 1; }
+        const int rblk = pr / BS, roff = pr % BS;
+        if (ty == rblk) {                               // owners of row pr publish it scaled by 1/pivot
+            const double pa = colre[buf][pr], pb = colim[buf][pr];
+            const double den = 1.0 / (pa * pa + pb * pb);
+            const double ir = pa * den, ii = -pb * den;
+            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                const double x = are[I][j]; const double y = aim[I][j];
+                rowre[buf][1][tx * BS + j] = x * ir - y * ii; rowim[buf][1][tx * BS + j] = x * ii + y * ir; })
+            if (tx == 0) { pivinv[buf][0] = ir; pivinv[buf][1] = ii; }
+        }
+        const double cpr = colre[buf][p], cpi = colim[buf][p];   // old a_pp: multiplier of the swapped row
+        __syncthreads();
+        const double ir = pivinv[buf][0], ii = pivinv[buf][1];  // 1/pivot
+        if (ty == rblk && pr != p) {                    // row swap: row pr takes the old row p
+            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                are[I][j] = rowre[buf][0][tx * BS + j]; aim[I][j] = rowim[buf][0][tx * BS + j]; })
+        }
+        double rpr[BS], rpi[BS], ur[BS], ui[BS];        // scaled pivot row; the same with column p zeroed
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int c = tx * BS + j;
+            rpr[j] = rowre[buf][1][c];
+            rpi[j] = rowim[buf][1][c];
+            ur[j] = (c == p) ? 0.0 : rpr[j];
+            ui[j] = (c == p) ? 0.0 : rpi[j];
+        }
+        double fr[BS], fi[BS];                          // multipliers of my rows (0 for the pivot row)
+        #pragma unroll
+        for (int i = 0; i < BS; i++) {
+            const int r = ty * BS + i;
+            const double cr = colre[buf][r], ci = colim[buf][r];
+            fr[i] = (r == p) ? 0.0 : ((r == pr) ? cpr : cr);
+            fi[i] = (r == p) ? 0.0 : ((r == pr) ? cpi : ci);
+        }
+        #pragma unroll
+        for (int i = 0; i < BS; i++)
+            #pragma unroll
+            for (int j = 0; j < BS; j++) {
+                are[i][j] -= fr[i] * ur[j] - fi[i] * ui[j];
+                aim[i][j] -= fr[i] * ui[j] + fi[i] * ur[j];
+            }
+        if (tx == pblk) {                               // column p: -f/pivot (pivot row fixed next)
+            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
+                are[i][I] = -(fr[i] * ir - fi[i] * ii); aim[i][I] = -(fr[i] * ii + fi[i] * ir); })
+        }
+        if (ty == pblk) {                               // pivot row: scaled row, 1/pivot in column p
+            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
+                const bool dg = (tx * BS + j == p);
+                are[I][j] = dg ? ir : rpr[j]; aim[I][j] = dg ? ii : rpi[j]; })
+        }
+    }
+#undef INV_SEL
+    __syncthreads();
+    if (t == 0) {   // compose the column swaps that undo the row interchanges
+        for (int x = 0; x < NP; x++) idx[x] = x;
+        for (int p = NP - 1; p >= 0; p--) { const int q = perm[p]; const int tmp = idx[p]; idx[p] = idx[q]; idx[q] = tmp; }
+        for (int x = 0; x < NP; x++) outpos[idx[x]] = x;
+    }
+    __syncthreads();
+    // stage the (column-permuted) inverse through LDS so that both output layouts are
+    // written with coalesced stores; rows padded by one double against bank conflicts
+    extern __shared__ double stage[];          // one plane at a time: NP x (NP+1)
+    constexpr int LDP = NP + 1;
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        #pragma unroll
+        for (int j = 0; j < BS; j++) {
+            const int oc = outpos[tx * BS + j];
+            #pragma unroll
+            for (int i = 0; i < BS; i++) stage[(ty * BS + i) * LDP + oc] = pass ? aim[i][j] : are[i][j];
+        }
+        __syncthreads();
+        for (int e = t; e < NP * NP; e += NTH) {
+            const int hi = e / NP, lo = e % NP;       // NP is a compile-time constant
+            T[pass * pl + e] = stage[hi * LDP + lo];  // row-major: (r=hi, c=lo)
+            A[pass * pl + e] = stage[lo * LDP + hi];  // column-major: (r=lo, c=hi)
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (fast path, Np <= 64): blocked Gauss-Jordan inverse, 4 pivots per panel, rank-4 updates on
+// the fp64 MFMA.  The matrix lives in registers in accumulator layout (wave w owns rows
+// 16w..16w+15 of all columns: d4 M[Np/8]).  Per panel:
+//   1. the 4 panel columns go to LDS;
+//   2. wave 0 (lane = row) runs the pivoted in-place Gauss-Jordan steps on the Np x 4 panel only
+//      (pivot search = DPP max-scan of a packed |x|^2/row key, row exchange and pivot-row
+//      broadcast = v_readlane): that yields the pivot rows, and -F*B^-1 (rows off the pivot
+//      block) / B^-1 (pivot block), i.e. exactly the multipliers of the rank-4 block step and
+//      the in-place inverse entries;
+//   3. the (at most 8) rows touched by the interchanges go through LDS, and the rows that land
+//      on the pivot positions are published as the MFMA B operand;
+//   4. every wave: M += A * M[P,:] with A = multipliers (minus identity on the pivot rows) --
+//      2 MFMAs per 16x8-complex tile -- then the pivot columns are overwritten with the multipliers.
+// Same pivot sequence as the unblocked elimination (the panel columns are fully updated when
+// their pivots are chosen).  3 barriers per panel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lane_read(double v, int l)     // l wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long key)
+{
+    const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
+    return ok > key ? ok : key;
+}
+
+// maximum of a 64-bit key over the wave (result valid in lane 63, returned wave-uniform)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key)
+{
+    key = dpp_max_step<0x111, 0xF>(key);      // row_shr:1
+    key = dpp_max_step<0x112, 0xF>(key);      // row_shr:2
+    key = dpp_max_step<0x114, 0xF>(key);      // row_shr:4
+    key = dpp_max_step<0x118, 0xF>(key);      // row_shr:8   -> lane 15 of each row holds the row maximum
+    key = dpp_max_step<0x142, 0xA>(key);      // row_bcast:15 into rows 1 and 3
+    key = dpp_max_step<0x143, 0xC>(key);      // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)key, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(key >> 32), 63);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+template <int NP>
+__global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, double *__restrict__ LinvT,
+                    int n0, int *__restrict__ status)
+{
+    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
+    // LDS: the working buffers of the elimination, overlaid by the output staging plane at the end
+    constexpr int O_ROWBUF = 0, O_PROW = O_ROWBUF + 8 * PW, O_G = O_PROW + 8 * PW, O_F = O_G + 16 * NP,
+                  WORK = O_F + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
+    __shared__ double smem[SM];
+    __shared__ int perm[NP], slot_of[NP], piv_all[NP], outpos[NP], idx[NP];
+    double *rowbuf = smem + O_ROWBUF;                   // [8][PW]      rows touched by the interchanges
+    double *Prow = smem + O_PROW;                       // [2][4][PW]   pivot rows (B operand), by panel parity
+    double *Gm = smem + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
+    double *Fm = smem + O_F;                            // [2][NP][4]   panel columns re/im
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const double *Ln = L + (size_t)n * panel;
+
+    d4 M[NG];
+    #pragma unroll
+    for (int g = 0; g < NG; g++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
+
+    for (int pn = 0; pn < NP / 4; pn++) {
+        const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
+        double *Gre = Gm + par * 8 * NP, *Gim = Gre + 4 * NP;
+        double *Pr = Prow + par * 4 * PW;
+        // ---- 1. publish the panel columns
+        {
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                double *dst = Fm + (c16 < 8 ? 0 : 4 * NP);
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) dst[(16 * w + kk + 4 * r) * 4 + s] = M[g][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. wave 0: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row position
+        if (w == 0) {
+            double xr[4], xi[4];
+            int orig = lane;
+            const bool live = lane < NP;
+            const int lrow = live ? lane : 0;
+            #pragma unroll
+            for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int p = p0 + s;
+                unsigned long long key = 0;
+                if (live && lane >= p)
+                    key = ((unsigned long long)__double_as_longlong(xr[s] * xr[s] + xi[s] * xi[s]) & ~63ull) | (unsigned long long)(63 - lane);
+                key = wave_max_u64(key);
+                const int pr = 63 - (int)(key & 63ull);
+                if (lane == 0) { piv_all[p] = pr; if ((key >> 6) == 0) *status = 1; }
+                // exchange positions p and pr; the row now at p (old row pr) is the pivot row
+                double yr[4], yi[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double ar = lane_read(xr[q], p), ai = lane_read(xi[q], p);
+                    yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr);
+                    xr[q] = (lane == pr) ? ar : xr[q];
+                    xi[q] = (lane == pr) ? ai : xi[q];
+                }
+                const int oa = __builtin_amdgcn_readlane(orig, p), ob = __builtin_amdgcn_readlane(orig, pr);
+                orig = (lane == p) ? ob : (lane == pr) ? oa : orig;
+                const double den = 1.0 / (yr[s] * yr[s] + yi[s] * yi[s]);
+                const double ir = yr[s] * den, ii = -yi[s] * den;
+                const double fr = xr[s], fi = xi[s];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double rr = (q == s) ? ir : yr[q] * ir - yi[q] * ii;      // scaled pivot row
+                    const double ri = (q == s) ? ii : yr[q] * ii + yi[q] * ir;
+                    const double br = (q == s) ? 0.0 : xr[q], bi = (q == s) ? 0.0 : xi[q];
+                    xr[q] = (lane == p) ? rr : br - (fr * rr - fi * ri);
+                    xi[q] = (lane == p) ? ri : bi - (fr * ri + fi * rr);
+                }
+            }
+            const unsigned long long moved = __ballot(live && orig != lane);
+            if (live) {
+                #pragma unroll
+                for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
+                perm[lane] = orig;
+                slot_of[lane] = (orig != lane) ? __popcll(moved & ((1ull << lane) - 1ull)) : -1;
+            }
+        }
+        __syncthreads();
+        // ---- 3. row interchanges of the whole matrix (only the touched rows move); the rows
+        //         landing on the pivot positions also become the B operand of the block step
+        {
+            const int s0 = perm[p0], s1 = perm[p0 + 1], s2 = perm[p0 + 2], s3 = perm[p0 + 3];
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = 16 * w + kk + 4 * r;
+                const int sl = slot_of[x];
+                if (sl >= 0) {
+                    #pragma unroll
+                    for (int g = 0; g < NG; g++) rowbuf[sl * PW + 16 * g + c16] = M[g][r];
+                }
+                const int ps = (x == s0) ? 0 : (x == s1) ? 1 : (x == s2) ? 2 : (x == s3) ? 3 : -1;
+                if (ps >= 0) {
+                    #pragma unroll
+                    for (int g = 0; g < NG; g++) Pr[ps * PW + 16 * g + c16] = M[g][r];
+                }
+            }
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int x = 16 * w + kk + 4 * r;
+            if (slot_of[x] >= 0) {
+                const int sl = slot_of[perm[x]];
+                #pragma unroll
+                for (int g = 0; g < NG; g++) M[g][r] = rowbuf[sl * PW + 16 * g + c16];
+            }
+        }
+        // ---- 4. rank-4 block step on the MFMA, then the pivot columns take the multipliers
+        {
+            const int arow = 16 * w + c16;
+            const double are = Gre[arow * 4 + kk] - ((arow == p0 + kk) ? 1.0 : 0.0);
+            const double aim = Gim[arow * 4 + kk];
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double b1, b2;
+                panel_b(Pr + kk * PW + 16 * g, c16, b1, b2);
+                M[g] = MFMA(are, b1, M[g]);
+                M[g] = MFMA(aim, b2, M[g]);
+            }
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                const double *src = (c16 < 8) ? Gre : Gim;
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) M[g][r] = src[(16 * w + kk + 4 * r) * 4 + s];
+                    }
+                }
+            }
+        }
+        // no barrier here: the next panel writes F (last read before barrier 2), and the buffers
+        // read above (G, Prow) alternate with the panel parity
+    }
+    // compose the column swaps that undo the row interchanges
+    if (t == 0) {
+        for (int x = 0; x < NP; x++) idx[x] = x;
+        for (int p = NP - 1; p >= 0; p--) { const int q = piv_all[p]; const int tmp = idx[p]; idx[p] = idx[q]; idx[q] = tmp; }
+        for (int x = 0; x < NP; x++) outpos[idx[x]] = x;
+    }
+    __syncthreads();
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((c16 >> 3) == pass) {
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int oc = outpos[8 * g + (c16 & 7)];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) smem[(16 * w + kk + 4 * r) * LDP + oc] = M[g][r];
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < NP * NP; e += NTH) {
+            const int hi = e / NP, lo = e % NP;
+            T[pass * pl + e] = smem[hi * LDP + lo];
+            A[pass * pl + e] = smem[lo * LDP + hi];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: step propagator  P[n] = Linv[n+1] * R[n]   (n = 0..nt-2)
+// (the implicit solve L(t_{n+1}) w_{n+1} = R(t_n) w_n of forward_evolution.jl:181-220,
+//  done once for all right-hand sides).  Outputs P as panel (row-major; the
+// left operand of the adjoint sweep as P^H) and as column-major planes (left
+// operand of the forward sweep).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_propagator(const double *__restrict__ LinvA,
+                                                    const double *__restrict__ R,
+                                                    double *__restrict__ Pr, double *__restrict__ Pc,
+                                                    int Np)
+{
+    __shared__ __attribute__((aligned(32))) double Bs[LV_KC][16 * LV_NG];
+    const int n = blockIdx.y;
+    const int ngroups = Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int gb = blockIdx.x % gtiles, rb4 = blockIdx.x / gtiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const int rb = rb4 * 4 + wave;
+    const bool row_ok = rb * 16 < Np;
+    const int arow = rb * 16 + c16;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    const double *Are = LinvA + (size_t)(n + 1) * 2 * pl, *Aim = Are + pl;
+    const double *Bsrc = R + (size_t)n * panel;
+
+    d4 acc[LV_NG];
+    for (int g = 0; g < LV_NG; g++) acc[g] = (d4){0, 0, 0, 0};
+    for (int kc = 0; kc < Np; kc += LV_KC) {
+        {
+            int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+            int gcol = gb * 16 * LV_NG + c4;
+            double4 v = make_double4(0, 0, 0, 0);
+            if (gcol < PW) v = *reinterpret_cast<const double4 *>(Bsrc + (size_t)(kc + r) * PW + gcol);
+            *reinterpret_cast<double4 *>(&Bs[r][c4]) = v;
+        }
+        double are[4], aim[4];
+        if (row_ok) {
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                size_t e = (size_t)arow + (size_t)Np * (kc + 4 * s + kk);
+                are[s] = Are[e]; aim[s] = Aim[e];
+            }
+        }
+        __syncthreads();
+        if (row_ok) {
+            #pragma unroll
+            for (int s = 0; s < 4; s++)
+                #pragma unroll
+                for (int g = 0; g < LV_NG; g++) {
+                    double b1, b2;
+                    panel_b(&Bs[4 * s + kk][16 * g], c16, b1, b2);
+                    acc[g] = MFMA(are[s], b1, acc[g]);
+                    acc[g] = MFMA(aim[s], b2, acc[g]);
+                }
+        }
+        __syncthreads();
+    }
+    if (!row_ok) return;
+    double *Prn = Pr + (size_t)n * panel, *Pcn = Pc + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int g = 0; g < LV_NG; g++) {
+        const int grp = gb * LV_NG + g;
+        if (grp >= ngroups) continue;
+        const int ccol = grp * 8 + (c16 & 7);
+        const bool is_im = c16 >= 8;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            Prn[(size_t)row * PW + grp * 16 + c16] = acc[g][r];
+            Pcn[(is_im ? pl : 0) + (size_t)row + (size_t)Np * ccol] = acc[g][r];
+        }
+    }
+}
+
+extern "C" {
+
+int qgdk_inverse(const qgdk_ctx *c)
+{
+    const int nmat = c->nt - 1;
+    switch (c->Np) {
+    case 16: SET_LDS_ONCE((k_inverse_reg<16, 16>), 2176); hipLaunchKernelGGL((k_inverse_reg<16, 16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 64:   // blocked elimination with MFMA rank-4 updates (the register-blocked VALU kernel measured 0.22 ms)
+        if (!getenv("QGD_INVERSE_VALU")) {
+            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+        }
+        SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    default: break;
+    }
+    const size_t pl = (size_t)c->Np * c->Np;
+    size_t aux = (size_t)(3 * c->Np + 16) * sizeof(double);
+    size_t mat = 2 * pl * sizeof(double);
+    int use_lds = (aux + mat <= 150 * 1024) ? 1 : 0;
+    size_t shm = aux + (use_lds ? mat : 0);
+    if (use_lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_inverse, dim3(c->nt - 1), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT,
+                           (double *)nullptr, c->Np, 1, 1, c->status);
+    } else {
+        // global scratch: process in batches of inv_batch matrices
+        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+            int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+            hipLaunchKernelGGL(k_inverse, dim3(nb), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT,
+                               c->inv_scratch, c->Np, n0, 0, c->status);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+int qgdk_propagator(const qgdk_ctx *c)
+{
+    const int ngroups = c->Np / 8;
+    const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
+    const int rtiles = (c->Np + 63) / 64;
+    hipLaunchKernelGGL(k_propagator, dim3(gtiles * rtiles, c->nt - 1), dim3(256), 0, c->stream, c->LinvA, c->R,
+                       c->Pr, c->Pc, c->Np);
+    return (int)hipGetLastError();
+}
+
+
+} // extern "C"
