@@ -277,19 +277,20 @@ __global__ __launch_bounds__(TG * TG) void k_inverse_reg(const double *__restric
 // ---------------------------------------------------------------------------
 // K2 (fast path, Np <= 64): blocked Gauss-Jordan inverse, 4 pivots per panel, rank-4 updates on
 // the fp64 MFMA.  The matrix lives in registers in accumulator layout (wave w owns rows
-// 16w..16w+15 of all columns: d4 M[Np/8]).  Per panel:
+// 16w..16w+15 of all columns: d4 M[Np/8]) and rows are never moved: pivoting is implicit (the
+// p-th pivot row rho(p) stays where it is) and the row/column permutation
+// A^-1[i][rho(j)] = M[rho(i)][j] is applied when the result is written.  Per panel:
 //   1. the 4 panel columns go to LDS;
 //   2. wave 0 (lane = row) runs the pivoted in-place Gauss-Jordan steps on the Np x 4 panel only
-//      (pivot search = DPP max-scan of a packed |x|^2/row key, row exchange and pivot-row
-//      broadcast = v_readlane): that yields the pivot rows, and -F*B^-1 (rows off the pivot
-//      block) / B^-1 (pivot block), i.e. exactly the multipliers of the rank-4 block step and
-//      the in-place inverse entries;
-//   3. the (at most 8) rows touched by the interchanges go through LDS, and the rows that land
-//      on the pivot positions are published as the MFMA B operand;
+//      (pivot search = DPP max-scan of a packed |x|^2/row key, pivot-row broadcast =
+//      v_readlane): that yields the pivot rows, and -F*B^-1 (rows off the pivot block) /
+//      B^-1 (pivot block), i.e. exactly the multipliers of the rank-4 block step and the
+//      in-place inverse entries;
+//   3. the owners of the 4 pivot rows publish them: they already are an MFMA B operand;
 //   4. every wave: M += A * M[P,:] with A = multipliers (minus identity on the pivot rows) --
 //      2 MFMAs per 16x8-complex tile -- then the pivot columns are overwritten with the multipliers.
-// Same pivot sequence as the unblocked elimination (the panel columns are fully updated when
-// their pivots are chosen).  3 barriers per panel.
+// Pivot = largest modulus among the unused rows (compared on the upper 26 bits of |x|^2), the
+// panel columns being fully updated when their pivots are chosen.  3 barriers per panel.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double lane_read(double v, int l)     // l wave-uniform
 {
@@ -299,17 +300,14 @@ __device__ __forceinline__ double lane_read(double v, int l)     // l wave-unifo
 }
 
 template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long key)
+__device__ __forceinline__ unsigned dpp_max_step(unsigned key)
 {
-    const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-    const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
-    return ok > key ? ok : key;
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, ROWMASK, 0xF, false);
+    return o > key ? o : key;
 }
 
-// maximum of a 64-bit key over the wave (result valid in lane 63, returned wave-uniform)
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key)
+// maximum of a 32-bit key over the wave, returned wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned key)
 {
     key = dpp_max_step<0x111, 0xF>(key);      // row_shr:1
     key = dpp_max_step<0x112, 0xF>(key);      // row_shr:2
@@ -317,23 +315,37 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long ke
     key = dpp_max_step<0x118, 0xF>(key);      // row_shr:8   -> lane 15 of each row holds the row maximum
     key = dpp_max_step<0x142, 0xA>(key);      // row_bcast:15 into rows 1 and 3
     key = dpp_max_step<0x143, 0xC>(key);      // row_bcast:31 into rows 2 and 3
-    const int lo = __builtin_amdgcn_readlane((int)(unsigned)key, 63);
-    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(key >> 32), 63);
-    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    return (unsigned)__builtin_amdgcn_readlane((int)key, 63);
+}
+
+__device__ __forceinline__ double fast_rcp(double d)             // v_rcp_f64 + 2 Newton steps (full precision)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    return r;
 }
 
 template <int NP>
 __global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, double *__restrict__ LinvT,
-                    int n0, int *__restrict__ status)
+                    int n0, int *__restrict__ status
+#ifdef QGD_INV_PROFILE      // scripts/ubench/inverse_bench.hip: cycles of workgroup 0 / wave 0 per phase
+                    , unsigned long long *prof)
 {
+    long long prof_last = clock64();
+#define INV_PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&prof[i], (unsigned long long)(now_ - prof_last)); prof_last = now_; } } while (0)
+#else
+                    )
+{
+#define INV_PROF(i) do { } while (0)
+#endif
     constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
     // LDS: the working buffers of the elimination, overlaid by the output staging plane at the end
-    constexpr int O_ROWBUF = 0, O_PROW = O_ROWBUF + 8 * PW, O_G = O_PROW + 8 * PW, O_F = O_G + 16 * NP,
+    constexpr int O_PROW = 0, O_G = O_PROW + 8 * PW, O_F = O_G + 16 * NP,
                   WORK = O_F + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
     __shared__ double smem[SM];
-    __shared__ int perm[NP], slot_of[NP], piv_all[NP], outpos[NP], idx[NP];
-    double *rowbuf = smem + O_ROWBUF;                   // [8][PW]      rows touched by the interchanges
+    __shared__ int rho[NP], rinv[NP];                   // rho[p] = row of the p-th pivot
     double *Prow = smem + O_PROW;                       // [2][4][PW]   pivot rows (B operand), by panel parity
     double *Gm = smem + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
     double *Fm = smem + O_F;                            // [2][NP][4]   panel columns re/im
@@ -348,6 +360,8 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
     for (int g = 0; g < NG; g++)
         #pragma unroll
         for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
+    INV_PROF(0);
+    bool used = lane >= NP;                             // wave 0: this lane's row has been a pivot row
 
     for (int pn = 0; pn < NP / 4; pn++) {
         const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
@@ -368,35 +382,25 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
             }
         }
         __syncthreads();
-        // ---- 2. wave 0: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row position
+        INV_PROF(1);
+        // ---- 2. wave 0: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row
         if (w == 0) {
             double xr[4], xi[4];
-            int orig = lane;
-            const bool live = lane < NP;
-            const int lrow = live ? lane : 0;
+            const int lrow = (lane < NP) ? lane : 0;
             #pragma unroll
             for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
             #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const int p = p0 + s;
-                unsigned long long key = 0;
-                if (live && lane >= p)
-                    key = ((unsigned long long)__double_as_longlong(xr[s] * xr[s] + xi[s] * xi[s]) & ~63ull) | (unsigned long long)(63 - lane);
-                key = wave_max_u64(key);
-                const int pr = 63 - (int)(key & 63ull);
-                if (lane == 0) { piv_all[p] = pr; if ((key >> 6) == 0) *status = 1; }
-                // exchange positions p and pr; the row now at p (old row pr) is the pivot row
+                const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
+                unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
+                key = wave_max_u32(key);
+                const int pr = 63 - (int)(key & 63u);
+                if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
+                used = used || (lane == pr);
                 double yr[4], yi[4];
                 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const double ar = lane_read(xr[q], p), ai = lane_read(xi[q], p);
-                    yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr);
-                    xr[q] = (lane == pr) ? ar : xr[q];
-                    xi[q] = (lane == pr) ? ai : xi[q];
-                }
-                const int oa = __builtin_amdgcn_readlane(orig, p), ob = __builtin_amdgcn_readlane(orig, pr);
-                orig = (lane == p) ? ob : (lane == pr) ? oa : orig;
-                const double den = 1.0 / (yr[s] * yr[s] + yi[s] * yi[s]);
+                for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
+                const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
                 const double ir = yr[s] * den, ii = -yi[s] * den;
                 const double fr = xr[s], fi = xi[s];
                 #pragma unroll
@@ -404,31 +408,23 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
                     const double rr = (q == s) ? ir : yr[q] * ir - yi[q] * ii;      // scaled pivot row
                     const double ri = (q == s) ? ii : yr[q] * ii + yi[q] * ir;
                     const double br = (q == s) ? 0.0 : xr[q], bi = (q == s) ? 0.0 : xi[q];
-                    xr[q] = (lane == p) ? rr : br - (fr * rr - fi * ri);
-                    xi[q] = (lane == p) ? ri : bi - (fr * ri + fi * rr);
+                    xr[q] = (lane == pr) ? rr : br - (fr * rr - fi * ri);
+                    xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
                 }
             }
-            const unsigned long long moved = __ballot(live && orig != lane);
-            if (live) {
+            if (lane < NP) {
                 #pragma unroll
                 for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
-                perm[lane] = orig;
-                slot_of[lane] = (orig != lane) ? __popcll(moved & ((1ull << lane) - 1ull)) : -1;
             }
         }
         __syncthreads();
-        // ---- 3. row interchanges of the whole matrix (only the touched rows move); the rows
-        //         landing on the pivot positions also become the B operand of the block step
+        INV_PROF(2);
+        // ---- 3. the owners of the pivot rows publish them as the B operand of the block step
         {
-            const int s0 = perm[p0], s1 = perm[p0 + 1], s2 = perm[p0 + 2], s3 = perm[p0 + 3];
+            const int s0 = rho[p0], s1 = rho[p0 + 1], s2 = rho[p0 + 2], s3 = rho[p0 + 3];
             #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int x = 16 * w + kk + 4 * r;
-                const int sl = slot_of[x];
-                if (sl >= 0) {
-                    #pragma unroll
-                    for (int g = 0; g < NG; g++) rowbuf[sl * PW + 16 * g + c16] = M[g][r];
-                }
                 const int ps = (x == s0) ? 0 : (x == s1) ? 1 : (x == s2) ? 2 : (x == s3) ? 3 : -1;
                 if (ps >= 0) {
                     #pragma unroll
@@ -437,19 +433,11 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
             }
         }
         __syncthreads();
-        #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int x = 16 * w + kk + 4 * r;
-            if (slot_of[x] >= 0) {
-                const int sl = slot_of[perm[x]];
-                #pragma unroll
-                for (int g = 0; g < NG; g++) M[g][r] = rowbuf[sl * PW + 16 * g + c16];
-            }
-        }
+        INV_PROF(3);
         // ---- 4. rank-4 block step on the MFMA, then the pivot columns take the multipliers
         {
             const int arow = 16 * w + c16;
-            const double are = Gre[arow * 4 + kk] - ((arow == p0 + kk) ? 1.0 : 0.0);
+            const double are = Gre[arow * 4 + kk] - ((arow == rho[p0 + kk]) ? 1.0 : 0.0);
             const double aim = Gim[arow * 4 + kk];
             #pragma unroll
             for (int g = 0; g < NG; g++) {
@@ -470,25 +458,24 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
                 }
             }
         }
+        INV_PROF(4);
         // no barrier here: the next panel writes F (last read before barrier 2), and the buffers
         // read above (G, Prow) alternate with the panel parity
     }
-    // compose the column swaps that undo the row interchanges
-    if (t == 0) {
-        for (int x = 0; x < NP; x++) idx[x] = x;
-        for (int p = NP - 1; p >= 0; p--) { const int q = piv_all[p]; const int tmp = idx[p]; idx[p] = idx[q]; idx[q] = tmp; }
-        for (int x = 0; x < NP; x++) outpos[idx[x]] = x;
-    }
     __syncthreads();
+    // A^-1[rinv[x]][rho[j]] = M[x][j]
     double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    int orow[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) orow[r] = rinv[16 * w + kk + 4 * r] * LDP;
     #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         if ((c16 >> 3) == pass) {
             #pragma unroll
             for (int g = 0; g < NG; g++) {
-                const int oc = outpos[8 * g + (c16 & 7)];
+                const int oc = rho[8 * g + (c16 & 7)];
                 #pragma unroll
-                for (int r = 0; r < 4; r++) smem[(16 * w + kk + 4 * r) * LDP + oc] = M[g][r];
+                for (int r = 0; r < 4; r++) smem[orow[r] + oc] = M[g][r];
             }
         }
         __syncthreads();
@@ -499,6 +486,8 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
         }
         __syncthreads();
     }
+    INV_PROF(5);
+#undef INV_PROF
 }
 
 // ---------------------------------------------------------------------------
@@ -588,7 +577,11 @@ int qgdk_inverse(const qgdk_ctx *c)
     case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 64:   // blocked elimination with MFMA rank-4 updates (the register-blocked VALU kernel measured 0.22 ms)
         if (!getenv("QGD_INVERSE_VALU")) {
-            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status
+#ifdef QGD_INV_PROFILE
+                               , (unsigned long long *)nullptr
+#endif
+                               ); return (int)hipGetLastError();
         }
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
