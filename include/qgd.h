@@ -170,6 +170,16 @@ int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, in
  * 1 = every phase (default), 2 = only the named phase. */
 int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 
+
+/* Operator path of the step-matrix and gradient kernels.  mode 0: automatic (sparse when every
+ * row of the assembled Hamiltonian has at most min(16, N/2) entries and N <= 64 -- the drift +
+ * a_k +/- a_k^dagger operators of src/multi_qudit_systems.jl -- else dense), 1: dense fp64 MFMA
+ * kernels, 2: sparse (ELL) kernels, QGD_ERR_UNSUPPORTED when the operators do not qualify.
+ * qgd_get_operator_path: out3 = {path in use (1 dense, 2 sparse), entries per row of the union
+ * pattern, entries per row of the widest control operator}. */
+int qgd_set_operator_path(qgd_handle h, int32_t mode);
+int qgd_get_operator_path(qgd_handle h, int32_t *out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ struct qgd_handle_s {
     double *scal_static = nullptr;
     std::vector<Phase> phases;
     std::vector<double> u0v0_panel;   // host copy of the initial panel
+    bool sparse_available = false;    // the ELL lists were built and fit the sparse kernels
 };
 
 namespace {
@@ -374,6 +375,62 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     for (int o = 0; o < n_ops; o++) { put(2 + 2 * o, d->asym_ops + (size_t)o * N * N); put(3 + 2 * o, d->sym_ops + (size_t)o * N * N); }
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.ops, ops.size()));
     CREATE_TRY(hipMemcpy(k.ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
+    // sparse-operator path: ELL over the union pattern of all planes + one ELL list per control.
+    // Used when a row of A has at most 16 and at most Np/2 entries (the drift + a_k +/- a_k^dagger
+    // operators of multi_qudit_systems.jl have 1 + 2*subsystems); QGD_DENSE_OPS=1 keeps the MFMA path.
+    {
+        const size_t planes = 2 + 2 * (size_t)n_ops;
+        std::vector<std::vector<int>> cols(Np);
+        int Z = 1, Zo = 1;
+        for (size_t r = 0; r < Np; r++) {
+            for (size_t cidx = 0; cidx < Np; cidx++) {
+                bool nz = false;
+                for (size_t q = 0; q < planes && !nz; q++) nz = ops[q * pl + r + Np * cidx] != 0.0;
+                if (nz) cols[r].push_back((int)cidx);
+            }
+            Z = std::max(Z, (int)cols[r].size());
+            for (int o = 0; o < n_ops; o++) {
+                int cnt = 0;
+                for (int cidx : cols[r]) cnt += (ops[(2 + 2 * (size_t)o) * pl + r + Np * cidx] != 0.0 || ops[(3 + 2 * (size_t)o) * pl + r + Np * cidx] != 0.0);
+                Zo = std::max(Zo, cnt);
+            }
+        }
+        k.ell_z = Z; k.op_z = Zo;
+        h->sparse_available = Np <= 64 && Z <= 16 && 2 * (size_t)Z <= Np && qgdk_sparse_supported(k.Np, k.m, n_ops, Z);
+        k.use_sparse = h->sparse_available && !getenv("QGD_DENSE_OPS");
+        if (h->sparse_available) {
+            std::vector<int32_t> ecol((size_t)Z * Np), ocol((size_t)std::max(n_ops, 1) * Zo * Np);
+            std::vector<double> eval(planes * Z * Np, 0.0), oval((size_t)std::max(n_ops, 1) * 2 * Zo * Np, 0.0);
+            for (size_t r = 0; r < Np; r++) {
+                for (int e = 0; e < Z; e++) {
+                    const int cidx = e < (int)cols[r].size() ? cols[r][e] : (int)r;
+                    ecol[(size_t)e * Np + r] = cidx;
+                    if (e < (int)cols[r].size())
+                        for (size_t q = 0; q < planes; q++) eval[(q * Z + e) * Np + r] = ops[q * pl + r + Np * cidx];
+                }
+                for (int o = 0; o < n_ops; o++) {
+                    int e = 0;
+                    for (int cidx : cols[r]) {
+                        const double kv = ops[(2 + 2 * (size_t)o) * pl + r + Np * cidx], sv = ops[(3 + 2 * (size_t)o) * pl + r + Np * cidx];
+                        if (kv == 0.0 && sv == 0.0) continue;
+                        ocol[((size_t)o * Zo + e) * Np + r] = cidx;
+                        oval[(((size_t)2 * o) * Zo + e) * Np + r] = kv;
+                        oval[(((size_t)2 * o + 1) * Zo + e) * Np + r] = sv;
+                        e++;
+                    }
+                    for (; e < Zo; e++) ocol[((size_t)o * Zo + e) * Np + r] = (int)r;
+                }
+            }
+            CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_col, ecol.size()));
+            CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_val, eval.size()));
+            CREATE_RC(dev_alloc(h, h->static_bufs, &k.op_col, ocol.size()));
+            CREATE_RC(dev_alloc(h, h->static_bufs, &k.op_val, oval.size()));
+            CREATE_TRY(hipMemcpy(k.ell_col, ecol.data(), ecol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(k.ell_val, eval.data(), eval.size() * sizeof(double), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(k.op_col, ocol.data(), ocol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(k.op_val, oval.data(), oval.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     // guard projector
     k.have_guard = 0;
     if (d->guard) for (size_t e = 0; e < (size_t)4 * N * N; e++) if (d->guard[e] != 0.0) { k.have_guard = 1; break; }
@@ -790,6 +847,24 @@ int qgd_dist_finish(qgd_handle h, double *grad, double *out3)
     if (rc) return rc;
     if (grad) HIP_TRY(h, hipMemcpy(grad, h->k.grad, sizeof(double) * h->k.n_pcof, hipMemcpyDeviceToHost));
     if (out3) HIP_TRY(h, hipMemcpy(out3, h->k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return QGD_OK;
+}
+
+int qgd_set_operator_path(qgd_handle h, int32_t mode)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (mode < 0 || mode > 2) return fail(h, QGD_ERR_ARGUMENT, "operator path: 0 automatic, 1 dense, 2 sparse");
+    if (mode == 2 && !h->sparse_available)
+        return fail(h, QGD_ERR_UNSUPPORTED, "the operators are too dense (or N > 64) for the sparse kernels");
+    h->k.use_sparse = (mode == 2) || (mode == 0 && h->sparse_available && !getenv("QGD_DENSE_OPS"));
+    h->forward_valid = false; h->derivs_valid = false;
+    return QGD_OK;
+}
+
+int qgd_get_operator_path(qgd_handle h, int32_t *out3)
+{
+    if (!h || !out3) return QGD_ERR_ARGUMENT;
+    out3[0] = h->k.use_sparse ? 2 : 1; out3[1] = h->k.ell_z; out3[2] = h->k.op_z;
     return QGD_OK;
 }
 

@@ -14,6 +14,13 @@ typedef struct qgdk_ctx {
     hipStream_t stream;
     // device buffers
     double *ops;        // [(2+2 n_ops)][Np*Np] column-major planes: K_sys, S_sys, Asym_1, Sym_1, ...
+    // sparse-operator path (qgd_k_sparse.hip): ELL over the union pattern of all operators, and
+    // one ELL list per control operator.  Padding entries point at the row itself with value 0.
+    int use_sparse, ell_z, op_z;
+    int32_t *ell_col;   // [ell_z][Np]
+    double *ell_val;    // [(2+2 n_ops)][ell_z][Np]   planes in the order of `ops`
+    int32_t *op_col;    // [n_ops][op_z][Np]
+    double *op_val;     // [n_ops][2][op_z][Np]       (Asym_o, Sym_o)
     double *guard;      // [2N][2N] column-major
     double *guard_diag; // [2N] when the projector is diagonal (have_guard == 2)
     double *target;     // panel [Np][2cp]
@@ -77,6 +84,9 @@ int qgdk_contract(const qgdk_ctx *c);
 int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
+int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);
+int qgdk_build_LR_sparse(const qgdk_ctx *c);
+int qgdk_gradient_sparse(const qgdk_ctx *c);
 #ifdef __cplusplus
 }
 #endif

@@ -176,7 +176,6 @@ __global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ o
                                                     int n_ops, const double *__restrict__ cw)
 {
     constexpr int NP = 64, NGW = 4, SW = 16 * NGW;   // slab width in doubles
-    constexpr int ND = (M > 1) ? M - 1 : 1;
     extern __shared__ double smem[];
     double *Dbuf = smem;                               // [M-1][NP][SW]
     const int n = blockIdx.x >> 1, h = blockIdx.x & 1;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(512) void k_build_LR64(const double *__restrict__ o
     const int rb = wave & 3, gh = wave >> 2;           // row block, pair of groups inside the slab
     const int arow = rb * 16 + c16;
     constexpr int PW = 2 * NP;
-    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const size_t panel = (size_t)NP * PW;
 
     d4 Lacc[2], Racc[2], T[M][2];                      // T[q]: accumulator of D_{q+1}
     #pragma unroll
@@ -328,6 +327,7 @@ int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt, const double *qt)
 
 int qgdk_build_LR(const qgdk_ctx *c)
 {
+    if (c->use_sparse) return qgdk_build_LR_sparse(c);
     if (c->Np == 64) {           // fused LDS-resident path (order <= 10: D_1..D_{m-1} slabs fit in LDS)
         switch (c->m) {
         case 1: return launch_build_LR64<1>(c);

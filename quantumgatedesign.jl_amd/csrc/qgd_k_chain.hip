@@ -557,7 +557,6 @@ int qgdk_terminal(const qgdk_ctx *c, int write_y)
 // rank that owns the final time puts y_N (written by k_terminal into yhist) in its extra slot
 int qgdk_adjoint_blocks(const qgdk_ctx *c)
 {
-    const size_t hstep = (size_t)c->Np * 2 * c->cp;
     double *own = c->phiX + (size_t)c->part_rank * phix_chunk(c);
     ChainArgs a{};
     a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = own;

@@ -478,6 +478,11 @@ int qgdk_derivs(const qgdk_ctx *c)
 
 int qgdk_gradient(const qgdk_ctx *c)
 {
+    if (c->n_ops == 0) return 0;                       // no control parameters: nothing to differentiate
+    if (c->use_sparse) {
+        const int rc = qgdk_gradient_sparse(c);
+        return rc ? rc : qgdk_contract(c);
+    }
     size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
     double *gp = nullptr;
     if (c->panel_scratch) { gp = c->panel_scratch; shm = (size_t)c->n_ops * c->m * 2 * sizeof(double); }
@@ -518,7 +523,7 @@ int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, d
     return (int)hipGetLastError();
 }
 
-int qgdk_gradient_needs_derivs(const qgdk_ctx *c) { return !(c->Np == 64 && c->m <= 5 && c->n_ops >= 1); }
+int qgdk_gradient_needs_derivs(const qgdk_ctx *c) { return !(c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)); }
 
 
 } // extern "C"

@@ -170,6 +170,17 @@ class DeviceProblem:
         """0: no events, 1: every phase (default), 2: only ``phase``."""
         _lib.check(self.h, self.lib.qgd_set_timing(self.h, int(mode), None if phase is None else phase.encode()))
 
+    def set_operator_path(self, mode):
+        """"auto" | "dense" (fp64 MFMA kernels) | "sparse" (ELL kernels; raises if the operators do not qualify)."""
+        code = {"auto": 0, "dense": 1, "sparse": 2}[mode]
+        _lib.check(self.h, self.lib.qgd_set_operator_path(self.h, code))
+
+    def operator_path(self):
+        """(path in use, entries per row of the union pattern, entries per row of the widest control)."""
+        out = (C.c_int32 * 3)()
+        _lib.check(self.h, self.lib.qgd_get_operator_path(self.h, out))
+        return ("sparse" if out[0] == 2 else "dense", out[1], out[2])
+
     def timings(self):
         cap = 32
         names = (C.c_char_p * cap)()

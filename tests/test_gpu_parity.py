@@ -340,3 +340,50 @@ def test_error_behaviour_on_device(qgd):
     with pytest.raises(qgd._lib.QGDError) as e:
         qgd.DeviceProblem(bad, 4)                       # asymmetric "symmetric" operator: ArgumentError
     assert e.value.code == qgd._lib.QGD_ERR_ARGUMENT and "not symmetric" in str(e.value)
+
+
+@pytest.mark.parametrize("which,order", [("cnot3", 2), ("cnot3", 4), ("cnot3", 8), ("cnot3", 10), ("cnot3", 12),
+                                         ("cnot3", 14), ("cnot3", 16), ("cnot2", 6), ("guarded", 8)])
+def test_sparse_and_dense_operator_paths_agree(qgd, which, order):
+    """The ELL (sparse-operator) kernels and the dense fp64 MFMA kernels build the same L_n, R_n and
+    the same gradient, and both match the numpy statement of the algorithm."""
+    kw = dict(nsteps=24, tf=12.0) if which == "cnot3" else {}
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, **kw)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    out = {}
+    for path in ("sparse", "dense"):
+        dp = qgd.DeviceProblem(prob, order)
+        dp.set_operator_path(path)
+        assert dp.operator_path()[0] == path
+        dp.set_controls(ctrl); dp.set_target(target)
+        grad, out3 = dp.discrete_adjoint(pcof)
+        L, R = dp.intermediate("L"), dp.intermediate("R")
+        assert np.abs(L - ref["L"]).max() < 1e-13 and np.abs(R - ref["R"]).max() < 1e-13, path
+        assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max(), path
+        out[path] = (grad, out3, L, R)
+        dp.close()
+    gs, gd = out["sparse"][0], out["dense"][0]
+    assert np.abs(gs - gd).max() <= 1e-12 * np.abs(gd).max()
+    assert np.abs(out["sparse"][2] - out["dense"][2]).max() < 1e-14
+
+
+def test_operator_path_selection(qgd):
+    """cnot3 (drift diagonal + a_k +/- a_k^dagger on three subsystems) has 7 entries per row and 2 per
+    control operator -> sparse; a random dense problem stays on the MFMA kernels and refuses 'sparse'."""
+    import os
+    if os.environ.get("QGD_DENSE_OPS"):
+        pytest.skip("QGD_DENSE_OPS overrides the automatic choice")
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=4, tf=4.0)
+    dp = qgd.DeviceProblem(prob, 8)
+    assert dp.operator_path() == ("sparse", 7, 2)
+    dp.set_operator_path("dense"); assert dp.operator_path()[0] == "dense"
+    dp.set_operator_path("auto"); assert dp.operator_path()[0] == "sparse"
+    dp.close()
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=40, c=4, n_ops=2, nsteps=4)
+    dp = qgd.DeviceProblem(prob, 4)
+    assert dp.operator_path()[0] == "dense"
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.set_operator_path("sparse")
+    assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
+    dp.close()
