@@ -421,6 +421,11 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
                     for (; e < Zo; e++) ocol[((size_t)o * Zo + e) * Np + r] = (int)r;
                 }
             }
+            std::vector<uint8_t> einv(Np * Np, 0xff);
+            for (size_t r = 0; r < Np; r++)
+                for (size_t e = 0; e < cols[r].size(); e++) einv[r * Np + cols[r][e]] = (uint8_t)e;
+            CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_inv, einv.size()));
+            CREATE_TRY(hipMemcpy(k.ell_inv, einv.data(), einv.size(), hipMemcpyHostToDevice));
             CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_col, ecol.size()));
             CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_val, eval.size()));
             CREATE_RC(dev_alloc(h, h->static_bufs, &k.op_col, ocol.size()));

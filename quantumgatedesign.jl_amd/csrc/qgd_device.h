@@ -18,6 +18,7 @@ typedef struct qgdk_ctx {
     // one ELL list per control operator.  Padding entries point at the row itself with value 0.
     int use_sparse, ell_z, op_z;
     int32_t *ell_col;   // [ell_z][Np]
+    uint8_t *ell_inv;   // [Np][Np]: slot of column c in row r of the union pattern, 0xff when absent
     double *ell_val;    // [(2+2 n_ops)][ell_z][Np]   planes in the order of `ops`
     int32_t *op_col;    // [n_ops][op_z][Np]
     double *op_val;     // [n_ops][2][op_z][Np]       (Asym_o, Sym_o)

@@ -12,30 +12,70 @@
 #include "qgd_kernels_common.h"
 
 struct c2 { double re, im; };
+
+// -DQGD_SPARSE_PROFILE: cycles of workgroup 0 / thread 0 between the marks below, summed over launches
+// (read back with qgdk_sparse_profile; development aid, not compiled into the shipped library)
+#ifdef QGD_SPARSE_PROFILE
+__device__ unsigned long long g_sparse_prof[32];
+#define SP_PROF_BEGIN long long prof_last_ = clock64();
+#define SP_PROF(i) do { if (blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&g_sparse_prof[i], (unsigned long long)(now_ - prof_last_)); prof_last_ = now_; } } while (0)
+#else
+#define SP_PROF_BEGIN
+#define SP_PROF(i) do { } while (0)
+#endif
 __device__ __forceinline__ void cfma(c2 &acc, const c2 a, const c2 x)
 {
     acc.re = __builtin_fma(a.re, x.re, acc.re); acc.re = __builtin_fma(-a.im, x.im, acc.re);
     acc.im = __builtin_fma(a.re, x.im, acc.im); acc.im = __builtin_fma(a.im, x.re, acc.im);
 }
 
-// assemble A_d(t_n) = K - iS over the union pattern into LDS: As[(d*Z + e)*64 + r] = (K, -S)
+// sum over each row of 16 lanes, result in lane 15 of the row (DPP inclusive scan, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_step(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v = dpp_add_step<0x111>(v);     // row_shr:1
+    v = dpp_add_step<0x112>(v);     // row_shr:2
+    v = dpp_add_step<0x114>(v);     // row_shr:4
+    v = dpp_add_step<0x118>(v);     // row_shr:8
+    return v;
+}
+
+// assemble A_d(t_n) = K - iS, d = 0..nd-1, over the union pattern into LDS:
+// As[(d*Z + e)*64 + r] = (K, -S).  One (entry, row) pair per thread: the operator values are
+// fetched once and combined with the coefficients of every derivative order.
 __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ ell_val,
                                              const double *__restrict__ tab, int n, int m, int nd,
                                              int n_ops, int Z, int Np, int tid, int nth)
 {
-    for (int item = tid; item < nd * Z * 64; item += nth) {
-        const int r = item & 63, e = (item >> 6) % Z, d = (item >> 6) / Z;
-        double K = 0.0, S = 0.0;
-        if (r < Np) {
-            const size_t per = (size_t)Z * Np, at = (size_t)e * Np + r;
-            if (d == 0) { K = ell_val[at]; S = ell_val[per + at]; }
-            const double *t = tab + (((size_t)n * (m + 1) + d) * n_ops) * 2;
-            for (int o = 0; o < n_ops; o++) {
-                K = __builtin_fma(t[2 * o + 1], ell_val[(size_t)(2 + 2 * o) * per + at], K);
-                S = __builtin_fma(t[2 * o], ell_val[(size_t)(3 + 2 * o) * per + at], S);
-            }
+    const size_t per = (size_t)Z * Np;
+    for (int pair = tid; pair < Z * 64; pair += nth) {
+        const int r = pair & 63, e = pair >> 6;
+        const bool live = r < Np;
+        const size_t at = (size_t)e * Np + (live ? r : 0);
+        double kv[QGD_MAX_OPS_DEV + 1], sv[QGD_MAX_OPS_DEV + 1];
+        kv[0] = live ? ell_val[at] : 0.0;
+        sv[0] = live ? ell_val[per + at] : 0.0;
+        #pragma unroll
+        for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {
+            const bool on = live && o < n_ops;
+            kv[o + 1] = on ? ell_val[(size_t)(2 + 2 * o) * per + at] : 0.0;
+            sv[o + 1] = on ? ell_val[(size_t)(3 + 2 * o) * per + at] : 0.0;
         }
-        As[item] = (c2){K, -S};
+        for (int d = 0; d < nd; d++) {
+            const double *t = tab + (((size_t)n * (m + 1) + d) * n_ops) * 2;
+            double K = (d == 0) ? kv[0] : 0.0, S = (d == 0) ? sv[0] : 0.0;
+            #pragma unroll
+            for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {
+                if (o < n_ops) { K = __builtin_fma(t[2 * o + 1], kv[o + 1], K); S = __builtin_fma(t[2 * o], sv[o + 1], S); }
+            }
+            As[(d * Z + e) * 64 + r] = (c2){K, -S};
+        }
     }
 }
 
@@ -48,6 +88,7 @@ __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ 
 // ---------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict__ ell_col,
+                                                      const uint8_t *__restrict__ ell_inv,
                                                       const double *__restrict__ ell_val,
                                                       const double *__restrict__ tab,
                                                       double *__restrict__ L, double *__restrict__ R,
@@ -63,8 +104,10 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
     const int vc = min(32, Np - slab * 32);             // valid columns of this slab
     const int cl = 4 * w, c0 = slab * 32 + cl;          // first owned column (slab-local / global)
     const bool active = (r < Np) && (cl < vc);
+    SP_PROF_BEGIN
 
     assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, 512);
+    SP_PROF(0);
     for (int item = tid; item < Z * 64; item += 512) {
         const int rr = item & 63, e = item >> 6;
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
@@ -78,20 +121,23 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
         Lacc[c] = (c2){id, 0.0}; Racc[c] = (c2){id, 0.0};
     }
     __syncthreads();
-    // source 0 is the identity: A_d I = A_d, scattered to the owned columns
+    SP_PROF(1);
+    // source 0 is the identity: A_d I = A_d.  ell_inv[r][col] = slot of column col in row r (0xff: none)
     if (active) {
-        for (int e = 0; e < Z; e++) {
-            const int cc = Ecol[e * 64 + r] - c0;
-            if (cc >= 0 && cc < 4) {
+        const uint32_t slots = *reinterpret_cast<const uint32_t *>(ell_inv + (size_t)r * Np + c0);
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int e = (slots >> (8 * c)) & 0xff;
+            if (e != 0xff) {
                 #pragma unroll
                 for (int d = 0; d < M; d++) {
                     const c2 a = As[(d * Z + e) * 64 + r];
-                    #pragma unroll
-                    for (int c = 0; c < 4; c++) if (cc == c) { T[d][c].re += a.re; T[d][c].im += a.im; }
+                    T[d][c].re += a.re; T[d][c].im += a.im;
                 }
             }
         }
     }
+    SP_PROF(2);
     #pragma unroll
     for (int i = 1; i <= M; i++) {
         const double inv = 1.0 / (double)i, cL = cw[2 * i + 1], cR = cw[2 * i];
@@ -108,7 +154,7 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
         for (int c = 0; c < 4; c++) Ds[r * DS + cl + c] = Di[c];
         __syncthreads();
         if (active) {
-            for (int e = 0; e < Z; e++) {
+            _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
                 const c2 *src = Ds + Ecol[e * 64 + r] * DS + cl;
                 c2 x[4];
                 #pragma unroll
@@ -122,6 +168,7 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
             }
         }
     }
+    SP_PROF(3);
     // output through LDS so that panel rows are written as contiguous segments
     const int PW = 2 * Np, SW = 2 * vc;                 // panel width, width of this slab's part of a row
     double *st = reinterpret_cast<double *>(Ds);        // [64][65]
@@ -141,17 +188,22 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
             dst[(size_t)row * PW + k] = st[row * 65 + k];
         }
     }
+    SP_PROF(4);
 }
 
 // ---------------------------------------------------------------------------
-// K9+K10 (sparse path, Np <= 64): everything the gradient needs at one time point, see the
-// dense k_gradpoint64 (qgd_k_grad.hip) for the passes.  Workgroup = (time point, group of 8
-// columns), 4 waves x 2 columns, lane = row.  psi_0..psi_{m-1} in LDS, g_1..g_m in registers,
-// the g_j acting as right operand staged in LDS.  The inner products with dA/dp, dA/dq use
-// per-operator ELL lists (op_col/op_val), not the union pattern.
+// K9+K10 (sparse path, Np <= 64): everything the gradient needs at one time point (the passes
+// of the dense k_gradpoint64, qgd_k_grad.hip, reordered so that one state slab in LDS is enough).
+// Workgroup = (time point, group of 8 columns), 4 waves x 2 columns, lane = row.
+//   G passes first (they depend on lambda only): g_i += -(1/j) A_{j-1-i} g_j, g_1..g_m in registers;
+//   then source-major over psi_i, i = 0..m-1 (only the current source is in LDS):
+//     D part  T[i+d+1] += A_d psi_i,   psi_{i+1} = T[i+1]/(i+1)
+//     S part  per operator o (its own ELL list): U = Sym_o psi_i, V = Asym_o psi_i,
+//             sigP[o][j-1-i] += (1/j) Re<-iU, g_j>,  sigQ[o][j-1-i] += (1/j) Re<V, g_j>,  j > i.
 // ---------------------------------------------------------------------------
-template <int M>
-__global__ __launch_bounds__(256) void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
+template <int M, int NOPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(M <= 4 ? 3 : 2, M <= 4 ? 3 : 2)))
+void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
                                                        const double *__restrict__ ell_val,
                                                        const int32_t *__restrict__ op_col,
                                                        const double *__restrict__ op_val,
@@ -162,75 +214,57 @@ __global__ __launch_bounds__(256) void k_gradpoint_ell(const int32_t *__restrict
                                                        const double *__restrict__ cw, int Np, int cp,
                                                        int nt, int n_ops, int Z, int Zo)
 {
-    constexpr int PS = 9, ND = (M > 1) ? M - 1 : 1;     // row stride of a state slab in complex numbers
+    constexpr int PS = 9, ND = (M > 1) ? M - 1 : 1, NO = NOPS_LIM(NOPS);
     extern __shared__ double smem_raw[];
     c2 *As = reinterpret_cast<c2 *>(smem_raw);          // [ND][Z][64]
-    c2 *psi = As + (size_t)ND * Z * 64;                 // [M][64][PS]
-    c2 *gsrc = psi + (size_t)M * 64 * PS;               // [64][PS]
-    double *sig = reinterpret_cast<double *>(gsrc + 64 * PS);   // [n_ops][M][2]
-    int *Ecol = reinterpret_cast<int *>(sig + n_ops * M * 2 + (n_ops * M * 2 & 1));   // [Z][64]
+    c2 *buf = As + (size_t)ND * Z * 64;                 // [64][PS]   the current right operand
+    c2 *Ov = buf + 64 * PS;                             // [n_ops][Zo][64] (Asym_o, Sym_o) values
+    double *red = reinterpret_cast<double *>(Ov + (size_t)n_ops * Zo * 64);   // [n_ops*M*2][16] partial sums
+    int *Ecol = reinterpret_cast<int *>(red + n_ops * M * 2 * 16);      // [Z][64]
+    int *Ocol = Ecol + Z * 64;                          // [n_ops][Zo][64]
     const int grp = blockIdx.x, n = blockIdx.y;
     const int tid = threadIdx.x, w = tid >> 6, r = tid & 63, cl = 2 * w;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc;
     const bool live = r < Np;
+    SP_PROF_BEGIN
 
     if (M > 1) assemble_ell(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
+    SP_PROF(16);
     for (int item = tid; item < Z * 64; item += 256) {
         const int rr = item & 63, e = item >> 6;
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
-    for (int e = tid; e < n_ops * M * 2; e += 256) sig[e] = 0.0;
+    for (int item = tid; item < n_ops * Zo * 64; item += 256) {
+        const int rr = item & 63, oe = item >> 6, o = oe / Zo, e = oe % Zo;
+        const bool ok = rr < Np;
+        Ocol[item] = ok ? op_col[(size_t)oe * Np + rr] : 0;
+        Ov[item] = ok ? (c2){op_val[((size_t)(2 * o) * Zo + e) * Np + rr], op_val[((size_t)(2 * o + 1) * Zo + e) * Np + rr]} : (c2){0.0, 0.0};
+    }
     // own elements of psi_0 and the seeds g_j = c_j dt^j lam_{n+1} - c_j (-dt)^j lam_n
-    c2 ps[M][2], g[M][2];
+    c2 ps[2], g[M][2];
     #pragma unroll
     for (int c = 0; c < 2; c++) {
         const size_t o = (size_t)(live ? r : 0) * PWc + grp * 16 + cl + c;
-        ps[0][c] = live ? (c2){hist[(size_t)n * hstep + o], hist[(size_t)n * hstep + o + 8]} : (c2){0.0, 0.0};
+        ps[c] = live ? (c2){hist[(size_t)n * hstep + o], hist[(size_t)n * hstep + o + 8]} : (c2){0.0, 0.0};
         const c2 ln = (live && n >= 1) ? (c2){lam[(size_t)n * hstep + o], lam[(size_t)n * hstep + o + 8]} : (c2){0.0, 0.0};
         const c2 lx = (live && n <= nt - 2) ? (c2){lam[(size_t)(n + 1) * hstep + o], lam[(size_t)(n + 1) * hstep + o + 8]} : (c2){0.0, 0.0};
         #pragma unroll
         for (int j = 1; j <= M; j++)
             g[j - 1][c] = (c2){cw[2 * j] * lx.re - cw[2 * j + 1] * ln.re, cw[2 * j] * lx.im - cw[2 * j + 1] * ln.im};
-        psi[r * PS + cl + c] = ps[0][c];
     }
-    __syncthreads();
-
-    // ---- D passes, source-major: psi_{i+1} = T[i+1]/(i+1), T[i+d+1] += A_d psi_i
-    {
-        c2 T[M][2];
-        #pragma unroll
-        for (int q = 0; q < M; q++) { T[q][0] = (c2){0.0, 0.0}; T[q][1] = (c2){0.0, 0.0}; }
-        #pragma unroll
-        for (int i = 0; i + 1 < M; i++) {
-            for (int e = 0; e < Z; e++) {
-                const c2 *src = psi + ((size_t)i * 64 + Ecol[e * 64 + r]) * PS + cl;
-                const c2 x0 = src[0], x1 = src[1];
-                #pragma unroll
-                for (int d = 0; d + i + 1 < M; d++) {
-                    const c2 a = As[(d * Z + e) * 64 + r];
-                    cfma(T[i + d + 1][0], a, x0); cfma(T[i + d + 1][1], a, x1);
-                }
-            }
-            const double inv = 1.0 / (double)(i + 1);
-            #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                ps[i + 1][c] = (c2){T[i + 1][c].re * inv, T[i + 1][c].im * inv};
-                psi[((size_t)(i + 1) * 64 + r) * PS + cl + c] = ps[i + 1][c];
-            }
-            __syncthreads();
-        }
-    }
+    SP_PROF(17);
     // ---- G passes: g_i += -(1/j) A_{j-1-i} g_j (A^H = -A), i = 1..j-1, j = m..2
     #pragma unroll
     for (int j = M; j >= 2; j--) {
-        gsrc[r * PS + cl] = g[j - 1][0]; gsrc[r * PS + cl + 1] = g[j - 1][1];
+        if (j < M) __syncthreads();                     // the previous right operand has been consumed
+        buf[r * PS + cl] = g[j - 1][0]; buf[r * PS + cl + 1] = g[j - 1][1];
         __syncthreads();
         c2 t[M][2];
         #pragma unroll
         for (int q = 0; q < M; q++) { t[q][0] = (c2){0.0, 0.0}; t[q][1] = (c2){0.0, 0.0}; }
-        for (int e = 0; e < Z; e++) {
-            const c2 *src = gsrc + (size_t)Ecol[e * 64 + r] * PS + cl;
+        _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
+            const c2 *src = buf + (size_t)Ecol[e * 64 + r] * PS + cl;
             const c2 x0 = src[0], x1 = src[1];
             #pragma unroll
             for (int i = 1; i <= j - 1; i++) {
@@ -246,64 +280,100 @@ __global__ __launch_bounds__(256) void k_gradpoint_ell(const int32_t *__restrict
                 g[i - 1][c].re = __builtin_fma(sc, t[i][c].re, g[i - 1][c].re);
                 g[i - 1][c].im = __builtin_fma(sc, t[i][c].im, g[i - 1][c].im);
             }
-        __syncthreads();
     }
-    // ---- S passes: U_i = Sym_o psi_i, V_i = Asym_o psi_i,
-    //      sigP[d] += (1/j) Re<-i U_i, g_j>, sigQ[d] += (1/j) Re<V_i, g_j>, d = j-1-i
-    for (int o = 0; o < n_ops; o++) {
-        c2 U[M][2], V[M][2];
+    SP_PROF(18);
+    // ---- sources psi_0..psi_{m-1}
+    c2 T[M][2];
+    double sp[NO][M], sq[NO][M];
+    #pragma unroll
+    for (int q = 0; q < M; q++) { T[q][0] = (c2){0.0, 0.0}; T[q][1] = (c2){0.0, 0.0}; }
+    #pragma unroll
+    for (int o = 0; o < NO; o++)
         #pragma unroll
-        for (int i = 0; i < M; i++) { U[i][0] = U[i][1] = V[i][0] = V[i][1] = (c2){0.0, 0.0}; }
-        if (live) {
-            for (int e = 0; e < Zo; e++) {
-                const size_t at = ((size_t)o * Zo + e) * Np + r;
-                const int col = op_col[at];
-                const double kv = op_val[((size_t)(2 * o) * Zo + e) * Np + r], sv = op_val[((size_t)(2 * o + 1) * Zo + e) * Np + r];
+        for (int d = 0; d < M; d++) { sp[o][d] = 0.0; sq[o][d] = 0.0; }
+    #pragma unroll
+    for (int i = 0; i < M; i++) {
+        __syncthreads();                                // first pass: also orders the prologue's LDS writes
+        buf[r * PS + cl] = ps[0]; buf[r * PS + cl + 1] = ps[1];
+        __syncthreads();
+        if (i + 1 < M) {
+            _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
+                const c2 *src = buf + (size_t)Ecol[e * 64 + r] * PS + cl;
+                const c2 x0 = src[0], x1 = src[1];
                 #pragma unroll
-                for (int i = 0; i < M; i++) {
-                    const c2 *src = psi + ((size_t)i * 64 + col) * PS + cl;
-                    #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        const c2 x = src[c];
-                        U[i][c].re = __builtin_fma(sv, x.re, U[i][c].re); U[i][c].im = __builtin_fma(sv, x.im, U[i][c].im);
-                        V[i][c].re = __builtin_fma(kv, x.re, V[i][c].re); V[i][c].im = __builtin_fma(kv, x.im, V[i][c].im);
-                    }
+                for (int d = 0; d + i + 1 < M; d++) {
+                    const c2 a = As[(d * Z + e) * 64 + r];
+                    cfma(T[i + d + 1][0], a, x0); cfma(T[i + d + 1][1], a, x1);
                 }
             }
         }
-        double sp[M], sq[M];
+        SP_PROF(19);
         #pragma unroll
-        for (int d = 0; d < M; d++) { sp[d] = 0.0; sq[d] = 0.0; }
-        #pragma unroll
-        for (int i = 0; i < M; i++)
+        for (int o = 0; o < NO; o++) {
+            if (!NOPS_ON(NOPS, o, n_ops)) continue;
+            c2 U[2] = {{0.0, 0.0}, {0.0, 0.0}}, V[2] = {{0.0, 0.0}, {0.0, 0.0}};
+            _Pragma("unroll 1") for (int e = 0; e < Zo; e++) {
+                const int at = (o * Zo + e) * 64 + r;
+                const c2 kv = Ov[at];                   // (Asym_o, Sym_o)
+                const c2 *src = buf + (size_t)Ocol[at] * PS + cl;
+                #pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const c2 x = src[c];
+                    U[c].re = __builtin_fma(kv.im, x.re, U[c].re); U[c].im = __builtin_fma(kv.im, x.im, U[c].im);
+                    V[c].re = __builtin_fma(kv.re, x.re, V[c].re); V[c].im = __builtin_fma(kv.re, x.im, V[c].im);
+                }
+            }
             #pragma unroll
             for (int j = i + 1; j <= M; j++) {
                 double ap = 0.0, aq = 0.0;
                 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    ap += U[i][c].im * g[j - 1][c].re - U[i][c].re * g[j - 1][c].im;
-                    aq += V[i][c].re * g[j - 1][c].re + V[i][c].im * g[j - 1][c].im;
+                    ap += U[c].im * g[j - 1][c].re - U[c].re * g[j - 1][c].im;
+                    aq += V[c].re * g[j - 1][c].re + V[c].im * g[j - 1][c].im;
                 }
-                sp[j - 1 - i] += ap / (double)j;
-                sq[j - 1 - i] += aq / (double)j;
+                sp[o][j - 1 - i] += ap * (1.0 / (double)j);
+                sq[o][j - 1 - i] += aq * (1.0 / (double)j);
+                // keep the running sums materialised here (the unrolled code otherwise keeps every
+                // product alive until the final reduction: 2x the register count)
+                asm volatile("" : "+v"(sp[o][j - 1 - i]), "+v"(sq[o][j - 1 - i]));
             }
+        }
+        SP_PROF(20);
+        if (i + 1 < M) {
+            const double inv = 1.0 / (double)(i + 1);
+            ps[0] = (c2){T[i + 1][0].re * inv, T[i + 1][0].im * inv};
+            ps[1] = (c2){T[i + 1][1].re * inv, T[i + 1][1].im * inv};
+        }
+    }
+    SP_PROF(21);
+    #pragma unroll
+    for (int o = 0; o < NO; o++) {
+        if (!NOPS_ON(NOPS, o, n_ops)) continue;
         #pragma unroll
         for (int d = 0; d < M; d++) {
-            #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { sp[d] += __shfl_down(sp[d], off); sq[d] += __shfl_down(sq[d], off); }
-            if (r == 0) { atomicAdd(&sig[(o * M + d) * 2], sp[d]); atomicAdd(&sig[(o * M + d) * 2 + 1], sq[d]); }
+            const double a = row16_sum(live ? sp[o][d] : 0.0), b = row16_sum(live ? sq[o][d] : 0.0);
+            if ((r & 15) == 15) {                       // one partial sum per 16 rows and wave
+                red[((o * M + d) * 2) * 16 + (tid >> 4)] = a;
+                red[((o * M + d) * 2 + 1) * 16 + (tid >> 4)] = b;
+            }
         }
     }
     __syncthreads();
-    for (int e = tid; e < n_ops * M * 2; e += 256)
-        atomicAdd(&sigma[(size_t)n * n_ops * M * 2 + e], sig[e]);
+    for (int e = tid; e < n_ops * M * 2; e += 256) {
+        double v = 0.0;
+        #pragma unroll
+        for (int q = 0; q < 16; q++) v += red[e * 16 + q];
+        atomicAdd(&sigma[(size_t)n * n_ops * M * 2 + e], v);
+    }
+    SP_PROF(22);
 }
 
 static size_t lds_build_ell(int M, int Z) { return ((size_t)M * Z * 64 + 64 * 33) * 16 + (size_t)Z * 64 * 4; }
-static size_t lds_grad_ell(int M, int Z, int n_ops)
+static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 {
     const int nd = (M > 1) ? M - 1 : 1;
-    return ((size_t)nd * Z * 64 + (size_t)(M + 1) * 64 * 9) * 16 + ((size_t)n_ops * M * 2 + 1) * 8 + (size_t)Z * 64 * 4;
+    return ((size_t)nd * Z * 64 + 64 * 9 + (size_t)n_ops * Zo * 64) * 16 + (size_t)n_ops * M * 2 * 16 * 8 +
+           ((size_t)Z * 64 + (size_t)n_ops * Zo * 64) * 4;
 }
 
 template <int M>
@@ -312,19 +382,28 @@ static int launch_build_ell(const qgdk_ctx *c)
     const size_t shm = lds_build_ell(M, c->ell_z);
     SET_LDS_ONCE((k_build_LR_ell<M>), shm);
     hipLaunchKernelGGL((k_build_LR_ell<M>), dim3(c->nt, (c->Np + 31) / 32), dim3(512), shm, c->stream, c->ell_col,
-                       c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
+                       c->ell_inv, c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
+    return (int)hipGetLastError();
+}
+
+template <int M, int NOPS>
+static int launch_grad_ell_n(const qgdk_ctx *c)
+{
+    const size_t shm = lds_grad_ell(M, c->ell_z, c->n_ops, c->op_z);
+    SET_LDS_ONCE((k_gradpoint_ell<M, NOPS>), shm);
+    hipLaunchKernelGGL((k_gradpoint_ell<M, NOPS>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ell_col, c->ell_val,
+                       c->op_col, c->op_val, c->tab, c->hist, c->lam, c->sigma, c->cw, c->Np, c->cp, c->nt, c->n_ops,
+                       c->ell_z, c->op_z);
     return (int)hipGetLastError();
 }
 
 template <int M>
 static int launch_grad_ell(const qgdk_ctx *c)
 {
-    const size_t shm = lds_grad_ell(M, c->ell_z, c->n_ops);
-    SET_LDS_ONCE((k_gradpoint_ell<M>), shm);
-    hipLaunchKernelGGL((k_gradpoint_ell<M>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ell_col, c->ell_val,
-                       c->op_col, c->op_val, c->tab, c->hist, c->lam, c->sigma, c->cw, c->Np, c->cp, c->nt, c->n_ops,
-                       c->ell_z, c->op_z);
-    return (int)hipGetLastError();
+#define CALL_GE(N) return launch_grad_ell_n<M, N>(c)
+    DISPATCH_NOPS(c->n_ops, CALL_GE)
+#undef CALL_GE
+    return 0;
 }
 
 #define DISPATCH_M(m, FN) \
@@ -338,8 +417,17 @@ extern "C" {
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z)
 {
     if (Np > 64 || m < 1 || m > 8 || Z < 1) return 0;
-    return lds_build_ell(m, Z) <= 150 * 1024 && lds_grad_ell(m, Z, n_ops) <= 150 * 1024;
+    return lds_build_ell(m, Z) <= 150 * 1024 && lds_grad_ell(m, Z, n_ops, Z) <= 150 * 1024;
 }
+
+#ifdef QGD_SPARSE_PROFILE
+int qgdk_sparse_profile(unsigned long long *out32, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sparse_prof), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sparse_prof), z, sizeof z); }
+    return (int)e;
+}
+#endif
 
 int qgdk_build_LR_sparse(const qgdk_ctx *c) { DISPATCH_M(c->m, launch_build_ell) }
 int qgdk_gradient_sparse(const qgdk_ctx *c) { DISPATCH_M(c->m, launch_grad_ell) }
