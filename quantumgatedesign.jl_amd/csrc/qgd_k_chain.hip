@@ -74,146 +74,141 @@ __device__ __forceinline__ void chain_a(const double *__restrict__ Pn, int Np, i
     }
 }
 
-// NP > 0: compile-time size, 8 waves = (row block, K slice).  The state lives in LDS as the
-// KSPLIT partial sums the waves produced (double buffered): the next step's B fragments are the
-// sums of those partials, so a step needs ONE barrier.  The A fragments (and, for the adjoint, the
-// forcing in accumulator layout) of the next PF steps are in flight in a register ring.
-template <int NP, int MODE>
-__global__ __launch_bounds__(512) void k_chain_fast(const ChainArgs a)
+// same, but the adjoint's imaginary part is returned un-negated (sign = -1 is applied to the B
+// operand instead): nothing touches the loaded registers until the MFMA, so the loads stay in flight
+template <bool ADJ>
+__device__ __forceinline__ void chain_a_raw(const double *__restrict__ Pn, int Np, int arow, int k,
+                                            double &are, double &aim)
+{
+    const size_t pl = (size_t)Np * Np;
+    if (!ADJ) {
+        const double *P = Pn + (size_t)arow + (size_t)Np * k;
+        are = P[0];
+        aim = P[pl];
+    } else {
+        const double *P = Pn + (size_t)k * 2 * Np + (arow >> 3) * 16 + (arow & 7);
+        are = P[0];
+        aim = P[8];
+    }
+}
+
+// NP > 0: compile-time size.  The steps of a chain are sequential, but the LEFT operands (P_n,
+// and the forcing of the adjoint) do not depend on the state: NT = 4 teams of NP/16 waves take the
+// steps round-robin, team t computing steps t, t+4, ...  Each team issues the loads of its next
+// step right after finishing one and then sits out the three steps of the other teams at the step
+// barriers, so its operands have three step times to arrive -- with plain compiler-managed
+// registers (a register ring inside one wave does not survive the compiler's vmcnt bookkeeping on
+// gfx9, where loads and the history stores share one counter).  One barrier per step; the state is
+// double buffered in LDS; a wave owns 16 rows over the full K range (no partial sums), the history
+// is stored straight from the accumulators.  NG column groups per workgroup share the A fragments.
+#ifndef QGD_CHAIN_NT
+#define QGD_CHAIN_NT 4
+#endif
+template <int NP, int MODE, int NG>
+__global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const ChainArgs a)
 {
     constexpr bool ADJ = (MODE >= 2);
-    constexpr int NRB = NP / 16;
-    constexpr int KSPLIT = (8 / NRB) < (NP / 4) ? (8 / NRB) : (NP / 4);
-    constexpr int NACT = NRB * KSPLIT;
-    constexpr int KS = NP / 4 / KSPLIT;
-    constexpr int PF = 3;
-    constexpr int EPT = (NP * 16 + 511) / 512;           // panel elements per thread
-    static_assert(NRB * 16 == NP && KS * KSPLIT * 4 == NP && NACT <= 8, "tile");
-    __shared__ __attribute__((aligned(16))) double part[2][KSPLIT][NP * 16];
+    constexpr int NRB = NP / 16, NT = QGD_CHAIN_NT, KST = NP / 4, NTH = NP * 4 * NT;
+    __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
-    int b, grp;
-    chain_block_of<MODE>(a, b, grp);
+    int b, grp0;
+    {
+        ChainArgs a2 = a; a2.ngroups = a.ngroups / NG;
+        chain_block_of<MODE>(a2, b, grp0);
+        grp0 *= NG;
+    }
     if (b >= a.nblocks) return;
     const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
     const int PWc = (MODE == 0) ? 2 * NP : 2 * a.cp;
     const size_t hstep = (size_t)NP * PWc;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kk = lane >> 4;
-    const bool active = wave < NACT;
-    const int rb = wave / KSPLIT, kq = wave % KSPLIT;
+    const int team = wave / NRB, rb = wave % NRB;
     const int arow = rb * 16 + c16;
-    const int nsteps = e0 - s0;
+    const int nsteps = (e0 > s0) ? e0 - s0 : 0;
 
-    // start state into part[0][0], zeros into the other partial slots
-    #pragma unroll
-    for (int t2 = 0; t2 < EPT; t2++) {
-        const int e = tid + t2 * 512;
-        if (e < NP * 16) {
-            const int row = e >> 4, c = e & 15;
-            double v;
-            if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
-            else if (MODE == 2) v = 0.0;
-            else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
-            part[0][0][e] = v;
-            #pragma unroll
-            for (int w2 = 1; w2 < KSPLIT; w2++) part[0][w2][e] = 0.0;
-        }
+    // start state into part[0]
+    for (int e = tid; e < NG * NP * 16; e += NTH) {
+        const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
+        double v;
+        if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
+        else if (MODE == 2) v = 0.0;
+        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
+        part[0][g][el] = v;
     }
-    double rre[PF][KS], rim[PF][KS], rfo[PF][4];
+    double are[KST], aim[KST], fo[NG][4];
     auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
-    auto issue = [&](int slot, int st) {                 // loads for step st into ring slot
+    auto issue = [&](int st) {                            // left operand (and forcing) of step st
         const int n = step_index(st);
-        if (active) {
-            const double *Pn = chain_matrix(a, n);
+        const double *Pn = chain_matrix(a, n);
+        #pragma unroll
+        for (int i = 0; i < KST; i++) chain_a_raw<ADJ>(Pn, NP, arow, i * 4 + kk, are[i], aim[i]);
+        if (ADJ) {
+            const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
             #pragma unroll
-            for (int i = 0; i < KS; i++) chain_a<ADJ>(Pn, NP, arow, (kq * KS + i) * 4 + kk, rre[slot][i], rim[slot][i]);
-            if (ADJ && kq == 0) {                        // forcing f_n in accumulator layout
-                const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
+            for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    rfo[slot][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16];
-            }
+                    fo[g][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16];
         }
     };
-    #pragma unroll
-    for (int q = 0; q < PF; q++) if (q < nsteps) issue(q, q);
+    if (team < nsteps) issue(team);
     __syncthreads();
 
-    int buf = 0;
-    // one step on ring slot q; `refill` (>= 0) is the step whose operands replace the slot
-    auto do_step = [&](int q, int st, int refill) {
-        const int n = step_index(st);
-        if (active) {
-            d4 acc = (d4){0, 0, 0, 0};
+    int done = 0;                                         // step barriers this wave has passed
+    for (int st = team; st < nsteps; st += NT) {
+        while (done < st) { __syncthreads(); done++; }   // steps of the other teams
+        const int buf = st & 1, n = step_index(st);
+        d4 acc[NG][2];
+        #pragma unroll
+        for (int g = 0; g < NG; g++) { acc[g][0] = (d4){0, 0, 0, 0}; acc[g][1] = (d4){0, 0, 0, 0}; }
+        #pragma unroll
+        for (int i = 0; i < KST; i++) {
+            const int ko = (i * 4 + kk) * 16;
             #pragma unroll
-            for (int i = 0; i < KS; i++) {
-                const int ko = ((kq * KS + i) * 4 + kk) * 16;
-                double v1 = part[buf][0][ko + c16], v2 = part[buf][0][ko + (c16 ^ 8)];
-                #pragma unroll
-                for (int w2 = 1; w2 < KSPLIT; w2++) { v1 += part[buf][w2][ko + c16]; v2 += part[buf][w2][ko + (c16 ^ 8)]; }
-                acc = MFMA(rre[q][i], v1, acc);
-                acc = MFMA(rim[q][i], (c16 < 8) ? -v2 : v2, acc);
+            for (int g = 0; g < NG; g++) {
+                const double v1 = part[buf][g][ko + c16], v2 = part[buf][g][ko + (c16 ^ 8)];
+                acc[g][0] = MFMA(are[i], v1, acc[g][0]);
+                acc[g][1] = MFMA(aim[i], ((c16 < 8) != ADJ) ? -v2 : v2, acc[g][1]);
             }
+        }
+        const int nout = ADJ ? n : n + 1;                 // time index of the state this step produces
+        double res[NG][4];
+        #pragma unroll
+        for (int g = 0; g < NG; g++)
             #pragma unroll
             for (int r = 0; r < 4; r++) {
-                double v = acc[r];
-                if (ADJ && kq == 0) v += rfo[q][r];
-                part[buf ^ 1][kq][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
+                double v = acc[g][0][r] + acc[g][1][r];
+                if (ADJ) v += fo[g][r];
+                res[g][r] = v;
+                part[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
             }
-        }
-        // history: part[buf] holds the state that the previous step produced (the start state is
-        // not an output)
-        if ((MODE == 1 || MODE == 3) && st > 0) {
-            const int ncur = ADJ ? n + 1 : n;
+        __syncthreads(); done++;                          // the next team starts; the rest is off the critical path
+        if (MODE == 1 || MODE == 3) {
             #pragma unroll
-            for (int t2 = 0; t2 < EPT; t2++) {
-                const int e = tid + t2 * 512;
-                if (e < NP * 16) {
-                    double v = part[buf][0][e];
-                    #pragma unroll
-                    for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
-                    a.out[(size_t)ncur * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = v;
-                }
-            }
+            for (int g = 0; g < NG; g++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    a.out[(size_t)nout * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16] = res[g][r];
         }
-        if (refill >= 0) issue(q, refill);
-        __syncthreads();
-        buf ^= 1;
-    };
-    // steady state: whole groups of PF steps, no conditionals (keeps the compiler's vmcnt
-    // bookkeeping exact so that PF-1 sets of loads really stay in flight); the refill index is
-    // clamped, the last groups reload the final matrix harmlessly
-    const int nfull = (nsteps / PF) * PF;
-    for (int st0 = 0; st0 < nfull; st0 += PF) {
-        #pragma unroll
-        for (int q = 0; q < PF; q++) {
-            const int nxt = st0 + q + PF;
-            do_step(q, st0 + q, nxt < nsteps ? nxt : nsteps - 1);
-        }
+        if (st + NT < nsteps) issue(st + NT);
     }
-    #pragma unroll
-    for (int q = 0; q < PF; q++)
-        if (nfull + q < nsteps) do_step(q, nfull + q, -1);
-    // final state = sum of the partials in part[buf]
-    const int nlast = ADJ ? s0 : e0;                     // its time index
-    #pragma unroll
-    for (int t2 = 0; t2 < EPT; t2++) {
-        const int e = tid + t2 * 512;
-        if (e < NP * 16) {
-            double v = part[buf][0][e];
-            #pragma unroll
-            for (int w2 = 1; w2 < KSPLIT; w2++) v += part[buf][w2][e];
-            const int row = e >> 4, c = e & 15;
-            if ((MODE == 1 || MODE == 3) && nsteps > 0)
-                a.out[(size_t)nlast * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+    while (done < nsteps) { __syncthreads(); done++; }
+    // final state (part[nsteps & 1]) of the block
+    if (MODE == 0 || MODE == 2) {
+        const int buf = nsteps & 1;
+        for (int e = tid; e < NG * NP * 16; e += NTH) {
+            const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
+            const double v = part[buf][g][el];
             if (MODE == 0) {
                 const size_t pl = (size_t)NP * NP;
                 double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
-                const int col = grp * 8 + (c & 7);
+                const int col = (grp0 + g) * 8 + (c & 7);
                 pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)NP * col] = v;
-                pr[(size_t)row * 2 * NP + grp * 16 + c] = v;
+                pr[(size_t)row * 2 * NP + (grp0 + g) * 16 + c] = v;
+            } else {
+                a.phi[(size_t)b * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c] = v;
             }
-            if (MODE == 2) a.phi[(size_t)b * hstep + (size_t)row * PWc + grp * 16 + c] = v;
         }
     }
 }
@@ -289,12 +284,16 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
 template <int MODE>
 static int launch_chain(const ChainArgs &a, hipStream_t stream)
 {
-    const int nwg = (MODE == 0) ? 8 * a.ngroups * ((a.nblocks + 7) / 8) : a.nblocks * a.ngroups;
+    constexpr int NG = (MODE == 0) ? 2 : 1;               // the matrix-matrix chains pair up column groups
+    const bool fast = (a.Np == 16 || a.Np == 32 || a.Np == 48 || a.Np == 64) && a.ngroups % NG == 0;
+    const int ng = fast ? a.ngroups / NG : a.ngroups;
+    const int nwg = (MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng;
     if (nwg <= 0) return 0;
-    switch (a.Np) {
-    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
-    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
-    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE>), dim3(nwg), dim3(512), 0, stream, a); break;
+    switch (fast ? a.Np : 0) {
+    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE, NG>), dim3(nwg), dim3(16 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE, NG>), dim3(nwg), dim3(32 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
+    case 48: hipLaunchKernelGGL((k_chain_fast<48, MODE, NG>), dim3(nwg), dim3(48 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
     default: {
         size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
         hipLaunchKernelGGL((k_chain_generic<MODE>), dim3(nwg), dim3(256), shm, stream, a);
