@@ -6,27 +6,31 @@
 // K0: control tables  tab[n][d][k][pq] = sum_l G[k][n][d][l] * pcof[off_k + l]
 // (fill_p_mat!/fill_q_mat!, Control.jl:125-149, for the whole grid at once)
 // ---------------------------------------------------------------------------
-__global__ void k_tables(const double *__restrict__ G, const int64_t *__restrict__ goff,
+__global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
                          const double *__restrict__ pcof, double *__restrict__ tab, int nt, int m,
                          int n_ops, double *__restrict__ scal, int *__restrict__ status)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 4) scal[idx] = 0.0;            // objective scalars and the singularity flag start at zero
-    if (idx == 4) *status = 0;
-    int total = nt * (m + 1) * n_ops * 2;
-    if (idx >= total) return;
-    int pq = idx & 1;
-    int k = (idx >> 1) % n_ops;
-    int d = ((idx >> 1) / n_ops) % (m + 1);
-    int n = ((idx >> 1) / n_ops) / (m + 1);
-    int nc = ncoef[k];
-    // G for control k: [pq][nt][m+1][nc]
-    const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
-    const double *pc = pcof + poff[k];
+    // 16 lanes per table entry: contiguous 128-byte reads of the basis row, DPP sum over the 16 lanes
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < 4) scal[gid] = 0.0;            // objective scalars and the singularity flag start at zero
+    if (gid == 4) *status = 0;
+    const int idx = gid >> 4, sub = gid & 15;
+    const int total = nt * (m + 1) * n_ops * 2;
     double s = 0.0;
-    for (int l = 0; l < nc; l++) s += g[l] * pc[l];
-    tab[idx] = s;
+    if (idx < total) {
+        const int pq = idx & 1;
+        const int k = (idx >> 1) % n_ops;
+        const int d = ((idx >> 1) / n_ops) % (m + 1);
+        const int n = ((idx >> 1) / n_ops) / (m + 1);
+        const int nc = ncoef[k];
+        // G for control k: [pq][nt][m+1][nc]
+        const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
+        const double *pc = pcof + poff[k];
+        for (int l = sub; l < nc; l += 16) s = __builtin_fma(g[l], pc[l], s);
+    }
+    s = row16_sum(s);
+    if (idx < total && sub == 15) tab[idx] = s;
 }
 
 // general path: tables given by the host in Julia layout [(1+m), n_ops, nt]
@@ -312,7 +316,7 @@ extern "C" {
 int qgdk_tables(const qgdk_ctx *c, const double *pcof)
 {
     int total = c->nt * (c->m + 1) * c->n_ops * 2;
-    hipLaunchKernelGGL(k_tables, dim3((total + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
+    hipLaunchKernelGGL(k_tables, dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
                        c->poff, pcof, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
     return (int)hipGetLastError();
 }

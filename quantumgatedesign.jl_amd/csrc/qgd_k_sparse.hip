@@ -29,23 +29,6 @@ __device__ __forceinline__ void cfma(c2 &acc, const c2 a, const c2 x)
     acc.im = __builtin_fma(a.re, x.im, acc.im); acc.im = __builtin_fma(a.im, x.re, acc.im);
 }
 
-// sum over each row of 16 lanes, result in lane 15 of the row (DPP inclusive scan, no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ double dpp_add_step(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-    return v + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v)
-{
-    v = dpp_add_step<0x111>(v);     // row_shr:1
-    v = dpp_add_step<0x112>(v);     // row_shr:2
-    v = dpp_add_step<0x114>(v);     // row_shr:4
-    v = dpp_add_step<0x118>(v);     // row_shr:8
-    return v;
-}
-
 // assemble A_d(t_n) = K - iS, d = 0..nd-1, over the union pattern into LDS:
 // As[(d*Z + e)*64 + r] = (K, -S).  One (entry, row) pair per thread: the operator values are
 // fetched once and combined with the coefficients of every derivative order.

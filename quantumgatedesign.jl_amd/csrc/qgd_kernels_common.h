@@ -40,6 +40,23 @@ __device__ __forceinline__ void panel_b(const double *row16, int c16, double &b1
     b2 = (c16 < 8) ? -t : t;
 }
 
+// sum over each row of 16 lanes, result in lane 15 of the row (DPP inclusive scan, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_step(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v = dpp_add_step<0x111>(v);     // row_shr:1
+    v = dpp_add_step<0x112>(v);     // row_shr:2
+    v = dpp_add_step<0x114>(v);     // row_shr:4
+    v = dpp_add_step<0x118>(v);     // row_shr:8
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // A-fragment providers: value of the LEFT operand at (row, k)
 // ---------------------------------------------------------------------------
