@@ -361,7 +361,8 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
         #pragma unroll
         for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
     INV_PROF(0);
-    bool used = lane >= NP;                             // wave 0: this lane's row has been a pivot row
+    bool used = lane >= NP;                             // panel wave: this lane's row has been a pivot row
+    const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
 
     for (int pn = 0; pn < NP / 4; pn++) {
         const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
@@ -383,8 +384,10 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
         }
         __syncthreads();
         INV_PROF(1);
-        // ---- 2. wave 0: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row
-        if (w == 0) {
+        // ---- 2. one wave (a different one in neighbouring workgroups, so that the serial phases of
+        //         the workgroups sharing a CU sit on different SIMDs): pivoted in-place Gauss-Jordan
+        //         on the NP x 4 panel, lane = row
+        if (w == pw) {
             double xr[4], xi[4];
             const int lrow = (lane < NP) ? lane : 0;
             #pragma unroll
