@@ -281,10 +281,9 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
     }
 }
 
-template <int MODE>
-static int launch_chain(const ChainArgs &a, hipStream_t stream)
+template <int MODE, int NG>
+static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
 {
-    constexpr int NG = (MODE == 0) ? 2 : 1;               // the matrix-matrix chains pair up column groups
     const bool fast = (a.Np == 16 || a.Np == 32 || a.Np == 48 || a.Np == 64) && a.ngroups % NG == 0;
     const int ng = fast ? a.ngroups / NG : a.ngroups;
     const int nwg = (MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng;
@@ -300,6 +299,16 @@ static int launch_chain(const ChainArgs &a, hipStream_t stream)
     }
     }
     return (int)hipGetLastError();
+}
+
+template <int MODE>
+static int launch_chain(const ChainArgs &a, hipStream_t stream)
+{
+    // the matrix-matrix chains (block propagators) pair up column groups when one group per
+    // workgroup would need more than one workgroup per CU: half the L2 traffic for the step
+    // matrices at the same MFMA time; small grids keep one group per workgroup (shorter steps)
+    if (MODE == 0 && a.ngroups % 2 == 0 && (long long)a.nblocks * a.ngroups > 256) return launch_chain_ng<MODE, 2>(a, stream);
+    return launch_chain_ng<MODE, 1>(a, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -387,3 +387,20 @@ def test_operator_path_selection(qgd):
         dp.set_operator_path("sparse")
     assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
     dp.close()
+
+
+@pytest.mark.parametrize("N,c,order", [(20, 4, 6), (40, 12, 4), (64, 8, 8)])
+def test_mid_size_dense_problems(qgd, N, c, order):
+    """Random dense problems padded to 32, 48 and 64 rows: the register-blocked inverses, the
+    team-pipelined sweeps at every compiled size and the dense MFMA operator kernels, against the
+    numpy statement of the algorithm."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=70, tf=0.7)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    shape = (2 * N, 1 + order // 2, prob.nsteps + 1, c)
+    hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((2 * N, prob.nsteps + 1, c), order="F")
+    grad = np.zeros(len(pcof))
+    qgd.discrete_adjoint_(grad, hist, lam, forcing, prob, ctrl, pcof, target, order=order)
+    assert close(hist, pp.history_real(ref["ws"]), 1e-11)
+    assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
+    qgd.clear_cache()
