@@ -43,34 +43,40 @@ def workload(qgd, nsteps, tf):
     return prob, ctrl, pcof, target
 
 
-def phase_model(N, c, m, n_ops, nt):
-    """Algorithmic work per launch of each device phase (DESIGN.md 'Kernels')."""
+def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
+    """Algorithmic work per launch of the phases that are ONE kernel launch (DESIGN.md 'Kernels').
+    The two sweeps (five launches of the chain kernel each) and the gradient (scalars + contraction)
+    are several launches; they appear in the per-phase breakdown but a `roofline` object describes
+    one kernel, so the dominant kernel is chosen among the single-launch phases."""
     cgemm = 8.0 * N ** 3                       # complex N x N x N product, real flops
     apply_ = 8.0 * N * N * c                   # one Hamiltonian application on all columns
+    mat_b = 16.0 * N * N                       # one complex N x N matrix, bytes
     hist_b = 16.0 * N * c                      # one complex state panel, bytes
-    return {
-        "build_LR": ("mfma", nt * (m * (m - 1) / 2) * cgemm),
-        "inverse": ("mfma", (nt - 1) * cgemm),
+    model = {
+        # inverse by Gauss-Jordan = one cgemm of flops; the fused kernel also forms P = L^-1 R
+        "inverse": ("mfma", (nt - 1) * cgemm * (2 if fused_propagator else 1)),
         "propagator": ("mfma", (nt - 1) * cgemm),
-        "sweep_forward": ("hbm", (nt - 1) * (16.0 * N * N + 2 * hist_b)),
-        "sweep_adjoint": ("hbm", (nt - 2) * (16.0 * N * N + 3 * hist_b)),
-        "derivs": ("mfma", nt * (m * (m + 1) / 2) * apply_),
-        "gradient": ("mfma", nt * ((m * (m - 1) / 2) + n_ops * m) * apply_),
-        "lambda": ("mfma", (nt - 1) * apply_),
+        "lambda": ("hbm", (nt - 1) * (mat_b + 2 * hist_b)),
         "guard": ("hbm", nt * (3 * hist_b)),
     }
+    if sparse_ops:   # ELL kernels: flops are negligible, the kernel exists to write L_n and R_n
+        model["build_LR"] = ("hbm", nt * 2 * mat_b)
+    else:
+        model["build_LR"] = ("mfma", nt * (m * (m - 1) / 2) * cgemm)
+    return model
 
 
-KERNEL_OF_PHASE = {"build_LR": "void k_build_LR64<4, 3>", "inverse": "void k_inverse_reg<64, 16>", "propagator": "k_propagator",
-                   "gradient": "void k_gradpoint64<4, 3>", "lambda": "k_lambda", "guard": "k_guard_diag"}
+KERNEL_OF_PHASE = {"build_LR": "void k_build_LR_ell<4>", "inverse": "void k_inverse_mfma<64>", "propagator": "k_propagator",
+                   "lambda": "k_lambda", "guard": "k_guard_diag"}
+PMC_PROFILE = "r01_v6_pmc_fetch_write.json"
 
 
 def measured_traffic(phase):
     """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_v3_pmc_fetch_write.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this
-    same command; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so it is doubled --
+    (profiles/PMC_PROFILE: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this same command;
+    on gfx950 FETCH_SIZE counts half of a wide coalesced read, so it is doubled --
     MI355X_MICROARCH.md 'HBM').  None when no profile of that kernel is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_fetch_write.json")
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     kern = KERNEL_OF_PHASE.get(phase)
     if not kern or not os.path.exists(path):
         return None
@@ -171,8 +177,10 @@ def main():
             continue                      # first call pays one-time launch/JIT costs
         for k, v in dp.timings().items():
             breakdown[k] = breakdown.get(k, 0.0) + v / (nwarm - 1)
-    known = set(phase_model(1, 1, 1, 1, 2)) | {"sweep_forward2", "sweep_adjoint2"}
-    dom_raw = max((k for k in breakdown if k in known), key=breakdown.get)
+    path = dp.operator_path() if hasattr(dp, "operator_path") else ("sparse", 0, 0)
+    model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1,
+                        sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in breakdown))
+    dom_raw = max((k for k in breakdown if k in model), key=breakdown.get)
     dp.set_timing(2, dom_raw)
     dp.discrete_adjoint(pcof)
     phase_ms = {}
@@ -192,14 +200,10 @@ def main():
     if rank == 0:
         for k in phase_ms:
             phase_ms[k] /= args.steps
-        model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1)
-        # the dominant kernel, timed live in the timed region (the two halves of a sweep are separate
-        # launches of the same kernel family: the roofline object is quoted on the one bracketed)
-        dom = dict(merge).get(dom_raw, dom_raw)
+        # the dominant kernel among the single-launch phases, timed live in the timed region
+        dom = dom_raw
         timed = {dom: phase_ms[dom_raw]}
         bound, work = model[dom]
-        if dom_raw in dict(merge) or dom_raw in dict(merge).values():
-            work *= 0.5
         for extra, base in merge:
             if extra in breakdown:
                 breakdown[base] = breakdown.get(base, 0.0) + breakdown.pop(extra)
@@ -221,10 +225,11 @@ def main():
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
                        "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
-            "roofline": {"kernel": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+            "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom).replace("void ", ""), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": measured_traffic(dom),
                          "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
+            "operator_path": path[0],
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),
         }

@@ -269,7 +269,8 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
     }
     { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
     { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
-    { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
+    if (qgdk_propagator_is_fused(&k)) { K_TRY(h, qgdk_propagator(&k)); }   // k_inverse_mfma formed P_n already
+    else { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
     { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
     h->forward_valid = false;
     h->derivs_valid = false;
@@ -781,10 +782,10 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     memset(out, 0, need * sizeof(double));
     if (s == "Linv") {
         std::vector<double> b(nt * 2 * pl);
-        HIP_TRY(h, hipMemcpy(b.data(), k.LinvA, b.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(b.data(), k.LinvT, b.size() * sizeof(double), hipMemcpyDeviceToHost));   // row-major planes
         for (size_t n = 1; n < nt; n++) for (size_t r = 0; r < N; r++) for (size_t c = 0; c < N; c++) {
-            out[((n * N + r) * N + c) * 2] = b[n * 2 * pl + r + Np * c];
-            out[((n * N + r) * N + c) * 2 + 1] = b[n * 2 * pl + pl + r + Np * c];
+            out[((n * N + r) * N + c) * 2] = b[n * 2 * pl + r * Np + c];
+            out[((n * N + r) * N + c) * 2 + 1] = b[n * 2 * pl + pl + r * Np + c];
         }
         return QGD_OK;
     }

@@ -71,6 +71,7 @@ int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double 
 int qgdk_build_LR(const qgdk_ctx *c);
 int qgdk_inverse(const qgdk_ctx *c);
 int qgdk_propagator(const qgdk_ctx *c);
+int qgdk_propagator_is_fused(const qgdk_ctx *c);
 int qgdk_forward_blocks(const qgdk_ctx *c);
 int qgdk_forward_finish(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);

@@ -328,8 +328,8 @@ __device__ __forceinline__ double fast_rcp(double d)             // v_rcp_f64 + 
 
 template <int NP>
 __global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, double *__restrict__ LinvT,
-                    int n0, int *__restrict__ status
+void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                    double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status
 #ifdef QGD_INV_PROFILE      // scripts/ubench/inverse_bench.hip: cycles of workgroup 0 / wave 0 per phase
                     , unsigned long long *prof)
 {
@@ -466,11 +466,23 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
         // read above (G, Prow) alternate with the panel parity
     }
     __syncthreads();
-    // A^-1[rinv[x]][rho[j]] = M[x][j]
-    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    // ---- output.  A^-1[rinv[x]][rho[j]] = M[x][j] goes through LDS one plane at a time (real parts,
+    // then imaginary parts): each staged plane is written out as LinvT (left operand of
+    // lambda = L^-H y) and is at once the A operand of one half of the step propagator
+    //   P_{n-1} = L_n^-1 R_{n-1} = Are [Rre|Rim] + Aim [-Rim|Rre]
+    // (forward_evolution.jl:181-220, the implicit solve done for all right-hand sides).  For the
+    // product wave w owns the column groups 2w, 2w+1 of P over all rows: R is read once.
+    double *T = LinvT + (size_t)n * 2 * pl;
+    const double *Rn = R + (size_t)(n - 1) * panel;
     int orow[4];
     #pragma unroll
     for (int r = 0; r < 4; r++) orow[r] = rinv[16 * w + kk + 4 * r] * LDP;
+    constexpr int NRT = NP / 16, GPW = NG / NW;            // row tiles, column groups per wave
+    d4 acc[NRT][GPW];
+    #pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+        #pragma unroll
+        for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = (d4){0, 0, 0, 0};
     #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         if ((c16 >> 3) == pass) {
@@ -482,11 +494,49 @@ void k_inverse_mfma(const double *__restrict__ L, double *__restrict__ LinvA, do
             }
         }
         __syncthreads();
-        for (int e = t; e < NP * NP; e += NTH) {
-            const int hi = e / NP, lo = e % NP;
-            T[pass * pl + e] = smem[hi * LDP + lo];
-            A[pass * pl + e] = smem[lo * LDP + hi];
+        for (int e = t; e < NP * NP; e += NTH) T[pass * pl + e] = smem[(e / NP) * LDP + (e % NP)];
+        #pragma unroll 4
+        for (int ks = 0; ks < NP / 4; ks++) {
+            const int k = 4 * ks + kk;
+            double bf[GPW];
+            #pragma unroll
+            for (int gg = 0; gg < GPW; gg++) {
+                const double *row = Rn + (size_t)k * PW + 16 * (GPW * w + gg);
+                if (pass == 0) bf[gg] = row[c16];
+                else { const double v = row[c16 ^ 8]; bf[gg] = (c16 < 8) ? -v : v; }
+            }
+            #pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const double af = smem[(16 * rt + c16) * LDP + k];
+                #pragma unroll
+                for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
+            }
         }
+        __syncthreads();
+    }
+    // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
+    // column-major planes (left operand of the forward sweep) through LDS
+    double *Prn = Pr + (size_t)(n - 1) * panel, *Pcn = Pc + (size_t)(n - 1) * 2 * pl;
+    #pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+        #pragma unroll
+        for (int gg = 0; gg < GPW; gg++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++)
+                Prn[(size_t)(16 * rt + kk + 4 * r) * PW + 16 * (GPW * w + gg) + c16] = acc[rt][gg][r];
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((c16 >> 3) == pass) {
+            #pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+                #pragma unroll
+                for (int gg = 0; gg < GPW; gg++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        smem[(8 * (GPW * w + gg) + (c16 & 7)) * LDP + 16 * rt + kk + 4 * r] = acc[rt][gg][r];   // [col][row]
+        }
+        __syncthreads();
+        for (int e = t; e < NP * NP; e += NTH) Pcn[pass * pl + e] = smem[(e / NP) * LDP + (e % NP)];
         __syncthreads();
     }
     INV_PROF(5);
@@ -580,7 +630,7 @@ int qgdk_inverse(const qgdk_ctx *c)
     case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 64:   // blocked elimination with MFMA rank-4 updates (the register-blocked VALU kernel measured 0.22 ms)
         if (!getenv("QGD_INVERSE_VALU")) {
-            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status
+            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status
 #ifdef QGD_INV_PROFILE
                                , (unsigned long long *)nullptr
 #endif
@@ -609,8 +659,11 @@ int qgdk_inverse(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
+int qgdk_propagator_is_fused(const qgdk_ctx *c) { return c->Np == 64 && !getenv("QGD_INVERSE_VALU"); }
+
 int qgdk_propagator(const qgdk_ctx *c)
 {
+    if (qgdk_propagator_is_fused(c)) return 0;                    // k_inverse_mfma produced P_n already
     const int ngroups = c->Np / 8;
     const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
     const int rtiles = (c->Np + 63) / 64;

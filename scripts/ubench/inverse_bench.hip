@@ -23,16 +23,18 @@ int main(int argc, char **argv)
                 L[n * panel + r * PW + (c >> 3) * 16 + (c & 7)] = re;
                 L[n * panel + r * PW + (c >> 3) * 16 + 8 + (c & 7)] = im;
             }
-    double *dL, *dA, *dT; int *dS; unsigned long long *dprof;
+    double *dL, *dA, *dT, *dR, *dPr, *dPc; int *dS; unsigned long long *dprof;
     hipMalloc(&dL, L.size() * 8); hipMalloc(&dA, (nmat + 1) * 2 * pl * 8); hipMalloc(&dT, (nmat + 1) * 2 * pl * 8);
+    hipMalloc(&dR, L.size() * 8); hipMalloc(&dPr, L.size() * 8); hipMalloc(&dPc, L.size() * 8);
     hipMalloc(&dS, 4); hipMemset(dS, 0, 4); hipMalloc(&dprof, 64 * 8); hipMemset(dprof, 0, 64 * 8);
     hipMemcpy(dL, L.data(), L.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dR, L.data(), L.size() * 8, hipMemcpyHostToDevice);   // R := L shifted by one: P_{n-1} = L_n^-1 L_{n-1}
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
 #ifdef QGD_INV_PROFILE
-        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dA, dT, 1, dS, dprof);
+        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS, dprof);
 #else
-        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dA, dT, 1, dS);
+        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS);
 #endif
     };
     for (int i = 0; i < 5; i++) launch();
@@ -57,11 +59,26 @@ int main(int argc, char **argv)
             }
             err = fmax(err, std::abs(s - (r == c ? 1.0 : 0.0)));
         }
+    // P_0 = L_1^-1 R_0 with R_0 = L_0: check L_1 P_0 = L_0 on the panel copy and the plane copy
+    std::vector<double> Pp(panel), Pq(2 * pl);
+    hipMemcpy(Pp.data(), dPr, panel * 8, hipMemcpyDeviceToHost); hipMemcpy(Pq.data(), dPc, 2 * pl * 8, hipMemcpyDeviceToHost);
+    double errp = 0, errq = 0;
+    auto Lat = [&](int n, int r, int c) { return std::complex<double>(L[n * panel + r * PW + (c >> 3) * 16 + (c & 7)], L[n * panel + r * PW + (c >> 3) * 16 + 8 + (c & 7)]); };
+    for (int r = 0; r < NP; r++)
+        for (int c = 0; c < NP; c++) {
+            std::complex<double> s1 = 0, s2 = 0;
+            for (int k = 0; k < NP; k++) {
+                s1 += Lat(1, r, k) * std::complex<double>(Pp[k * PW + (c >> 3) * 16 + (c & 7)], Pp[k * PW + (c >> 3) * 16 + 8 + (c & 7)]);
+                s2 += Lat(1, r, k) * std::complex<double>(Pq[k + NP * c], Pq[pl + k + NP * c]);
+            }
+            errp = fmax(errp, std::abs(s1 - Lat(0, r, c))); errq = fmax(errq, std::abs(s2 - Lat(0, r, c)));
+        }
+    printf("max |L1 P0 - R0| = %.2e (panel), %.2e (planes)\n", errp, errq);
     int st; hipMemcpy(&st, dS, 4, hipMemcpyDeviceToHost);
     printf("max |Linv L - I| = %.2e, status %d\n", err, st);
 #ifdef QGD_INV_PROFILE
     unsigned long long prof[64]; hipMemcpy(prof, dprof, sizeof prof, hipMemcpyDeviceToHost);
-    const char *names[] = {"load", "1 publish", "2 panel GJ (wave 0)", "3 pivot rows", "4 mfma+cols", "output"};
+    const char *names[] = {"load", "1 publish", "2 panel GJ (one wave)", "3 pivot rows", "4 mfma+cols", "output + propagator"};
     for (int i = 0; i < 6; i++) printf("  %-22s %10.0f cycles (clock64 ticks) per matrix\n", names[i], (double)prof[i] / 50.0);
 #endif
     return 0;
