@@ -282,7 +282,7 @@ int forward_end(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
-    { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }
+    if (!qgdk_guard_is_fused(&k)) { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }   // else: done by the history pass
     if (k.part_rank == k.part_world - 1) {   // the rank that owns the final time
         PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target));
     }

@@ -75,6 +75,7 @@ int qgdk_propagator_is_fused(const qgdk_ctx *c);
 int qgdk_forward_blocks(const qgdk_ctx *c);
 int qgdk_forward_finish(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
+int qgdk_guard_is_fused(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
 int qgdk_adjoint_blocks(const qgdk_ctx *c);
 int qgdk_adjoint_finish(const qgdk_ctx *c);

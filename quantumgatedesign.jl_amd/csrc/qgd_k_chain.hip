@@ -32,6 +32,14 @@ struct ChainArgs {
     int pm_bpr; long long pm_chunk;
     // forcing/history slot of time index n is n + n / f_bpr                          (f_bpr = 0: n)
     int f_bpr;
+    // MODE 1 with a diagonal guard projector (multi_qudit_systems.jl:316-349): the history pass also
+    // writes the adjoint forcing f_n = -(2 dt/tf) trap_n W w_n and accumulates the guard penalty
+    // (dt/tf) sum_n trap_n w_n^T W w_n (infidelity.jl:56-96) of the states it produces
+    const double *guard_diag;   // [2N] or null
+    double *guard_forcing;      // [.][Np][2cp]
+    double *scal;               // scal[2] += penalty
+    int gN, n_off, nt_glob, count_first;
+    double dt, tf;
 };
 
 __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
@@ -104,6 +112,9 @@ __device__ __forceinline__ void chain_a_raw(const double *__restrict__ Pn, int N
 #ifndef QGD_CHAIN_NT
 #define QGD_CHAIN_NT 4
 #endif
+#ifdef QGD_CHAIN_PROFILE
+__device__ long long g_chain_prof[64 * 4];
+#endif
 template <int NP, int MODE, int NG>
 __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const ChainArgs a)
 {
@@ -126,6 +137,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
     const int team = wave / NRB, rb = wave % NRB;
     const int arow = rb * 16 + c16;
     const int nsteps = (e0 > s0) ? e0 - s0 : 0;
+    double pen = 0.0;                                     // guard penalty of the states this thread handles
 
     // start state into part[0]
     for (int e = tid; e < NG * NP * 16; e += NTH) {
@@ -135,8 +147,22 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         else if (MODE == 2) v = 0.0;
         else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
         part[0][g][el] = v;
+        if (MODE == 1 && a.guard_diag && s0 == 0) {      // the window's first point is nobody's product
+            const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
+            const double trap = (a.n_off == 0) ? 0.5 : 1.0;
+            a.guard_forcing[(size_t)row * PWc + (grp0 + g) * 16 + c] = -(2.0 * a.dt / a.tf) * trap * wv * v;
+            if (a.count_first) pen += trap * wv * v * v;
+        }
     }
     double are[KST], aim[KST], fo[NG][4];
+    double gw[4] = {0.0, 0.0, 0.0, 0.0};                 // guard weights of this lane's accumulator elements
+    if (MODE == 1 && a.guard_diag) {
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 + kk + 4 * r;
+            gw[r] = (row < a.gN) ? a.guard_diag[row + ((c16 >= 8) ? a.gN : 0)] : 0.0;
+        }
+    }
     auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
     auto issue = [&](int st) {                            // left operand (and forcing) of step st
         const int n = step_index(st);
@@ -155,9 +181,15 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
     if (team < nsteps) issue(team);
     __syncthreads();
 
+#ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
+#define CH_STAMP(slot) do { if (blockIdx.x == 0 && rb == 0 && lane == 0 && st < 64) g_chain_prof[st * 4 + (slot)] = clock64(); } while (0)
+#else
+#define CH_STAMP(slot) do { } while (0)
+#endif
     int done = 0;                                         // step barriers this wave has passed
     for (int st = team; st < nsteps; st += NT) {
         while (done < st) { __syncthreads(); done++; }   // steps of the other teams
+        CH_STAMP(0);
         const int buf = st & 1, n = step_index(st);
         d4 acc[NG][2];
         #pragma unroll
@@ -172,6 +204,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                 acc[g][1] = MFMA(aim[i], ((c16 < 8) != ADJ) ? -v2 : v2, acc[g][1]);
             }
         }
+        CH_STAMP(1);
         const int nout = ADJ ? n : n + 1;                 // time index of the state this step produces
         double res[NG][4];
         #pragma unroll
@@ -183,7 +216,9 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                 res[g][r] = v;
                 part[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
             }
+        CH_STAMP(2);
         __syncthreads(); done++;                          // the next team starts; the rest is off the critical path
+        CH_STAMP(3);
         if (MODE == 1 || MODE == 3) {
             #pragma unroll
             for (int g = 0; g < NG; g++)
@@ -191,9 +226,31 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                 for (int r = 0; r < 4; r++)
                     a.out[(size_t)nout * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16] = res[g][r];
         }
+        if (MODE == 1 && a.guard_diag) {
+            const double trap = (nout + a.n_off == a.nt_glob - 1) ? 0.5 : 1.0, sc = -(2.0 * a.dt / a.tf) * trap;
+            #pragma unroll
+            for (int g = 0; g < NG; g++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = rb * 16 + kk + 4 * r;
+                    a.guard_forcing[(size_t)nout * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c16] = sc * gw[r] * res[g][r];
+                    pen += trap * gw[r] * res[g][r] * res[g][r];
+                }
+        }
         if (st + NT < nsteps) issue(st + NT);
     }
     while (done < nsteps) { __syncthreads(); done++; }
+    if (MODE == 1 && a.guard_diag) {                     // one atomic per workgroup
+        __shared__ double pred[NTH / 16];
+        pen = row16_sum(pen);
+        if ((lane & 15) == 15) pred[tid >> 4] = pen;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < NTH / 16; q++) tot += pred[q];
+            atomicAdd(&a.scal[2], tot * a.dt / a.tf);
+        }
+    }
     // final state (part[nsteps & 1]) of the block
     if (MODE == 0 || MODE == 2) {
         const int buf = nsteps & 1;
@@ -490,6 +547,12 @@ __global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT
 
 extern "C" {
 
+// diagonal guard projector + compiled-size sweeps: k_chain_fast<.,1,.> does the guard work
+static inline bool guard_is_fused(const qgdk_ctx *c)
+{
+    return c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64) && !getenv("QGD_GUARD_KERNEL");
+}
+
 // forward, phase (i): block propagators of the owned blocks into this rank's chunk of PiX
 int qgdk_forward_blocks(const qgdk_ctx *c)
 {
@@ -535,11 +598,18 @@ int qgdk_forward_finish(const qgdk_ctx *c)
     s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
     s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = c->blk_hi - c->blk_lo; s3.blen = c->scan_blen;
     s3.ngroups = c->cp / 8;
+    if (guard_is_fused(c)) {
+        s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
+        s3.n_off = c->n_off; s3.nt_glob = c->nt_glob; s3.count_first = (c->n_off == 0) ? 1 : 0; s3.dt = c->dt; s3.tf = c->tf;
+    }
     return launch_chain<1>(s3, c->stream);
 }
 
+int qgdk_guard_is_fused(const qgdk_ctx *c) { return guard_is_fused(c) ? 1 : 0; }
+
 int qgdk_guard(const qgdk_ctx *c)
 {
+    if (guard_is_fused(c)) return 0;          // the history pass of the forward sweep wrote forcing and penalty
     const int count_first = (c->n_off == 0) ? 1 : 0;
     if (c->have_guard == 2) {   // diagonal projector
         hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
