@@ -196,6 +196,17 @@ def main():
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # forward-only (eval_forward: tables .. history, guard, overlaps), reported beside the metric
+    fwd_elapsed = None
+    if not use_dist:
+        dp.set_timing(0)
+        dp.eval_forward(pcof)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.eval_forward(pcof)
+        barrier()
+        fwd_elapsed = time.perf_counter() - t1
 
     if rank == 0:
         for k in phase_ms:
@@ -230,6 +241,7 @@ def main():
                          "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
+            "forward_only_timesteps_per_s": (total_timesteps / fwd_elapsed) if fwd_elapsed else None,
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),
         }
