@@ -16,5 +16,7 @@ from .evolution import (DeviceProblem, device_problem, clear_cache, eval_forward
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)
 from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup
-from .optimize import optimize_gate, OptimizationHistory
+from .optimize import optimize_gate, OptimizationHistory, read_optimization_history
+from .convergence import (get_histories, richardson_extrap_rel_err, richardson_extrap_sol, observed_orders,
+                          save_histories, load_histories)
 from . import _lib

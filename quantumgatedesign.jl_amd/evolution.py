@@ -218,8 +218,8 @@ def clear_cache():
 # ---------------------------------------------------------------------------
 # reference-shaped API
 # ---------------------------------------------------------------------------
-def _history_shape(prob, order):
-    return (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+def _history_shape(prob, order, saveEveryNsteps=1):
+    return (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps // saveEveryNsteps, prob.N_initial_conditions)
 
 
 def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None):
@@ -227,19 +227,28 @@ def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, 
     ``[2N, 1+order/2, 1+nsteps, N_initial_conditions]`` (Fortran order) in place."""
     if forcing is not None:
         raise NotImplementedError("forcing (forward-sensitivity gradient, SURVEY f2) is not on the device path yet")
-    if saveEveryNsteps != 1:
-        raise NotImplementedError("saveEveryNsteps != 1")
-    if uv_history.shape != _history_shape(prob, order) or not uv_history.flags.f_contiguous:
-        raise ValueError(f"uv_history must be Fortran-ordered with shape {_history_shape(prob, order)}")
+    save = int(saveEveryNsteps)
+    if save < 1:
+        raise ValueError("saveEveryNsteps must be a positive integer")
+    shape = _history_shape(prob, order, save)
+    if uv_history.shape != shape or not uv_history.flags.f_contiguous:
+        raise ValueError(f"uv_history must be Fortran-ordered with shape {shape}")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
-    dp.eval_forward(pcof, uv_history)
+    if save == 1:
+        dp.eval_forward(pcof, uv_history)
+        return None
+    # the device keeps every time point; the stored ones are n = 0, save, 2 save, ... <= nsteps
+    # (forward_evolution.jl:104,178,239-241: slot 1 + div(n, saveEveryNsteps) when n % saveEveryNsteps == 0)
+    full = np.zeros(_history_shape(prob, order), order="F")
+    dp.eval_forward(pcof, full)
+    uv_history[...] = full[:, :, ::save, :][:, :, :shape[2], :]
     return None
 
 
 def eval_forward(prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None):
     """forward_evolution.jl:15-29: complex state history ``[N, 1+nsteps, N_initial_conditions]``."""
-    hist = np.zeros(_history_shape(prob, order), order="F")
+    hist = np.zeros(_history_shape(prob, order, int(saveEveryNsteps)), order="F")
     eval_forward_(hist, prob, controls, pcof, order=order, saveEveryNsteps=saveEveryNsteps, forcing=forcing)
     return real_to_complex(hist[:, 0, :, :])
 

@@ -36,12 +36,26 @@ class OptimizationHistory:
     def __len__(self):
         return len(self.iter_count)
 
+    FIELDS = ("iter_count", "ipopt_obj_value", "wall_time", "pcof", "grad_pcof", "analytic_obj_value",
+              "infidelity", "guard_penalty", "ridge_penalty")
+
+    def write(self, filename):
+        """write(obj::OptimizationHistory, filename) (src/ipopt_optimal_control.jl:74-86): the same nine
+        keys, as a numpy ``.npz`` archive (the reference writes JLD2, which needs Julia)."""
+        np.savez(filename, **{k: np.asarray(getattr(self, k)) for k in self.FIELDS})
+
     def __repr__(self):
         if not len(self):
             return "OptimizationHistory\n0 iterations performed."
         i = int(np.argmin(self.infidelity))
         return (f"OptimizationHistory\n{len(self)} iterations performed.\n{self.wall_time[-1]} seconds elapsed.\n"
                 f"Minimum infidelity was {self.infidelity[i]}, at iteration {i + 1}.")
+
+
+def read_optimization_history(filename):
+    """read_optimization_history (src/ipopt_optimal_control.jl:91-104) for the ``.npz`` written above."""
+    data = np.load(filename if str(filename).endswith(".npz") else str(filename) + ".npz")
+    return OptimizationHistory(**{k: list(data[k]) for k in OptimizationHistory.FIELDS})
 
 
 class _Stop(Exception):
@@ -58,8 +72,6 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
     N_coeff = get_number_of_control_parameters(controls)
     if len(pcof_init) != N_coeff:
         raise ValueError("length of pcof_init does not match the controls")          # :203
-    if filename is not None:
-        raise NotImplementedError("JLD2 output (SURVEY f4) is out of scope; use the returned history")
     dp = device_problem(schro_prob, order)
     dp.set_controls(controls)
     dp.set_target(target)
@@ -87,6 +99,8 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
         hist.guard_penalty.append(last["guard"]); hist.ridge_penalty.append(last["ridge"])
         if print_level >= 5:
             print(f"iter {len(hist):4d}  objective {last['obj']:.6e}  infidelity {last['infid']:.6e}  guard {last['guard']:.3e}")
+        if filename is not None:                                                    # update_jld2, :223-241
+            hist.write(filename)
         if last["obj"] < 1e-7:
             raise _Stop
 
@@ -110,4 +124,6 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
         hist.grad_pcof.append(last["grad"]); hist.analytic_obj_value.append(last["obj"])
         hist.infidelity.append(last["infid"]); hist.guard_penalty.append(last["guard"])
         hist.ridge_penalty.append(last["ridge"])
+    if filename is not None:
+        hist.write(filename)
     return hist

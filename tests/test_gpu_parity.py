@@ -404,3 +404,24 @@ def test_mid_size_dense_problems(qgd, N, c, order):
     assert close(hist, pp.history_real(ref["ws"]), 1e-11)
     assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
     qgd.clear_cache()
+
+
+def test_save_every_nsteps_and_convergence_report(qgd):
+    """saveEveryNsteps (forward_evolution.jl:104,239-241) stores every k-th point of the same sweep, and
+    get_histories (src/Tests/test_convergence.jl:20-146) reproduces the reference's convergence test
+    (forward_convergence.jl:47-65): observed order = nominal +/- 0.5 from Richardson estimates."""
+    prob = qgd.construct_rabi_prob(tf=1.0, nsteps=8, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    ctrl = qgd.FortranBSplineControl(16, 17, prob.tf)          # one polynomial piece: smooth to every order
+    pcof = np.random.default_rng(5).random(ctrl.N_coeff)
+    full = qgd.eval_forward(prob, ctrl, pcof, order=4)
+    sub = qgd.eval_forward(prob, ctrl, pcof, order=4, saveEveryNsteps=4)
+    assert sub.shape == (2, 3, prob.N_initial_conditions) and np.array_equal(sub, full[:, ::4, :])
+    ret = qgd.get_histories(prob, ctrl, pcof, 5, orders=(2, 4, 6), base_nsteps=8, quiet=True)
+    for order in (2, 4, 6):
+        summary = ret[f"Order {order} (QGD)"]
+        assert summary["nsteps"] == [8, 16, 32, 64, 128]
+        assert all(h.shape == summary["histories"][0].shape for h in summary["histories"])
+        obs = qgd.observed_orders(summary)
+        good = [o for o, e in zip(obs, summary["richardson_errors"][2:]) if e > 1e-12]   # above rounding
+        assert good and all(abs(o - order) < 0.6 for o in good), (order, obs, summary["richardson_errors"])
+    qgd.clear_cache()

@@ -200,3 +200,33 @@ def test_oracle_is_not_imported_by_the_package(qgd):
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle-free", ""), os.path.join(dirpath, f)
+
+
+def test_richardson_and_history_io(qgd, tmp_path):
+    """Richardson extrapolation (src/Tests/test_convergence.jl:233-250) on a manufactured error model,
+    and the npz round trips of the convergence dictionaries and of OptimizationHistory
+    (src/ipopt_optimal_control.jl:74-104)."""
+    exact = np.linspace(1.0, 2.0, 7)
+    err = np.cos(np.arange(7))
+    order, h = 4, 0.1
+    A_2h = exact + err * (2 * h) ** order
+    A_h = exact + err * h ** order
+    assert np.allclose(qgd.richardson_extrap_sol(A_h, A_2h, order), exact, atol=1e-15)
+    est = qgd.richardson_extrap_rel_err(A_h, A_2h, order)
+    assert abs(est - np.linalg.norm(A_h - exact) / np.linalg.norm(exact)) < 1e-12
+    ret = {"Order 4 (QGD)": dict(order=4, nsteps=[10, 20], step_sizes=[0.1, 0.05], elapsed_times=[1.0, 2.0],
+                                 histories=[np.ones((2, 3, 1), complex), 2j * np.ones((2, 3, 1))],
+                                 richardson_errors=[float("nan"), 1e-3])}
+    qgd.save_histories(ret, tmp_path / "conv.npz")
+    back = qgd.load_histories(tmp_path / "conv.npz")
+    assert back["Order 4 (QGD)"]["nsteps"] == [10, 20]
+    assert np.array_equal(back["Order 4 (QGD)"]["histories"][1], ret["Order 4 (QGD)"]["histories"][1])
+    h = qgd.OptimizationHistory()
+    for i in range(3):
+        h.iter_count.append(i); h.ipopt_obj_value.append(1.0 / (i + 1)); h.wall_time.append(0.1 * i)
+        h.pcof.append(np.full(4, i, float)); h.grad_pcof.append(np.full(4, -i, float))
+        h.analytic_obj_value.append(1.0 / (i + 1)); h.infidelity.append(0.5 / (i + 1))
+        h.guard_penalty.append(0.0); h.ridge_penalty.append(0.01 * i)
+    h.write(tmp_path / "opt.npz")
+    g = qgd.read_optimization_history(tmp_path / "opt.npz")
+    assert len(g) == 3 and np.array_equal(g.pcof[2], h.pcof[2]) and g.infidelity == h.infidelity
