@@ -1,4 +1,6 @@
-"""Per-phase cycle profile of the sparse kernels (library built with -DQGD_SPARSE_PROFILE)."""
+"""Per-phase cycle profile of the sparse kernels.  Build the library with the hooks first:
+    make -C quantumgatedesign.jl_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -DQGD_SPARSE_PROFILE"
+(and rebuild without the flag afterwards)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch, numpy as np
