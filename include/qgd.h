@@ -171,6 +171,12 @@ int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, in
 int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 
 
+/* eval_grad_forced (src/eval_grad_forced.jl:17-194): the same gradient by forward sensitivities --
+ * one forced forward sweep per control parameter, all parameters batched as extra column groups of
+ * the blocked scan.  The reference's cross-check of the discrete adjoint (agreement to rounding).
+ * Needs qgd_set_control_basis and qgd_set_target; N <= 64; single GPU. */
+int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad);
+
 /* Operator path of the step-matrix and gradient kernels.  mode 0: automatic (sparse when every
  * row of the assembled Hamiltonian has at most min(16, N/2) entries and N <= 64 -- the drift +
  * a_k +/- a_k^dagger operators of src/multi_qudit_systems.jl -- else dense), 1: dense fp64 MFMA

@@ -31,7 +31,9 @@ struct qgd_handle_s {
     bool timing = (getenv("QGD_NO_PHASE_TIMING") == nullptr);
     std::string timing_only;            // when non-empty: only this phase is bracketed by events
     std::string err;
-    std::vector<void *> static_bufs, grid_bufs, basis_bufs;
+    std::vector<void *> static_bufs, grid_bufs, basis_bufs, forced_bufs;
+    std::vector<double> target_host;   // stacked real target [2N x c] (forced gradient: the overlaps are host arithmetic)
+    size_t forced_key = 0;             // (nt, n_pcof) the forced-gradient buffers were sized for
     bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
     std::vector<int32_t> ncoef, poff;
     std::vector<int64_t> goff;
@@ -106,6 +108,7 @@ int alloc_grid(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     free_pool(h->grid_bufs);
+    free_pool(h->forced_bufs); h->forced_key = 0;
     // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
     //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
     {
@@ -510,7 +513,7 @@ void qgd_destroy(qgd_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
-    free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs);
+    free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs); free_pool(h->forced_bufs);
     for (auto &p : h->phases) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->host_in) (void)hipHostFree(h->host_in);
@@ -540,6 +543,7 @@ int qgd_set_target(qgd_handle h, const double *target_real)
         t[o + 8] = target_real[k.N + i + (size_t)2 * k.N * col];
     }
     HIP_TRY(h, hipMemcpy(k.target, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->target_host.assign(target_real, target_real + (size_t)2 * k.N * k.c);
     k.have_target = 1;
     return QGD_OK;
 }
@@ -550,6 +554,7 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     free_pool(h->basis_bufs);
+    free_pool(h->forced_bufs); h->forced_key = 0;
     h->have_basis = false;
     k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr; if (h->status_static) k.status = h->status_static;
     h->ncoef.assign(k.n_ops, 0); h->poff.assign(k.n_ops, 0); h->goff.assign(k.n_ops, 0);
@@ -677,6 +682,58 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
                 dst[i] = f[o]; dst[N + i] = f[o + 8];
             }
         }
+    }
+    return QGD_OK;
+}
+
+int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad)
+{
+    if (!h || !pcof || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");
+    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced gradient is single-GPU");
+    if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || qgdk_forced_lds(k.Np, k.m) > 150 * 1024)
+        return fail(h, QGD_ERR_UNSUPPORTED, "forced gradient on the device needs N <= 64 (and order <= 16 at N = 64)");
+    int rc;
+    if ((rc = run_forward(h, pcof, n_pcof))) return rc;
+    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+    const size_t nt = k.nt, hstep = (size_t)k.Np * 2 * k.cp, NB = (size_t)k.n_ops * 2 * k.m;
+    const size_t cpS = (size_t)k.n_pcof * k.cp, hstepS = (size_t)k.Np * 2 * cpS, B = k.scan_blocks;
+    const size_t key = nt * 1000003u + (size_t)k.n_pcof;
+    if (h->forced_key != key) {
+        free_pool(h->forced_bufs); h->forced_key = 0;
+        if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_BR, nt * NB * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_BL, nt * NB * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_phi, B * hstepS))) return rc;
+        if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_bnd, (B + 1) * hstepS))) return rc;
+        if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_gacc, (size_t)k.n_pcof + 1))) return rc;
+        h->forced_key = key;
+    }
+    HIP_TRY(h, hipMemsetAsync(k.fs_bnd, 0, hstepS * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.fs_gacc, 0, ((size_t)k.n_pcof + 1) * sizeof(double), k.stream));
+    { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }
+    { PhaseTimer t(h, "forced_sweeps"); K_TRY(h, qgdk_forced_chains(&k)); }
+    if ((rc = check_status(h))) return rc;
+    std::vector<double> sN(hstepS), gacc(k.n_pcof), scal(4);
+    HIP_TRY(h, hipMemcpy(sN.data(), k.fs_bnd + B * hstepS, hstepS * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(gacc.data(), k.fs_gacc, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(scal.data(), k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    // d(infidelity) = -(2/N_ess^2) (<w_N,R> <s_N,R> + <w_N,T> <s_N,T>), T = [R_im; -R_re] (infidelity.jl:13-17)
+    const size_t N = k.N, PWs = 2 * cpS;
+    const double a = scal[0], b = scal[1], f = -2.0 / ((double)k.n_ess * k.n_ess);
+    for (int p = 0; p < k.n_pcof; p++) {
+        double sR = 0.0, sT = 0.0;
+        for (int col = 0; col < k.c; col++)
+            for (size_t i = 0; i < N; i++) {
+                const size_t o = panel_index((int)i, p * k.cp + col, (int)PWs);
+                const double sre = sN[o], sim = sN[o + 8];
+                const double rre = h->target_host[i + 2 * N * col], rim = h->target_host[N + i + 2 * N * col];
+                sR += sre * rre + sim * rim;
+                sT += sre * rim - sim * rre;
+            }
+        grad[p] = f * (a * sR + b * sT) + gacc[p];
     }
     return QGD_OK;
 }

@@ -59,6 +59,10 @@ typedef struct qgdk_ctx {
     int scan_blocks2, scan_g;
     double *PiC2, *PiR2, *phi2, *bnd2, *bndY2;
     int part_rank, part_world, n_off, nt_glob;
+    // forced (forward-sensitivity) gradient, qgd_k_forced.hip: basis responses and sensitivity scan buffers
+    double *fs_BR, *fs_BL;   // [nt][n_ops*2*m][Np][2cp]
+    double *fs_phi, *fs_bnd; // [B][Np][2cpS], [B+1][Np][2cpS], cpS = n_pcof * cp
+    double *fs_gacc;         // [n_pcof]
     int *status;
     double cw_host[2 * 20];
 } qgdk_ctx;
@@ -88,6 +92,9 @@ int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);
+size_t qgdk_forced_lds(int Np, int m);
+int qgdk_forced_basis(const qgdk_ctx *c);
+int qgdk_forced_chains(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 #ifdef __cplusplus

@@ -40,6 +40,15 @@ struct ChainArgs {
     double *scal;               // scal[2] += penalty
     int gN, n_off, nt_glob, count_first;
     double dt, tf;
+    // MODE 4/5 (forward sensitivities of the forced gradient, eval_grad_forced.jl:17-194): one column
+    // group per (control parameter, state column group).  fs_mode 1: the forcing of step n is
+    // assembled from the 2m basis responses of the parameter's control,
+    //   q_n = sum_{tau,d} G^tau_l(n,d) BR[n][b] - G^tau_l(n+1,d) BL[n+1][b],  b = (k*2+tau)*m + d
+    int fs_mode, fs_m, fs_nops, fs_gpc, fs_nt;   // gpc: state column groups per parameter
+    const double *fs_BR, *fs_BL;                 // [nt][NB][Np][2*cp_state], already multiplied by L^-1
+    const double *fs_G; const int64_t *fs_goff; const int32_t *fs_ncoef, *fs_poff;
+    const double *fs_gf;                         // adjoint forcing f_n [nt][Np][2*cp_state]: guard part = -<f_n, s_n>
+    double *fs_gacc;                             // [n_pcof] guard sums
 };
 
 __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
@@ -118,7 +127,9 @@ __device__ long long g_chain_prof[64 * 4];
 template <int NP, int MODE, int NG>
 __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const ChainArgs a)
 {
-    constexpr bool ADJ = (MODE >= 2);
+    constexpr bool ADJ = (MODE == 2 || MODE == 3);      // backward in time with P^H
+    constexpr bool FORC = (MODE >= 2);                    // affine: a forcing term is added every step
+    constexpr bool ZERO = (MODE == 2 || MODE == 4);       // zero start, the final state is the block's affine part
     constexpr int NRB = NP / 16, NT = QGD_CHAIN_NT, KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
         double v;
         if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
-        else if (MODE == 2) v = 0.0;
+        else if (ZERO) v = 0.0;
         else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
         part[0][g][el] = v;
         if (MODE == 1 && a.guard_diag && s0 == 0) {      // the window's first point is nobody's product
@@ -169,13 +180,41 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         const double *Pn = chain_matrix(a, n);
         #pragma unroll
         for (int i = 0; i < KST; i++) chain_a_raw<ADJ>(Pn, NP, arow, i * 4 + kk, are[i], aim[i]);
-        if (ADJ) {
+        if (FORC && !(MODE >= 4 && a.fs_mode == 1)) {
             const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     fo[g][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16];
+        }
+        if (MODE >= 4 && a.fs_mode == 1) {               // assemble the sensitivity forcing of step n -> n+1
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int par = (grp0 + g) / a.fs_gpc, cg = (grp0 + g) % a.fs_gpc;
+                int k = 0;
+                while (k + 1 < a.fs_nops && par >= a.fs_poff[k + 1]) k++;
+                const int l = par - a.fs_poff[k], nc = a.fs_ncoef[k];
+                const int NB = a.fs_nops * 2 * a.fs_m, PWb = 16 * a.fs_gpc;
+                const size_t pstep = (size_t)NP * PWb;
+                double accf[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int tau = 0; tau < 2; tau++)
+                    for (int d = 0; d < a.fs_m; d++) {
+                        const double *gk = a.fs_G + a.fs_goff[k];
+                        const double g0 = gk[(((size_t)tau * a.fs_nt + n) * (a.fs_m + 1) + d) * nc + l];
+                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + 1) * (a.fs_m + 1) + d) * nc + l];
+                        const int bidx = (k * 2 + tau) * a.fs_m + d;
+                        const double *br = a.fs_BR + ((size_t)n * NB + bidx) * pstep + cg * 16 + c16;
+                        const double *bl = a.fs_BL + ((size_t)(n + 1) * NB + bidx) * pstep + cg * 16 + c16;
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const size_t ro = (size_t)(rb * 16 + kk + 4 * r) * PWb;
+                            accf[r] += g0 * br[ro] - g1 * bl[ro];
+                        }
+                    }
+                #pragma unroll
+                for (int r = 0; r < 4; r++) fo[g][r] = accf[r];
+            }
         }
     };
     if (team < nsteps) issue(team);
@@ -212,19 +251,28 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
             #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double v = acc[g][0][r] + acc[g][1][r];
-                if (ADJ) v += fo[g][r];
+                if (FORC) v += fo[g][r];
                 res[g][r] = v;
                 part[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
             }
         CH_STAMP(2);
         __syncthreads(); done++;                          // the next team starts; the rest is off the critical path
         CH_STAMP(3);
-        if (MODE == 1 || MODE == 3) {
+        if (MODE == 1 || MODE == 3 || (MODE == 5 && a.out)) {
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     a.out[(size_t)nout * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16] = res[g][r];
+        }
+        if (MODE == 5 && a.fs_gf) {                      // guard part of dJ/dtheta: -<f_n, s_n>, real stacked form
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int cg = (grp0 + g) % a.fs_gpc, PWb = 16 * a.fs_gpc;
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    pen -= a.fs_gf[(size_t)nout * NP * PWb + (size_t)(rb * 16 + kk + 4 * r) * PWb + cg * 16 + c16] * res[g][r];
+            }
         }
         if (MODE == 1 && a.guard_diag) {
             const double trap = (nout + a.n_off == a.nt_glob - 1) ? 0.5 : 1.0, sc = -(2.0 * a.dt / a.tf) * trap;
@@ -251,8 +299,19 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
             atomicAdd(&a.scal[2], tot * a.dt / a.tf);
         }
     }
+    if (MODE == 5 && a.fs_gf) {                          // NG == 1: one parameter per workgroup
+        __shared__ double pred5[NTH / 16];
+        pen = row16_sum(pen);
+        if ((lane & 15) == 15) pred5[tid >> 4] = pen;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < NTH / 16; q++) tot += pred5[q];
+            atomicAdd(&a.fs_gacc[grp0 / a.fs_gpc], tot);
+        }
+    }
     // final state (part[nsteps & 1]) of the block
-    if (MODE == 0 || MODE == 2) {
+    if (MODE == 0 || ZERO || (MODE == 5 && a.phi)) {
         const int buf = nsteps & 1;
         for (int e = tid; e < NG * NP * 16; e += NTH) {
             const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
@@ -351,8 +410,9 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
     case 48: hipLaunchKernelGGL((k_chain_fast<48, MODE, NG>), dim3(nwg), dim3(48 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
     case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
     default: {
+        if (MODE >= 4) return (int)hipErrorNotSupported;
         size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
-        hipLaunchKernelGGL((k_chain_generic<MODE>), dim3(nwg), dim3(256), shm, stream, a);
+        hipLaunchKernelGGL((k_chain_generic<(MODE >= 4 ? 1 : MODE)>), dim3(nwg), dim3(256), shm, stream, a);
     }
     }
     return (int)hipGetLastError();
@@ -706,6 +766,36 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
     s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = c->blk_hi - c->blk_lo;
     s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
     return launch_chain<3>(s3, c->stream);
+}
+
+// Sensitivities of all control parameters at once (forced gradient): column group = (parameter, state
+// column group).  (i) affine part of every block from zero, (ii) one chain over the block propagators of
+// the forward sweep -> s at the block boundaries (the last one is s_N), (iii) with a guard: replay the
+// blocks accumulating -<f_n, s_n>.
+int qgdk_forced_chains(const qgdk_ctx *c)
+{
+    if (!(c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64)) return (int)hipErrorNotSupported;
+    const int cpS = c->n_pcof * c->cp, B = c->scan_blocks;
+    const size_t hstepS = (size_t)c->Np * 2 * cpS;
+    ChainArgs f{};
+    f.Np = c->Np; f.cp = cpS; f.fs_mode = 1; f.fs_m = c->m; f.fs_nops = c->n_ops; f.fs_gpc = c->cp / 8; f.fs_nt = c->nt;
+    f.fs_BR = c->fs_BR; f.fs_BL = c->fs_BL; f.fs_G = c->G; f.fs_goff = c->goff; f.fs_ncoef = c->ncoef; f.fs_poff = c->poff;
+    ChainArgs a = f;   // (i)
+    a.S = c->nt - 1; a.Pmat = c->Pc; a.phi = c->fs_phi; a.nblocks = B; a.blen = c->scan_blen; a.ngroups = cpS / 8;
+    int rc = launch_chain<4>(a, c->stream);
+    if (rc) return rc;
+    ChainArgs s2{};    // (ii)
+    s2.Np = c->Np; s2.cp = cpS; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+    s2.start = c->fs_bnd; s2.start_stride = 0; s2.out = c->fs_bnd; s2.forcing = c->fs_phi; s2.nblocks = 1; s2.blen = B;
+    s2.ngroups = cpS / 8; s2.fs_gpc = c->cp / 8;
+    if ((rc = launch_chain<5>(s2, c->stream))) return rc;
+    if (c->have_guard) {   // (iii)
+        ChainArgs g = f;
+        g.S = c->nt - 1; g.Pmat = c->Pc; g.start = c->fs_bnd; g.start_stride = (long long)hstepS; g.nblocks = B; g.blen = c->scan_blen;
+        g.ngroups = cpS / 8; g.fs_gf = c->forcing; g.fs_gacc = c->fs_gacc;
+        if ((rc = launch_chain<5>(g, c->stream))) return rc;
+    }
+    return 0;
 }
 
 int qgdk_lambda(const qgdk_ctx *c)

@@ -170,6 +170,13 @@ class DeviceProblem:
         """0: no events, 1: every phase (default), 2: only ``phase``."""
         _lib.check(self.h, self.lib.qgd_set_timing(self.h, int(mode), None if phase is None else phase.encode()))
 
+    def eval_grad_forced(self, pcof):
+        """Gradient by forward sensitivities (eval_grad_forced.jl:17-194); needs controls and target."""
+        pcof = np.ascontiguousarray(pcof, dtype=np.float64)
+        grad = np.zeros(len(pcof))
+        _lib.check(self.h, self.lib.qgd_eval_grad_forced(self.h, _vp(pcof), len(pcof), _vp(grad)))
+        return grad
+
     def set_operator_path(self, mode):
         """"auto" | "dense" (fp64 MFMA kernels) | "sparse" (ELL kernels; raises if the operators do not qualify)."""
         code = {"auto": 0, "dense": 1, "sparse": 2}[mode]
@@ -251,6 +258,18 @@ def eval_forward(prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None)
     hist = np.zeros(_history_shape(prob, order, int(saveEveryNsteps)), order="F")
     eval_forward_(hist, prob, controls, pcof, order=order, saveEveryNsteps=saveEveryNsteps, forcing=forcing)
     return real_to_complex(hist[:, 0, :, :])
+
+
+def eval_grad_forced(prob, controls, pcof, target, order=2, cost_type="Infidelity"):
+    """eval_grad_forced(prob, controls, pcof, target; order, cost_type) (src/eval_grad_forced.jl:17-60):
+    the gradient of infidelity + guard penalty by differentiating the forward sweep (one forced sweep
+    per control parameter).  On the device all parameters run at once as extra columns of the scan."""
+    if cost_type not in ("Infidelity", ":Infidelity"):
+        raise NotImplementedError("cost_type other than :Infidelity")
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    dp.set_target(target)
+    return dp.eval_grad_forced(pcof)
 
 
 def eval_adjoint(prob, controls, pcof, terminal_condition, order=2, forcing=None):

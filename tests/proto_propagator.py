@@ -131,3 +131,64 @@ def history_real(ws):
     arr = np.stack(ws, axis=0)                       # [1+m, nt, N, c]
     real = np.concatenate([arr.real, arr.imag], axis=2)  # [1+m, nt, 2N, c]
     return np.asfortranarray(np.transpose(real, (2, 0, 1, 3)))
+
+
+def forced_gradient(prob, Gp, Gq, offsets, pcof, target, order, ref=None, return_all=False):
+    """Forward-sensitivity ("forced") gradient in the same time-parallel form the device uses
+    (reference: src/eval_grad_forced.jl:17-194 -- one forced forward sweep per control parameter).
+
+    dA_d(t_n)/dtheta_l = Gp_l^(d)(t_n) (-i Sym_k) + Gq_l^(d)(t_n) Asym_k, so the forcing of every
+    parameter of control k is a combination of 2m *basis responses* per time point: for
+    (tau, d) the Taylor recursion U_0 = 0, U_{j+1} = (sum_i A_{j-i} U_i + [j >= d] Omega w_{j-d})/(j+1),
+    rhoR = sum_j c_j dt^j U_j, rhoL = sum_j c_j (-dt)^j U_j.  The sensitivity obeys
+        L_{n+1} s_{n+1} = R_n s_n + sum G(t_n) rhoR_n - sum G(t_{n+1}) rhoL_{n+1}.
+    """
+    if ref is None:
+        ref = evaluate(prob, Gp, Gq, offsets, pcof, target, order)
+    m = order // 2
+    N, c, nsteps = prob.N_tot_levels, prob.N_initial_conditions, prob.nsteps
+    dt = prob.tf / nsteps
+    nt = nsteps + 1
+    Ac, ws, Linv, P, psi = ref["Ac"], ref["ws"], ref["Linv"], ref["P"], ref["psi"]
+    cj = [coefficient(j, m, m) for j in range(m + 1)]
+    T = np.asarray(target)
+    ovl = np.sum(np.conj(T) * psi[-1])
+    W = prob.guard_subspace_projector
+    trap = np.ones(nt); trap[0] = trap[-1] = 0.5
+    wreal = np.concatenate([psi.real, psi.imag], axis=1)
+    Ww = np.einsum("ij,njc->nic", W, wreal)
+    Wc = Ww[:, :N] + 1j * Ww[:, N:]                       # <Ww, s>_real = Re(conj(Wc) s)
+    rhoR = {}
+    rhoL = {}
+    for k in range(prob.N_operators):
+        for tau, Om in (("p", -1j * prob.sym_operators[k]), ("q", prob.asym_operators[k] + 0j)):
+            for d in range(m):
+                U = [np.zeros((nt, N, c), dtype=complex)]
+                for j in range(m):
+                    acc = np.zeros((nt, N, c), dtype=complex)
+                    for i in range(j + 1):
+                        acc += Ac[:, j - i] @ U[i]
+                    if j >= d:
+                        acc += Om @ ws[j - d]
+                    U.append(acc / (j + 1))
+                rhoR[k, tau, d] = sum(cj[j] * dt ** j * U[j] for j in range(1, m + 1))
+                rhoL[k, tau, d] = sum(cj[j] * (-dt) ** j * U[j] for j in range(1, m + 1))
+    grad = np.zeros(len(pcof))
+    sN = {}
+    for k, (gp, gq, off) in enumerate(zip(Gp, Gq, offsets)):
+        for l in range(gp.shape[2]):
+            s = np.zeros((N, c), dtype=complex)
+            gsum = 0.0                                    # guard part; s_0 = 0 contributes nothing
+            for n in range(nsteps):
+                r = np.zeros((N, c), dtype=complex)
+                for d in range(m):
+                    r += gp[n, d, l] * rhoR[k, "p", d][n] + gq[n, d, l] * rhoR[k, "q", d][n]
+                    r -= gp[n + 1, d, l] * rhoL[k, "p", d][n + 1] + gq[n + 1, d, l] * rhoL[k, "q", d][n + 1]
+                s = P[n] @ s + Linv[n + 1] @ r
+                gsum += trap[n + 1] * np.sum(np.conj(Wc[n + 1]) * s).real
+            sN[off + l] = s
+            grad[off + l] = (-(2.0 / prob.N_ess_levels ** 2) * (np.conj(ovl) * np.sum(np.conj(T) * s)).real
+                             + (2.0 * dt / prob.tf) * gsum)
+    if return_all:
+        return grad, rhoR, rhoL, sN
+    return grad

@@ -425,3 +425,30 @@ def test_save_every_nsteps_and_convergence_report(qgd):
         good = [o for o, e in zip(obs, summary["richardson_errors"][2:]) if e > 1e-12]   # above rounding
         assert good and all(abs(o - order) < 0.6 for o in good), (order, obs, summary["richardson_errors"])
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_forced_gradient_reference_contract(qgd, orc, order):
+    """The reference's own contract (test/GradientTests/compare_gradients.jl:47-65): the discrete adjoint
+    and the forced (forward-sensitivity) gradient agree to rounding -- both on the device here -- and
+    the device forced gradient matches the oracle's eval_grad_forced."""
+    for name, prob, ctrl, pcof, target in cases.gradient_cases(qgd):
+        g_adj = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+        g_for = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+        g_orc = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+        scale = np.abs(g_adj).max()
+        assert np.abs(g_for - g_adj).max() <= 1e-12 * scale, (name, order)
+        assert np.abs(g_for - g_orc).max() <= 1e-10 * scale, (name, order)
+    qgd.clear_cache()
+
+
+@pytest.mark.parametrize("which,order,kw", [("cnot2", 4, {}), ("guarded", 8, {}), ("dense_guard", 6, {}),
+                                            ("cnot3", 8, dict(nsteps=40, tf=40.0)), ("cnot3", 4, dict(nsteps=130, tf=65.0))])
+def test_forced_gradient_configs(qgd, which, order, kw):
+    """Forced gradient vs discrete adjoint on the benchmark-shaped problems (guard penalties, carrier
+    controls, several scan blocks): agreement to 1e-11 relative."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, **kw)
+    g_adj = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+    g_for = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+    assert np.abs(g_for - g_adj).max() <= 1e-11 * np.abs(g_adj).max()
+    qgd.clear_cache()
