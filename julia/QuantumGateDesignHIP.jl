@@ -118,4 +118,22 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Array{Float64,4},
     return grad
 end
 
+"""
+    hip_eval_grad_forced(prob, controls, pcof, target; order=2)
+
+Drop-in for `eval_grad_forced` (src/eval_grad_forced.jl:17-60): the gradient by forward
+sensitivities, all control parameters in one device call.
+"""
+function hip_eval_grad_forced(prob::SchrodingerProb, controls, pcof::Vector{Float64},
+        target::AbstractMatrix{<:Number}; order::Int=2)
+    dp = device_problem(prob, order)
+    set_controls!(dp, prob, controls, pcof)
+    tr = Matrix{Float64}(vcat(real(target), imag(target)))
+    check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
+    grad = zeros(length(pcof))
+    check(dp.handle, ccall((:qgd_eval_grad_forced, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}),
+          dp.handle, pcof, length(pcof), grad))
+    return grad
+end
+
 end # module
