@@ -249,6 +249,130 @@ class CarrierControl(AbstractControl):
         return gp, gq
 
 
+class BSpline2Control(AbstractControl):
+    """Hard-coded quadratic B-spline ("Juqbox" spline, bspline_control.jl:21-249): ``D1`` coefficients
+    for p followed by ``D1`` for q, uniform knots with spacing tf/(D1-2), three overlapping pieces per
+    point.  Derivatives of order > 2 vanish (bspline2, :139-205)."""
+
+    def __init__(self, D1: int, tf: float):
+        D1 = int(D1)
+        if D1 < 3:
+            raise ValueError(f"Number of coefficients per spline (D1 = {D1}) must be >= 3.")   # :31-33
+        self.D1, self.tf = D1, float(tf)
+        self.Nseg = 2
+        self.N_coeff = 2 * D1
+        self.dtknot = self.tf / (D1 - 2)
+        self.tcenter = self.dtknot * (np.arange(1, D1 + 1) - 1.5)
+
+    def _basis(self, times, dmax):
+        """[len(times), dmax+1, D1]: the three non-zero pieces at every time (bspline2, :151-201)."""
+        times = np.asarray(times, float)
+        B = np.zeros((len(times), dmax + 1, self.D1))
+        width = 3 * self.dtknot
+        k = np.clip(np.ceil(times / self.dtknot + 2).astype(np.int64), 3, self.D1)     # 1-based, :149-150
+        rows = np.arange(len(times))
+        for piece, kk in enumerate((k, k - 1, k - 2)):
+            tau = (times - self.tcenter[kk - 1]) / width
+            vals = [(9 / 8 + 4.5 * tau + 4.5 * tau ** 2, (4.5 + 9 * tau) / width, np.full_like(tau, 9 / width ** 2)),
+                    (0.75 - 9 * tau ** 2, -18 * tau / width, np.full_like(tau, -18 / width ** 2)),
+                    (9 / 8 - 4.5 * tau + 4.5 * tau ** 2, (-4.5 + 9 * tau) / width, np.full_like(tau, 9 / width ** 2))][piece]
+            for d in range(min(dmax, 2) + 1):
+                B[rows, d, kk - 1] = vals[d]
+        return B
+
+    def grad_tables(self, times, dmax):
+        B = self._basis(times, dmax)
+        gp = np.zeros((B.shape[0], dmax + 1, self.N_coeff))
+        gq = np.zeros_like(gp)
+        gp[:, :, :self.D1] = B
+        gq[:, :, self.D1:] = B
+        return gp, gq
+
+
+def BSplineControl(tf: float, D1: int, omega: Sequence[float]):
+    """BSplineControl(tf, D1, omega) (bspline_control.jl:257-268): quadratic B-spline envelopes times carrier
+    waves in the Juqbox ``bcarrier2`` layout (bspline_backend.jl:783-848): per frequency ``D1``
+    coefficients of the cos/p envelope then ``D1`` of the sin/q envelope,
+    p = sum_f b1 cos(w t) - b2 sin(w t), q = sum_f b1 sin(w t) + b2 cos(w t) -- which is exactly
+    CarrierControl over BSpline2Control."""
+    return CarrierControl(BSpline2Control(D1, tf), list(omega))
+
+
+class ZeroControl(AbstractControl):
+    """p = q = 0 with ``N_coeff`` inert coefficients (zero_control.jl:1-12)."""
+
+    def __init__(self, N_coeff: int, tf: float):
+        self.N_coeff, self.tf = int(N_coeff), float(tf)
+
+    def grad_tables(self, times, dmax):
+        z = np.zeros((len(np.asarray(times)), dmax + 1, self.N_coeff))
+        return z, z.copy()
+
+
+class GeneralGRAPEControl(GRAPEControl):
+    """Piecewise monomials (generalized_grape_control.jl:1-34): in region r,
+    p = pcof[r] * local_t**monomial_order with local_t in [0,1); monomial_order = 0 is GRAPE."""
+
+    def __init__(self, N_amplitudes: int, tf: float, monomial_order: int):
+        super().__init__(N_amplitudes, tf)
+        self.monomial_order = int(monomial_order)
+
+    def grad_tables(self, times, dmax):
+        times = np.asarray(times, float)
+        gp = np.zeros((len(times), dmax + 1, self.N_coeff))
+        gq = np.zeros_like(gp)
+        idx = self.find_region_index(times)
+        width = self.tf / self.N_amplitudes
+        local = (times - width * idx) / width
+        rows = np.arange(len(times))
+        mo = self.monomial_order
+        for d in range(min(dmax, mo) + 1):
+            v = math.factorial(mo) / math.factorial(mo - d) * local ** (mo - d) / width ** d
+            gp[rows, d, idx] = v
+            gq[rows, d, idx + self.N_amplitudes] = v
+        return gp, gq
+
+
+class _TrigControl(AbstractControl):
+    """Two-coefficient trigonometric controls (sincos_control.jl:1-97): p = f_p(w t) pcof[0],
+    q = f_q(w t) pcof[1] with f in {sin, cos}."""
+    _p_phase = 0.0   # sin(x + phase): 0 -> sin, pi/2 -> cos
+    _q_phase = 0.0
+    N_coeff = 2
+
+    def __init__(self, tf: float, frequency: float = 1.0):
+        self.tf, self.frequency = float(tf), float(frequency)
+
+    def grad_tables(self, times, dmax):
+        times = np.asarray(times, float)
+        gp = np.zeros((len(times), dmax + 1, self.N_coeff))
+        gq = np.zeros_like(gp)
+        w = self.frequency
+        for d in range(dmax + 1):
+            gp[:, d, 0] = w ** d * np.sin(w * times + self._p_phase + d * np.pi / 2)
+            if self.N_coeff > 1:
+                gq[:, d, 1] = w ** d * np.sin(w * times + self._q_phase + d * np.pi / 2)
+        return gp, gq
+
+
+class SinCosControl(_TrigControl):
+    _p_phase, _q_phase = 0.0, np.pi / 2
+
+
+class SinControl(_TrigControl):
+    _p_phase, _q_phase = 0.0, 0.0
+
+
+class CosControl(_TrigControl):
+    _p_phase, _q_phase = np.pi / 2, np.pi / 2
+
+
+class SingleSymCosControl(_TrigControl):
+    """p = cos(w t) pcof[0], q = 0 (sincos_control.jl:99-115)."""
+    _p_phase = np.pi / 2
+    N_coeff = 1
+
+
 # ---------------------------------------------------------------------------
 # collections of controls (Control.jl:67-96)
 # ---------------------------------------------------------------------------

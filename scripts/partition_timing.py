@@ -1,0 +1,29 @@
+"""Per-rank device time of the time-partitioned evaluation, all ranks in one process on one GPU
+(collectives = device copies, not timed): what each rank would spend computing at world = 1, 2, 4, 8."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import torch, numpy as np
+from __graft_entry__ import import_package
+qgd = import_package()
+import cases
+prob, target = qgd.cnot3_problem(nsteps=550, tf=550.0)
+ctrl = cases.cnot3_controls(qgd, prob)
+pcof = (np.random.default_rng(0).random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
+for world in (1, 2, 4, 8):
+    backs = [qgd.DeviceBackend(prob, 8, ctrl, target, r, world) for r in range(world)]
+    grp = qgd.LocalGroup(backs)
+    for b in backs:   # serialise the ranks (they share this one GPU): per-rank event times then mean what they say
+        for name in ("forward_begin", "forward_end", "adjoint_begin", "adjoint_end"):
+            fn = getattr(b, name)
+            setattr(b, name, (lambda f: (lambda *a: (f(*a), torch.cuda.synchronize())[0]))(fn))
+    for b in backs: b.set_timing(1)
+    for _ in range(3): res = grp.discrete_adjoint(pcof)
+    per_rank = []
+    for b in backs:
+        t = b.timings()
+        per_rank.append(sum(t.values()))
+    t0 = backs[0].timings()
+    sizes = [backs[0].exchange_buffer(w)[0].numel() * 8 / 1e6 for w in (0, 1, 2)]
+    print(f"world {world}: per-rank device ms max {max(per_rank):.3f} min {min(per_rank):.3f}; exchange MB (all-gather PiX, all-gather phiX, all-reduce) {sizes[0]:.2f} {sizes[1]:.3f} {sizes[2]:.4f}")
+    print("   rank 0 phases:", {k: round(v, 3) for k, v in sorted(t0.items(), key=lambda kv: -kv[1])})
+    for b in backs: b.close()

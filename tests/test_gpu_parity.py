@@ -452,3 +452,28 @@ def test_forced_gradient_configs(qgd, which, order, kw):
     g_for = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order)
     assert np.abs(g_for - g_adj).max() <= 1e-11 * np.abs(g_adj).max()
     qgd.clear_cache()
+
+
+def test_legacy_controls_on_device(qgd):
+    """BSplineControl (bcarrier2 layout), GeneralGRAPEControl and SinCosControl drive the device stepper:
+    adjoint == forced to rounding and == central differences of the device objective."""
+    prob = qgd.construct_rand_prob(6, 3, tf=1.2, nsteps=24, scale=0.4)
+    ctrl = [qgd.BSplineControl(prob.tf, 5, [0.0, 1.9]), qgd.GeneralGRAPEControl(3, prob.tf, 2), qgd.SinCosControl(prob.tf, frequency=2.5)]
+    rng = np.random.default_rng(12)
+    pcof = 0.5 * rng.standard_normal(qgd.get_number_of_control_parameters(ctrl))
+    target = cases.rand_target(prob)
+    order = 6
+    g_adj = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+    g_for = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+    assert np.abs(g_adj - g_for).max() <= 1e-12 * np.abs(g_adj).max()
+    dp = qgd.device_problem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+
+    def obj(p):
+        a, b, g = dp.eval_forward(p)
+        return 1 - (a * a + b * b) / prob.N_ess_levels ** 2 + g
+
+    for l in rng.choice(len(pcof), 6, replace=False):
+        e = np.zeros(len(pcof)); e[l] = 1e-6
+        fd = (obj(pcof + e) - obj(pcof - e)) / 2e-6
+        assert abs(fd - g_adj[l]) <= 2e-8 * max(1.0, np.abs(g_adj).max()), (l, fd, g_adj[l])
+    qgd.clear_cache()

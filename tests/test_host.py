@@ -230,3 +230,59 @@ def test_richardson_and_history_io(qgd, tmp_path):
     h.write(tmp_path / "opt.npz")
     g = qgd.read_optimization_history(tmp_path / "opt.npz")
     assert len(g) == 3 and np.array_equal(g.pcof[2], h.pcof[2]) and g.infidelity == h.infidelity
+
+
+def _quad_piece_sum(D1, tf, coeffs, t):
+    """bspline2 (src/Controls/bspline_control.jl:139-165), restated term by term for one time."""
+    dtknot = tf / (D1 - 2); width = 3 * dtknot
+    tc = dtknot * (np.arange(1, D1 + 1) - 1.5)
+    k = min(max(3, int(np.ceil(t / dtknot + 2))), D1)
+    tau = lambda kk: (t - tc[kk - 1]) / width
+    return (coeffs[k - 1] * (9 / 8 + 4.5 * tau(k) + 4.5 * tau(k) ** 2) + coeffs[k - 2] * (0.75 - 9 * tau(k - 1) ** 2)
+            + coeffs[k - 3] * (9 / 8 - 4.5 * tau(k - 2) + 4.5 * tau(k - 2) ** 2))
+
+
+def test_legacy_control_families(qgd):
+    """Control families of SURVEY row f3: hard-coded quadratic B-spline, the Juqbox bcarrier2 layout
+    (= carrier waves over it), piecewise monomials, trigonometric and zero controls.  Checks the
+    reference's own control tests (test/ControlTests/test_control_derivatives.jl:26-27,111-124): every
+    stored derivative is the time derivative of the one below it, and values match the formulas."""
+    rng = np.random.default_rng(8)
+    tf, D1 = 7.0, 9
+    b2 = qgd.BSpline2Control(D1, tf)
+    pc = rng.standard_normal(b2.N_coeff)
+    ts = np.linspace(0.0, tf, 41)
+    for t in ts:
+        assert abs(b2.eval_p(t, pc) - _quad_piece_sum(D1, tf, pc[:D1], t)) < 1e-14
+        assert abs(b2.eval_q(t, pc) - _quad_piece_sum(D1, tf, pc[D1:], t)) < 1e-14
+    assert np.allclose(b2.grad_tables(ts[1:-1], 0)[0][:, 0, :D1].sum(axis=1), 1.0)      # partition of unity
+    assert np.all(b2.grad_tables(ts, 4)[0][:, 3:] == 0.0)                                 # quadratic pieces
+    with pytest.raises(ValueError):
+        qgd.BSpline2Control(2, tf)
+    # bcarrier2 (bspline_backend.jl:783-848): p = sum_f b1 cos(w t) - b2 sin(w t), q = sum_f b1 sin + b2 cos
+    omega = [0.0, 1.3, -2.1]
+    bc = qgd.BSplineControl(tf, D1, omega)
+    pcc = rng.standard_normal(bc.N_coeff)
+    assert bc.N_coeff == 2 * D1 * len(omega)
+    for t in ts[::5]:
+        p = q = 0.0
+        for f, w in enumerate(omega):
+            o1 = f * 2 * D1
+            f1 = _quad_piece_sum(D1, tf, pcc[o1:o1 + D1], t); f2 = _quad_piece_sum(D1, tf, pcc[o1 + D1:o1 + 2 * D1], t)
+            p += f1 * np.cos(w * t) - f2 * np.sin(w * t); q += f1 * np.sin(w * t) + f2 * np.cos(w * t)
+        assert abs(bc.eval_p(t, pcc) - p) < 1e-13 and abs(bc.eval_q(t, pcc) - q) < 1e-13
+    families = [b2, bc, qgd.GeneralGRAPEControl(4, tf, 3), qgd.SinCosControl(tf, frequency=1.7), qgd.SinControl(tf, 0.6),
+                qgd.CosControl(tf, 2.2), qgd.SingleSymCosControl(tf, 1.1), qgd.ZeroControl(3, tf)]
+    h = 1e-6
+    for ctrl in families:
+        pc = rng.standard_normal(ctrl.N_coeff)
+        for t in (0.31, 2.47, 5.9):          # away from knots / region boundaries
+            for d in range(3):
+                for ev in (ctrl.eval_p_derivative, ctrl.eval_q_derivative):
+                    fd = (ev(t + h, pc, d) - ev(t - h, pc, d)) / (2 * h)
+                    assert abs(fd - ev(t, pc, d + 1)) <= 2e-7 * max(1.0, abs(fd)), (type(ctrl).__name__, t, d)
+    g = qgd.GeneralGRAPEControl(4, 8.0, 2)
+    assert abs(g.eval_p(5.0, np.arange(8.0)) - 2.0 * 0.5 ** 2) < 1e-15                   # region 2, local_t = 0.5
+    s = qgd.SinCosControl(3.0, frequency=2.0)
+    assert abs(s.eval_p(0.4, [1.5, 0.7]) - 1.5 * np.sin(0.8)) < 1e-15 and abs(s.eval_q(0.4, [1.5, 0.7]) - 0.7 * np.cos(0.8)) < 1e-15
+    assert qgd.ZeroControl(5, 1.0).eval_p(0.3, np.ones(5)) == 0.0
