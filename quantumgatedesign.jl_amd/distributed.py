@@ -58,10 +58,13 @@ class DeviceBackend:
     def exchange_buffer(self, which):
         """(whole buffer, this rank's chunk) as torch CUDA tensors over the library's memory."""
         import torch
-        ptr, tot, off, own = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-        _lib.check(self.h, self.lib.qgd_exchange_buffer(self.h, which, C.byref(ptr), C.byref(tot), C.byref(off), C.byref(own)))
-        whole = torch.as_tensor(_DevArray(ptr.value, tot.value), device="cuda")
-        return whole, whole[off.value:off.value + own.value]
+        cache = self.__dict__.setdefault("_xbuf", {})      # the buffers live as long as the control basis
+        if which not in cache:
+            ptr, tot, off, own = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+            _lib.check(self.h, self.lib.qgd_exchange_buffer(self.h, which, C.byref(ptr), C.byref(tot), C.byref(off), C.byref(own)))
+            whole = torch.as_tensor(_DevArray(ptr.value, tot.value), device="cuda")
+            cache[which] = (whole, whole[off.value:off.value + own.value])
+        return cache[which]
 
     def forward_begin(self, pcof):
         pc = np.ascontiguousarray(pcof, dtype=np.float64)
@@ -100,7 +103,8 @@ class TorchComm:
         self.dist, self.group = dist, group
 
     def all_gather(self, whole, own):
-        self.dist.all_gather_into_tensor(whole, own.clone(), group=self.group)
+        # in place: `own` is this rank's chunk of `whole` (NCCL/RCCL in-place all-gather layout)
+        self.dist.all_gather_into_tensor(whole, own, group=self.group)
 
     def all_reduce(self, whole):
         self.dist.all_reduce(whole, group=self.group)
