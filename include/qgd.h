@@ -153,8 +153,9 @@ int qgd_set_partition(qgd_handle h, int32_t rank, int32_t world);
 int qgd_get_partition(qgd_handle h, int32_t *out8);
 /* Run all device work of the handle on the caller's HIP stream (e.g. torch's current stream). */
 int qgd_set_stream(qgd_handle h, void *hip_stream);
-/* which: 0 block propagators (all-gather), 1 adjoint affine parts (all-gather),
- * 2 gradient + {<w,R>, <w,T>, guard, 0} (all-reduce sum).  Sizes in doubles. */
+/* which: 0 window propagators, per rank [planes | panel] of the product of its step matrices
+ * (all-gather, 4 N^2 doubles per rank), 1 window affine parts of the adjoint, per rank [phi | y_N]
+ * (all-gather), 2 gradient + {<w,R>, <w,T>, guard, 0} (all-reduce sum).  Sizes in doubles. */
 int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *total_doubles,
                         size_t *own_offset, size_t *own_doubles);
 int qgd_dist_forward_begin(qgd_handle h, const double *pcof, int32_t n_pcof);

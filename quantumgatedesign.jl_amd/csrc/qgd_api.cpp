@@ -120,12 +120,13 @@ int alloc_grid(qgd_handle h)
         if (B0 < 1) B0 = 1;
         k.bpr = (B0 + W - 1) / W;
         for (;;) {   // every rank must own at least one non-empty block
-            k.scan_blocks = k.bpr * W;
-            k.scan_blen = (S + k.scan_blocks - 1) / k.scan_blocks;
+            k.blocks_glob = k.bpr * W;
+            k.scan_blen = (S + k.blocks_glob - 1) / k.blocks_glob;
             const int nonempty = (S + k.scan_blen - 1) / k.scan_blen;
             if ((W - 1) * k.bpr < nonempty || k.bpr == 1) break;
             k.bpr--;
         }
+        k.scan_blocks = k.bpr;     // the scan inside a rank's window runs over its own blocks
         k.part_rank = h->part_rank; k.part_world = W;
         k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr; k.blk_hi_clamped = k.blk_hi;
         const int s_lo = k.blk_lo * k.scan_blen;
@@ -159,8 +160,12 @@ int alloc_grid(qgd_handle h)
     // blocked scan of the sweeps: chain length 2*blen + B; exchange buffers hold every rank's chunk
     {
         const size_t nb = (size_t)k.scan_blocks, W = (size_t)k.part_world;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiX, W * 2 * k.bpr * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiX, W * (k.bpr + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiX, 2 * nb * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiX, (nb + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.RX, W * 4 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiRX, W * 2 * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.wbnd, (W + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.wbndY, (W + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.psi0, hstep))) return rc;
@@ -877,7 +882,7 @@ int qgd_get_partition(qgd_handle h, int32_t *out8)
     if (!h || !out8) return QGD_ERR_ARGUMENT;
     const qgdk_ctx &k = h->k;
     out8[0] = k.n_off; out8[1] = k.n_off + k.nt - 1;   // first / last global time point of the window
-    out8[2] = k.scan_blocks; out8[3] = k.bpr; out8[4] = k.scan_blen; out8[5] = k.part_rank; out8[6] = k.part_world;
+    out8[2] = k.blocks_glob; out8[3] = k.bpr; out8[4] = k.scan_blen; out8[5] = k.part_rank; out8[6] = k.part_world;
     out8[7] = k.nt_glob;
     return QGD_OK;
 }
@@ -900,11 +905,11 @@ int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *tot
     const qgdk_ctx &k = h->k;
     const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp, W = (size_t)k.part_world;
     if (which == 0) {          // block propagators, all-gather
-        const size_t chunk = (size_t)2 * k.bpr * 2 * pl;
-        *dev_ptr = k.PiX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
+        const size_t chunk = (size_t)4 * pl;               // [R planes | R panel] of one window
+        *dev_ptr = k.RX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
     } else if (which == 1) {   // affine parts + y_N, all-gather
-        const size_t chunk = (size_t)(k.bpr + 1) * hstep;
-        *dev_ptr = k.phiX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
+        const size_t chunk = (size_t)2 * hstep;            // [phi^rank | y_N]
+        *dev_ptr = k.phiRX; *total_doubles = W * chunk; *own_offset = (size_t)k.part_rank * chunk; *own_doubles = chunk;
     } else if (which == 2) {   // gradient + scalars, all-reduce(sum)
         if (!k.redbuf) return fail(h, QGD_ERR_STATE, "no control basis set");
         *dev_ptr = k.redbuf; *total_doubles = (size_t)k.n_pcof + 4; *own_offset = 0; *own_doubles = (size_t)k.n_pcof + 4;

@@ -48,13 +48,16 @@ typedef struct qgdk_ctx {
     double *panel_scratch; // large N: per-workgroup panel slabs of k_derivs/k_gradsweep in HBM instead of LDS
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.
-    double *PiX;        // exchange buffer: per rank [bpr x PiC | bpr x PiR], 2*Np*Np doubles each
-    double *phiX;       // exchange buffer: per rank [bpr x phi | y_N], Np*2cp doubles each
-    double *bnd, *bndY; // [B+1][Np][2cp] states at block boundaries (every rank holds all)
+    double *PiX;        // own blocks: [B x PiC | B x PiR], 2*Np*Np doubles each (B = scan_blocks = blocks of this rank)
+    double *phiX;       // own blocks: [B x phi], Np*2cp doubles each
+    double *bnd, *bndY; // [B+1][Np][2cp] states at the boundaries of the own blocks
+    double *RX;         // exchange buffer 0: per rank [R planes | R panel], R = product of the rank's window
+    double *phiRX;      // exchange buffer 1: per rank [phi^rank | y_N (last rank)]
+    double *wbnd, *wbndY; // [W+1][Np][2cp] scratch of the chains over the windows
     double *psi0;       // initial panel [Np][2cp]
     double *zero_panel; // [Np][2cp] of zeros
     double *redbuf;     // [n_pcof + 4]: grad followed by scal (one all-reduce)
-    int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped;
+    int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped, blocks_glob;   // scan_blocks = bpr (local)
     // second scan level over the block propagators: scan_blocks2 super-blocks of scan_g blocks
     int scan_blocks2, scan_g;
     double *PiC2, *PiR2, *phi2, *bnd2, *bndY2;

@@ -613,50 +613,81 @@ static inline bool guard_is_fused(const qgdk_ctx *c)
     return c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64) && !getenv("QGD_GUARD_KERNEL");
 }
 
-// forward, phase (i): block propagators of the owned blocks into this rank's chunk of PiX
+// ---------------------------------------------------------------------------
+// The scan over time has three levels.  A rank owns a window of B = bpr blocks (level 1: blen steps
+// each); inside the window the block boundaries are reached by a second level (B2 super-blocks of g
+// blocks) when B > 8; across ranks only the product of a whole window, R_r = Pi_{B-1} ... Pi_0
+// (forward) and its affine part phi^rank_r (adjoint), are exchanged -- 128 KB + 16 KB per rank --
+// and every rank runs the short chain over the windows before / after its own.
+//   PiX  : local  [B x Pi planes | B x Pi panel]          phiX : local [B x phi]
+//   RX   : exchange buffer 0, per rank [R planes | R panel]
+//   phiRX: exchange buffer 1, per rank [phi^rank | y_N (last rank only)]
+// ---------------------------------------------------------------------------
+static inline size_t rx_chunk(const qgdk_ctx *c) { return (size_t)4 * c->Np * c->Np; }
+static inline size_t phirx_chunk(const qgdk_ctx *c) { return (size_t)2 * c->Np * 2 * c->cp; }
+
+// forward, part 1 (no other rank needed): block propagators, super-block propagators, window product
 int qgdk_forward_blocks(const qgdk_ctx *c)
 {
+    const size_t pl2 = (size_t)2 * c->Np * c->Np;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    int rc;
     ChainArgs a{};
     a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pc;
-    a.PiC = c->PiX + (size_t)c->part_rank * pix_chunk(c);
-    a.PiR = a.PiC + (size_t)c->bpr * 2 * c->Np * c->Np;
-    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
-    return launch_chain<0>(a, c->stream);
+    a.PiC = c->PiX; a.PiR = c->PiX + (size_t)B * pl2;
+    a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    if ((rc = launch_chain<0>(a, c->stream))) return rc;
+    if (B2 > 1) {      // super-block propagators from the block propagators
+        ChainArgs a2{};
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
+        a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+    }
+    if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
+        ChainArgs r{};
+        r.Np = c->Np; r.cp = c->cp; r.ngroups = c->Np / 8; r.nblocks = 1;
+        if (B2 > 1) { r.S = B2; r.blen = B2; r.Pmat = c->PiC2; } else { r.S = B; r.blen = B; r.Pmat = c->PiX; }
+        r.PiC = c->RX + (size_t)c->part_rank * rx_chunk(c); r.PiR = r.PiC + pl2;
+        if ((rc = launch_chain<0>(r, c->stream))) return rc;
+    }
+    return 0;
 }
 
-// forward, phases (ii)+(iii): boundary states over ALL blocks (every rank), then the owned blocks.
-// Phase (ii) is itself a scan over the B block propagators when B is large (second level:
-// super-blocks of scan_g blocks): chain length g + B2 + g instead of B.
+// forward, part 2 (after the all-gather of RX): state at the window start, at the super-block and block
+// starts, then the history of the own blocks
 int qgdk_forward_finish(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
     int rc;
-    // bnd[0] = bnd2[0] = psi_0 were written when the grid was allocated (the initial state is constant)
+    if (c->part_rank > 0) {   // psi at the window start = R_{r-1} ... R_0 psi_0
+        ChainArgs w{};
+        w.Np = c->Np; w.cp = c->cp; w.S = c->part_rank; w.Pmat = c->RX; w.pm_bpr = 1; w.pm_chunk = (long long)rx_chunk(c);
+        w.start = c->psi0; w.start_stride = 0; w.out = c->wbnd; w.nblocks = 1; w.blen = c->part_rank; w.ngroups = c->cp / 8;
+        if ((rc = launch_chain<1>(w, c->stream))) return rc;
+        const double *ws = c->wbnd + (size_t)c->part_rank * hstep;
+        HIPCHK(hipMemcpyAsync(c->bnd, ws, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->bnd2, ws, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->hist, ws, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }   // rank 0: bnd[0] = bnd2[0] = hist[0] = psi_0 were written when the grid was allocated
     if (B2 <= 1) {
         ChainArgs s2{};
-        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX;
         s2.start = c->bnd; s2.start_stride = 0; s2.out = c->bnd; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
         if ((rc = launch_chain<1>(s2, c->stream))) return rc;
     } else {
-        ChainArgs a2{};   // (ii-a) super-block propagators from the block propagators
-        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
-        a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
-        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
-        ChainArgs b2{};   // (ii-b) states at super-block starts
+        ChainArgs b2{};   // states at super-block starts
         b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiC2; b2.start = c->bnd2; b2.start_stride = 0; b2.out = c->bnd2;
         b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
         if ((rc = launch_chain<1>(b2, c->stream))) return rc;
-        ChainArgs c2{};   // (ii-c) states at every block start
-        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = c->PiX; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
+        ChainArgs c2{};   // states at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = c->PiX;
         c2.start = c->bnd2; c2.start_stride = (long long)hstep; c2.out = c->bnd; c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
         if ((rc = launch_chain<1>(c2, c->stream))) return rc;
     }
-    if (c->blk_lo > 0)   // rank 0's hist[0] = psi_0 is constant
-        HIPCHK(hipMemcpyAsync(c->hist, c->bnd + (size_t)c->blk_lo * hstep, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
-    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd + (size_t)c->blk_lo * hstep;
-    s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = c->blk_hi - c->blk_lo; s3.blen = c->scan_blen;
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->bnd;
+    s3.start_stride = (long long)hstep; s3.out = c->hist; s3.nblocks = B; s3.blen = c->scan_blen;
     s3.ngroups = c->cp / 8;
     if (guard_is_fused(c)) {
         s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
@@ -684,26 +715,39 @@ int qgdk_guard(const qgdk_ctx *c)
 int qgdk_terminal(const qgdk_ctx *c, int write_y)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
+    double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;     // y_N for the other ranks
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep);
     return (int)hipGetLastError();
 }
 
-// adjoint, phase (i): affine parts phi_b of the owned blocks into this rank's chunk of phiX; the
-// rank that owns the final time puts y_N (written by k_terminal into yhist) in its extra slot
+// adjoint, part 1 (no other rank needed): affine parts of the blocks, of the super-blocks, of the window
 int qgdk_adjoint_blocks(const qgdk_ctx *c)
 {
-    double *own = c->phiX + (size_t)c->part_rank * phix_chunk(c);
+    const size_t pl2 = (size_t)2 * c->Np * c->Np;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    const double *PiRx = c->PiX + (size_t)B * pl2;       // panel copies of the block propagators
+    int rc;
     ChainArgs a{};
-    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = own;
-    a.nblocks = c->blk_hi - c->blk_lo; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
-    int rc = launch_chain<2>(a, c->stream);
-    if (rc) return rc;
-    // the last rank's k_terminal wrote y_N into its extra slot (and into bndY/bndY2/yhist) directly;
-    // the other ranks' extra slots are never read
-    return 0;
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = c->phiX;
+    a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
+    if ((rc = launch_chain<2>(a, c->stream))) return rc;
+    if (B2 > 1) {      // affine parts of the super-blocks (their propagators PiR2 come from the forward sweep)
+        ChainArgs a2{};
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.forcing = c->phiX; a2.phi = c->phi2;
+        a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
+        if ((rc = launch_chain<2>(a2, c->stream))) return rc;
+    }
+    if (c->part_world > 1) {   // affine part of the whole window, into this rank's chunk of phiRX
+        ChainArgs r{};
+        r.Np = c->Np; r.cp = c->cp; r.ngroups = c->cp / 8; r.nblocks = 1;
+        if (B2 > 1) { r.S = B2; r.blen = B2; r.Pmat = c->PiR2; r.forcing = c->phi2; }
+        else { r.S = B; r.blen = B; r.Pmat = PiRx; r.forcing = c->phiX; }
+        r.phi = c->phiRX + (size_t)c->part_rank * phirx_chunk(c);
+        if ((rc = launch_chain<2>(r, c->stream))) return rc;
+    }
+    return 0;   // the last rank's k_terminal wrote y_N into its second slot of phiRX (and into bndY/bndY2/yhist)
 }
 
 // y_N = L(t_N)^H lambda_N for a caller-given terminal lambda (eval_adjoint): one adjoint chain step with
@@ -718,52 +762,54 @@ int qgdk_apply_LH(const qgdk_ctx *c)
     int rc = launch_chain<3>(a, c->stream);
     if (rc) return rc;
     const double *yN = c->yhist + (size_t)(c->nt - 1) * hstep;
-    double *slot = c->phiX + (size_t)c->part_rank * phix_chunk(c) + (size_t)c->bpr * hstep;
+    double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
     HIPCHK(hipMemcpyAsync(slot, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->bndY + (size_t)c->scan_blocks * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)c->scan_blocks2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
-// adjoint, phases (ii)+(iii); phase (ii) two-level like the forward one
+// adjoint, part 2 (after the all-gather of phiRX): y at the window end, at the super-block and block
+// ends, then the history of the own blocks
 int qgdk_adjoint_finish(const qgdk_ctx *c)
 {
-    const size_t hstep = (size_t)c->Np * 2 * c->cp;
-    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
-    const double *yN = c->phiX + (size_t)(c->part_world - 1) * phix_chunk(c) + (size_t)c->bpr * hstep;
-    const double *PiRx = c->PiX + (size_t)c->bpr * 2 * c->Np * c->Np;      // panel copies inside the chunks
+    const size_t hstep = (size_t)c->Np * 2 * c->cp, pl2 = (size_t)2 * c->Np * c->Np;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g, W = c->part_world, r = c->part_rank;
+    const double *PiRx = c->PiX + (size_t)B * pl2;
     int rc;
-    const bool last = (c->part_rank == c->part_world - 1);
-    if (!last) HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (r < W - 1) {   // y at the window end: y <- R_q^H y + phi^rank_q for q = W-1 .. r+1, from y_N
+        const int nq = W - 1 - r;
+        ChainArgs w{};
+        w.Np = c->Np; w.cp = c->cp; w.S = nq; w.nblocks = 1; w.blen = nq; w.ngroups = c->cp / 8;
+        w.Pmat = c->RX + (size_t)(r + 1) * rx_chunk(c) + pl2; w.pm_bpr = 1; w.pm_chunk = (long long)rx_chunk(c);
+        w.forcing = c->phiRX + (size_t)(r + 1) * phirx_chunk(c); w.f_bpr = 1;       // slot of q is 2q: [phi | y_N] per rank
+        w.start = c->phiRX + (size_t)(W - 1) * phirx_chunk(c) + hstep; w.start_stride = 0; w.out = c->wbndY;
+        if ((rc = launch_chain<3>(w, c->stream))) return rc;
+        // out[q'] = y before window r+1+q': y at the end of this rank's window is out[0]
+        HIPCHK(hipMemcpyAsync(c->bndY + (size_t)B * hstep, c->wbndY, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, c->wbndY, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->wbndY, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     if (B2 <= 1) {
         ChainArgs s2{};
-        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = PiRx; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+        s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = PiRx;
         s2.start = c->bndY + (size_t)B * hstep; s2.start_stride = 0; s2.out = c->bndY;
-        s2.forcing = c->phiX; s2.f_bpr = c->bpr; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+        s2.forcing = c->phiX; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
         if ((rc = launch_chain<3>(s2, c->stream))) return rc;
     } else {
-        ChainArgs a2{};   // (ii-a) affine parts of the super-blocks (their propagators PiR2 come from the forward sweep)
-        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.pm_bpr = c->bpr; a2.pm_chunk = (long long)pix_chunk(c);
-        a2.forcing = c->phiX; a2.f_bpr = c->bpr; a2.phi = c->phi2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
-        if ((rc = launch_chain<2>(a2, c->stream))) return rc;
-        if (!last) HIPCHK(hipMemcpyAsync(c->bndY2 + (size_t)B2 * hstep, yN, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        ChainArgs b2{};   // (ii-b) y at super-block starts
+        ChainArgs b2{};   // y at super-block starts
         b2.Np = c->Np; b2.cp = c->cp; b2.S = B2; b2.Pmat = c->PiR2; b2.start = c->bndY2 + (size_t)B2 * hstep; b2.start_stride = 0;
         b2.out = c->bndY2; b2.forcing = c->phi2; b2.nblocks = 1; b2.blen = B2; b2.ngroups = c->cp / 8;
         if ((rc = launch_chain<3>(b2, c->stream))) return rc;
-        ChainArgs c2{};   // (ii-c) y at every block start
-        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = PiRx; c2.pm_bpr = c->bpr; c2.pm_chunk = (long long)pix_chunk(c);
-        c2.start = c->bndY2 + hstep; c2.start_stride = (long long)hstep; c2.out = c->bndY; c2.forcing = c->phiX; c2.f_bpr = c->bpr;
+        ChainArgs c2{};   // y at every block start
+        c2.Np = c->Np; c2.cp = c->cp; c2.S = B; c2.Pmat = PiRx;
+        c2.start = c->bndY2 + hstep; c2.start_stride = (long long)hstep; c2.out = c->bndY; c2.forcing = c->phiX;
         c2.nblocks = B2; c2.blen = g; c2.ngroups = c->cp / 8;
         if ((rc = launch_chain<3>(c2, c->stream))) return rc;
     }
-    // y at the end of this rank's window
-    if (!last)
-        HIPCHK(hipMemcpyAsync(c->yhist + (size_t)(c->nt - 1) * hstep, c->bndY + (size_t)c->blk_hi_clamped * hstep,
-                              hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     ChainArgs s3{};
-    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.start = c->bndY + (size_t)(c->blk_lo + 1) * hstep;
-    s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = c->blk_hi - c->blk_lo;
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.start = c->bndY + hstep;
+    s3.start_stride = (long long)hstep; s3.out = c->yhist; s3.forcing = c->forcing; s3.nblocks = B;
     s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
     return launch_chain<3>(s3, c->stream);
 }
@@ -785,7 +831,7 @@ int qgdk_forced_chains(const qgdk_ctx *c)
     int rc = launch_chain<4>(a, c->stream);
     if (rc) return rc;
     ChainArgs s2{};    // (ii)
-    s2.Np = c->Np; s2.cp = cpS; s2.S = B; s2.Pmat = c->PiX; s2.pm_bpr = c->bpr; s2.pm_chunk = (long long)pix_chunk(c);
+    s2.Np = c->Np; s2.cp = cpS; s2.S = B; s2.Pmat = c->PiX;
     s2.start = c->fs_bnd; s2.start_stride = 0; s2.out = c->fs_bnd; s2.forcing = c->fs_phi; s2.nblocks = 1; s2.blen = B;
     s2.ngroups = cpS / 8; s2.fs_gpc = c->cp / 8;
     if ((rc = launch_chain<5>(s2, c->stream))) return rc;

@@ -138,8 +138,3 @@ __device__ __forceinline__ void combine_opvals(const OpVals &v, const double *cf
 #define DISPATCH_NOPS(n_ops, CALL) \
     switch (n_ops) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
                      default: CALL(-1); break; }
-
-// Exchange layout (DESIGN.md "Multi-GPU"): PiX = one chunk per rank, chunk = [bpr x PiC | bpr x PiR];
-// phiX = one chunk per rank, chunk = [bpr x phi | 1 x y_N (last rank only)].
-static inline size_t pix_chunk(const qgdk_ctx *c) { return (size_t)2 * c->bpr * 2 * c->Np * c->Np; }
-static inline size_t phix_chunk(const qgdk_ctx *c) { return (size_t)(c->bpr + 1) * c->Np * 2 * c->cp; }

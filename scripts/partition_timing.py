@@ -24,6 +24,6 @@ for world in (1, 2, 4, 8):
         per_rank.append(sum(t.values()))
     t0 = backs[0].timings()
     sizes = [backs[0].exchange_buffer(w)[0].numel() * 8 / 1e6 for w in (0, 1, 2)]
-    print(f"world {world}: per-rank device ms max {max(per_rank):.3f} min {min(per_rank):.3f}; exchange MB (all-gather PiX, all-gather phiX, all-reduce) {sizes[0]:.2f} {sizes[1]:.3f} {sizes[2]:.4f}")
+    print(f"world {world}: per-rank device ms max {max(per_rank):.3f} min {min(per_rank):.3f}; exchange MB (all-gather RX, all-gather phiRX, all-reduce) {sizes[0]:.2f} {sizes[1]:.3f} {sizes[2]:.4f}")
     print("   rank 0 phases:", {k: round(v, 3) for k, v in sorted(t0.items(), key=lambda kv: -kv[1])})
     for b in backs: b.close()
