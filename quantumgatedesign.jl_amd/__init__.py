@@ -8,7 +8,7 @@ The directory name contains a dot, so the package is loaded through
 from .schrodinger_prob import SchrodingerProb
 from .controls import (AbstractControl, GRAPEControl, FortranBSplineControl, GeneralBSplineControl,
                        CarrierControl, BSpline2Control, BSplineControl, ZeroControl, GeneralGRAPEControl,
-                       SinCosControl, SinControl, CosControl, SingleSymCosControl, get_number_of_control_parameters, get_control_vector_slice,
+                       SinCosControl, SinControl, CosControl, SingleSymCosControl, HermiteControl, HermiteCarrierControl, get_number_of_control_parameters, get_control_vector_slice,
                        fill_p_mat, fill_q_mat, control_basis, bspline_basis_derivatives)
 from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_prob, guard_projector,
                        create_initial_conditions, create_gate, basis_state, lowering_operators_system,

@@ -298,6 +298,75 @@ def BSplineControl(tf: float, D1: int, omega: Sequence[float]):
     return CarrierControl(BSpline2Control(D1, tf), list(omega))
 
 
+class HermiteControl(AbstractControl):
+    """Piecewise Hermite interpolation (hermite_control.jl:1-283): on each of the ``N_points-1`` equal
+    intervals p is the polynomial of degree ``2 N_derivatives + 1`` that matches the value and the first
+    ``N_derivatives`` derivatives given at both end points.  The control vector holds, for p and then
+    for q, ``[1+N_derivatives, N_points]`` (derivative order fastest) numbers which are turned into
+    scaled Taylor coefficients ``dt^j p^(j)/j!`` by ``scaling_type`` (:217-234): "Taylor" 1,
+    "Derivative" ``dt^j/j!`` (the parameters are the derivatives), "Heuristic" ``(j+1)! 2^j``."""
+
+    def __init__(self, N_points: int, tf: float, N_derivatives: int, scaling_type: str = "Heuristic"):
+        if int(N_points) <= 1:
+            raise ValueError("N_points must be > 1")                                   # :44
+        self.N_points, self.tf, self.N_derivatives = int(N_points), float(tf), int(N_derivatives)
+        self.scaling_type = str(scaling_type).lstrip(":")
+        if self.scaling_type not in ("Taylor", "Derivative", "Heuristic"):
+            raise ValueError(self.scaling_type)                                        # :229
+        m = self.N_derivatives
+        self.N_coeff = self.N_points * (m + 1) * 2
+        self.dt = self.tf / (self.N_points - 1)
+        j = np.arange(m + 1)
+        fact = np.array([math.factorial(int(x)) for x in j], dtype=float)
+        self.scaling = {"Taylor": np.ones(m + 1), "Derivative": self.dt ** j / fact,
+                        "Heuristic": np.array([math.factorial(int(x) + 1) for x in j], dtype=float) * 2.0 ** j}[self.scaling_type]
+        # monomial coefficients of the interpolant in z = (t - t_left)/dt from the Taylor data at z = 0, 1
+        n = 2 * m + 2
+        A = np.zeros((n, n))
+        for jj in range(m + 1):
+            A[jj, jj] = 1.0
+            for k in range(jj, n):
+                A[m + 1 + jj, k] = math.comb(k, jj)
+        self._Minv = np.linalg.inv(A)
+
+    def _basis(self, times, dmax):
+        """[len(times), dmax+1, N_points*(m+1)] for one of p/q."""
+        times = np.asarray(times, float)
+        m, n = self.N_derivatives, 2 * self.N_derivatives + 2
+        if np.any(times < 0) or np.any(times > self.tf * (1 + np.finfo(float).eps)):
+            raise ValueError("Value is outside the interval [0,tf]")
+        reg = np.minimum(np.floor(times / self.dt).astype(np.int64), self.N_points - 2)   # find_region_index
+        z = (times - reg * self.dt) / self.dt
+        B = np.zeros((len(times), dmax + 1, self.N_points * (m + 1)))
+        rows = np.arange(len(times))
+        k = np.arange(n)
+        for d in range(min(dmax, n - 1) + 1):
+            fall = np.array([math.factorial(int(x)) / math.factorial(int(x) - d) if x >= d else 0.0 for x in k])
+            v = fall[None, :] * np.where(k[None, :] >= d, z[:, None] ** np.maximum(k[None, :] - d, 0), 0.0)
+            w = v @ self._Minv / self.dt ** d                     # weights on [left data | right data]
+            for jj in range(m + 1):
+                B[rows, d, reg * (m + 1) + jj] = w[:, jj] * self.scaling[jj]
+                B[rows, d, (reg + 1) * (m + 1) + jj] = w[:, m + 1 + jj] * self.scaling[jj]
+        return B
+
+    def grad_tables(self, times, dmax):
+        B = self._basis(times, dmax)
+        half = self.N_coeff // 2
+        gp = np.zeros((B.shape[0], dmax + 1, self.N_coeff))
+        gq = np.zeros_like(gp)
+        gp[:, :, :half] = B
+        gq[:, :, half:] = B
+        return gp, gq
+
+
+def HermiteCarrierControl(N_points: int, tf: float, N_derivatives: int, carrier_wave_freqs: Sequence[float],
+                          scaling_type: str = "Heuristic"):
+    """HermiteCarrierControl (hermite_carrier.jl:1-200): per carrier one block of Hermite-control
+    coefficients, p = sum_f h^p_f cos(w t) - h^q_f sin(w t), q = sum_f h^p_f sin(w t) + h^q_f cos(w t)
+    -- carrier waves over HermiteControl."""
+    return CarrierControl(HermiteControl(N_points, tf, N_derivatives, scaling_type), list(carrier_wave_freqs))
+
+
 class ZeroControl(AbstractControl):
     """p = q = 0 with ``N_coeff`` inert coefficients (zero_control.jl:1-12)."""
 

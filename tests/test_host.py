@@ -286,3 +286,41 @@ def test_legacy_control_families(qgd):
     s = qgd.SinCosControl(3.0, frequency=2.0)
     assert abs(s.eval_p(0.4, [1.5, 0.7]) - 1.5 * np.sin(0.8)) < 1e-15 and abs(s.eval_q(0.4, [1.5, 0.7]) - 0.7 * np.cos(0.8)) < 1e-15
     assert qgd.ZeroControl(5, 1.0).eval_p(0.3, np.ones(5)) == 0.0
+
+
+def test_hermite_control(qgd):
+    """HermiteControl (src/Controls/hermite_control.jl): the interpolant reproduces the data at the points
+    (test/ControlFunctionTests/hermite_control_points.jl), equals scipy's Hermite interpolant, is
+    C^m across points, and its stored derivatives are consistent (test_control_derivatives.jl:187)."""
+    from scipy.interpolate import BPoly
+    rng = np.random.default_rng(15)
+    tf, npts, m = 3.0, 5, 2
+    for scaling in ("Taylor", "Derivative", "Heuristic"):
+        hc = qgd.HermiteControl(npts, tf, m, scaling)
+        pc = rng.standard_normal(hc.N_coeff)
+        assert hc.N_coeff == npts * (m + 1) * 2
+        data = pc[:hc.N_coeff // 2].reshape(npts, m + 1)          # [point, derivative order]
+        dt = tf / (npts - 1)
+        for i in range(npts):
+            for j in range(m + 1):
+                taylor = hc.eval_p_derivative(min(i * dt, tf), pc, j) * dt ** j / math.factorial(j)
+                assert abs(taylor - data[i, j] * hc.scaling[j]) < 1e-11, (scaling, i, j)
+    hc = qgd.HermiteControl(npts, tf, m, "Derivative")             # parameters are the derivatives themselves
+    pc = rng.standard_normal(hc.N_coeff)
+    half = hc.N_coeff // 2
+    xi = np.linspace(0, tf, npts)
+    ref_p = BPoly.from_derivatives(xi, pc[:half].reshape(npts, m + 1))
+    ref_q = BPoly.from_derivatives(xi, pc[half:].reshape(npts, m + 1))
+    for t in np.linspace(0.01, tf - 0.01, 23):
+        for d in range(4):
+            assert abs(hc.eval_p_derivative(t, pc, d) - ref_p.derivative(d)(t) if d else hc.eval_p(t, pc) - ref_p(t)) < 1e-9
+            assert abs(hc.eval_q_derivative(t, pc, d) - (ref_q.derivative(d)(t) if d else ref_q(t))) < 1e-9
+    assert hc.eval_p_derivative(1.0, pc, 2 * m + 2) == 0.0        # degree 2m+1 pieces
+    car = qgd.HermiteCarrierControl(4, tf, 1, [0.0, 2.3], "Taylor")
+    assert car.N_coeff == 2 * 4 * 2 * 2
+    pcc = rng.standard_normal(car.N_coeff)
+    h = 1e-6
+    for t in (0.37, 1.9):
+        for d in range(3):
+            fd = (car.eval_q_derivative(t + h, pcc, d) - car.eval_q_derivative(t - h, pcc, d)) / (2 * h)
+            assert abs(fd - car.eval_q_derivative(t, pcc, d + 1)) <= 1e-6 * max(1.0, abs(fd))
