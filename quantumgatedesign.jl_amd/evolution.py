@@ -272,6 +272,28 @@ def eval_grad_forced(prob, controls, pcof, target, order=2, cost_type="Infidelit
     return dp.eval_grad_forced(pcof)
 
 
+def eval_grad_finite_difference(prob, controls, pcof, target, dpcof=1e-5, order=2, cost_type="Infidelity"):
+    """eval_grad_finite_difference (src/eval_grad_finite_difference.jl:1-72): centred differences of
+    infidelity + guard penalty, two device forward evaluations per control parameter (the third leg of
+    the reference's adjoint / forced / finite-difference contract, compare_gradients.jl:47-65)."""
+    if cost_type not in ("Infidelity", ":Infidelity"):
+        raise NotImplementedError("cost_type other than :Infidelity")
+    dp = device_problem(prob, order)
+    dp.set_controls(controls)
+    dp.set_target(target)
+    pcof = np.asarray(pcof, dtype=np.float64)
+
+    def cost(p):
+        a, b, guard = dp.eval_forward(p)
+        return 1.0 - (a * a + b * b) / prob.N_ess_levels ** 2 + guard
+
+    grad = np.zeros(len(pcof))
+    for i in range(len(pcof)):
+        e = np.zeros(len(pcof)); e[i] = dpcof
+        grad[i] = (cost(pcof + e) - cost(pcof - e)) / (2 * dpcof)
+    return grad
+
+
 def eval_adjoint(prob, controls, pcof, terminal_condition, order=2, forcing=None):
     """QuantumGateDesign.eval_adjoint (forward_evolution.jl:300-315), used by the reference's scripts
     (examples/cnot2_optimization.jl:56, regression.jl:49): lambda history ``[2N, 1+order/2, 1+nsteps, c]``

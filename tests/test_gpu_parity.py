@@ -439,6 +439,9 @@ def test_forced_gradient_reference_contract(qgd, orc, order):
         scale = np.abs(g_adj).max()
         assert np.abs(g_for - g_adj).max() <= 1e-12 * scale, (name, order)
         assert np.abs(g_for - g_orc).max() <= 1e-10 * scale, (name, order)
+        if order == 4:     # the third leg: centred differences (<= 1e-9 in the reference's test)
+            g_fd = qgd.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order)
+            assert np.abs(g_fd - g_adj).max() <= 3e-9 * max(1.0, scale), (name, order)
     qgd.clear_cache()
 
 
