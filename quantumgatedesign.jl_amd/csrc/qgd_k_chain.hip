@@ -40,6 +40,15 @@ struct ChainArgs {
     double *scal;               // scal[2] += penalty
     int gN, n_off, nt_glob, count_first;
     double dt, tf;
+    // MODE 1/3 prefix: before its own steps the workgroup of block b advances the common start state over
+    // the coarser levels of the scan -- windows of the other ranks (kind 0), super-blocks (kind 1), blocks
+    // (kind 2) -- so ONE launch replaces the chains over the levels (the prefixes are redundant work on
+    // otherwise idle CUs).  Forward: kind 0 n = 0..cnt-1, kind 1 n = 0..j-1, kind 2 n = first..b-1 with
+    // j = b / pre_g; adjoint: the mirror image from the top.
+    int npre, pre_kind[3], pre_g, pre_B2, pre_rank_count;
+    const double *pre_P[3], *pre_f[3];
+    int pre_pm_bpr[3], pre_f_bpr[3]; long long pre_pm_chunk[3];
+    double *pre_start_out;   // block 0 (forward) / the last block (adjoint) stores the state after the kind-0 segment here
     // MODE 4/5 (forward sensitivities of the forced gradient, eval_grad_forced.jl:17-194): one column
     // group per (control parameter, state column group).  fs_mode 1: the forcing of step n is
     // assembled from the 2m basis responses of the parameter's control,
@@ -149,6 +158,27 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
     const int arow = rb * 16 + c16;
     const int nsteps = (e0 > s0) ? e0 - s0 : 0;
     double pen = 0.0;                                     // guard penalty of the states this thread handles
+    // prefix segments (MODE 1/3): counts and first indices for this block
+    int pcnt[3] = {0, 0, 0}, pfirst[3] = {0, 0, 0}, npfx = 0;
+    if ((MODE == 1 || MODE == 3) && a.npre > 0) {
+        bool have1 = false;
+        for (int q = 0; q < a.npre; q++) have1 = have1 || (a.pre_kind[q] == 1);
+        const int j = have1 ? b / a.pre_g : 0;
+        const int ej = have1 ? (((j + 1) * a.pre_g < a.nblocks) ? (j + 1) * a.pre_g : a.nblocks) : a.nblocks;
+        for (int q = 0; q < a.npre; q++) {
+            const int kind = a.pre_kind[q];
+            if (!ADJ) {
+                pfirst[q] = (kind == 2 && have1) ? j * a.pre_g : 0;
+                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? j : b - pfirst[q];
+            } else {    // descending: first = highest index
+                pfirst[q] = (kind == 0) ? a.pre_rank_count - 1 : (kind == 1) ? a.pre_B2 - 1 : ej - 1;
+                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? a.pre_B2 - 1 - j : ej - 1 - b;
+            }
+            if (pcnt[q] < 0) pcnt[q] = 0;
+            npfx += pcnt[q];
+        }
+    }
+    const int total = npfx + nsteps;
 
     // start state into part[0]
     for (int e = tid; e < NG * NP * 16; e += NTH) {
@@ -158,7 +188,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         else if (ZERO) v = 0.0;
         else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
         part[0][g][el] = v;
-        if (MODE == 1 && a.guard_diag && s0 == 0) {      // the window's first point is nobody's product
+        if (MODE == 1 && a.guard_diag && s0 == 0 && !(a.npre > 0 && a.pre_kind[0] == 0)) {   // the window's first point is nobody's product
             const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
             const double trap = (a.n_off == 0) ? 0.5 : 1.0;
             a.guard_forcing[(size_t)row * PWc + (grp0 + g) * 16 + c] = -(2.0 * a.dt / a.tf) * trap * wv * v;
@@ -176,17 +206,27 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
     }
     auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
     auto issue = [&](int st) {                            // left operand (and forcing) of step st
-        const int n = step_index(st);
-        const double *Pn = chain_matrix(a, n);
+        int n, fbpr = a.f_bpr;
+        const double *Pn, *fsrc = a.forcing;
+        if (st >= npfx) { n = step_index(st - npfx); Pn = chain_matrix(a, n); }
+        else {                                            // a prefix step
+            int q = 0, sl = st;
+            while (sl >= pcnt[q]) { sl -= pcnt[q]; q++; }
+            n = ADJ ? pfirst[q] - sl : pfirst[q] + sl;
+            const size_t pl2 = (size_t)2 * NP * NP;
+            Pn = a.pre_pm_bpr[q] ? a.pre_P[q] + (size_t)(n / a.pre_pm_bpr[q]) * a.pre_pm_chunk[q] + (size_t)(n % a.pre_pm_bpr[q]) * pl2
+                                 : a.pre_P[q] + (size_t)n * pl2;
+            fsrc = a.pre_f[q]; fbpr = a.pre_f_bpr[q];
+        }
         #pragma unroll
         for (int i = 0; i < KST; i++) chain_a_raw<ADJ>(Pn, NP, arow, i * 4 + kk, are[i], aim[i]);
         if (FORC && !(MODE >= 4 && a.fs_mode == 1)) {
-            const size_t fb = (size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep;
+            const size_t fb = (size_t)(fbpr ? n + n / fbpr : n) * hstep;
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    fo[g][r] = a.forcing[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16];
+                    fo[g][r] = fsrc[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16];
         }
         if (MODE >= 4 && a.fs_mode == 1) {               // assemble the sensitivity forcing of step n -> n+1
             #pragma unroll
@@ -217,7 +257,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
             }
         }
     };
-    if (team < nsteps) issue(team);
+    if (team < total) issue(team);
     __syncthreads();
 
 #ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
@@ -226,10 +266,11 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
 #define CH_STAMP(slot) do { } while (0)
 #endif
     int done = 0;                                         // step barriers this wave has passed
-    for (int st = team; st < nsteps; st += NT) {
+    for (int st = team; st < total; st += NT) {
         while (done < st) { __syncthreads(); done++; }   // steps of the other teams
         CH_STAMP(0);
-        const int buf = st & 1, n = step_index(st);
+        const bool mainstep = st >= npfx;
+        const int buf = st & 1, n = step_index(mainstep ? st - npfx : 0);
         d4 acc[NG][2];
         #pragma unroll
         for (int g = 0; g < NG; g++) { acc[g][0] = (d4){0, 0, 0, 0}; acc[g][1] = (d4){0, 0, 0, 0}; }
@@ -258,12 +299,24 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         CH_STAMP(2);
         __syncthreads(); done++;                          // the next team starts; the rest is off the critical path
         CH_STAMP(3);
-        if (MODE == 1 || MODE == 3 || (MODE == 5 && a.out)) {
+        if (((MODE == 1 || MODE == 3) && mainstep) || (MODE == 5 && a.out)) {
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     a.out[(size_t)nout * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16] = res[g][r];
+        }
+        if ((MODE == 1 || MODE == 3) && a.pre_start_out && a.npre > 0 && a.pre_kind[0] == 0 && st == pcnt[0] - 1 &&
+            b == (ADJ ? a.nblocks - 1 : 0)) {
+            // the state at this window's start (forward) / end (adjoint): nobody's product inside the window
+            #pragma unroll
+            for (int g = 0; g < NG; g++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const size_t o = (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16;
+                    a.pre_start_out[o] = res[g][r];
+                    if (MODE == 1 && a.guard_diag) a.guard_forcing[o] = -(2.0 * a.dt / a.tf) * gw[r] * res[g][r];
+                }
         }
         if (MODE == 5 && a.fs_gf) {                      // guard part of dJ/dtheta: -<f_n, s_n>, real stacked form
             #pragma unroll
@@ -274,7 +327,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                     pen -= a.fs_gf[(size_t)nout * NP * PWb + (size_t)(rb * 16 + kk + 4 * r) * PWb + cg * 16 + c16] * res[g][r];
             }
         }
-        if (MODE == 1 && a.guard_diag) {
+        if (MODE == 1 && a.guard_diag && mainstep) {
             const double trap = (nout + a.n_off == a.nt_glob - 1) ? 0.5 : 1.0, sc = -(2.0 * a.dt / a.tf) * trap;
             #pragma unroll
             for (int g = 0; g < NG; g++)
@@ -285,9 +338,9 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                     pen += trap * gw[r] * res[g][r] * res[g][r];
                 }
         }
-        if (st + NT < nsteps) issue(st + NT);
+        if (st + NT < total) issue(st + NT);
     }
-    while (done < nsteps) { __syncthreads(); done++; }
+    while (done < total) { __syncthreads(); done++; }
     if (MODE == 1 && a.guard_diag) {                     // one atomic per workgroup
         __shared__ double pred[NTH / 16];
         pen = row16_sum(pen);
@@ -310,9 +363,9 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
             atomicAdd(&a.fs_gacc[grp0 / a.fs_gpc], tot);
         }
     }
-    // final state (part[nsteps & 1]) of the block
+    // final state (part[total & 1]) of the block
     if (MODE == 0 || ZERO || (MODE == 5 && a.phi)) {
-        const int buf = nsteps & 1;
+        const int buf = total & 1;
         for (int e = tid; e < NG * NP * 16; e += NTH) {
             const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
             const double v = part[buf][g][el];
@@ -607,6 +660,8 @@ __global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT
 
 extern "C" {
 
+static inline bool chain_is_fast(const qgdk_ctx *c) { return c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64; }
+
 // diagonal guard projector + compiled-size sweeps: k_chain_fast<.,1,.> does the guard work
 static inline bool guard_is_fused(const qgdk_ctx *c)
 {
@@ -660,6 +715,26 @@ int qgdk_forward_finish(const qgdk_ctx *c)
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
     int rc;
+    if (chain_is_fast(c)) {
+        // one launch: the workgroup of block b first advances psi_0 over the windows of the lower ranks, the
+        // super-blocks and the blocks before b (prefix segments of k_chain_fast), then writes its history
+        ChainArgs s3{};
+        s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->psi0; s3.start_stride = 0;
+        s3.out = c->hist; s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
+        int q = 0;
+        if (c->part_rank > 0) {
+            s3.pre_kind[q] = 0; s3.pre_P[q] = c->RX; s3.pre_pm_bpr[q] = 1; s3.pre_pm_chunk[q] = (long long)rx_chunk(c);
+            s3.pre_rank_count = c->part_rank; s3.pre_start_out = c->hist; q++;
+        }
+        if (B2 > 1) { s3.pre_kind[q] = 1; s3.pre_P[q] = c->PiC2; q++; }
+        if (B > 1) { s3.pre_kind[q] = 2; s3.pre_P[q] = c->PiX; q++; }
+        s3.npre = q; s3.pre_g = g; s3.pre_B2 = B2;
+        if (guard_is_fused(c)) {
+            s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
+            s3.n_off = c->n_off; s3.nt_glob = c->nt_glob; s3.count_first = (c->n_off == 0) ? 1 : 0; s3.dt = c->dt; s3.tf = c->tf;
+        }
+        return launch_chain<1>(s3, c->stream);
+    }
     if (c->part_rank > 0) {   // psi at the window start = R_{r-1} ... R_0 psi_0
         ChainArgs w{};
         w.Np = c->Np; w.cp = c->cp; w.S = c->part_rank; w.Pmat = c->RX; w.pm_bpr = 1; w.pm_chunk = (long long)rx_chunk(c);
@@ -777,6 +852,24 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
     const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g, W = c->part_world, r = c->part_rank;
     const double *PiRx = c->PiX + (size_t)B * pl2;
     int rc;
+    if (chain_is_fast(c)) {
+        // one launch, mirror image of the forward one: y_N is advanced over the windows of the higher ranks,
+        // the super-blocks and the blocks after b, then the block writes its y history
+        ChainArgs s3{};
+        s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.forcing = c->forcing; s3.out = c->yhist;
+        s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8; s3.start_stride = 0;
+        s3.start = (r == W - 1) ? c->yhist + (size_t)(c->nt - 1) * hstep : c->phiRX + (size_t)(W - 1) * phirx_chunk(c) + hstep;
+        int q = 0;
+        if (r < W - 1) {
+            s3.pre_kind[q] = 0; s3.pre_P[q] = c->RX + (size_t)(r + 1) * rx_chunk(c) + pl2; s3.pre_pm_bpr[q] = 1;
+            s3.pre_pm_chunk[q] = (long long)rx_chunk(c); s3.pre_f[q] = c->phiRX + (size_t)(r + 1) * phirx_chunk(c); s3.pre_f_bpr[q] = 1;
+            s3.pre_rank_count = W - 1 - r; s3.pre_start_out = c->yhist + (size_t)(c->nt - 1) * hstep; q++;
+        }
+        if (B2 > 1) { s3.pre_kind[q] = 1; s3.pre_P[q] = c->PiR2; s3.pre_f[q] = c->phi2; q++; }
+        if (B > 1) { s3.pre_kind[q] = 2; s3.pre_P[q] = PiRx; s3.pre_f[q] = c->phiX; q++; }
+        s3.npre = q; s3.pre_g = g; s3.pre_B2 = B2;
+        return launch_chain<3>(s3, c->stream);
+    }
     if (r < W - 1) {   // y at the window end: y <- R_q^H y + phi^rank_q for q = W-1 .. r+1, from y_N
         const int nq = W - 1 - r;
         ChainArgs w{};
