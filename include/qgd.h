@@ -172,6 +172,12 @@ int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, in
 int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 
 
+/* eval_forward(prob, controls, pcof; forcing) (src/forward_evolution.jl:15-70, forcing path :118-129,
+ * :167-206): w' = A w + F with the scaled Taylor coefficients of F given at every time point,
+ * forcing[2N, order/2, 1+nsteps, n_cols] (column-major).  N <= 64; single GPU. */
+int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, const double *forcing,
+                            double *uv_history, double *out3);
+
 /* eval_grad_forced (src/eval_grad_forced.jl:17-194): the same gradient by forward sensitivities --
  * one forced forward sweep per control parameter, all parameters batched as extra column groups of
  * the blocked scan.  The reference's cross-check of the discrete adjoint (agreement to rounding).

@@ -21,7 +21,7 @@ EXPORTS = [
     "qgd_apply_hamiltonian", "qgd_get_intermediate", "qgd_get_timings",
     "qgd_set_partition", "qgd_get_partition", "qgd_set_stream", "qgd_exchange_buffer",
     "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
-    "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced",
+    "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
     L.qgd_dist_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.qgd_set_timing.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
     L.qgd_eval_grad_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.qgd_eval_forward_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qgd_set_operator_path.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_get_operator_path.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_eval_adjoint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

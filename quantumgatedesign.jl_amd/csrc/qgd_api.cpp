@@ -34,6 +34,8 @@ struct qgd_handle_s {
     std::vector<void *> static_bufs, grid_bufs, basis_bufs, forced_bufs;
     std::vector<double> target_host;   // stacked real target [2N x c] (forced gradient: the overlaps are host arithmetic)
     size_t forced_key = 0;             // (nt, n_pcof) the forced-gradient buffers were sized for
+    std::vector<void *> forcing_bufs;  // eval_forward with a user forcing
+    size_t forcing_key = 0;
     bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
     std::vector<int32_t> ncoef, poff;
     std::vector<int64_t> goff;
@@ -109,6 +111,7 @@ int alloc_grid(qgd_handle h)
     qgdk_ctx &k = h->k;
     free_pool(h->grid_bufs);
     free_pool(h->forced_bufs); h->forced_key = 0;
+    free_pool(h->forcing_bufs); h->forcing_key = 0;
     // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
     //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
     {
@@ -518,7 +521,7 @@ void qgd_destroy(qgd_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
-    free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs); free_pool(h->forced_bufs);
+    free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs); free_pool(h->forced_bufs); free_pool(h->forcing_bufs);
     for (auto &p : h->phases) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->host_in) (void)hipHostFree(h->host_in);
@@ -688,6 +691,56 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             }
         }
     }
+    return QGD_OK;
+}
+
+int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, const double *forcing,
+                            double *uv_history, double *out3)
+{
+    if (!h || !forcing) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced forward sweep is single-GPU");
+    if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || (size_t)(k.m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024)
+        return fail(h, QGD_ERR_UNSUPPORTED, "eval_forward with forcing on the device needs N <= 64");
+    int rc = forward_begin(h, pcof, n_pcof);
+    if (rc) return rc;
+    const size_t nt = k.nt, m = k.m, N = k.N, n2 = 2 * N, PWc = 2 * k.cp, hstep = (size_t)k.Np * PWc, B = k.scan_blocks;
+    if (h->forcing_key != nt) {
+        free_pool(h->forcing_bufs); h->forcing_key = 0;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_F, nt * m * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_E, nt * m * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XR, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XL, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_Q, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_phi, (B + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_bnd, (B + 2) * hstep))) return rc;
+        h->forcing_key = nt;
+    }
+    {   // forcing [2N, m, nt, c] (Julia layout, forward_evolution.jl:42-44) -> panels [nt][m][Np][2cp]
+        std::vector<double> f(nt * m * hstep, 0.0);
+        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) for (size_t j = 0; j < m; j++) {
+            const double *src = forcing + ((col * nt + n) * m + j) * n2;
+            double *dst = f.data() + (n * m + j) * hstep;
+            for (size_t i = 0; i < N; i++) {
+                const size_t o = panel_index((int)i, (int)col, (int)PWc);
+                dst[o] = src[i]; dst[o + 8] = src[N + i];
+            }
+        }
+        HIP_TRY(h, hipMemcpy(k.ff_F, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    { PhaseTimer t(h, "forcing_terms"); K_TRY(h, qgdk_forcing_terms(&k)); }
+    { PhaseTimer t(h, "sweep_forced"); K_TRY(h, qgdk_forcing_sweep(&k)); }
+    { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard_kernel(&k)); }
+    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }
+    h->forward_valid = false;      // this history is not the one the adjoint sweep differentiates
+    if (uv_history) {
+        { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+        K_TRY(h, qgdk_forcing_add_derivs(&k));     // w_j = D_j w_0 + E_j
+        h->derivs_valid = false;
+    }
+    if ((rc = fetch_results(h, nullptr, out3))) return rc;
+    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
     return QGD_OK;
 }
 

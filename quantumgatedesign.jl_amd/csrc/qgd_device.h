@@ -66,6 +66,8 @@ typedef struct qgdk_ctx {
     double *fs_BR, *fs_BL;   // [nt][n_ops*2*m][Np][2cp]
     double *fs_phi, *fs_bnd; // [B][Np][2cpS], [B+1][Np][2cpS], cpS = n_pcof * cp
     double *fs_gacc;         // [n_pcof]
+    // eval_forward with a user forcing: F, E [nt][m][Np][2cp]; XR, XL, Q [nt][Np][2cp]; scan buffers
+    double *ff_F, *ff_E, *ff_XR, *ff_XL, *ff_Q, *ff_phi, *ff_bnd;
     int *status;
     double cw_host[2 * 20];
 } qgdk_ctx;
@@ -98,6 +100,10 @@ int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);
 size_t qgdk_forced_lds(int Np, int m);
 int qgdk_forced_basis(const qgdk_ctx *c);
 int qgdk_forced_chains(const qgdk_ctx *c);
+int qgdk_forcing_terms(const qgdk_ctx *c);
+int qgdk_forcing_add_derivs(const qgdk_ctx *c);
+int qgdk_forcing_sweep(const qgdk_ctx *c);
+int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 #ifdef __cplusplus

@@ -776,6 +776,12 @@ int qgdk_guard_is_fused(const qgdk_ctx *c) { return guard_is_fused(c) ? 1 : 0; }
 int qgdk_guard(const qgdk_ctx *c)
 {
     if (guard_is_fused(c)) return 0;          // the history pass of the forward sweep wrote forcing and penalty
+    return qgdk_guard_kernel(c);
+}
+
+// the stand-alone guard kernels (also used after a forced forward sweep, whose history pass has no guard part)
+int qgdk_guard_kernel(const qgdk_ctx *c)
+{
     const int count_first = (c->n_off == 0) ? 1 : 0;
     if (c->have_guard == 2) {   // diagonal projector
         hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
@@ -935,6 +941,29 @@ int qgdk_forced_chains(const qgdk_ctx *c)
         if ((rc = launch_chain<5>(g, c->stream))) return rc;
     }
     return 0;
+}
+
+// forward sweep with a forcing term per step (eval_forward(...; forcing)): affine parts of the blocks,
+// chain over the block propagators, history pass
+int qgdk_forcing_sweep(const qgdk_ctx *c)
+{
+    if (!chain_is_fast(c)) return (int)hipErrorNotSupported;
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const int B = c->scan_blocks;
+    int rc;
+    ChainArgs a{};     // affine parts from zero
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pc; a.forcing = c->ff_Q; a.phi = c->ff_phi;
+    a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
+    if ((rc = launch_chain<4>(a, c->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ff_bnd, c->psi0, hstep * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    ChainArgs s2{};    // states at the block boundaries
+    s2.Np = c->Np; s2.cp = c->cp; s2.S = B; s2.Pmat = c->PiX; s2.start = c->ff_bnd; s2.start_stride = 0; s2.out = c->ff_bnd;
+    s2.forcing = c->ff_phi; s2.nblocks = 1; s2.blen = B; s2.ngroups = c->cp / 8;
+    if ((rc = launch_chain<5>(s2, c->stream))) return rc;
+    ChainArgs s3{};    // history
+    s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->ff_bnd; s3.start_stride = (long long)hstep;
+    s3.out = c->hist; s3.forcing = c->ff_Q; s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
+    return launch_chain<5>(s3, c->stream);
 }
 
 int qgdk_lambda(const qgdk_ctx *c)

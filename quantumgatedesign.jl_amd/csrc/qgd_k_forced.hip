@@ -135,7 +135,109 @@ __global__ __launch_bounds__(256) void k_forced_solve(const double *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// eval_forward with a user forcing (forward_evolution.jl:118-129,167-206): w' = A w + F with the scaled
+// Taylor coefficients F_j(t_n) = F^(j)(t_n)/j! given.  compute_derivatives! adds F_j inside the
+// recursion (hermite.jl:88-92): w_j = D_j w_0 + E_j with E_0 = 0, E_{j+1} = (sum_{i>=1} A_{j-i} E_i + F_j)/(j+1).
+// This kernel forms E_1..E_m (kept for the derivative history) and rhoR = sum c_j dt^j E_j,
+// rhoL = sum c_j (-dt)^j E_j; the step becomes psi_{n+1} = P_n psi_n + L_{n+1}^-1 (rhoR_n - rhoL_{n+1}).
+// One workgroup = (time point, column group); LDS: E[m], rhoR, rhoL.
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_forcing_terms(const double *__restrict__ ops,
+                                                       const double *__restrict__ tab,
+                                                       const double *__restrict__ F, double *__restrict__ E,
+                                                       double *__restrict__ XR, double *__restrict__ XL,
+                                                       const double *__restrict__ cw, int Np, int cp,
+                                                       int n_ops, int m)
+{
+    extern __shared__ double smem[];
+    const int ps = Np * 16;
+    double *U = smem, *rR = U + (size_t)m * ps, *rL = rR + ps;
+    const int grp = blockIdx.x, n = blockIdx.y;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = threadIdx.x; e < ps; e += 256) { rR[e] = 0.0; rL[e] = 0.0; }
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+        const double *Fj = F + ((size_t)n * m + j) * hstep + grp * 16;
+        for (int rb = wave; rb * 16 < Np; rb += 4) {
+            d4 acc;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = Fj[(size_t)(rb * 16 + kk + 4 * r) * PWc + c16];
+            for (int i = 1; i <= j; i++) {
+                OpCoef cf;
+                load_coef(cf, tab, n, j - i, m, n_ops);
+                const d4 t = panel_product(Np, rb, c16, kk, U + (size_t)(i - 1) * ps, 16,
+                    [&](int arow, int kcol, double &are, double &aim) {
+                        assembled_a<NOPS>(ops, Np, n_ops, cf, arow, kcol, are, aim);
+                    });
+                #pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] += t[r];
+            }
+            const double inv = 1.0 / (double)(j + 1), cR = cw[2 * (j + 1)], cL = cw[2 * (j + 1) + 1];
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (rb * 16 + kk + 4 * r) * 16 + c16;
+                const double u = acc[r] * inv;
+                U[(size_t)j * ps + o] = u;
+                E[((size_t)n * m + j) * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = u;
+                rR[o] += cR * u; rL[o] += cL * u;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < ps; e += 256) {
+        XR[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = rR[e];
+        XL[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = rL[e];
+    }
+}
+
+// Q[n] = XR[n] - XL[n+1] (both already multiplied by L_{n+1}^-1), n = 0..nt-2; dpsi += E
+__global__ void k_forcing_combine(const double *__restrict__ XR, const double *__restrict__ XL, double *__restrict__ Q,
+                                  size_t hstep, int nt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)(nt - 1) * hstep) Q[i] = XR[i] - XL[i + hstep];
+}
+
+__global__ void k_add_inplace(double *__restrict__ dst, const double *__restrict__ src, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] += src[i];
+}
+
 extern "C" {
+
+// forcing terms of eval_forward(...; forcing): E, then Q[n] = L_{n+1}^-1 (rhoR_n - rhoL_{n+1})
+int qgdk_forcing_terms(const qgdk_ctx *c)
+{
+    const size_t shm = (size_t)(c->m + 2) * c->Np * 16 * sizeof(double);
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+#define CALL_FT(N) do { HIPCHK(hipFuncSetAttribute((const void *)k_forcing_terms<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_forcing_terms<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->ff_F, c->ff_E, \
+                           c->ff_XR, c->ff_XL, c->cw, c->Np, c->cp, c->n_ops, c->m); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_FT)
+#undef CALL_FT
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_forced_solve, dim3(c->cp / 8, c->nt, 2), dim3(256), (size_t)c->Np * 16 * sizeof(double), c->stream,
+                       c->LinvT, c->ff_XR, c->ff_XL, c->Np, c->cp, 1, c->nt);
+    const size_t cnt = (size_t)(c->nt - 1) * hstep;
+    hipLaunchKernelGGL(k_forcing_combine, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->ff_XR, c->ff_XL, c->ff_Q, hstep, c->nt);
+    return (int)hipGetLastError();
+}
+
+// derivative history with forcing: w_j = D_j w_0 + E_j -- except at the final time, where the reference
+// stores the derivatives WITHOUT the forcing (forward_evolution.jl:229-236 calls compute_derivatives!
+// without forcing_matrix there; its own comment asks whether that is intended).  Mirrored.
+int qgdk_forcing_add_derivs(const qgdk_ctx *c)
+{
+    const size_t cnt = (size_t)(c->nt - 1) * c->m * c->Np * 2 * c->cp;
+    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->dpsi, c->ff_E, cnt);
+    return (int)hipGetLastError();
+}
 
 size_t qgdk_forced_lds(int Np, int m) { return (size_t)(2 * m + 2) * Np * 16 * sizeof(double); }
 

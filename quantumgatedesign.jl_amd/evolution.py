@@ -170,6 +170,19 @@ class DeviceProblem:
         """0: no events, 1: every phase (default), 2: only ``phase``."""
         _lib.check(self.h, self.lib.qgd_set_timing(self.h, int(mode), None if phase is None else phase.encode()))
 
+    def eval_forward_forced(self, pcof, forcing, uv_history=None):
+        """eval_forward with a forcing array ``[2N, order/2, 1+nsteps, n_cols]`` (Fortran order): the scaled
+        Taylor coefficients of the forcing at every time point (forward_evolution.jl:118-129)."""
+        pcof = np.ascontiguousarray(pcof, dtype=np.float64)
+        forcing = np.asfortranarray(forcing, dtype=np.float64)
+        want = (2 * self.N, self.m, self.nsteps + 1, self.c)
+        if forcing.shape != want:
+            raise ValueError(f"forcing must have shape {want}")
+        out3 = np.zeros(3)
+        _lib.check(self.h, self.lib.qgd_eval_forward_forced(self.h, _vp(pcof), len(pcof), _vp(forcing),
+                                                             None if uv_history is None else _vp(uv_history), _vp(out3)))
+        return out3
+
     def eval_grad_forced(self, pcof):
         """Gradient by forward sensitivities (eval_grad_forced.jl:17-194); needs controls and target."""
         pcof = np.ascontiguousarray(pcof, dtype=np.float64)
@@ -232,8 +245,6 @@ def _history_shape(prob, order, saveEveryNsteps=1):
 def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, forcing=None):
     """eval_forward! (forward_evolution.jl:33-70): fills ``uv_history``
     ``[2N, 1+order/2, 1+nsteps, N_initial_conditions]`` (Fortran order) in place."""
-    if forcing is not None:
-        raise NotImplementedError("forcing (forward-sensitivity gradient, SURVEY f2) is not on the device path yet")
     save = int(saveEveryNsteps)
     if save < 1:
         raise ValueError("saveEveryNsteps must be a positive integer")
@@ -242,13 +253,14 @@ def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, 
         raise ValueError(f"uv_history must be Fortran-ordered with shape {shape}")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
+    run = dp.eval_forward if forcing is None else (lambda p, hist: dp.eval_forward_forced(p, forcing, hist))
     if save == 1:
-        dp.eval_forward(pcof, uv_history)
+        run(pcof, uv_history)
         return None
     # the device keeps every time point; the stored ones are n = 0, save, 2 save, ... <= nsteps
     # (forward_evolution.jl:104,178,239-241: slot 1 + div(n, saveEveryNsteps) when n % saveEveryNsteps == 0)
     full = np.zeros(_history_shape(prob, order), order="F")
-    dp.eval_forward(pcof, full)
+    run(pcof, full)
     uv_history[...] = full[:, :, ::save, :][:, :, :shape[2], :]
     return None
 

@@ -480,3 +480,24 @@ def test_legacy_controls_on_device(qgd):
         fd = (obj(pcof + e) - obj(pcof - e)) / 2e-6
         assert abs(fd - g_adj[l]) <= 2e-8 * max(1.0, np.abs(g_adj).max()), (l, fd, g_adj[l])
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("which,order", [("cnot2", 4), ("guarded", 6), ("cnot3", 8)])
+def test_eval_forward_with_forcing(qgd, orc, which, order):
+    """eval_forward(...; forcing) (forward_evolution.jl:118-129,167-206): the whole derivative history and the
+    objective scalars with a random forcing, against the oracle's forced forward sweep."""
+    kw = dict(nsteps=40, tf=20.0) if which == "cnot3" else {}
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, **kw)
+    m = order // 2
+    rng = np.random.default_rng(31)
+    forcing = np.asfortranarray(0.3 * rng.standard_normal((prob.real_system_size, m, prob.nsteps + 1, prob.N_initial_conditions)))
+    h_ref = orc.eval_forward(prob, ctrl, pcof, order=order, forcing=forcing)
+    hist = np.zeros(h_ref.shape, order="F")
+    qgd.eval_forward_(hist, prob, ctrl, pcof, order=order, forcing=forcing)
+    assert close(hist, h_ref)
+    psi = qgd.eval_forward(prob, ctrl, pcof, order=order, forcing=forcing)
+    assert close(psi, h_ref[:prob.N_tot_levels, 0] + 1j * h_ref[prob.N_tot_levels:, 0])
+    # and without forcing the same entry point reproduces the ordinary sweep
+    plain = qgd.eval_forward(prob, ctrl, pcof, order=order, forcing=np.zeros_like(forcing))
+    assert close(plain, qgd.eval_forward(prob, ctrl, pcof, order=order), 1e-13)
+    qgd.clear_cache()
