@@ -12,7 +12,8 @@ from .controls import (AbstractControl, GRAPEControl, FortranBSplineControl, Gen
                        fill_p_mat, fill_q_mat, control_basis, bspline_basis_derivatives)
 from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_prob, guard_projector,
                        create_initial_conditions, create_gate, basis_state, lowering_operators_system,
-                       control_ops, multi_qudit_hamiltonian_dispersive, cnot2_problem, cnot3_problem)
+                       control_ops, multi_qudit_hamiltonian_dispersive, cnot2_problem, cnot3_problem,
+                       multi_qudit_hamiltonian_jayne, JaynesCummingsProblem, rotating_frame_qubit, dahlquist_problem)
 from .evolution import (DeviceProblem, device_problem, clear_cache, eval_forward, eval_forward_, eval_adjoint, eval_grad_forced, eval_grad_finite_difference, discrete_adjoint,
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)

@@ -145,6 +145,66 @@ def DispersiveProblem(subsystem_sizes, essential_subsystem_sizes, transition_fre
                                             preconditioner_type=preconditioner_type)
 
 
+def multi_qudit_hamiltonian_jayne(subsystem_sizes, transition_freqs, rotation_freq, kerr_coeffs, jayne_cummings_coeffs):
+    """multi_qudit_systems.jl:81-116: one rotation frequency for all subsystems, self- and cross-Kerr
+    terms, and the exchange coupling g_pq (a_q' a_p + a_q a_p')."""
+    kerr = np.asarray(kerr_coeffs, float)
+    jc = np.asarray(jayne_cummings_coeffs, float)
+    assert np.array_equal(kerr, kerr.T) and np.array_equal(jc, jc.T) and not np.any(np.diag(jc))
+    Q = len(subsystem_sizes)
+    n = int(np.prod(subsystem_sizes))
+    H = np.zeros((n, n), dtype=complex)
+    low = lowering_operators_system(subsystem_sizes)
+    for q in range(Q):
+        a = low[q]
+        H += (transition_freqs[q] - rotation_freq) * (a.T @ a)
+        H -= 0.5 * kerr[q, q] * (a.T @ a.T @ a @ a)
+        for p in range(q + 1, Q):
+            ap = low[p]
+            H -= kerr[p, q] * (ap.T @ ap @ a.T @ a)
+            H += jc[p, q] * (a.T @ ap + a @ ap.T)
+    return H
+
+
+def JaynesCummingsProblem(subsystem_sizes, essential_subsystem_sizes, transition_freqs, rotation_freq, kerr_coeffs,
+                          jayne_cummings_coeffs, tf, nsteps, sparse_rep=True, bitstring_ordered=True,
+                          gmres_abstol=1e-10, gmres_reltol=1e-10, preconditioner_type="LUPreconditioner"):
+    """multi_qudit_systems.jl:169-217 (the reference body refers to undefined ``u0, v0``; the evident
+    intent -- the initial conditions it builds two lines earlier -- is used)."""
+    H = multi_qudit_hamiltonian_jayne(subsystem_sizes, transition_freqs, rotation_freq, kerr_coeffs, jayne_cummings_coeffs)
+    sym_ops, asym_ops = control_ops(subsystem_sizes)
+    guard = guard_projector(subsystem_sizes, essential_subsystem_sizes)
+    U0 = create_initial_conditions(subsystem_sizes, essential_subsystem_sizes, bitstring_ordered)
+    return SchrodingerProb.from_hamiltonian(H, sym_ops, asym_ops, U0, tf, nsteps,
+                                            int(np.prod(essential_subsystem_sizes)), guard,
+                                            gmres_abstol=gmres_abstol, gmres_reltol=gmres_reltol,
+                                            preconditioner_type=preconditioner_type)
+
+
+def rotating_frame_qubit(N_ess_levels, N_guard_levels, tf=1.0, nsteps=10, detuning_frequency=1.0,
+                         self_kerr_coefficient=1.0):
+    """Single qubit in the rotating frame (rotating_frame_qubit.jl:8-41): frequencies in GHz, multiplied
+    by 2 pi; controls a + a', a - a'; initial conditions = the essential basis states."""
+    n = int(N_ess_levels) + int(N_guard_levels)
+    a = np.diag(np.sqrt(np.arange(1.0, n)), 1)
+    S = 2 * np.pi * detuning_frequency * (a.T @ a) - 0.5 * 2 * np.pi * self_kerr_coefficient * (a.T @ a.T @ a @ a)
+    u0 = np.zeros((n, N_ess_levels)); u0[np.arange(N_ess_levels), np.arange(N_ess_levels)] = 1.0
+    return SchrodingerProb(S, np.zeros((n, n)), [a + a.T], [a - a.T], u0, np.zeros_like(u0), None, tf, nsteps, N_ess_levels)
+
+
+def dahlquist_problem(lam, initial_condition=1.0, with_control=False):
+    """The scalar test equation y' = lambda y (dahlquist_problem.jl:1-47): H = i lambda must be real
+    (lambda purely imaginary); tf = 1, 10 steps; optionally one symmetric control operator [1]."""
+    Hs = 1j * complex(lam)
+    if abs(Hs.imag) > 0:
+        raise ValueError("lambda must be purely imaginary (the scalar Hamiltonian i*lambda must be Hermitian)")
+    ic = complex(initial_condition)
+    sym_ops = [np.ones((1, 1))] if with_control else []
+    asym_ops = [np.zeros((1, 1))] if with_control else []
+    return SchrodingerProb(np.array([[Hs.real]]), np.array([[0.0]]), sym_ops, asym_ops,
+                           np.array([[ic.real]]), np.array([[ic.imag]]), None, 1.0, 10, 1)
+
+
 def construct_rabi_prob(tf=np.pi, gmres_abstol=1e-10, gmres_reltol=1e-10, nsteps=100):
     """Two-level Rabi oscillator (rabi_oscillator.jl:7-22): |Omega| = 1/2 for
     tf = pi gives a SWAP."""

@@ -501,3 +501,21 @@ def test_eval_forward_with_forcing(qgd, orc, which, order):
     plain = qgd.eval_forward(prob, ctrl, pcof, order=order, forcing=np.zeros_like(forcing))
     assert close(plain, qgd.eval_forward(prob, ctrl, pcof, order=order), 1e-13)
     qgd.clear_cache()
+
+
+def test_dahlquist_and_rotating_frame_on_device(qgd):
+    """The scalar test equation y' = lambda y (dahlquist_problem.jl) integrates to exp(lambda t) (N = 1: the
+    smallest padded problem), and a rotating-frame qubit's adjoint gradient matches its forced gradient."""
+    lam = 2.0j
+    prob = qgd.dahlquist_problem(lam, initial_condition=0.6 - 0.8j)
+    psi = qgd.eval_forward(prob, [], np.zeros(0), order=12)
+    t = np.linspace(0, prob.tf, prob.nsteps + 1)
+    assert np.abs(psi[0, :, 0] - (0.6 - 0.8j) * np.exp(lam * t)).max() < 1e-13
+    q = qgd.rotating_frame_qubit(2, 2, tf=2.0, nsteps=40, detuning_frequency=0.3, self_kerr_coefficient=0.2)
+    ctrl = qgd.BSplineControl(q.tf, 6, [0.0, 0.7])
+    pcof = 0.2 * np.random.default_rng(2).standard_normal(ctrl.N_coeff)
+    target = cases.rand_target(q)
+    g_adj = qgd.discrete_adjoint(q, ctrl, pcof, target, order=6)
+    g_for = qgd.eval_grad_forced(q, ctrl, pcof, target, order=6)
+    assert np.abs(g_adj - g_for).max() <= 1e-12 * np.abs(g_adj).max()
+    qgd.clear_cache()

@@ -324,3 +324,24 @@ def test_hermite_control(qgd):
         for d in range(3):
             fd = (car.eval_q_derivative(t + h, pcc, d) - car.eval_q_derivative(t - h, pcc, d)) / (2 * h)
             assert abs(fd - car.eval_q_derivative(t, pcc, d + 1)) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_more_problem_constructors(qgd):
+    """JaynesCummingsProblem, rotating_frame_qubit, dahlquist_problem (src/ProblemConstructors/)."""
+    sizes, ess = (3, 2), (2, 2)
+    kerr = np.array([[0.2, 0.01], [0.01, 0.3]]); jc = np.array([[0.0, 0.05], [0.05, 0.0]])
+    p = qgd.JaynesCummingsProblem(sizes, ess, [4.1, 4.8], 4.0, kerr, jc, 10.0, 20)
+    H = p.system_sym + 1j * p.system_asym                      # H = S + iK is Hermitian
+    assert np.allclose(H, H.conj().T) and p.N_tot_levels == 6 and p.N_ess_levels == 4
+    low = qgd.lowering_operators_system(sizes)
+    n0 = low[0].T @ low[0]; n1 = low[1].T @ low[1]
+    want = (0.1 * n0 + 0.8 * n1 - 0.1 * low[0].T @ low[0].T @ low[0] @ low[0] - 0.15 * low[1].T @ low[1].T @ low[1] @ low[1]
+            - 0.01 * n1 @ n0 + 0.05 * (low[0].T @ low[1] + low[0] @ low[1].T))
+    assert np.allclose(H, want)
+    q = qgd.rotating_frame_qubit(2, 1, tf=3.0, nsteps=30, detuning_frequency=0.5, self_kerr_coefficient=0.2)
+    assert q.N_tot_levels == 3 and np.allclose(np.diag(q.system_sym), [0.0, np.pi, 2 * np.pi - 0.2 * 2 * np.pi])
+    assert np.allclose(q.sym_operators[0], q.sym_operators[0].T) and np.allclose(q.asym_operators[0], -q.asym_operators[0].T)
+    d = qgd.dahlquist_problem(2.0j, initial_condition=1.0 + 0.5j, with_control=True)
+    assert d.N_tot_levels == 1 and d.system_sym[0, 0] == -2.0 and d.N_operators == 1 and d.v0[0, 0] == 0.5
+    with pytest.raises(ValueError):
+        qgd.dahlquist_problem(1.0 + 1.0j)
