@@ -36,7 +36,7 @@ struct qgd_handle_s {
     size_t forced_key = 0;             // (nt, n_pcof) the forced-gradient buffers were sized for
     std::vector<void *> forcing_bufs;  // eval_forward with a user forcing
     size_t forcing_key = 0;
-    bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false, guard_valid = false;
+    bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false;
     std::vector<int32_t> ncoef, poff;
     std::vector<int64_t> goff;
     double *pcof_dev = nullptr;
@@ -131,7 +131,7 @@ int alloc_grid(qgd_handle h)
         }
         k.scan_blocks = k.bpr;     // the scan inside a rank's window runs over its own blocks
         k.part_rank = h->part_rank; k.part_world = W;
-        k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr; k.blk_hi_clamped = k.blk_hi;
+        k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr;
         const int s_lo = k.blk_lo * k.scan_blen;
         const int s_hi = std::min(S, k.blk_hi * k.scan_blen);
         if (s_lo >= S) return fail(h, QGD_ERR_UNSUPPORTED, "too few timesteps for this many ranks (a rank would own no step)");

@@ -57,7 +57,7 @@ typedef struct qgdk_ctx {
     double *psi0;       // initial panel [Np][2cp]
     double *zero_panel; // [Np][2cp] of zeros
     double *redbuf;     // [n_pcof + 4]: grad followed by scal (one all-reduce)
-    int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blk_hi_clamped, blocks_glob;   // scan_blocks = bpr (local)
+    int scan_blocks, scan_blen, bpr, blk_lo, blk_hi, blocks_glob;   // scan_blocks = bpr (blocks of this rank); blk_lo/hi: its global block range
     // second scan level over the block propagators: scan_blocks2 super-blocks of scan_g blocks
     int scan_blocks2, scan_g;
     double *PiC2, *PiR2, *phi2, *bnd2, *bndY2;
