@@ -192,7 +192,7 @@ int alloc_grid(qgd_handle h)
     }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
-    if (need > 150 * 1024) {
+    if (need > 150 * 1024 || Np > 64) {      // (the blocked kernel for Np > 64 always works in a slab)
         k.inv_batch = 512;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.inv_scratch, (size_t)k.inv_batch * 2 * pl))) return rc;
     } else {

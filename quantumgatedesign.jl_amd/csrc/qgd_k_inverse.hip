@@ -544,6 +544,141 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 }
 
 // ---------------------------------------------------------------------------
+// K2 (any Np > 64 whose panels fit in LDS, Np <= 288): blocked Gauss-Jordan with the matrix in an
+// HBM/L2 work slab (panel layout) and 16 pivots per panel.  The same scheme as k_inverse_mfma --
+// implicit pivoting, the pivoted in-place elimination of the Np x 16 panel yields the multipliers,
+// rank-16 trailing updates on the fp64 MFMA -- but the panel is factored by the whole workgroup in
+// LDS and the matrix streams through the accumulators tile by tile: the slab is read and written
+// once per 16 pivots instead of once per pivot (the unblocked k_inverse moves 2 N^3 * 16 bytes).
+// ---------------------------------------------------------------------------
+#define INVB_NB 16
+__global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restrict__ L,
+                                                         double *__restrict__ LinvA,
+                                                         double *__restrict__ LinvT,
+                                                         double *__restrict__ scratch, int Np, int n0,
+                                                         int *__restrict__ status)
+{
+    constexpr int NB = INVB_NB;
+    extern __shared__ double smem[];
+    const int PW = 2 * Np;
+    double *Fre = smem, *Fim = Fre + (size_t)Np * NB;          // panel columns -> multipliers
+    double *Bp = Fim + (size_t)Np * NB;                         // [NB][PW] pivot rows (B operand)
+    double *fre = Bp + (size_t)NB * PW, *fim = fre + Np;        // column s of the panel before the step
+    double *yrow = fim + Np;                                    // [2*NB] scaled pivot row
+    double *redv = yrow + 2 * NB;                               // [8]
+    int *redi = reinterpret_cast<int *>(redv + 8);              // [8]
+    int *rho = redi + 8, *rinv = rho + Np, *used = rinv + Np;
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, nth = blockDim.x, wave = t >> 6, lane = t & 63, nw = nth >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    double *W = scratch + (size_t)blockIdx.x * panel;
+    const double *Ln = L + (size_t)n * panel;
+    for (size_t e = t; e < panel; e += nth) W[e] = Ln[e];
+    for (int r = t; r < Np; r += nth) used[r] = 0;
+    __syncthreads();
+
+    for (int p0 = 0; p0 < Np; p0 += NB) {
+        // ---- 1. the 16 panel columns into LDS
+        for (int e = t; e < Np * NB; e += nth) {
+            const int r = e / NB, col = p0 + (e % NB);
+            const size_t o = (size_t)r * PW + (col >> 3) * 16 + (col & 7);
+            Fre[e] = W[o]; Fim[e] = W[o + 8];
+        }
+        __syncthreads();
+        // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
+        for (int s = 0; s < NB; s++) {
+            double best = -1.0; int bi = 0;
+            for (int r = t; r < Np; r += nth) {
+                const double a = Fre[r * NB + s], b = Fim[r * NB + s];
+                fre[r] = a; fim[r] = b;
+                const double v = a * a + b * b;
+                if (!used[r] && v > best) { best = v; bi = r; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_down(best, off);
+                const int oi = __shfl_down(bi, off);
+                if (ob > best) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
+            __syncthreads();
+            int pr = redi[0]; double pb = redv[0];
+            for (int w = 1; w < nw; w++) if (redv[w] > pb) { pb = redv[w]; pr = redi[w]; }
+            if (t < NB) {                                    // scaled pivot row (the pivot entry becomes 1/pivot)
+                const double a = fre[pr], b = fim[pr];
+                const double den = 1.0 / (a * a + b * b), ir = a * den, ii = -b * den;
+                const double x = Fre[pr * NB + t], y = Fim[pr * NB + t];
+                yrow[t] = (t == s) ? ir : x * ir - y * ii;
+                yrow[NB + t] = (t == s) ? ii : x * ii + y * ir;
+            }
+            if (t == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; used[pr] = 1; if (!(pb > 0.0)) *status = 1; }
+            __syncthreads();
+            for (int e = t; e < Np * NB; e += nth) {
+                const int r = e / NB, q = e % NB;
+                const double rr = yrow[q], ri = yrow[NB + q];
+                if (r == pr) { Fre[e] = rr; Fim[e] = ri; }
+                else {
+                    const double f1 = fre[r], f2 = fim[r];
+                    const double br = (q == s) ? 0.0 : Fre[e], bi2 = (q == s) ? 0.0 : Fim[e];
+                    Fre[e] = br - (f1 * rr - f2 * ri);
+                    Fim[e] = bi2 - (f1 * ri + f2 * rr);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- 3. the 16 pivot rows (their values before the block step) as B operand
+        for (int e = t; e < NB * PW; e += nth) Bp[e] = W[(size_t)rho[p0 + e / PW] * PW + (e % PW)];
+        __syncthreads();
+        // ---- 4. rank-16 block step, tile by tile: M += A M[P,:], A = multipliers (minus identity on the
+        //         pivot rows); the pivot columns then take the multipliers (the in-place inverse entries)
+        const int ngroups = Np / 8, gp = p0 >> 3;
+        for (int ti = wave; ti < (Np / 16) * ngroups; ti += nw) {
+            const int rb = ti / ngroups, g = ti % ngroups;
+            const int arow = 16 * rb + c16;
+            d4 acc;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16];
+            #pragma unroll
+            for (int ks = 0; ks < NB / 4; ks++) {
+                const int sidx = 4 * ks + kk;
+                const double are = Fre[arow * NB + sidx] - ((arow == rho[p0 + sidx]) ? 1.0 : 0.0);
+                const double aim = Fim[arow * NB + sidx];
+                double b1, b2;
+                panel_b(Bp + (size_t)sidx * PW + 16 * g, c16, b1, b2);
+                acc = MFMA(are, b1, acc);
+                acc = MFMA(aim, b2, acc);
+            }
+            if (g == gp || g == gp + 1) {
+                const int sidx = 8 * (g - gp) + (c16 & 7);
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * rb + kk + 4 * r;
+                    acc[r] = (c16 < 8) ? Fre[row * NB + sidx] : Fim[row * NB + sidx];
+                }
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16] = acc[r];
+        }
+        __syncthreads();
+    }
+    // A^-1[rinv[x]][rho[j]] = M[x][j]
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    for (size_t e = t; e < pl; e += nth) {
+        const int x = e / Np, j = e % Np;
+        const size_t o = (size_t)x * PW + (j >> 3) * 16 + (j & 7);
+        const double re = W[o], im = W[o + 8];
+        const size_t i = rinv[x], c = rho[j];
+        T[i * Np + c] = re; T[pl + i * Np + c] = im;
+        A[i + Np * c] = re; A[pl + i + Np * c] = im;
+    }
+}
+
+static inline size_t inverse_blocked_lds(int Np)
+{
+    return ((size_t)2 * Np * INVB_NB + (size_t)INVB_NB * 2 * Np + 2 * Np + 2 * INVB_NB + 8) * sizeof(double) + (size_t)(8 + 3 * Np) * sizeof(int);
+}
+
+// ---------------------------------------------------------------------------
 // K3: step propagator  P[n] = Linv[n+1] * R[n]   (n = 0..nt-2)
 // (the implicit solve L(t_{n+1}) w_{n+1} = R(t_n) w_n of forward_evolution.jl:181-220,
 //  done once for all right-hand sides).  Outputs P as panel (row-major; the
@@ -638,6 +773,16 @@ int qgdk_inverse(const qgdk_ctx *c)
         }
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
+    }
+    if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED")) {
+        const size_t shm = inverse_blocked_lds(c->Np);
+        HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+            const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+            hipLaunchKernelGGL(k_inverse_blocked, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch,
+                               c->Np, n0, c->status);
+        }
+        return (int)hipGetLastError();
     }
     const size_t pl = (size_t)c->Np * c->Np;
     size_t aux = (size_t)(3 * c->Np + 16) * sizeof(double);
