@@ -190,6 +190,14 @@ int alloc_grid(qgd_handle h)
         const size_t slabs = nt * (size_t)(k.cp / 8);
         if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16))) return rc;
     }
+    k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr;
+    if (k.panel_scratch && !getenv("QGD_DENSE_OLD")) {   // GEMM-style large-N kernels (qgd_k_dense.hip)
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.Afrag, nt * m * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.Dfrag, nt * m * 2 * pl))) return rc;
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.OpFrag, (size_t)std::max(k.n_ops, 1) * 2 * pl))) return rc;
+        if (qgdk_dense_operator_frag(&k)) return fail(h, QGD_ERR_NO_DEVICE, "operator fragment kernel failed to launch");
+        k.dense_gemm = 1;
+    }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
     if (need > 150 * 1024 || Np > 64) {      // (the blocked kernel for Np > 64 always works in a slab)

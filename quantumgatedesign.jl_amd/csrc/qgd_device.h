@@ -46,6 +46,9 @@ typedef struct qgdk_ctx {
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *inv_scratch;
     double *panel_scratch; // large N: per-workgroup panel slabs of k_derivs/k_gradsweep in HBM instead of LDS
+    // large N, GEMM-style kernels (qgd_k_dense.hip): A_d(t_n), D_j(t_n) and {S_o, K_o} in MFMA fragment order
+    int dense_gemm;
+    double *Afrag, *Dfrag, *OpFrag;
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.
     double *PiX;        // own blocks: [B x PiC | B x PiR], 2*Np*Np doubles each (B = scan_blocks = blocks of this rank)
@@ -105,6 +108,10 @@ int qgdk_forcing_add_derivs(const qgdk_ctx *c);
 int qgdk_forcing_sweep(const qgdk_ctx *c);
 int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
+int qgdk_dense_operator_frag(const qgdk_ctx *c);
+int qgdk_dense_build_LR(const qgdk_ctx *c);
+int qgdk_dense_derivs(const qgdk_ctx *c);
+int qgdk_dense_gradient(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 #ifdef __cplusplus
 }

@@ -332,6 +332,7 @@ int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt, const double *qt)
 int qgdk_build_LR(const qgdk_ctx *c)
 {
     if (c->use_sparse) return qgdk_build_LR_sparse(c);
+    if (c->dense_gemm) return qgdk_dense_build_LR(c);
     if (c->Np == 64) {           // fused LDS-resident path (order <= 10: D_1..D_{m-1} slabs fit in LDS)
         switch (c->m) {
         case 1: return launch_build_LR64<1>(c);

@@ -1,0 +1,414 @@
+// qgd_k_dense.hip -- large N (panels do not fit in LDS): every contraction of the path as a batched
+// complex GEMM on the f64 MFMA, left operands pre-arranged in "fragment order".
+//
+// Why a separate set of kernels.  For N > 64 the recursion kernels of qgd_k_build / qgd_k_grad assemble
+// every element of A_d(t_n) = K_d - i S_d from the 2 + 2 N_op operator planes at the point of use:
+// 1 + 2 N_op loads per MFMA pair, and the kernels sit at ~23 % of the MFMA peak, bound by L1 traffic.
+// Here A_d(t_n) is assembled ONCE per evaluation (k_assemble_frag, 16 N^2 bytes per (n, d)) into the
+// order in which a wave consumes it:
+//     frag[(rb * N/4 + k4) * 64 + lane] = { Re, Im } of A(16 rb + lane%16, 4 k4 + lane/16)
+// so the A operand of a 16x16x4 MFMA pair is one contiguous 1 KB global_load_dwordx4 per wave, and
+// the [-Bim | Bre] right operand comes from [Bre | Bim] by a DPP row rotation instead of a second load.
+// A wave owns a 32 x 32-complex-column tile (2 row blocks x 4 column groups): 6 loads per 16 MFMAs.
+//
+// What is computed (same mathematics as the small-N kernels; reference lines there):
+//   k_level_f     D_{j+1}(t_n) = 1/(j+1) ( sum_{i=1..j} A_{j-i} D_i + A_j ),  L, R += c_{j+1} (-+dt)^{j+1} D_{j+1}
+//                 (compute_derivatives! hermite.jl:56-101 on the identity, build_LHS!/build_RHS! :389-427)
+//   k_derivs_f    w_{j}(t_n) = D_j(t_n) w_0(t_n), j = 1..m: m GEMMs instead of the m(m+1)/2 of the
+//                 recursion, because the D_j are already there (they are what L and R were summed from)
+//   k_ginit / k_gsweep_f / k_ginner_f   the O(m^2) reverse sweep and the sigma inner products of
+//                 accumulate_gradient_arbitrary_fast! (eval_grad_discrete_adjoint.jl:582-800)
+//
+// Workgroup -> tile mapping is XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, so
+// id%8 selects the XCD and all tiles of one time point (which share A_d(t_n) and the panels of t_n)
+// are given ids that land on the same XCD, i.e. in the same L2.
+#include "qgd_kernels_common.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define DN_RB 2          // 16-row blocks per wave
+#define DN_NG 4          // 16-wide column groups per wave (= per workgroup)
+#define DN_ROWS (4 * DN_RB * 16)   // rows per workgroup tile
+
+// [-Bim | Bre] from [Bre | Bim]: rotate the 16-lane row by 8 and negate lanes 0..7
+__device__ __forceinline__ double swap8_signed(double b1, int sign_hi)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);
+    return __hiloint2double(hi ^ sign_hi, lo);
+}
+
+// position of element (row, k) in fragment order
+__device__ __forceinline__ size_t frag_index(int Np, int row, int k)
+{
+    return ((size_t)(row >> 4) * (Np >> 2) + (k >> 2)) * 64 + (size_t)((k & 3) * 16 + (row & 15));
+}
+
+struct DenseTile {
+    int n, sub, rb[DN_RB], g[DN_NG];     // time point, sub-index (level / source), row blocks and groups (-1 = outside)
+    int lane, c16, kk, sign_hi;
+};
+
+// grid = 8 * T * ceil(nt / 8) workgroups, T = tiles * nsub per time point
+__device__ __forceinline__ bool dense_tile(DenseTile &t, int nrb, int ngroups, int nsub, int nt)
+{
+    const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
+    const int T = rtiles * ctiles * nsub;
+    const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+    t.n = (s / T) * 8 + xcd;
+    if (t.n >= nt) return false;
+    int r = s % T;
+    t.sub = r / (rtiles * ctiles);
+    r %= rtiles * ctiles;
+    const int rt = r / ctiles, ct = r % ctiles;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    t.lane = threadIdx.x & 63; t.c16 = t.lane & 15; t.kk = t.lane >> 4;
+    t.sign_hi = (t.c16 < 8) ? (int)0x80000000 : 0;
+    #pragma unroll
+    for (int i = 0; i < DN_RB; i++) { const int rb = (rt * 4 + wave) * DN_RB + i; t.rb[i] = rb < nrb ? rb : -1; }
+    #pragma unroll
+    for (int i = 0; i < DN_NG; i++) { const int g = ct * DN_NG + i; t.g[i] = g < ngroups ? g : -1; }
+    return t.rb[0] >= 0;
+}
+
+static inline int dense_grid(int nrb, int ngroups, int nsub, int nt)
+{
+    const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
+    return 8 * rtiles * ctiles * nsub * ((nt + 7) / 8);
+}
+
+// acc += A * B for the wave's tile.  A: fragment order (complex); B: panel with row stride ldb.
+// Row blocks / groups outside the matrix are clamped to the first one (computed, never stored).
+__device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseTile &t, const d2 *__restrict__ A,
+                                           const double *__restrict__ B, size_t ldb, int Np)
+{
+    const d2 *ap[DN_RB];
+    const double *bp[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) ap[r] = A + (size_t)(t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * (Np >> 2) * 64 + t.lane;
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bp[g] = B + (size_t)t.kk * ldb + (size_t)(t.g[g] >= 0 ? t.g[g] : t.g[0]) * 16 + t.c16;
+    const int nk4 = Np >> 2;
+    // software pipeline: the operands of step k4+1 are in flight while the 16 MFMAs of step k4 issue
+    d2 a[DN_RB], an[DN_RB];
+    double b[DN_NG], bn[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) a[r] = ap[r][0];
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) b[g] = bp[g][0];
+    #pragma unroll 2
+    for (int k4 = 0; k4 < nk4; k4++) {
+        const int kn = (k4 + 1 < nk4) ? k4 + 1 : k4;
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) an[r] = ap[r][(size_t)kn * 64];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) bn[g] = bp[g][(size_t)kn * 4 * ldb];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            const double b2 = swap8_signed(b[g], t.sign_hi);
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++) {
+                acc[r][g] = MFMA(a[r].x, b[g], acc[r][g]);
+                acc[r][g] = MFMA(a[r].y, b2, acc[r][g]);
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) a[r] = an[r];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) b[g] = bn[g];
+    }
+}
+
+// U += S * B, V += K * B with real left operands packed as {S, K} pairs in fragment order
+__device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB][DN_NG], const DenseTile &t,
+                                            const d2 *__restrict__ A, const double *__restrict__ B, size_t ldb, int Np)
+{
+    const d2 *ap[DN_RB];
+    const double *bp[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) ap[r] = A + (size_t)(t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * (Np >> 2) * 64 + t.lane;
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bp[g] = B + (size_t)t.kk * ldb + (size_t)(t.g[g] >= 0 ? t.g[g] : t.g[0]) * 16 + t.c16;
+    const int nk4 = Np >> 2;
+    d2 a[DN_RB], an[DN_RB];
+    double b[DN_NG], bn[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) a[r] = ap[r][0];
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) b[g] = bp[g][0];
+    #pragma unroll 2
+    for (int k4 = 0; k4 < nk4; k4++) {
+        const int kn = (k4 + 1 < nk4) ? k4 + 1 : k4;
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) an[r] = ap[r][(size_t)kn * 64];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) bn[g] = bp[g][(size_t)kn * 4 * ldb];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++)
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++) {
+                U[r][g] = MFMA(a[r].x, b[g], U[r][g]);
+                V[r][g] = MFMA(a[r].y, b[g], V[r][g]);
+            }
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) a[r] = an[r];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) b[g] = bn[g];
+    }
+}
+
+#define ZERO_ACC(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
+
+// ---------------------------------------------------------------------------
+// A_d(t_n), d = 0..m-1, in fragment order.  grid (Np^2/256, m, nt)
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_assemble_frag(const double *__restrict__ ops, const double *__restrict__ tab,
+                                                       d2 *__restrict__ Afrag, int Np, int n_ops, int m)
+{
+    const int n = blockIdx.z, d = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = e & 63;
+    const size_t f = e >> 6;
+    const int k4 = (int)(f % (Np >> 2)), rb = (int)(f / (Np >> 2));
+    OpCoef cf;
+    load_coef(cf, tab, n, d, m, n_ops);
+    double are, aim;
+    assembled_a<NOPS>(ops, Np, n_ops, cf, rb * 16 + (lane & 15), k4 * 4 + (lane >> 4), are, aim);
+    Afrag[((size_t)n * m + d) * Np * Np + e] = (d2){are, aim};
+}
+
+// { S_o, K_o } pairs of the control operators in fragment order (once per problem).  grid (Np^2/256, n_ops)
+__global__ __launch_bounds__(256) void k_operator_frag(const double *__restrict__ ops, d2 *__restrict__ OpFrag, int Np)
+{
+    const int o = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = e & 63;
+    const size_t f = e >> 6;
+    const int k4 = (int)(f % (Np >> 2)), rb = (int)(f / (Np >> 2));
+    const size_t pl = (size_t)Np * Np;
+    const size_t src = (size_t)(rb * 16 + (lane & 15)) + (size_t)Np * (k4 * 4 + (lane >> 4));
+    OpFrag[(size_t)o * pl + e] = (d2){ops[(size_t)(3 + 2 * o) * pl + src], ops[(size_t)(2 + 2 * o) * pl + src]};
+}
+
+// ---------------------------------------------------------------------------
+// one level of the recursion on the identity; D: [nt][m] panels [Np][2Np], Dfrag: the same in fragment order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_f(const d2 *__restrict__ Afrag, double *__restrict__ D,
+                                                 double *__restrict__ Dfrag, double *__restrict__ L,
+                                                 double *__restrict__ R, int Np, int m, int nt, int j, double cL, double cR)
+{
+    DenseTile t;
+    if (!dense_tile(t, Np >> 4, Np >> 3, 1, nt)) return;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, fr = (size_t)Np * Np;
+    double *Dn = D + (size_t)t.n * m * panel;
+    const d2 *An = Afrag + (size_t)t.n * m * fr;
+    d4 acc[DN_RB][DN_NG];
+    ZERO_ACC(acc);
+    for (int i = 1; i <= j; i++) cgemm_tile(acc, t, An + (size_t)(j - i) * fr, Dn + (size_t)(i - 1) * panel, PW, Np);
+    const double inv = 1.0 / (double)(j + 1);
+    const double *Aj = reinterpret_cast<const double *>(An + (size_t)j * fr);
+    double *Dout = Dn + (size_t)j * panel, *Fout = Dfrag + ((size_t)t.n * m + j) * 2 * fr;
+    double *Ln = L + (size_t)t.n * panel, *Rn = R + (size_t)t.n * panel;
+    const int is_im = t.c16 >> 3;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            const int ccol = t.g[g] * 8 + (t.c16 & 7);
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t.rb[r] * 16 + t.kk + 4 * e;
+                const size_t fi = 2 * frag_index(Np, row, ccol) + is_im;
+                const double val = (acc[r][g][e] + Aj[fi]) * inv;
+                const size_t o = (size_t)row * PW + t.g[g] * 16 + t.c16;
+                Dout[o] = val;
+                Fout[fi] = val;
+                if (j == 0) {
+                    const double id = (!is_im && row == ccol) ? 1.0 : 0.0;
+                    Ln[o] = id + cL * val;
+                    Rn[o] = id + cR * val;
+                } else {
+                    Ln[o] += cL * val;
+                    Rn[o] += cR * val;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// w_{j+1}(t_n) = D_{j+1}(t_n) w_0(t_n), j = 0..m-1 (sub-index).  dpsi: [nt][m] panels [Np][2cp]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derivs_f(const d2 *__restrict__ Dfrag, const double *__restrict__ hist,
+                                                  double *__restrict__ dpsi, int Np, int cp, int m, int nt)
+{
+    DenseTile t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt)) return;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
+    d4 acc[DN_RB][DN_NG];
+    ZERO_ACC(acc);
+    cgemm_tile(acc, t, Dfrag + ((size_t)t.n * m + t.sub) * fr, hist + (size_t)t.n * hstep, PWc, Np);
+    double *out = dpsi + ((size_t)t.n * m + t.sub) * hstep;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
+                out[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16] = acc[r][g][e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gradient: seeds g_j = c_j dt^j lambda_{n+1} [n <= nt-2] - c_j (-dt)^j lambda_n [n >= 1], j = 1..m
+// Gp: [nt][m] panels [Np][2cp].  grid (ceil(hstep/256), nt)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ginit(const double *__restrict__ lam, const double *__restrict__ cw,
+                                               double *__restrict__ Gp, size_t hstep, int m, int nt)
+{
+    const int n = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= hstep) return;
+    const double ln = (n >= 1) ? lam[(size_t)n * hstep + e] : 0.0;
+    const double lx = (n <= nt - 2) ? lam[(size_t)(n + 1) * hstep + e] : 0.0;
+    for (int j = 1; j <= m; j++) Gp[((size_t)n * m + (j - 1)) * hstep + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+}
+
+// reverse sweep, level j: g_i -= (1/j) A_{j-1-i} g_j for i = 1..j-1 (sub-index = i-1); A^H = -A
+__global__ __launch_bounds__(256) void k_gsweep_f(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
+                                                  int m, int nt, int j)
+{
+    DenseTile t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
+    const int i = t.sub + 1;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
+    d4 acc[DN_RB][DN_NG];
+    ZERO_ACC(acc);
+    cgemm_tile(acc, t, Afrag + ((size_t)t.n * m + (j - 1 - i)) * fr, Gp + ((size_t)t.n * m + (j - 1)) * hstep, PWc, Np);
+    double *out = Gp + ((size_t)t.n * m + (i - 1)) * hstep;
+    const double sc = -1.0 / (double)j;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
+                out[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16] += sc * acc[r][g][e];
+        }
+    }
+}
+
+// sigma[n][o][d][2] += (1/j) < (dA_d/d{p,q}_o) psi_i, g_j >, j = i+1+d, for the source level i (sub-index)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_f(const d2 *__restrict__ OpFrag, const double *__restrict__ hist,
+                                                  const double *__restrict__ dpsi, const double *__restrict__ Gp,
+                                                  double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
+{
+    extern __shared__ double sig[];          // [n_ops][m][2]
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    __syncthreads();
+    DenseTile t;
+    const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt);
+    if (active) {
+        const int i = t.sub;
+        const int PWc = 2 * cp;
+        const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
+        const double *src = (i == 0) ? hist + (size_t)t.n * hstep : dpsi + ((size_t)t.n * m + (i - 1)) * hstep;
+        for (int o = 0; o < n_ops; o++) {
+            d4 U[DN_RB][DN_NG], V[DN_RB][DN_NG];
+            ZERO_ACC(U);
+            ZERO_ACC(V);
+            rgemm2_tile(U, V, t, OpFrag + (size_t)o * fr, src, PWc, Np);
+            _Pragma("unroll 1")
+            for (int j = i + 1; j <= m; j++) {
+                const double *gj = Gp + ((size_t)t.n * m + (j - 1)) * hstep;
+                double sp = 0.0, sq = 0.0;
+                #pragma unroll
+                for (int r = 0; r < DN_RB; r++) {
+                    if (t.rb[r] < 0) continue;
+                    #pragma unroll
+                    for (int g = 0; g < DN_NG; g++) {
+                        if (t.g[g] < 0) continue;
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const double g1 = gj[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16];
+                            const double g2 = swap8_signed(g1, t.sign_hi);
+                            sq += V[r][g][e] * g1;       // Re <K psi, g>
+                            sp += U[r][g][e] * g2;       // Re <-i S psi, g>
+                        }
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
+                if (t.lane == 0) {
+                    const int d = j - 1 - i;
+                    atomicAdd(&sig[(o * m + d) * 2], sp / (double)j);
+                    atomicAdd(&sig[(o * m + d) * 2 + 1], sq / (double)j);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active && t.n >= nt) return;
+    const int dmax = m - t.sub;              // only d = 0 .. m-1-i were touched
+    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x)
+        if ((e >> 1) % m < dmax) atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + e], sig[e]);
+}
+
+extern "C" {
+
+int qgdk_dense_operator_frag(const qgdk_ctx *c)
+{
+    if (c->n_ops == 0) return 0;
+    hipLaunchKernelGGL(k_operator_frag, dim3(c->Np * c->Np / 256, c->n_ops), dim3(256), 0, c->stream, c->ops,
+                       reinterpret_cast<d2 *>(c->OpFrag), c->Np);
+    return (int)hipGetLastError();
+}
+
+int qgdk_dense_build_LR(const qgdk_ctx *c)
+{
+    d2 *Af = reinterpret_cast<d2 *>(c->Afrag);
+#define CALL_AF(N) hipLaunchKernelGGL((k_assemble_frag<N>), dim3(c->Np * c->Np / 256, c->m, c->nt), dim3(256), 0, c->stream, \
+                                      c->ops, c->tab, Af, c->Np, c->n_ops, c->m)
+    DISPATCH_NOPS(c->n_ops, CALL_AF)
+#undef CALL_AF
+    const int grid = dense_grid(c->Np / 16, c->Np / 8, 1, c->nt);
+    for (int j = 0; j < c->m; j++)
+        hipLaunchKernelGGL(k_level_f, dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->Np, c->m, c->nt, j,
+                           c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
+    return (int)hipGetLastError();
+}
+
+int qgdk_dense_derivs(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_derivs_f, dim3(dense_grid(c->Np / 16, c->cp / 8, c->m, c->nt)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt);
+    return (int)hipGetLastError();
+}
+
+int qgdk_dense_gradient(const qgdk_ctx *c)
+{
+    const size_t hstep = (size_t)c->Np * 2 * c->cp;
+    const d2 *Af = reinterpret_cast<const d2 *>(c->Afrag);
+    double *Gp = c->panel_scratch;
+    hipLaunchKernelGGL(k_ginit, dim3((unsigned)((hstep + 255) / 256), c->nt), dim3(256), 0, c->stream, c->lam, c->cw, Gp, hstep,
+                       c->m, c->nt);
+    for (int j = c->m; j >= 2; j--)
+        hipLaunchKernelGGL(k_gsweep_f, dim3(dense_grid(c->Np / 16, c->cp / 8, j - 1, c->nt)), dim3(256), 0, c->stream, Af, Gp,
+                           c->Np, c->cp, c->m, c->nt, j);
+    hipLaunchKernelGGL(k_ginner_f, dim3(dense_grid(c->Np / 16, c->cp / 8, c->m, c->nt)), dim3(256),
+                       (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream, reinterpret_cast<const d2 *>(c->OpFrag), c->hist,
+                       c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
+    return (int)hipGetLastError();
+}
+
+} // extern "C"

@@ -465,6 +465,7 @@ extern "C" {
 
 int qgdk_derivs(const qgdk_ctx *c)
 {
+    if (c->dense_gemm && !c->use_sparse) return qgdk_dense_derivs(c);
     size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
     double *gp = nullptr;
     if (c->panel_scratch) { gp = c->panel_scratch; shm = 0; }
@@ -481,6 +482,10 @@ int qgdk_gradient(const qgdk_ctx *c)
     if (c->n_ops == 0) return 0;                       // no control parameters: nothing to differentiate
     if (c->use_sparse) {
         const int rc = qgdk_gradient_sparse(c);
+        return rc ? rc : qgdk_contract(c);
+    }
+    if (c->dense_gemm) {
+        const int rc = qgdk_dense_gradient(c);
         return rc ? rc : qgdk_contract(c);
     }
     size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
