@@ -121,6 +121,10 @@ int alloc_grid(qgd_handle h)
         if (S < 24) B0 = 1;
         if (B0 > 64) B0 = 64;
         if (B0 < 1) B0 = 1;
+        if (k.Np > 64 && k.Np <= 288) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile
+            const int ngt = std::max(k.Np / 32, k.cp / 32);
+            B0 = std::min(B0, std::max(8, 256 / std::max(ngt, 1)));
+        }
         k.bpr = (B0 + W - 1) / W;
         for (;;) {   // every rank must own at least one non-empty block
             k.blocks_glob = k.bpr * W;

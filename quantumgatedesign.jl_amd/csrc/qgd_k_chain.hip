@@ -450,6 +450,143 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
     }
 }
 
+// Large N: one workgroup = one (block, tile of 4 column groups = 32 complex columns), all Np rows.
+// The step matrix is streamed once per 32 columns instead of once per 8 (the generic kernel is bound by
+// exactly that L2 traffic), the state tile lives in ONE LDS buffer [Np][64] (128 KB at Np = 256) and the
+// new state in the accumulators until every wave has finished reading the old one.  The 16-wide group
+// slot of an LDS row is XOR-ed with row%4 so that the four k-rows of a B fragment fall in different banks.
+// 8 waves, wave w owns row blocks w*RBW .. w*RBW+RBW-1; A fragments of step k4+1 are in flight while
+// the MFMAs of step k4 issue.  Two barriers per step (a step is >= 25 us of MFMA time at these sizes).
+template <int MODE, int RBW>
+__global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
+{
+    constexpr bool ADJ = (MODE >= 2);
+    extern __shared__ double cur[];
+    const int Np = a.Np, nrb = Np >> 4, ngt = (a.ngroups + 3) >> 2;
+    int b, ct;
+    if (MODE == 0) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; b = xcd + 8 * (slot / ngt); ct = slot % ngt; }
+    else { b = blockIdx.x / ngt; ct = blockIdx.x % ngt; }
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * Np : 2 * a.cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    // B operand [-Bim | Bre]; the adjoint's A fragment is loaded un-conjugated, the sign goes here
+    const int sign_hi = ((c16 < 8) != ADJ) ? (int)0x80000000 : 0;
+    for (int e = tid; e < Np * 64; e += blockDim.x) {
+        const int row = e >> 6, g = (e >> 4) & 3, c = e & 15, grp = ct * 4 + g;
+        double v = 0.0;
+        if (grp < a.ngroups) {
+            if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+            else if (MODE != 2) v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+        }
+        cur[(size_t)row * 64 + ((g ^ (row & 3)) << 4) + c] = v;
+    }
+    __syncthreads();
+    int rb[RBW];
+    #pragma unroll
+    for (int r = 0; r < RBW; r++) rb[r] = wave * RBW + r;
+    for (int st = 0; st < e0 - s0; st++) {
+        const int n = ADJ ? e0 - 1 - st : s0 + st;
+        const int nout = ADJ ? n : n + 1;
+        const double *Pn = chain_matrix(a, n);
+        d4 acc[RBW][4];
+        #pragma unroll
+        for (int r = 0; r < RBW; r++)
+            #pragma unroll
+            for (int g = 0; g < 4; g++) acc[r][g] = (d4){0, 0, 0, 0};
+        int arow[RBW];
+        #pragma unroll
+        for (int r = 0; r < RBW; r++) arow[r] = (rb[r] < nrb ? rb[r] : 0) * 16 + c16;
+        // A fragments two k-steps ahead (a k-step is 8*RBW MFMAs, ~0.2 us per wave; L2 latency is several of those)
+        double are[RBW], aim[RBW], n1re[RBW], n1im[RBW], n2re[RBW], n2im[RBW];
+        #pragma unroll
+        for (int r = 0; r < RBW; r++) {
+            chain_a_raw<ADJ>(Pn, Np, arow[r], kk, are[r], aim[r]);
+            chain_a_raw<ADJ>(Pn, Np, arow[r], 4 + kk, n1re[r], n1im[r]);
+        }
+        #pragma unroll 2
+        for (int k0 = 0; k0 < Np; k0 += 4) {
+            const int kn = (k0 + 8 < Np) ? k0 + 8 : k0;
+            #pragma unroll
+            for (int r = 0; r < RBW; r++) chain_a_raw<ADJ>(Pn, Np, arow[r], kn + kk, n2re[r], n2im[r]);
+            const double *brow = cur + (size_t)(k0 + kk) * 64 + c16;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const double b1 = brow[(g ^ kk) << 4];
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);
+                const double b2 = __hiloint2double(hi ^ sign_hi, lo);
+                #pragma unroll
+                for (int r = 0; r < RBW; r++) {
+                    acc[r][g] = MFMA(are[r], b1, acc[r][g]);
+                    acc[r][g] = MFMA(aim[r], b2, acc[r][g]);
+                }
+            }
+            #pragma unroll
+            for (int r = 0; r < RBW; r++) { are[r] = n1re[r]; aim[r] = n1im[r]; n1re[r] = n2re[r]; n1im[r] = n2im[r]; }
+        }
+        __syncthreads();            // every wave has read the old state
+        #pragma unroll
+        for (int r = 0; r < RBW; r++) {
+            if (rb[r] >= nrb) continue;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int grp = ct * 4 + g;
+                if (grp >= a.ngroups) continue;
+                #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = rb[r] * 16 + kk + 4 * e;
+                    double v = acc[r][g][e];
+                    const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16;
+                    if (ADJ) v += a.forcing[a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho];
+                    cur[(size_t)row * 64 + ((g ^ kk) << 4) + c16] = v;
+                    if (MODE == 1 || MODE == 3) a.out[ho] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 0 || MODE == 2) {
+        const size_t pl = (size_t)Np * Np;
+        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+        for (int e = tid; e < Np * 64; e += blockDim.x) {
+            const int row = e >> 6, g = (e >> 4) & 3, c = e & 15, grp = ct * 4 + g;
+            if (grp >= a.ngroups) continue;
+            const double v = cur[(size_t)row * 64 + ((g ^ (row & 3)) << 4) + c];
+            if (MODE == 0) {
+                const int col = grp * 8 + (c & 7);
+                pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)Np * col] = v;
+                pr[(size_t)row * 2 * Np + grp * 16 + c] = v;
+            } else {
+                a.phi[(size_t)b * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
+{
+    const int ngt = (a.ngroups + 3) / 4, nrb = a.Np / 16;
+    const int nwg = (MODE == 0) ? 8 * ngt * ((a.nblocks + 7) / 8) : a.nblocks * ngt;
+    const size_t shm = (size_t)a.Np * 64 * sizeof(double);
+    if (nwg <= 0) return 0;
+#define CALL_CD(R) do { SET_LDS_ONCE((k_chain_dense<MODE, R>), shm); \
+        hipLaunchKernelGGL((k_chain_dense<MODE, R>), dim3(nwg), dim3(512), shm, stream, a); } while (0)
+    if (nrb <= 8) CALL_CD(1); else if (nrb <= 16) CALL_CD(2); else CALL_CD(3);
+#undef CALL_CD
+    return (int)hipGetLastError();
+}
+
+// the dense chain pays when a tile of 4 groups is (nearly) full and the state tile fits in LDS
+static bool chain_is_dense(const ChainArgs &a)
+{
+    static const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;
+    return !off && a.Np > 64 && a.Np <= 288 && a.ngroups >= 3;
+}
+
 template <int MODE, int NG>
 static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
 {
@@ -464,6 +601,7 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
     case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
     default: {
         if (MODE >= 4) return (int)hipErrorNotSupported;
+        if (chain_is_dense(a)) return launch_chain_dense<(MODE >= 4 ? 1 : MODE)>(a, stream);
         size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
         hipLaunchKernelGGL((k_chain_generic<(MODE >= 4 ? 1 : MODE)>), dim3(nwg), dim3(256), shm, stream, a);
     }
