@@ -117,6 +117,39 @@ def cpu_baseline(qgd, orc, seconds_target=12.0):
     }
 
 
+def large_n_case(qgd, np, steps=3):
+    """BASELINE.json configs[4] (C5: random dense SchrodingerProb, N=256, 256 columns, 4 control operators,
+    order 12, tf=2, nsteps=200) -- the configuration where the MFMA roofline is the binding one.
+    Reported beside the headline line, never as `value`.  Flops are the ones the kernels EXECUTE (complex
+    N x N x N contractions of 8 N^3 flop): recursion on the identity m(m-1)/2, stage derivatives m, four chain
+    passes, inverse, propagator, lambda, reverse sweep m(m-1)/2, inner products N_op*m  -- per time point."""
+    import torch
+    N, c, n_ops, nsteps, order = 256, 256, 4, 200, 12
+    m = order // 2
+    prob = qgd.construct_rand_prob(N, n_ops, tf=2.0, nsteps=nsteps, scale=1.0 / N)
+    ctrl = [qgd.FortranBSplineControl(16, 20, prob.tf) for _ in range(n_ops)]
+    rng = np.random.default_rng(5)
+    pcof = rng.random(qgd.get_number_of_control_parameters(ctrl))
+    target = prob.u0 + 1j * prob.v0
+    dp = qgd.DeviceProblem(prob, order, device=0)
+    dp.set_controls(ctrl); dp.set_target(target)
+    dp.set_timing(0)
+    dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        grad, _ = dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    dp.close()
+    gemms = m * (m - 1) // 2 + m + 4.0 * nsteps / (nsteps + 1) + 3 + m * (m - 1) // 2 + n_ops * m
+    tflop = 8.0 * N ** 3 * gemms * (nsteps + 1) / 1e12
+    return {"workload": f"C5 synthetic: N={N}, {c} columns, {n_ops} control operators, order {order}, nsteps={nsteps}",
+            "timesteps_per_s": nsteps / sec, "ms_per_evaluation": sec * 1e3, "executed_tflop_per_evaluation": tflop,
+            "bound": "mfma", "achieved": tflop / sec, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": tflop / sec / PEAK_FP64_MATRIX_TFLOPS, "grad_norm": float(np.linalg.norm(grad))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +157,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nsteps", type=int, default=550, help="timesteps of the workload (tf = nsteps, dt = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-n", action="store_true", help="skip the secondary C5 (N=256) measurement")
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
     args = ap.parse_args()
 
@@ -245,6 +279,9 @@ def main():
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),
         }
+        if not use_dist and not args.no_large_n:
+            dp.close()
+            out["large_n"] = large_n_case(qgd, np)
         if not args.no_cpu_baseline:
             orc = import_oracle()
             out["cpu_baseline"] = cpu_baseline(qgd, orc)
