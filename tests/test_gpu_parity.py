@@ -200,6 +200,26 @@ def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
         b.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_time_partitioned_large_n(qgd, world):
+    """Time windows with the large-N kernels (GEMM tiles, 32-column chain tiles, blocked inverse): N=100,
+    32 columns, order 12, 60 steps split over 2 and 3 ranks on the one GPU."""
+    import torch
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=100, c=32, nsteps=60, tf=0.6)
+    order = 12
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g_ref, o_ref = dp.discrete_adjoint(pcof)
+    dp.close()
+    stream = torch.cuda.current_stream().cuda_stream
+    backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, world, device=0, stream=stream) for r in range(world)]
+    for g, o in qgd.LocalGroup(backs).discrete_adjoint(pcof):
+        assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+        assert np.abs(o - o_ref).max() <= 1e-12 * max(1.0, np.abs(o_ref).max())
+    for b in backs:
+        b.close()
+
+
 @pytest.mark.parametrize("order", [2, 4, 6, 10, 12])
 def test_cnot3_gradient_all_orders(qgd, order):
     """Every instantiation of the N=64 fast-path kernels (fused L/R build and fused gradient kernel
