@@ -220,10 +220,17 @@ def main():
     phase_ms = {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    nsamp = 0
+    for i in range(args.steps):
+        # the event pair around the dominant kernel costs ~20 us per evaluation (it drains the queue between two
+        # kernels): it brackets every 4th step of the timed region, the kernel's duration is the mean of those
+        sample = (i % 4 == 0)
+        dp.set_timing(2 if sample else 0, dom_raw)
         grad, out3 = dp.discrete_adjoint(pcof)
-        for k, v in dp.timings().items():
-            phase_ms[k] = phase_ms.get(k, 0.0) + v
+        if sample:
+            nsamp += 1
+            for k, v in dp.timings().items():
+                phase_ms[k] = phase_ms.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -268,7 +275,7 @@ def main():
 
     if rank == 0:
         for k in phase_ms:
-            phase_ms[k] /= args.steps
+            phase_ms[k] /= nsamp
         # the dominant kernel among the single-launch phases, timed live in the timed region
         dom = dom_raw
         timed = {dom: phase_ms[dom_raw]}
@@ -296,7 +303,7 @@ def main():
                        "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom).replace("void ", ""), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": measured_traffic(dom),
-                         "launch_ms": timed[dom], "algorithmic_work_per_launch": work},
+                         "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
             "weak_in_time": weak,

@@ -14,7 +14,7 @@ prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=256, c=256, n_ops=4, nste
 target = (prob.u0 + 1j * prob.v0)            # any fixed target; N_ess = N
 t0 = time.time()
 dp = qgd.DeviceProblem(prob, 12)
-dp.set_controls(ctrl); dp.set_target(target)
+dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(1)
 print(f"setup {time.time() - t0:.1f} s")
 for it in range(2):
     t0 = time.time()

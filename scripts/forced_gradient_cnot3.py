@@ -8,7 +8,7 @@ import cases
 prob, target = qgd.cnot3_problem(nsteps=550, tf=550.0)
 ctrl = cases.cnot3_controls(qgd, prob)
 pcof = (np.random.default_rng(0).random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
-dp = qgd.DeviceProblem(prob, 8); dp.set_controls(ctrl); dp.set_target(target)
+dp = qgd.DeviceProblem(prob, 8); dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(1)
 g_adj, _ = dp.discrete_adjoint(pcof)
 g_for = dp.eval_grad_forced(pcof)
 t0 = time.time(); K = 5

@@ -200,6 +200,39 @@ def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
         b.close()
 
 
+@pytest.mark.parametrize("which", ["cnot2", "cnot3", "guarded"])
+def test_graph_replay_matches_plain_launches(qgd, which, monkeypatch):
+    """With QGD_GRAPH=1 a handle replays the captured launch sequence (hipGraph) from the third full evaluation
+    on.  Replays with new pcof must give what a fresh handle (plain launches) gives, and setters must drop the graph."""
+    monkeypatch.setenv("QGD_GRAPH", "1")
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    order = 8 if which != "guarded" else 6
+    rng = np.random.default_rng(3)
+    pcs = [pcof * (1.0 + 0.3 * rng.standard_normal(len(pcof))) for _ in range(6)]
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    got = [dp.discrete_adjoint(p) for p in pcs]
+    monkeypatch.delenv("QGD_GRAPH")          # handles created from here on launch plainly
+    for i in (0, 3, 5):
+        fresh = qgd.DeviceProblem(prob, order); fresh.set_controls(ctrl); fresh.set_target(target)
+        g, o = fresh.discrete_adjoint(pcs[i])
+        fresh.close()
+        assert np.abs(got[i][0] - g).max() <= 1e-13 * np.abs(g).max(), i
+        assert np.abs(np.asarray(got[i][1]) - np.asarray(o)).max() <= 1e-13, i
+    # a setter in between: new target -> the graph is rebuilt, results follow the new target
+    target2 = np.roll(target, 1, axis=1)
+    dp.set_target(target2)
+    again = [dp.discrete_adjoint(p) for p in pcs[:4]]
+    fresh = qgd.DeviceProblem(prob, order); fresh.set_controls(ctrl); fresh.set_target(target2)
+    g, o = fresh.discrete_adjoint(pcs[3])
+    fresh.close()
+    assert np.abs(again[3][0] - g).max() <= 1e-13 * np.abs(g).max()
+    # history_precomputed after a replayed evaluation reuses its forward history
+    g2, _ = dp.discrete_adjoint(pcs[3], history_precomputed=True)
+    assert np.abs(g2 - g).max() <= 1e-13 * np.abs(g).max()
+    dp.close()
+    qgd.clear_cache()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_time_partitioned_large_n(qgd, world):
     """Time windows with the large-N kernels (GEMM tiles, 32-column chain tiles, blocked inverse): N=100,
