@@ -506,7 +506,6 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
             chain_a_raw<ADJ>(Pn, Np, arow[r], kk, are[r], aim[r]);
             chain_a_raw<ADJ>(Pn, Np, arow[r], 4 + kk, n1re[r], n1im[r]);
         }
-        #pragma unroll 2
         for (int k0 = 0; k0 < Np; k0 += 4) {
             const int kn = (k0 + 8 < Np) ? k0 + 8 : k0;
             #pragma unroll

@@ -26,9 +26,9 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#define DN_RB 2          // 16-row blocks per wave
-#define DN_NG 4          // 16-wide column groups per wave (= per workgroup)
-#define DN_ROWS (4 * DN_RB * 16)   // rows per workgroup tile
+// Tile shapes <RB, NG>: RB 16-row blocks x NG 16-wide column groups per wave (4 waves stack their row blocks).
+// <2,4> when there are at least 3 column groups; <4,2> and <4,1> for 2 and 1 groups (few initial conditions):
+// the same 64 or 32 accumulator registers and nearly the same loads per MFMA, no MFMAs spent on padding columns.
 
 // [-Bim | Bre] from [Bre | Bim]: rotate the 16-lane row by 8 and negate lanes 0..7
 __device__ __forceinline__ double swap8_signed(double b1, int sign_hi)
@@ -44,13 +44,15 @@ __device__ __forceinline__ size_t frag_index(int Np, int row, int k)
     return ((size_t)(row >> 4) * (Np >> 2) + (k >> 2)) * 64 + (size_t)((k & 3) * 16 + (row & 15));
 }
 
+template <int DN_RB, int DN_NG>
 struct DenseTile {
     int n, sub, rb[DN_RB], g[DN_NG];     // time point, sub-index (level / source), row blocks and groups (-1 = outside)
     int lane, c16, kk, sign_hi;
 };
 
 // grid = 8 * T * ceil(nt / 8) workgroups, T = tiles * nsub per time point
-__device__ __forceinline__ bool dense_tile(DenseTile &t, int nrb, int ngroups, int nsub, int nt)
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, int ngroups, int nsub, int nt)
 {
     const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
     const int T = rtiles * ctiles * nsub;
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool dense_tile(DenseTile &t, int nrb, int ngroups, i
     return t.rb[0] >= 0;
 }
 
-static inline int dense_grid(int nrb, int ngroups, int nsub, int nt)
+static inline int dense_grid(int DN_RB, int DN_NG, int nrb, int ngroups, int nsub, int nt)
 {
     const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
     return 8 * rtiles * ctiles * nsub * ((nt + 7) / 8);
@@ -79,7 +81,8 @@ static inline int dense_grid(int nrb, int ngroups, int nsub, int nt)
 
 // acc += A * B for the wave's tile.  A: fragment order (complex); B: panel with row stride ldb.
 // Row blocks / groups outside the matrix are clamped to the first one (computed, never stored).
-__device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseTile &t, const d2 *__restrict__ A,
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseTile<DN_RB, DN_NG> &t, const d2 *__restrict__ A,
                                            const double *__restrict__ B, size_t ldb, int Np)
 {
     const d2 *ap[DN_RB];
@@ -96,7 +99,6 @@ __device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseT
     for (int r = 0; r < DN_RB; r++) a[r] = ap[r][0];
     #pragma unroll
     for (int g = 0; g < DN_NG; g++) b[g] = bp[g][0];
-    #pragma unroll 2
     for (int k4 = 0; k4 < nk4; k4++) {
         const int kn = (k4 + 1 < nk4) ? k4 + 1 : k4;
         #pragma unroll
@@ -120,7 +122,8 @@ __device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseT
 }
 
 // U += S * B, V += K * B with real left operands packed as {S, K} pairs in fragment order
-__device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB][DN_NG], const DenseTile &t,
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB][DN_NG], const DenseTile<DN_RB, DN_NG> &t,
                                             const d2 *__restrict__ A, const double *__restrict__ B, size_t ldb, int Np)
 {
     const d2 *ap[DN_RB];
@@ -136,7 +139,6 @@ __device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB
     for (int r = 0; r < DN_RB; r++) a[r] = ap[r][0];
     #pragma unroll
     for (int g = 0; g < DN_NG; g++) b[g] = bp[g][0];
-    #pragma unroll 2
     for (int k4 = 0; k4 < nk4; k4++) {
         const int kn = (k4 + 1 < nk4) ? k4 + 1 : k4;
         #pragma unroll
@@ -194,11 +196,12 @@ __global__ __launch_bounds__(256) void k_operator_frag(const double *__restrict_
 // ---------------------------------------------------------------------------
 // one level of the recursion on the identity; D: [nt][m] panels [Np][2Np], Dfrag: the same in fragment order
 // ---------------------------------------------------------------------------
+template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) void k_level_f(const d2 *__restrict__ Afrag, double *__restrict__ D,
                                                  double *__restrict__ Dfrag, double *__restrict__ L,
                                                  double *__restrict__ R, int Np, int m, int nt, int j, double cL, double cR)
 {
-    DenseTile t;
+    DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, Np >> 3, 1, nt)) return;
     const int PW = 2 * Np;
     const size_t panel = (size_t)Np * PW, fr = (size_t)Np * Np;
@@ -243,10 +246,11 @@ __global__ __launch_bounds__(256) void k_level_f(const d2 *__restrict__ Afrag, d
 // ---------------------------------------------------------------------------
 // w_{j+1}(t_n) = D_{j+1}(t_n) w_0(t_n), j = 0..m-1 (sub-index).  dpsi: [nt][m] panels [Np][2cp]
 // ---------------------------------------------------------------------------
+template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) void k_derivs_f(const d2 *__restrict__ Dfrag, const double *__restrict__ hist,
                                                   double *__restrict__ dpsi, int Np, int cp, int m, int nt)
 {
-    DenseTile t;
+    DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, cp >> 3, m, nt)) return;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
@@ -283,10 +287,11 @@ __global__ __launch_bounds__(256) void k_ginit(const double *__restrict__ lam, c
 }
 
 // reverse sweep, level j: g_i -= (1/j) A_{j-1-i} g_j for i = 1..j-1 (sub-index = i-1); A^H = -A
+template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) void k_gsweep_f(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
                                                   int m, int nt, int j)
 {
-    DenseTile t;
+    DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
     const int i = t.sub + 1;
     const int PWc = 2 * cp;
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(256) void k_gsweep_f(const d2 *__restrict__ Afrag, 
 }
 
 // sigma[n][o][d][2] += (1/j) < (dA_d/d{p,q}_o) psi_i, g_j >, j = i+1+d, for the source level i (sub-index)
+template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_f(const d2 *__restrict__ OpFrag, const double *__restrict__ hist,
                                                   const double *__restrict__ dpsi, const double *__restrict__ Gp,
                                                   double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ double sig[];          // [n_ops][m][2]
     for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
     __syncthreads();
-    DenseTile t;
+    DenseTile<DN_RB, DN_NG> t;
     const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt);
     if (active) {
         const int i = t.sub;
@@ -381,17 +387,23 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
                                       c->ops, c->tab, Af, c->Np, c->n_ops, c->m)
     DISPATCH_NOPS(c->n_ops, CALL_AF)
 #undef CALL_AF
-    const int grid = dense_grid(c->Np / 16, c->Np / 8, 1, c->nt);
+    const int grid = dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt);     // Np/8 >= 9 column groups here
     for (int j = 0; j < c->m; j++)
-        hipLaunchKernelGGL(k_level_f, dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->Np, c->m, c->nt, j,
-                           c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
+        hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->Np, c->m,
+                           c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
     return (int)hipGetLastError();
 }
 
+// tile shape by the number of column groups of the state panels
+#define DISPATCH_SHAPE(ngroups, CALL) do { if ((ngroups) >= 3) CALL(2, 4); else if ((ngroups) == 2) CALL(4, 2); else CALL(4, 1); } while (0)
+
 int qgdk_dense_derivs(const qgdk_ctx *c)
 {
-    hipLaunchKernelGGL(k_derivs_f, dim3(dense_grid(c->Np / 16, c->cp / 8, c->m, c->nt)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt);
+    const int ng = c->cp / 8;
+#define CALL_DF(RB, NG) hipLaunchKernelGGL((k_derivs_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), 0, \
+                                           c->stream, reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt)
+    DISPATCH_SHAPE(ng, CALL_DF);
+#undef CALL_DF
     return (int)hipGetLastError();
 }
 
@@ -400,14 +412,21 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     const d2 *Af = reinterpret_cast<const d2 *>(c->Afrag);
     double *Gp = c->panel_scratch;
+    const int ng = c->cp / 8;
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((hstep + 255) / 256), c->nt), dim3(256), 0, c->stream, c->lam, c->cw, Gp, hstep,
                        c->m, c->nt);
-    for (int j = c->m; j >= 2; j--)
-        hipLaunchKernelGGL(k_gsweep_f, dim3(dense_grid(c->Np / 16, c->cp / 8, j - 1, c->nt)), dim3(256), 0, c->stream, Af, Gp,
-                           c->Np, c->cp, c->m, c->nt, j);
-    hipLaunchKernelGGL(k_ginner_f, dim3(dense_grid(c->Np / 16, c->cp / 8, c->m, c->nt)), dim3(256),
-                       (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream, reinterpret_cast<const d2 *>(c->OpFrag), c->hist,
-                       c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
+    for (int j = c->m; j >= 2; j--) {
+#define CALL_GS(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, \
+                                           c->stream, Af, Gp, c->Np, c->cp, c->m, c->nt, j)
+        DISPATCH_SHAPE(ng, CALL_GS);
+#undef CALL_GS
+    }
+#define CALL_GI(RB, NG) hipLaunchKernelGGL((k_ginner_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), \
+                                           (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream,                             \
+                                           reinterpret_cast<const d2 *>(c->OpFrag), c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,  \
+                                           c->n_ops, c->m, c->nt)
+    DISPATCH_SHAPE(ng, CALL_GI);
+#undef CALL_GI
     return (int)hipGetLastError();
 }
 
