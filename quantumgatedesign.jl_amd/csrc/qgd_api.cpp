@@ -205,19 +205,23 @@ int alloc_grid(qgd_handle h)
         HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
         HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     }
-    // derivative / gradient kernels: panels in LDS when they fit, otherwise slabs of HBM scratch
+    // derivative / gradient kernels.  N <= 64: panels in LDS.  N > 64: the GEMM-style kernels of qgd_k_dense.hip
+    // (faster than the LDS-panel kernels at every size measured, scripts/mid_n_timing.py), which keep the m seed
+    // panels g_j of a time point in HBM.  QGD_DENSE_OLD=1 keeps the older kernels (LDS panels, or HBM slabs when
+    // they do not fit) for comparison.
     k.panel_scratch = nullptr;
-    if (qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS")) {
-        const size_t slabs = nt * (size_t)(k.cp / 8);
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16))) return rc;
-    }
     k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr;
-    if (k.panel_scratch && !getenv("QGD_DENSE_OLD")) {   // GEMM-style large-N kernels (qgd_k_dense.hip)
+    const bool lds_too_small = qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS");
+    if (Np > 64 && !getenv("QGD_DENSE_OLD")) {
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, nt * m * hstep))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.Afrag, nt * m * 2 * pl))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.Dfrag, nt * m * 2 * pl))) return rc;
         if ((rc = dev_alloc(h, h->grid_bufs, &k.OpFrag, (size_t)std::max(k.n_ops, 1) * 2 * pl))) return rc;
         if (qgdk_dense_operator_frag(&k)) return fail(h, QGD_ERR_NO_DEVICE, "operator fragment kernel failed to launch");
         k.dense_gemm = 1;
+    } else if (lds_too_small) {
+        const size_t slabs = nt * (size_t)(k.cp / 8);
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16))) return rc;
     }
     // inverse work slabs when the matrix does not fit in LDS
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);

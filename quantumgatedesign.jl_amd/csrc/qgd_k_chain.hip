@@ -582,7 +582,7 @@ static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 // the dense chain pays when a tile of 4 groups is (nearly) full and the state tile fits in LDS
 static bool chain_is_dense(const ChainArgs &a)
 {
-    static const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;
+    const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;     // (comparison path; a getenv per launch is noise at these sizes)
     return !off && a.Np > 64 && a.Np <= 288 && a.ngroups >= 3;
 }
 

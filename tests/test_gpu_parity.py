@@ -310,10 +310,15 @@ def test_eval_adjoint_vs_oracle(qgd, orc, which, order):
     qgd.clear_cache()
 
 
-def test_large_n_fallback_paths(qgd):
-    """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12: generic recursion
-    kernels, global-memory Gauss-Jordan, panel slabs in HBM, three column groups -- vs the numpy
-    statement of the algorithm."""
+@pytest.mark.parametrize("older_kernels", [False, True])
+def test_large_n_fallback_paths(qgd, older_kernels, monkeypatch):
+    """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12 -- vs the numpy statement
+    of the algorithm.  older_kernels: QGD_DENSE_OLD=1 keeps the pre-GEMM large-N kernels (assembled-at-use
+    recursion, panel slabs in HBM, generic chain) alive as a comparison path."""
+    if older_kernels:
+        monkeypatch.setenv("QGD_DENSE_OLD", "1")
+        monkeypatch.setenv("QGD_CHAIN_GENERIC", "1")
+    qgd.clear_cache()
     prob, ctrl, pcof, target = cases.synthetic_case(qgd)
     order = 12
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
