@@ -112,6 +112,7 @@ int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
 int qgdk_dense_derivs(const qgdk_ctx *c);
 int qgdk_dense_gradient(const qgdk_ctx *c);
+int qgdk_dense_lambda(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 #ifdef __cplusplus
 }

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
 // eval_grad_discrete_adjoint.jl:22-40).  Single workgroup.
 //   scal[0] = <w_N,R>, scal[1] = <w_N,T>;  y_N = (2/Ness^2)(a R + b T) + f_N
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ hist,
+__global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hist,
                                                   const double *__restrict__ target,
                                                   const double *__restrict__ forcing,
                                                   double *__restrict__ yhist,
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ his
                                                   double *__restrict__ y2, double *__restrict__ y3,
                                                   double *__restrict__ y4)
 {
-    __shared__ double red[8];
-    const int PWc = 2 * cp;
+    __shared__ double red[32];
+    const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
     const size_t hstep = (size_t)Np * PWc;
     const double *w = hist + (size_t)(nt - 1) * hstep;
     double a = 0.0, b = 0.0;
@@ -730,10 +730,10 @@ __global__ __launch_bounds__(256) void k_terminal(const double *__restrict__ his
         }
     }
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[16 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
-    a = red[0] + red[1] + red[2] + red[3];
-    b = red[4] + red[5] + red[6] + red[7];
+    a = 0.0; b = 0.0;
+    for (int q = 0; q < nw; q++) { a += red[q]; b += red[16 + q]; }
     if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
     if (!write_y) return;
     const double sc = 2.0 / ((double)n_ess * (double)n_ess);
@@ -934,7 +934,7 @@ int qgdk_terminal(const qgdk_ctx *c, int write_y)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;     // y_N for the other ranks
-    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
+    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep);
     return (int)hipGetLastError();
@@ -1105,6 +1105,7 @@ int qgdk_forcing_sweep(const qgdk_ctx *c)
 
 int qgdk_lambda(const qgdk_ctx *c)
 {
+    if (c->dense_gemm && !c->use_sparse && c->nt > 1) return qgdk_dense_lambda(c);
     size_t shm = (size_t)c->Np * 16 * sizeof(double);
     hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
                        c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof);

@@ -121,6 +121,50 @@ __device__ __forceinline__ void cgemm_tile(d4 (&acc)[DN_RB][DN_NG], const DenseT
     }
 }
 
+// acc += A^H * B with A given as two column-major planes of A^T (re, im): element (A^H)(row, k) = conj(A^T'(...)),
+// i.e. planes indexed [row + Np*k] hold A(k, row).  The conjugation is a sign on the rotated right operand.
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void cgemm_tile_planes_conj(d4 (&acc)[DN_RB][DN_NG], const DenseTile<DN_RB, DN_NG> &t,
+                                                       const double *__restrict__ Are, const double *__restrict__ Aim,
+                                                       const double *__restrict__ B, size_t ldb, int Np)
+{
+    const double *apr[DN_RB], *api[DN_RB];
+    const double *bp[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        const size_t o = (size_t)(t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16 + (size_t)Np * t.kk;
+        apr[r] = Are + o; api[r] = Aim + o;
+    }
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bp[g] = B + (size_t)t.kk * ldb + (size_t)(t.g[g] >= 0 ? t.g[g] : t.g[0]) * 16 + t.c16;
+    const int nk4 = Np >> 2, sgn = t.sign_hi ^ (int)0x80000000;
+    double ar[DN_RB], ai[DN_RB], nr[DN_RB], ni[DN_RB], b[DN_NG], bn[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) { ar[r] = apr[r][0]; ai[r] = api[r][0]; }
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) b[g] = bp[g][0];
+    for (int k4 = 0; k4 < nk4; k4++) {
+        const int kn = (k4 + 1 < nk4) ? k4 + 1 : k4;
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) { nr[r] = apr[r][(size_t)kn * 4 * Np]; ni[r] = api[r][(size_t)kn * 4 * Np]; }
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) bn[g] = bp[g][(size_t)kn * 4 * ldb];
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            const double b2 = swap8_signed(b[g], sgn);
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++) {
+                acc[r][g] = MFMA(ar[r], b[g], acc[r][g]);
+                acc[r][g] = MFMA(ai[r], b2, acc[r][g]);
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) { ar[r] = nr[r]; ai[r] = ni[r]; }
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) b[g] = bn[g];
+    }
+}
+
 // U += S * B, V += K * B with real left operands packed as {S, K} pairs in fragment order
 template <int DN_RB, int DN_NG>
 __device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB][DN_NG], const DenseTile<DN_RB, DN_NG> &t,
@@ -272,6 +316,41 @@ __global__ __launch_bounds__(256) void k_derivs_f(const d2 *__restrict__ Dfrag, 
 }
 
 // ---------------------------------------------------------------------------
+// lambda_n = L_n^{-H} y_n, n = 1..nt-1 (the time point of a tile is n-1); also clears sigma and grad, which the
+// gradient kernels accumulate into.  LinvT: planes with L^{-1}(k, row) at [row + Np*k].
+// ---------------------------------------------------------------------------
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) void k_lambda_f(const double *__restrict__ LinvT, const double *__restrict__ yhist,
+                                                  double *__restrict__ lam, int Np, int cp, int nt,
+                                                  double *__restrict__ zero_a, int n_a, double *__restrict__ zero_b, int n_b)
+{
+    {
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        for (int e = gid; e < n_a; e += gsz) zero_a[e] = 0.0;
+        for (int e = gid; e < n_b; e += gsz) zero_b[e] = 0.0;
+    }
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, 1, nt - 1)) return;
+    const int n = t.n + 1, PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, pl = (size_t)Np * Np;
+    d4 acc[DN_RB][DN_NG];
+    ZERO_ACC(acc);
+    cgemm_tile_planes_conj(acc, t, LinvT + (size_t)n * 2 * pl, LinvT + (size_t)n * 2 * pl + pl, yhist + (size_t)n * hstep, PWc, Np);
+    double *out = lam + (size_t)n * hstep;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
+                out[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16] = acc[r][g][e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // gradient: seeds g_j = c_j dt^j lambda_{n+1} [n <= nt-2] - c_j (-dt)^j lambda_n [n >= 1], j = 1..m
 // Gp: [nt][m] panels [Np][2cp].  grid (ceil(hstep/256), nt)
 // ---------------------------------------------------------------------------
@@ -404,6 +483,17 @@ int qgdk_dense_derivs(const qgdk_ctx *c)
                                            c->stream, reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt)
     DISPATCH_SHAPE(ng, CALL_DF);
 #undef CALL_DF
+    return (int)hipGetLastError();
+}
+
+int qgdk_dense_lambda(const qgdk_ctx *c)
+{
+    const int ng = c->cp / 8;
+#define CALL_LF(RB, NG) hipLaunchKernelGGL((k_lambda_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, 1, c->nt - 1)), dim3(256), 0, \
+                                           c->stream, c->LinvT, c->yhist, c->lam, c->Np, c->cp, c->nt, c->sigma,                       \
+                                           c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof)
+    DISPATCH_SHAPE(ng, CALL_LF);
+#undef CALL_LF
     return (int)hipGetLastError();
 }
 
