@@ -351,6 +351,25 @@ def test_large_n_gemm_kernels(qgd, c):
     qgd.clear_cache()
 
 
+@pytest.mark.parametrize("N,c,order,n_ops,nsteps", [(65, 1, 2, 2, 9), (72, 9, 4, 1, 13), (96, 40, 6, 3, 11), (130, 17, 16, 2, 5),
+                                                  (200, 3, 2, 5, 7), (113, 24, 8, 3, 30), (255, 5, 4, 3, 6), (290, 12, 6, 2, 5)])
+def test_large_n_shape_sweep(qgd, N, c, order, n_ops, nsteps):
+    """Odd sizes for the N > 64 kernels: partial row tiles and column groups, 1..40 columns, orders 2..16, 1..5
+    control operators, N above the 288 limit of the blocked inverse / LDS chain -- history and gradient against
+    the numpy statement of the algorithm (scripts/shape_sweep.py prints the errors: 1e-15 / 1e-13)."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=nsteps, tf=0.02 * nsteps, seed=N + c)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    grad, _ = dp.discrete_adjoint(pcof)
+    hist = np.zeros((2 * N, order // 2 + 1, nsteps + 1, c), order="F")
+    qgd.eval_forward_(hist, prob, ctrl, pcof, order=order)
+    dp.close()
+    assert close(hist, pp.history_real(ref["ws"]), 1e-12)
+    assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
+    qgd.clear_cache()
+
+
 def test_edge_no_controls_is_pade(qgd):
     """Empty control set (N_operators = 0): the sweep is the diagonal Pade approximant of exp(A dt)
     applied nsteps times -- closed form, no oracle needed.  Also exercises N=5 (padding), 3 columns."""
