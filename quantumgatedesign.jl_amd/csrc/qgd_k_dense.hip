@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_operator_frag(const double *__restrict_
 // one level of the recursion on the identity; D: [nt][m] panels [Np][2Np], Dfrag: the same in fragment order
 // ---------------------------------------------------------------------------
 template <int DN_RB, int DN_NG>
-__global__ __launch_bounds__(256) void k_level_f(const d2 *__restrict__ Afrag, double *__restrict__ D,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_level_f(const d2 *__restrict__ Afrag, double *__restrict__ D,
                                                  double *__restrict__ Dfrag, double *__restrict__ L,
                                                  double *__restrict__ R, int Np, int m, int nt, int j, double cL, double cR)
 {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_level_f(const d2 *__restrict__ Afrag, d
 // w_{j+1}(t_n) = D_{j+1}(t_n) w_0(t_n), j = 0..m-1 (sub-index).  dpsi: [nt][m] panels [Np][2cp]
 // ---------------------------------------------------------------------------
 template <int DN_RB, int DN_NG>
-__global__ __launch_bounds__(256) void k_derivs_f(const d2 *__restrict__ Dfrag, const double *__restrict__ hist,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_derivs_f(const d2 *__restrict__ Dfrag, const double *__restrict__ hist,
                                                   double *__restrict__ dpsi, int Np, int cp, int m, int nt)
 {
     DenseTile<DN_RB, DN_NG> t;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_derivs_f(const d2 *__restrict__ Dfrag, 
 // gradient kernels accumulate into.  LinvT: planes with L^{-1}(k, row) at [row + Np*k].
 // ---------------------------------------------------------------------------
 template <int DN_RB, int DN_NG>
-__global__ __launch_bounds__(256) void k_lambda_f(const double *__restrict__ LinvT, const double *__restrict__ yhist,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lambda_f(const double *__restrict__ LinvT, const double *__restrict__ yhist,
                                                   double *__restrict__ lam, int Np, int cp, int nt,
                                                   double *__restrict__ zero_a, int n_a, double *__restrict__ zero_b, int n_b)
 {
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_ginit(const double *__restrict__ lam, c
 
 // reverse sweep, level j: g_i -= (1/j) A_{j-1-i} g_j for i = 1..j-1 (sub-index = i-1); A^H = -A
 template <int DN_RB, int DN_NG>
-__global__ __launch_bounds__(256) void k_gsweep_f(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gsweep_f(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
                                                   int m, int nt, int j)
 {
     DenseTile<DN_RB, DN_NG> t;
