@@ -515,7 +515,7 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
                                            (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream,                             \
                                            reinterpret_cast<const d2 *>(c->OpFrag), c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,  \
                                            c->n_ops, c->m, c->nt)
-    DISPATCH_SHAPE(ng, CALL_GI);
+    DISPATCH_SHAPE(ng, CALL_GI);      // (a 2 x 2 tile at 4 waves per SIMD was slower: 13.2 vs 11.4 ms at config 5)
 #undef CALL_GI
     return (int)hipGetLastError();
 }
