@@ -241,9 +241,10 @@ __global__ __launch_bounds__(256) void k_operator_frag(const double *__restrict_
 // one level of the recursion on the identity; D: [nt][m] panels [Np][2Np], Dfrag: the same in fragment order
 // ---------------------------------------------------------------------------
 template <int DN_RB, int DN_NG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_level_f(const d2 *__restrict__ Afrag, double *__restrict__ D,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_level_f(const d2 *__restrict__ Afrag, double *D,
                                                  double *__restrict__ Dfrag, double *__restrict__ L,
-                                                 double *__restrict__ R, int Np, int m, int nt, int j, double cL, double cR)
+                                                 double *__restrict__ R, const double *__restrict__ cw, int Np, int m, int nt, int j,
+                                                 double cL, double cR)
 {
     DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, Np >> 3, 1, nt)) return;
@@ -274,13 +275,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const size_t o = (size_t)row * PW + t.g[g] * 16 + t.c16;
                 Dout[o] = val;
                 Fout[fi] = val;
-                if (j == 0) {
+                if (j == m - 1) {       // L and R once, from the stored D_1..D_{m-1} (not a read-modify-write per level)
                     const double id = (!is_im && row == ccol) ? 1.0 : 0.0;
-                    Ln[o] = id + cL * val;
-                    Rn[o] = id + cR * val;
-                } else {
-                    Ln[o] += cL * val;
-                    Rn[o] += cR * val;
+                    double lv = id + cL * val, rv = id + cR * val;
+                    for (int q = 0; q < j; q++) {
+                        const double dq = Dn[(size_t)q * panel + o];
+                        lv += cw[2 * (q + 1) + 1] * dq;
+                        rv += cw[2 * (q + 1)] * dq;
+                    }
+                    Ln[o] = lv;
+                    Rn[o] = rv;
                 }
             }
         }
@@ -468,7 +472,7 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
 #undef CALL_AF
     const int grid = dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt);     // Np/8 >= 9 column groups here
     for (int j = 0; j < c->m; j++)
-        hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->Np, c->m,
+        hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->cw, c->Np, c->m,
                            c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
     return (int)hipGetLastError();
 }
