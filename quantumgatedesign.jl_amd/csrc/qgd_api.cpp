@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "qgd.h"
 #include "qgd_device.h"
@@ -476,31 +477,77 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
         h->sparse_available = Np <= 64 && Z <= 16 && 2 * (size_t)Z <= Np && qgdk_sparse_supported(k.Np, k.m, n_ops, Z);
         k.use_sparse = h->sparse_available && !getenv("QGD_DENSE_OPS");
         if (h->sparse_available) {
+            // Slot order.  Default: the e-th nonzero of each row.  When the union pattern is banded -- as many distinct
+            // offsets (column - row) as the fullest row has entries, which is the case for the drift + a_k +/- a_k^dagger
+            // operators (offsets 0, +-1, +-4, +-16 for subsystems (4,4,4)) -- slot e holds the SAME offset in every row
+            // and absent entries point at (row + offset) mod Np with value 0.  The kernels read the neighbour row of
+            // slot e for 64 consecutive rows in one ds_read_b128: with one common shift the 16 lanes of a bank group hit
+            // 16 different 16-byte slots; with per-row packing the shifts differ from lane to lane and half of the
+            // LDS cycles of k_build_LR_ell / k_gradpoint_ell were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+            auto diagonal_slots = [&](const std::vector<std::vector<int>> &cl, int zmax, std::vector<int> &offs) {
+                offs.clear();
+                for (size_t r = 0; r < Np; r++)
+                    for (int cidx : cl[r]) {
+                        const int s_ = cidx - (int)r;
+                        if (std::find(offs.begin(), offs.end(), s_) == offs.end()) offs.push_back(s_);
+                    }
+                std::sort(offs.begin(), offs.end());
+                return !offs.empty() && (int)offs.size() <= zmax && !getenv("QGD_ELL_ROW_PACKED");
+            };
+            // slots[r][e] = column of slot e in row r, present[r][e] = it is a stored entry
+            auto make_slots = [&](const std::vector<std::vector<int>> &cl, int zmax, std::vector<int> &sc, std::vector<char> &pr) {
+                std::vector<int> offs;
+                sc.assign((size_t)zmax * Np, 0); pr.assign((size_t)zmax * Np, 0);
+                if (diagonal_slots(cl, zmax, offs)) {
+                    for (size_t r = 0; r < Np; r++)
+                        for (int e = 0; e < zmax; e++) {
+                            const int s_ = e < (int)offs.size() ? offs[e] : 0;
+                            const int cidx = (int)r + s_;
+                            const bool have = e < (int)offs.size() && cidx >= 0 && cidx < (int)Np &&
+                                              std::find(cl[r].begin(), cl[r].end(), cidx) != cl[r].end();
+                            sc[(size_t)e * Np + r] = have ? cidx : (int)(((long long)r + s_ + 4 * (long long)Np) % (long long)Np);
+                            pr[(size_t)e * Np + r] = have;
+                        }
+                } else {
+                    for (size_t r = 0; r < Np; r++)
+                        for (int e = 0; e < zmax; e++) {
+                            const bool have = e < (int)cl[r].size();
+                            sc[(size_t)e * Np + r] = have ? cl[r][e] : (int)r;
+                            pr[(size_t)e * Np + r] = have;
+                        }
+                }
+            };
             std::vector<int32_t> ecol((size_t)Z * Np), ocol((size_t)std::max(n_ops, 1) * Zo * Np);
             std::vector<double> eval(planes * Z * Np, 0.0), oval((size_t)std::max(n_ops, 1) * 2 * Zo * Np, 0.0);
-            for (size_t r = 0; r < Np; r++) {
-                for (int e = 0; e < Z; e++) {
-                    const int cidx = e < (int)cols[r].size() ? cols[r][e] : (int)r;
-                    ecol[(size_t)e * Np + r] = cidx;
-                    if (e < (int)cols[r].size())
-                        for (size_t q = 0; q < planes; q++) eval[(q * Z + e) * Np + r] = ops[q * pl + r + Np * cidx];
-                }
-                for (int o = 0; o < n_ops; o++) {
-                    int e = 0;
-                    for (int cidx : cols[r]) {
-                        const double kv = ops[(2 + 2 * (size_t)o) * pl + r + Np * cidx], sv = ops[(3 + 2 * (size_t)o) * pl + r + Np * cidx];
-                        if (kv == 0.0 && sv == 0.0) continue;
-                        ocol[((size_t)o * Zo + e) * Np + r] = cidx;
-                        oval[(((size_t)2 * o) * Zo + e) * Np + r] = kv;
-                        oval[(((size_t)2 * o + 1) * Zo + e) * Np + r] = sv;
-                        e++;
-                    }
-                    for (; e < Zo; e++) ocol[((size_t)o * Zo + e) * Np + r] = (int)r;
-                }
-            }
             std::vector<uint8_t> einv(Np * Np, 0xff);
+            std::vector<int> sc; std::vector<char> pr;
+            make_slots(cols, Z, sc, pr);
             for (size_t r = 0; r < Np; r++)
-                for (size_t e = 0; e < cols[r].size(); e++) einv[r * Np + cols[r][e]] = (uint8_t)e;
+                for (int e = 0; e < Z; e++) {
+                    const int cidx = sc[(size_t)e * Np + r];
+                    ecol[(size_t)e * Np + r] = cidx;
+                    if (pr[(size_t)e * Np + r]) {
+                        for (size_t q = 0; q < planes; q++) eval[(q * Z + e) * Np + r] = ops[q * pl + r + Np * cidx];
+                        einv[r * Np + cidx] = (uint8_t)e;
+                    }
+                }
+            for (int o = 0; o < n_ops; o++) {
+                std::vector<std::vector<int>> ocl(Np);
+                for (size_t r = 0; r < Np; r++)
+                    for (int cidx : cols[r])
+                        if (ops[(2 + 2 * (size_t)o) * pl + r + Np * cidx] != 0.0 || ops[(3 + 2 * (size_t)o) * pl + r + Np * cidx] != 0.0)
+                            ocl[r].push_back(cidx);
+                make_slots(ocl, Zo, sc, pr);
+                for (size_t r = 0; r < Np; r++)
+                    for (int e = 0; e < Zo; e++) {
+                        const int cidx = sc[(size_t)e * Np + r];
+                        ocol[((size_t)o * Zo + e) * Np + r] = cidx;
+                        if (pr[(size_t)e * Np + r]) {
+                            oval[(((size_t)2 * o) * Zo + e) * Np + r] = ops[(2 + 2 * (size_t)o) * pl + r + Np * cidx];
+                            oval[(((size_t)2 * o + 1) * Zo + e) * Np + r] = ops[(3 + 2 * (size_t)o) * pl + r + Np * cidx];
+                        }
+                    }
+            }
             CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_inv, einv.size()));
             CREATE_TRY(hipMemcpy(k.ell_inv, einv.data(), einv.size(), hipMemcpyHostToDevice));
             CREATE_RC(dev_alloc(h, h->static_bufs, &k.ell_col, ecol.size()));

@@ -11,7 +11,7 @@
 // the flops left after exploiting the sparsity are below the cost of writing L and R.
 #include "qgd_kernels_common.h"
 
-struct c2 { double re, im; };
+struct __attribute__((aligned(16))) c2 { double re, im; };      // 16-byte aligned: LDS accesses become ds_read_b128 / ds_write_b128
 
 // -DQGD_SPARSE_PROFILE: cycles of workgroup 0 / thread 0 between the marks below, summed over launches
 // (read back with qgdk_sparse_profile; development aid, not compiled into the shipped library)
@@ -69,29 +69,30 @@ __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ 
 // Source-major like the dense kernel: when D_i is complete its contributions to every later
 // level are accumulated at once, so D_i's neighbour rows are read from LDS once.
 // ---------------------------------------------------------------------------
-template <int M>
-__global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict__ ell_col,
+template <int M, int NW>
+__global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restrict__ ell_col,
                                                       const uint8_t *__restrict__ ell_inv,
                                                       const double *__restrict__ ell_val,
                                                       const double *__restrict__ tab,
                                                       double *__restrict__ L, double *__restrict__ R,
                                                       const double *__restrict__ cw, int Np, int n_ops, int Z)
 {
-    constexpr int DS = 33;                              // row stride of the source slab in complex numbers
-    extern __shared__ double smem_raw[];
+    constexpr int NTH = 64 * NW, CW = 4 * NW;           // threads, complex columns per workgroup (NW waves x 4 columns)
+    constexpr int DS = CW + 1;                          // row stride of the source slab in complex numbers
+    extern __shared__ __attribute__((aligned(16))) double smem_raw[];
     c2 *As = reinterpret_cast<c2 *>(smem_raw);          // [M][Z][64]
     c2 *Ds = As + (size_t)M * Z * 64;                   // [64][DS]   (also the output staging area)
     int *Ecol = reinterpret_cast<int *>(Ds + 64 * DS);  // [Z][64]
     const int n = blockIdx.x, slab = blockIdx.y;
     const int tid = threadIdx.x, w = tid >> 6, r = tid & 63;
-    const int vc = min(32, Np - slab * 32);             // valid columns of this slab
-    const int cl = 4 * w, c0 = slab * 32 + cl;          // first owned column (slab-local / global)
+    const int vc = min(CW, Np - slab * CW);             // valid columns of this slab
+    const int cl = 4 * w, c0 = slab * CW + cl;          // first owned column (slab-local / global)
     const bool active = (r < Np) && (cl < vc);
     SP_PROF_BEGIN
 
-    assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, 512);
+    assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
     SP_PROF(0);
-    for (int item = tid; item < Z * 64; item += 512) {
+    for (int item = tid; item < Z * 64; item += NTH) {
         const int rr = item & 63, e = item >> 6;
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
         for (int c = 0; c < 4; c++) Ds[r * DS + cl + c] = Di[c];
         __syncthreads();
         if (active) {
+            // (an explicit one-entry-ahead prefetch of the neighbour row and operator values was measured: 66.5 vs
+            //  62.9 us -- the loop is not waiting on LDS latency)
             _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
                 const c2 *src = Ds + Ecol[e * 64 + r] * DS + cl;
                 c2 x[4];
@@ -154,21 +157,22 @@ __global__ __launch_bounds__(512) void k_build_LR_ell(const int32_t *__restrict_
     SP_PROF(3);
     // output through LDS so that panel rows are written as contiguous segments
     const int PW = 2 * Np, SW = 2 * vc;                 // panel width, width of this slab's part of a row
-    double *st = reinterpret_cast<double *>(Ds);        // [64][65]
+    constexpr int SS = 2 * CW + 1;
+    double *st = reinterpret_cast<double *>(Ds);        // [64][SS]
     #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         __syncthreads();
         #pragma unroll
         for (int c = 0; c < 4; c++) {
             const c2 v = pass ? Racc[c] : Lacc[c];
-            const int lc = cl + c, o = r * 65 + (lc >> 3) * 16 + (lc & 7);
+            const int lc = cl + c, o = r * SS + (lc >> 3) * 16 + (lc & 7);
             st[o] = v.re; st[o + 8] = v.im;
         }
         __syncthreads();
-        double *dst = (pass ? R : L) + (size_t)n * Np * PW + slab * 64;
-        for (int item = tid; item < Np * SW; item += 512) {
+        double *dst = (pass ? R : L) + (size_t)n * Np * PW + slab * 2 * CW;
+        for (int item = tid; item < Np * SW; item += NTH) {
             const int row = item / SW, k = item % SW;
-            dst[(size_t)row * PW + k] = st[row * 65 + k];
+            dst[(size_t)row * PW + k] = st[row * SS + k];
         }
     }
     SP_PROF(4);
@@ -198,7 +202,7 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
                                                        int nt, int n_ops, int Z, int Zo)
 {
     constexpr int PS = 9, ND = (M > 1) ? M - 1 : 1, NO = NOPS_LIM(NOPS);
-    extern __shared__ double smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) double smem_raw[];
     c2 *As = reinterpret_cast<c2 *>(smem_raw);          // [ND][Z][64]
     c2 *buf = As + (size_t)ND * Z * 64;                 // [64][PS]   the current right operand
     c2 *Ov = buf + 64 * PS;                             // [n_ops][Zo][64] (Asym_o, Sym_o) values
@@ -351,7 +355,7 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
     SP_PROF(22);
 }
 
-static size_t lds_build_ell(int M, int Z) { return ((size_t)M * Z * 64 + 64 * 33) * 16 + (size_t)Z * 64 * 4; }
+static size_t lds_build_ell(int M, int Z, int NW) { return ((size_t)M * Z * 64 + 64 * (4 * NW + 1)) * 16 + (size_t)Z * 64 * 4; }
 static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 {
     const int nd = (M > 1) ? M - 1 : 1;
@@ -359,14 +363,24 @@ static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
            ((size_t)Z * 64 + (size_t)n_ops * Zo * 64) * 4;
 }
 
+// Workgroup = (time point, 16 columns), 4 waves: 48 KB of LDS, three workgroups per CU.  With 32 columns and 8
+// waves (64 KB, two per CU) the 1102 workgroups of the 551-point benchmark grid need three rounds of 512 slots,
+// the third one almost empty; the smaller unit packs the same work into 2.9 rounds of 768.
+template <int M, int NW>
+static int launch_build_ell_nw(const qgdk_ctx *c)
+{
+    const size_t shm = lds_build_ell(M, c->ell_z, NW);
+    SET_LDS_ONCE((k_build_LR_ell<M, NW>), shm);
+    hipLaunchKernelGGL((k_build_LR_ell<M, NW>), dim3(c->nt, (c->Np + 4 * NW - 1) / (4 * NW)), dim3(64 * NW), shm, c->stream, c->ell_col,
+                       c->ell_inv, c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
+    return (int)hipGetLastError();
+}
+
 template <int M>
 static int launch_build_ell(const qgdk_ctx *c)
 {
-    const size_t shm = lds_build_ell(M, c->ell_z);
-    SET_LDS_ONCE((k_build_LR_ell<M>), shm);
-    hipLaunchKernelGGL((k_build_LR_ell<M>), dim3(c->nt, (c->Np + 31) / 32), dim3(512), shm, c->stream, c->ell_col,
-                       c->ell_inv, c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
-    return (int)hipGetLastError();
+    static const bool wide = getenv("QGD_BUILD_ELL_WIDE") != nullptr;
+    return wide ? launch_build_ell_nw<M, 8>(c) : launch_build_ell_nw<M, 4>(c);
 }
 
 template <int M, int NOPS>
@@ -400,7 +414,7 @@ extern "C" {
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z)
 {
     if (Np > 64 || m < 1 || m > 8 || Z < 1) return 0;
-    return lds_build_ell(m, Z) <= 150 * 1024 && lds_grad_ell(m, Z, n_ops, Z) <= 150 * 1024;
+    return lds_build_ell(m, Z, 8) <= 150 * 1024 && lds_grad_ell(m, Z, n_ops, Z) <= 150 * 1024;
 }
 
 #ifdef QGD_SPARSE_PROFILE
