@@ -363,9 +363,10 @@ static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
            ((size_t)Z * 64 + (size_t)n_ops * Zo * 64) * 4;
 }
 
-// Workgroup = (time point, 16 columns), 4 waves: 48 KB of LDS, three workgroups per CU.  With 32 columns and 8
-// waves (64 KB, two per CU) the 1102 workgroups of the 551-point benchmark grid need three rounds of 512 slots,
-// the third one almost empty; the smaller unit packs the same work into 2.9 rounds of 768.
+// Workgroup = (time point, 4*NW columns), NW waves.  NW = 8 (32 columns, 64 KB of LDS, two workgroups per CU) is the
+// default: 46.5 us on the 551-point benchmark grid against 49.8 us for NW = 4 (16 columns, 48 KB, three per CU,
+// QGD_BUILD_ELL_NARROW=1) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.
+// (Before the LDS accesses were 16-byte aligned both took 63 us, bound by bank conflicts.)
 template <int M, int NW>
 static int launch_build_ell_nw(const qgdk_ctx *c)
 {
@@ -379,8 +380,8 @@ static int launch_build_ell_nw(const qgdk_ctx *c)
 template <int M>
 static int launch_build_ell(const qgdk_ctx *c)
 {
-    static const bool wide = getenv("QGD_BUILD_ELL_WIDE") != nullptr;
-    return wide ? launch_build_ell_nw<M, 8>(c) : launch_build_ell_nw<M, 4>(c);
+    static const bool narrow = getenv("QGD_BUILD_ELL_NARROW") != nullptr;
+    return narrow ? launch_build_ell_nw<M, 4>(c) : launch_build_ell_nw<M, 8>(c);
 }
 
 template <int M, int NOPS>
