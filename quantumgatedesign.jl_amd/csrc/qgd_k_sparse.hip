@@ -90,12 +90,13 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     const bool active = (r < Np) && (cl < vc);
     SP_PROF_BEGIN
 
-    assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
-    SP_PROF(0);
     for (int item = tid; item < Z * 64; item += NTH) {
         const int rr = item & 63, e = item >> 6;
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
+    const uint32_t slots = active ? *reinterpret_cast<const uint32_t *>(ell_inv + (size_t)r * Np + c0) : 0xffffffffu;
+    assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
+    SP_PROF(0);
     c2 T[M][4], Lacc[4], Racc[4];
     #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -108,7 +109,6 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     SP_PROF(1);
     // source 0 is the identity: A_d I = A_d.  ell_inv[r][col] = slot of column col in row r (0xff: none)
     if (active) {
-        const uint32_t slots = *reinterpret_cast<const uint32_t *>(ell_inv + (size_t)r * Np + c0);
         #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int e = (slots >> (8 * c)) & 0xff;
@@ -216,18 +216,8 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
     const bool live = r < Np;
     SP_PROF_BEGIN
 
-    if (M > 1) assemble_ell(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
-    SP_PROF(16);
-    for (int item = tid; item < Z * 64; item += 256) {
-        const int rr = item & 63, e = item >> 6;
-        Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
-    }
-    for (int item = tid; item < n_ops * Zo * 64; item += 256) {
-        const int rr = item & 63, oe = item >> 6, o = oe / Zo, e = oe % Zo;
-        const bool ok = rr < Np;
-        Ocol[item] = ok ? op_col[(size_t)oe * Np + rr] : 0;
-        Ov[item] = ok ? (c2){op_val[((size_t)(2 * o) * Zo + e) * Np + rr], op_val[((size_t)(2 * o + 1) * Zo + e) * Np + rr]} : (c2){0.0, 0.0};
-    }
+    // (global loads first, in the order of their latency: the seeds and psi_0 go to registers and are in flight
+    //  while the lists and A_d(t_n) are brought into LDS)
     // own elements of psi_0 and the seeds g_j = c_j dt^j lam_{n+1} - c_j (-dt)^j lam_n
     c2 ps[2], g[M][2];
     #pragma unroll
@@ -239,6 +229,18 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
         #pragma unroll
         for (int j = 1; j <= M; j++)
             g[j - 1][c] = (c2){cw[2 * j] * lx.re - cw[2 * j + 1] * ln.re, cw[2 * j] * lx.im - cw[2 * j + 1] * ln.im};
+    }
+    if (M > 1) assemble_ell(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
+    SP_PROF(16);
+    for (int item = tid; item < Z * 64; item += 256) {
+        const int rr = item & 63, e = item >> 6;
+        Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
+    }
+    for (int item = tid; item < n_ops * Zo * 64; item += 256) {
+        const int rr = item & 63, oe = item >> 6, o = oe / Zo, e = oe % Zo;
+        const bool ok = rr < Np;
+        Ocol[item] = ok ? op_col[(size_t)oe * Np + rr] : 0;
+        Ov[item] = ok ? (c2){op_val[((size_t)(2 * o) * Zo + e) * Np + rr], op_val[((size_t)(2 * o + 1) * Zo + e) * Np + rr]} : (c2){0.0, 0.0};
     }
     SP_PROF(17);
     // ---- G passes: g_i += -(1/j) A_{j-1-i} g_j (A^H = -A), i = 1..j-1, j = m..2
