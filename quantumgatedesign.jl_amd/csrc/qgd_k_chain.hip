@@ -118,28 +118,45 @@ __device__ __forceinline__ void chain_a_raw(const double *__restrict__ Pn, int N
     }
 }
 
-// NP > 0: compile-time size.  The steps of a chain are sequential, but the LEFT operands (P_n,
-// and the forcing of the adjoint) do not depend on the state: NT = 4 teams of NP/16 waves take the
-// steps round-robin, team t computing steps t, t+4, ...  Each team issues the loads of its next
-// step right after finishing one and then sits out the three steps of the other teams at the step
-// barriers, so its operands have three step times to arrive -- with plain compiler-managed
-// registers (a register ring inside one wave does not survive the compiler's vmcnt bookkeeping on
-// gfx9, where loads and the history stores share one counter).  One barrier per step; the state is
-// double buffered in LDS; a wave owns 16 rows over the full K range (no partial sums), the history
-// is stored straight from the accumulators.  NG column groups per workgroup share the A fragments.
-#ifndef QGD_CHAIN_NT
-#define QGD_CHAIN_NT 4
+// NP > 0: compile-time size.  The steps of a chain are sequential, but the LEFT operands (P_n, and the forcing
+// of the adjoint) do not depend on the state: NT teams of NP/16 waves take the steps round-robin, team t
+// computing steps t, t+NT, ...  Each team issues the loads of its next step right after finishing one and then
+// sits out the steps of the other teams at the step barriers, so its operands have NT-1 step times to arrive --
+// with plain compiler-managed registers.  One barrier per step, an LDS-only one (see lds_barrier); the state is
+// double buffered in LDS; a wave owns 16 rows over the full K range (no partial sums), the history is stored
+// straight from the accumulators.  NG column groups per workgroup share the A fragments.
+// Teams per mode (scripts/ubench/chain_bench.hip, 64 blocks, us per launch for 9 / 36 steps, with the LDS-only
+// barrier below):            mode 0 (NG=2)   mode 1        mode 2   mode 3
+//      4 teams (1024 thr)    30.5            23.7 / 76.9   18.5     22.1 / --      (128 VGPRs: modes 1 and 3 spill)
+//      3 teams               31.6            18.3 / 55.1   20.0     19.2 / 58.1
+//      2 teams               29.2            16.9 / 51.6   17.2     19.9 / 65.3
+// QGD_CHAIN_NT (compile time) overrides the choice for every mode.
+#ifdef QGD_CHAIN_NT
+#define CHAIN_NT(MODE) QGD_CHAIN_NT
+#else
+#define CHAIN_NT(MODE) ((MODE) == 3 || (MODE) >= 4 ? 3 : 2)
 #endif
 #ifdef QGD_CHAIN_PROFILE
 __device__ long long g_chain_prof[64 * 4];
 #endif
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0)
+// + s_barrier: in the team pipeline below a wave reaches the next barrier right after issuing the global loads of
+// its step four steps ahead (and its history stores), so EVERY step barrier waited ~1100 cycles for another team's
+// prefetch to land (scripts/ubench/chain_bench.hip -DQGD_CHAIN_PROFILE: 2500 cycles of MFMAs, then 1500 to get
+// through the barrier; 370 in the last steps, which prefetch nothing).  All communication between the waves of a
+// chain goes through LDS; nothing written to global memory is read again inside the kernel.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NP, int MODE, int NG>
-__global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const ChainArgs a)
+__global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const ChainArgs a)
 {
     constexpr bool ADJ = (MODE == 2 || MODE == 3);      // backward in time with P^H
     constexpr bool FORC = (MODE >= 2);                    // affine: a forcing term is added every step
     constexpr bool ZERO = (MODE == 2 || MODE == 4);       // zero start, the final state is the block's affine part
-    constexpr int NRB = NP / 16, NT = QGD_CHAIN_NT, KST = NP / 4, NTH = NP * 4 * NT;
+    constexpr int NRB = NP / 16, NT = CHAIN_NT(MODE), KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
     int b, grp0;
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         }
     };
     if (team < total) issue(team);
-    __syncthreads();
+    lds_barrier();
 
 #ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
 #define CH_STAMP(slot) do { if (blockIdx.x == 0 && rb == 0 && lane == 0 && st < 64) g_chain_prof[st * 4 + (slot)] = clock64(); } while (0)
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
 #endif
     int done = 0;                                         // step barriers this wave has passed
     for (int st = team; st < total; st += NT) {
-        while (done < st) { __syncthreads(); done++; }   // steps of the other teams
+        while (done < st) { lds_barrier(); done++; }     // steps of the other teams
         CH_STAMP(0);
         const bool mainstep = st >= npfx;
         const int buf = st & 1, n = step_index(mainstep ? st - npfx : 0);
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
                 part[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
             }
         CH_STAMP(2);
-        __syncthreads(); done++;                          // the next team starts; the rest is off the critical path
+        lds_barrier(); done++;                            // the next team starts; the rest is off the critical path
         CH_STAMP(3);
         if (((MODE == 1 || MODE == 3) && mainstep) || (MODE == 5 && a.out)) {
             #pragma unroll
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(NP * 4 * QGD_CHAIN_NT) void k_chain_fast(const Chai
         }
         if (st + NT < total) issue(st + NT);
     }
-    while (done < total) { __syncthreads(); done++; }
+    while (done < total) { lds_barrier(); done++; }
     if (MODE == 1 && a.guard_diag) {                     // one atomic per workgroup
         __shared__ double pred[NTH / 16];
         pen = row16_sum(pen);
@@ -594,10 +611,10 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
     const int nwg = (MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng;
     if (nwg <= 0) return 0;
     switch (fast ? a.Np : 0) {
-    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE, NG>), dim3(nwg), dim3(16 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
-    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE, NG>), dim3(nwg), dim3(32 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
-    case 48: hipLaunchKernelGGL((k_chain_fast<48, MODE, NG>), dim3(nwg), dim3(48 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
-    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * QGD_CHAIN_NT), 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE, NG>), dim3(nwg), dim3(16 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
+    case 32: hipLaunchKernelGGL((k_chain_fast<32, MODE, NG>), dim3(nwg), dim3(32 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
+    case 48: hipLaunchKernelGGL((k_chain_fast<48, MODE, NG>), dim3(nwg), dim3(48 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
     default: {
         if (MODE >= 4) return (int)hipErrorNotSupported;
         if (chain_is_dense(a)) return launch_chain_dense<(MODE >= 4 ? 1 : MODE)>(a, stream);

@@ -5,6 +5,7 @@
 // Random step matrices (scaled to keep the products O(1)), random forcing; compares every output of
 // the launch with a host evaluation and prints the time per launch.
 #include "../../quantumgatedesign.jl_amd/csrc/qgd_k_chain.hip"
+extern "C" int qgdk_dense_lambda(const qgdk_ctx *) { return 0; }   // lives in qgd_k_dense.hip; not exercised here
 #include <cstdio>
 #include <vector>
 #include <complex>
