@@ -125,19 +125,20 @@ __device__ __forceinline__ void chain_a_raw(const double *__restrict__ Pn, int N
 // with plain compiler-managed registers.  One barrier per step, an LDS-only one (see lds_barrier); the state is
 // double buffered in LDS; a wave owns 16 rows over the full K range (no partial sums), the history is stored
 // straight from the accumulators.  NG column groups per workgroup share the A fragments.
-// Teams per mode (scripts/ubench/chain_bench.hip, 64 blocks, us per launch for 9 / 36 steps, with the LDS-only
-// barrier below):            mode 0 (NG=2)   mode 1        mode 2   mode 3
-//      4 teams (1024 thr)    30.5            23.7 / 76.9   18.5     22.1 / --      (128 VGPRs: modes 1 and 3 spill)
-//      3 teams               31.6            18.3 / 55.1   20.0     19.2 / 58.1
-//      2 teams               29.2            16.9 / 51.6   17.2     19.9 / 65.3
-// QGD_CHAIN_NT (compile time) overrides the choice for every mode.
+// Teams (scripts/ubench/chain_bench.hip, 64 blocks, us per launch; mode 0 with NG=2):
+//                              mode 0, 9 steps   mode 1, 24   mode 2, 9   mode 3, 24
+//   4 teams, __syncthreads     30.5              ~53          18.5        ~50        (128-VGPR cap: modes 1, 3 spill)
+//   3 teams, LDS-only barrier,
+//            buffer addressing 32.7              37.1         17.3        39.0
+//   2 teams, the same          28.7              33.7         14.9        34.1
+// QGD_CHAIN_NT (compile time) overrides the choice.
 #ifdef QGD_CHAIN_NT
 #define CHAIN_NT(MODE) QGD_CHAIN_NT
 #else
-#define CHAIN_NT(MODE) ((MODE) == 3 || (MODE) >= 4 ? 3 : 2)
+#define CHAIN_NT(MODE) 2
 #endif
 #ifdef QGD_CHAIN_PROFILE
-__device__ long long g_chain_prof[64 * 4];
+__device__ long long g_chain_prof[64 * 8];
 #endif
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0)
 // + s_barrier: in the team pipeline below a wave reaches the next barrier right after issuing the global loads of
@@ -145,6 +146,24 @@ __device__ long long g_chain_prof[64 * 4];
 // prefetch to land (scripts/ubench/chain_bench.hip -DQGD_CHAIN_PROFILE: 2500 cycles of MFMAs, then 1500 to get
 // through the barrier; 370 in the last steps, which prefetch nothing).  All communication between the waves of a
 // chain goes through LDS; nothing written to global memory is read again inside the kernel.
+// Buffer-addressed 8-byte load / store: address = descriptor base (SGPRs, wave-uniform) + soff (SGPR or constant)
+// + voff (one VGPR byte offset per lane).  No vector ALU instruction is needed to form the address.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const double *base)      // base must be wave-uniform
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double buffer_load_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buffer_store_f64(double x, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    u32x2 d; d.x = (unsigned)__double2loint(x); d.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -173,6 +192,11 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     const int c16 = lane & 15, kk = lane >> 4;
     const int team = wave / NRB, rb = wave % NRB;
     const int arow = rb * 16 + c16;
+    // left-operand fragment of step matrix P at (arow, 4 i + kk): planes (forward) / panel read as P^H (adjoint, the
+    // imaginary part un-negated: the sign goes to the B operand)
+    constexpr int A_STEP = ADJ ? 8 * NP : 4 * NP, A_IM = ADJ ? 8 : NP * NP;
+    const int a_lane = 8 * (ADJ ? kk * 2 * NP + (arow >> 3) * 16 + (arow & 7) : arow + NP * kk);     // bytes
+    const int o_lane = 8 * ((rb * 16 + kk) * PWc + c16);                                                // bytes        // this lane's element (row rb*16+kk, column c16) of a state panel
     const int nsteps = (e0 > s0) ? e0 - s0 : 0;
     double pen = 0.0;                                     // guard penalty of the states this thread handles
     // prefix segments (MODE 1/3): counts and first indices for this block
@@ -225,25 +249,35 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     auto issue = [&](int st) {                            // left operand (and forcing) of step st
         int n, fbpr = a.f_bpr;
         const double *Pn, *fsrc = a.forcing;
-        if (st >= npfx) { n = step_index(st - npfx); Pn = chain_matrix(a, n); }
+        // (everything here is wave-uniform; readfirstlane tells the compiler so, and the pointers stay in SGPRs)
+        if (st >= npfx) { n = __builtin_amdgcn_readfirstlane(step_index(st - npfx)); Pn = chain_matrix(a, n); }
         else {                                            // a prefix step
             int q = 0, sl = st;
             while (sl >= pcnt[q]) { sl -= pcnt[q]; q++; }
-            n = ADJ ? pfirst[q] - sl : pfirst[q] + sl;
+            q = __builtin_amdgcn_readfirstlane(q);
+            n = __builtin_amdgcn_readfirstlane(ADJ ? pfirst[q] - sl : pfirst[q] + sl);
             const size_t pl2 = (size_t)2 * NP * NP;
             Pn = a.pre_pm_bpr[q] ? a.pre_P[q] + (size_t)(n / a.pre_pm_bpr[q]) * a.pre_pm_chunk[q] + (size_t)(n % a.pre_pm_bpr[q]) * pl2
                                  : a.pre_P[q] + (size_t)n * pl2;
             fsrc = a.pre_f[q]; fbpr = a.pre_f_bpr[q];
         }
+        // Addresses = buffer descriptor on the step's matrix (SGPRs) + a per-lane byte offset computed once + constants:
+        // no vector ALU per load.  While the other team runs its burst of f64 MFMAs, a wave on the same SIMD gets about
+        // one VALU instruction per MFMA (64 cycles): with 64-bit addresses built in VGPRs, issuing these 32 loads took
+        // 2500 cycles (chain_bench -DQGD_CHAIN_PROFILE) -- longer than the step they are supposed to hide behind.
+        const __amdgpu_buffer_rsrc_t rP = buffer_of(Pn);
         #pragma unroll
-        for (int i = 0; i < KST; i++) chain_a_raw<ADJ>(Pn, NP, arow, i * 4 + kk, are[i], aim[i]);
+        for (int i = 0; i < KST; i++) {
+            are[i] = buffer_load_f64(rP, a_lane, i * A_STEP * 8);
+            aim[i] = buffer_load_f64(rP, a_lane, (i * A_STEP + A_IM) * 8);
+        }
         if (FORC && !(MODE >= 4 && a.fs_mode == 1)) {
-            const size_t fb = (size_t)(fbpr ? n + n / fbpr : n) * hstep;
+            const __amdgpu_buffer_rsrc_t rF = buffer_of(fsrc + (size_t)(fbpr ? n + n / fbpr : n) * hstep + (size_t)grp0 * 16);
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    fo[g][r] = fsrc[fb + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16];
+                    fo[g][r] = buffer_load_f64(rF, o_lane, (4 * r * PWc + g * 16) * 8);
         }
         if (MODE >= 4 && a.fs_mode == 1) {               // assemble the sensitivity forcing of step n -> n+1
             #pragma unroll
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     lds_barrier();
 
 #ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
-#define CH_STAMP(slot) do { if (blockIdx.x == 0 && rb == 0 && lane == 0 && st < 64) g_chain_prof[st * 4 + (slot)] = clock64(); } while (0)
+#define CH_STAMP(slot) do { if (blockIdx.x == 0 && rb == 0 && lane == 0 && st < 64) g_chain_prof[st * 8 + (slot)] = clock64(); } while (0)
 #else
 #define CH_STAMP(slot) do { } while (0)
 #endif
@@ -302,7 +336,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             }
         }
         CH_STAMP(1);
-        const int nout = ADJ ? n : n + 1;                 // time index of the state this step produces
+        const int nout = __builtin_amdgcn_readfirstlane(ADJ ? n : n + 1);   // time index of the state this step produces
         double res[NG][4];
         #pragma unroll
         for (int g = 0; g < NG; g++)
@@ -317,11 +351,12 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         lds_barrier(); done++;                            // the next team starts; the rest is off the critical path
         CH_STAMP(3);
         if (((MODE == 1 || MODE == 3) && mainstep) || (MODE == 5 && a.out)) {
+            const __amdgpu_buffer_rsrc_t rO = buffer_of(a.out + (size_t)nout * hstep + (size_t)grp0 * 16);
             #pragma unroll
             for (int g = 0; g < NG; g++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    a.out[(size_t)nout * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + (grp0 + g) * 16 + c16] = res[g][r];
+                    buffer_store_f64(res[g][r], rO, o_lane, (4 * r * PWc + g * 16) * 8);
         }
         if ((MODE == 1 || MODE == 3) && a.pre_start_out && a.npre > 0 && a.pre_kind[0] == 0 && st == pcnt[0] - 1 &&
             b == (ADJ ? a.nblocks - 1 : 0)) {
@@ -355,7 +390,9 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
                     pen += trap * gw[r] * res[g][r] * res[g][r];
                 }
         }
+        CH_STAMP(4);
         if (st + NT < total) issue(st + NT);
+        CH_STAMP(5);
     }
     while (done < total) { lds_barrier(); done++; }
     if (MODE == 1 && a.guard_diag) {                     // one atomic per workgroup

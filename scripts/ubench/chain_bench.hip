@@ -98,12 +98,12 @@ int main(int argc, char **argv)
     }
     printf("max |device - host| = %.3e (max |ref| %.3e)\n", err, ref_max);
 #ifdef QGD_CHAIN_PROFILE
-    long long pr[64 * 4];
+    long long pr[64 * 8];
     hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_chain_prof), sizeof pr);
-    printf("step: wake->mfma_done  ->lds_written  ->barrier_passed | wake(st) - barrier_passed(st-1)   [cycles, block 0]\n");
+    printf("step: wake->mfma_done  ->lds_written  ->barrier_passed  ->stores_issued  ->prefetch_issued | wake(st) - barrier_passed(st-1)   [cycles, block 0]\n");
     for (int st = 0; st < std::min(blen, 16); st++)
-        printf("%3d: %6lld %6lld %6lld | %6lld\n", st, pr[st * 4 + 1] - pr[st * 4], pr[st * 4 + 2] - pr[st * 4 + 1], pr[st * 4 + 3] - pr[st * 4 + 2],
-               st ? pr[st * 4] - pr[(st - 1) * 4 + 3] : 0LL);
+        printf("%3d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", st, pr[st * 8 + 1] - pr[st * 8], pr[st * 8 + 2] - pr[st * 8 + 1], pr[st * 8 + 3] - pr[st * 8 + 2],
+               pr[st * 8 + 4] - pr[st * 8 + 3], pr[st * 8 + 5] - pr[st * 8 + 4], st ? pr[st * 8] - pr[(st - 1) * 8 + 3] : 0LL);
 #endif
     return 0;
 }
