@@ -362,6 +362,8 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
         for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
     INV_PROF(0);
     bool used = lane >= NP;                             // panel wave: this lane's row has been a pivot row
+    // which wave factors the panels (rotating it differently across workgroups that share a CU, e.g. with
+    // blockIdx/256, changes nothing: 108-111 us for 550 matrices either way)
     const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
 
     for (int pn = 0; pn < NP / 4; pn++) {
@@ -388,6 +390,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
         //         the workgroups sharing a CU sit on different SIMDs): pivoted in-place Gauss-Jordan
         //         on the NP x 4 panel, lane = row
         if (w == pw) {
+            __builtin_amdgcn_s_setprio(1);      // the pivot chain is the critical path: ahead of other workgroups' MFMA bursts on this SIMD
             double xr[4], xi[4];
             const int lrow = (lane < NP) ? lane : 0;
             #pragma unroll
@@ -419,6 +422,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 #pragma unroll
                 for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         INV_PROF(2);
