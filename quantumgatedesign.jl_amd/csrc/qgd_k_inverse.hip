@@ -470,6 +470,8 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
         // read above (G, Prow) alternate with the panel parity
     }
     __syncthreads();
+    // (from here on the barriers order LDS traffic only -- lds_barrier: __syncthreads would also wait for the global
+    //  stores of the previous plane to be acknowledged, four times)
     // ---- output.  A^-1[rinv[x]][rho[j]] = M[x][j] goes through LDS one plane at a time (real parts,
     // then imaginary parts): each staged plane is written out as LinvT (left operand of
     // lambda = L^-H y) and is at once the A operand of one half of the step propagator
@@ -497,8 +499,15 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 for (int r = 0; r < 4; r++) smem[orow[r] + oc] = M[g][r];
             }
         }
-        __syncthreads();
-        for (int e = t; e < NP * NP; e += NTH) T[pass * pl + e] = smem[(e / NP) * LDP + (e % NP)];
+        lds_barrier();
+        {   // (buffer-addressed: descriptor and the constant part of the offset in SGPRs, no 64-bit vector adds)
+            const __amdgpu_buffer_rsrc_t rT = buffer_of(T + pass * pl);
+            #pragma unroll
+            for (int q = 0; q < NP * NP / NTH; q++) {
+                const int e = t + q * NTH;
+                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
+            }
+        }
         #pragma unroll 4
         for (int ks = 0; ks < NP / 4; ks++) {
             const int k = 4 * ks + kk;
@@ -516,7 +525,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
     // column-major planes (left operand of the forward sweep) through LDS
@@ -539,9 +548,16 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                     for (int r = 0; r < 4; r++)
                         smem[(8 * (GPW * w + gg) + (c16 & 7)) * LDP + 16 * rt + kk + 4 * r] = acc[rt][gg][r];   // [col][row]
         }
-        __syncthreads();
-        for (int e = t; e < NP * NP; e += NTH) Pcn[pass * pl + e] = smem[(e / NP) * LDP + (e % NP)];
-        __syncthreads();
+        lds_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t rC = buffer_of(Pcn + pass * pl);
+            #pragma unroll
+            for (int q = 0; q < NP * NP / NTH; q++) {
+                const int e = t + q * NTH;
+                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rC, t * 8, q * NTH * 8);
+            }
+        }
+        lds_barrier();
     }
     INV_PROF(5);
 #undef INV_PROF

@@ -57,6 +57,36 @@ __device__ __forceinline__ double row16_sum(double v)
     return v;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0)
+// + s_barrier: in the team pipeline below a wave reaches the next barrier right after issuing the global loads of
+// its step four steps ahead (and its history stores), so EVERY step barrier waited ~1100 cycles for another team's
+// prefetch to land (scripts/ubench/chain_bench.hip -DQGD_CHAIN_PROFILE: 2500 cycles of MFMAs, then 1500 to get
+// through the barrier; 370 in the last steps, which prefetch nothing).  All communication between the waves of a
+// chain goes through LDS; nothing written to global memory is read again inside the kernel.
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Buffer-addressed 8-byte load / store: address = descriptor base (SGPRs, wave-uniform) + soff (SGPR or constant)
+// + voff (one VGPR byte offset per lane).  No vector ALU instruction is needed to form the address.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const double *base)      // base must be wave-uniform
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double buffer_load_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buffer_store_f64(double x, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    u32x2 d; d.x = (unsigned)__double2loint(x); d.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+}
+
 // ---------------------------------------------------------------------------
 // A-fragment providers: value of the LEFT operand at (row, k)
 // ---------------------------------------------------------------------------
