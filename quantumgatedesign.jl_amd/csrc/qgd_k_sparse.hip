@@ -161,14 +161,14 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     double *st = reinterpret_cast<double *>(Ds);        // [64][SS]
     #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        __syncthreads();
+        lds_barrier();                                  // (LDS-only: the stores of L stay in flight while R is staged)
         #pragma unroll
         for (int c = 0; c < 4; c++) {
             const c2 v = pass ? Racc[c] : Lacc[c];
             const int lc = cl + c, o = r * SS + (lc >> 3) * 16 + (lc & 7);
             st[o] = v.re; st[o + 8] = v.im;
         }
-        __syncthreads();
+        lds_barrier();
         double *dst = (pass ? R : L) + (size_t)n * Np * PW + slab * 2 * CW;
         for (int item = tid; item < Np * SW; item += NTH) {
             const int row = item / SW, k = item % SW;
