@@ -301,10 +301,14 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
     qgdk_ctx &k = h->k;
     if (pcof) {
         if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
-        int rc = upload_pcof(h, pcof, n_pcof);
-        if (rc) return rc;
         PhaseTimer t(h, "tables");
-        K_TRY(h, qgdk_tables(&k, h->pcof_dev));
+        if (n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !getenv("QGD_PCOF_COPY")) {   // (a captured graph would freeze the values)
+            K_TRY(h, qgdk_tables_kernarg(&k, pcof, n_pcof));      // pcof rides in the kernel arguments: no copy packet
+        } else {
+            int rc = upload_pcof(h, pcof, n_pcof);
+            if (rc) return rc;
+            K_TRY(h, qgdk_tables(&k, h->pcof_dev));
+        }
     } else if (!h->have_tables && k.n_ops > 0) {
         return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
     }

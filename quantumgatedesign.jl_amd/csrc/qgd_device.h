@@ -80,6 +80,8 @@ extern "C" {
 #endif
 int qgdk_tables(const qgdk_ctx *c, const double *pcof_dev);
 int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double *qt_dev);
+#define QGD_PCOF_KERNARG 448      /* doubles of pcof that fit beside the other kernel arguments (4 KB) */
+int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof);
 int qgdk_build_LR(const qgdk_ctx *c);
 int qgdk_inverse(const qgdk_ctx *c);
 int qgdk_propagator(const qgdk_ctx *c);

@@ -1,6 +1,7 @@
 // qgd_k_build.hip -- control tables and the step matrices L_n, R_n
 // (conventions and layouts: qgd_kernels_common.h; algorithm: DESIGN.md)
 #include "qgd_kernels_common.h"
+#include <string.h>
 
 // ---------------------------------------------------------------------------
 // K0: control tables  tab[n][d][k][pq] = sum_l G[k][n][d][l] * pcof[off_k + l]
@@ -27,6 +28,35 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
         // G for control k: [pq][nt][m+1][nc]
         const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
         const double *pc = pcof + poff[k];
+        for (int l = sub; l < nc; l += 16) s = __builtin_fma(g[l], pc[l], s);
+    }
+    s = row16_sum(s);
+    if (idx < total && sub == 15) tab[idx] = s;
+}
+
+// The same with the coefficient vector passed BY VALUE in the kernel arguments (up to QGD_PCOF_KERNARG doubles):
+// an evaluation then starts with this kernel instead of with a 1.4 KB host-to-device copy packet and the gap
+// behind it (2.9 + 6 us on the timeline of one cnot3 evaluation).
+struct PcofArg { double v[QGD_PCOF_KERNARG]; };
+__global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                         const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
+                         const PcofArg pcof, double *__restrict__ tab, int nt, int m,
+                         int n_ops, double *__restrict__ scal, int *__restrict__ status)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < 4) scal[gid] = 0.0;
+    if (gid == 4) *status = 0;
+    const int idx = gid >> 4, sub = gid & 15;
+    const int total = nt * (m + 1) * n_ops * 2;
+    double s = 0.0;
+    if (idx < total) {
+        const int pq = idx & 1;
+        const int k = (idx >> 1) % n_ops;
+        const int d = ((idx >> 1) / n_ops) % (m + 1);
+        const int n = ((idx >> 1) / n_ops) / (m + 1);
+        const int nc = ncoef[k];
+        const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
+        const double *pc = pcof.v + poff[k];
         for (int l = sub; l < nc; l += 16) s = __builtin_fma(g[l], pc[l], s);
     }
     s = row16_sum(s);
@@ -318,6 +348,17 @@ int qgdk_tables(const qgdk_ctx *c, const double *pcof)
     int total = c->nt * (c->m + 1) * c->n_ops * 2;
     hipLaunchKernelGGL(k_tables, dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
                        c->poff, pcof, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
+    return (int)hipGetLastError();
+}
+
+int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    if (n_pcof > QGD_PCOF_KERNARG) return (int)hipErrorInvalidValue;
+    PcofArg arg;
+    memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
+    int total = c->nt * (c->m + 1) * c->n_ops * 2;
+    hipLaunchKernelGGL(k_tables_arg, dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
+                       c->poff, arg, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
     return (int)hipGetLastError();
 }
 
