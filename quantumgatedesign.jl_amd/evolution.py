@@ -125,6 +125,19 @@ class DeviceProblem:
 
     def discrete_adjoint(self, pcof, history_precomputed=False, uv_history=None, lambda_history=None,
                          adjoint_forcing=None):
+        if uv_history is None and lambda_history is None and adjoint_forcing is None and len(pcof) == self.n_pcof:
+            # the optimiser's call: persistent host buffers with cached pointers (three ndarray.ctypes look-ups
+            # cost 6 us, 1.5 % of a cnot3 evaluation)
+            io = self.__dict__.get("_io")
+            if io is None or len(io[0]) != self.n_pcof:
+                bufs = (np.zeros(self.n_pcof), np.zeros(self.n_pcof), np.zeros(3))
+                io = self._io = bufs + tuple(_vp(b) for b in bufs)
+            io[0][:] = pcof
+            rc = self.lib.qgd_discrete_adjoint(self.h, io[3], self.n_pcof, 1 if history_precomputed else 0, io[4],
+                                               None, None, None, io[5])
+            if rc:
+                _lib.check(self.h, rc)
+            return io[1].copy(), io[2].copy()
         pc = np.ascontiguousarray(pcof, dtype=np.float64)
         grad = np.zeros(len(pc))
         out3 = np.zeros(3)
