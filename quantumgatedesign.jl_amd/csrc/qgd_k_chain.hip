@@ -193,13 +193,23 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     const int total = npfx + nsteps;
 
     // start state into part[0]
+    auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
+    // The first step of a chain that starts from the identity (MODE 0) or from zero (MODE 2) needs no product: its
+    // result is the step matrix itself / the forcing.  It is loaded straight into the buffer step 1 reads.
+    constexpr bool SKIP0 = (MODE == 0 || MODE == 2);
+    const int first = (SKIP0 && total > 0) ? 1 : 0;
     for (int e = tid; e < NG * NP * 16; e += NTH) {
         const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
         double v;
-        if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
+        if (SKIP0 && first) {
+            const int n0 = step_index(0);
+            if (MODE == 0) v = chain_matrix(a, n0)[(c >= 8 ? (size_t)NP * NP : 0) + row + (size_t)NP * ((grp0 + g) * 8 + (c & 7))];
+            else v = a.forcing[(size_t)(a.f_bpr ? n0 + n0 / a.f_bpr : n0) * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c];
+        }
+        else if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
         else if (ZERO) v = 0.0;
         else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
-        part[0][g][el] = v;
+        part[first][g][el] = v;
         if (MODE == 1 && a.guard_diag && s0 == 0 && !(a.npre > 0 && a.pre_kind[0] == 0)) {   // the window's first point is nobody's product
             const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
             const double trap = (a.n_off == 0) ? 0.5 : 1.0;
@@ -216,7 +226,6 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             gw[r] = (row < a.gN) ? a.guard_diag[row + ((c16 >= 8) ? a.gN : 0)] : 0.0;
         }
     }
-    auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
     auto issue = [&](int st) {                            // left operand (and forcing) of step st
         int n, fbpr = a.f_bpr;
         const double *Pn, *fsrc = a.forcing;
@@ -279,7 +288,8 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             }
         }
     };
-    if (team < total) issue(team);
+    const int st0 = (team < first) ? team + NT : team;   // this team's first step
+    if (st0 < total) issue(st0);
     lds_barrier();
 
 #ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
@@ -287,8 +297,8 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
 #else
 #define CH_STAMP(slot) do { } while (0)
 #endif
-    int done = 0;                                         // step barriers this wave has passed
-    for (int st = team; st < total; st += NT) {
+    int done = first;                                     // step barriers this wave has passed
+    for (int st = st0; st < total; st += NT) {
         while (done < st) { lds_barrier(); done++; }     // steps of the other teams
         CH_STAMP(0);
         const bool mainstep = st >= npfx;
