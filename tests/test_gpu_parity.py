@@ -233,6 +233,29 @@ def test_graph_replay_matches_plain_launches(qgd, which, monkeypatch):
     qgd.clear_cache()
 
 
+@pytest.mark.parametrize("n_basis,force_copy", [(10, True), (300, False)])
+def test_pcof_upload_paths(qgd, n_basis, force_copy, monkeypatch):
+    """pcof travels in the kernel arguments of k_tables when it fits (<= 448 coefficients) and through a device
+    copy otherwise (here 2 x 600) or with QGD_PCOF_COPY=1: both against the numpy statement of the algorithm."""
+    if force_copy:
+        monkeypatch.setenv("QGD_PCOF_COPY", "1")
+    prob, target = qgd.cnot2_problem(nsteps=24, tf=24.0)
+    ctrl = [qgd.GeneralBSplineControl(2, n_basis, prob.tf) for _ in range(prob.N_operators)]
+    npar = qgd.get_number_of_control_parameters(ctrl)
+    assert (npar > 448) == (not force_copy)
+    pcof = 0.05 * (0.5 - np.random.default_rng(4).random(npar))
+    order = 6
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    for scale in (1.0, 0.5):            # two different vectors through the same handle
+        ref = pp.evaluate(prob, Gp, Gq, off, scale * pcof, target, order)
+        grad, _ = dp.discrete_adjoint(scale * pcof)
+        assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
+    dp.close()
+    qgd.clear_cache()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_time_partitioned_large_n(qgd, world):
     """Time windows with the large-N kernels (GEMM tiles, 32-column chain tiles, blocked inverse): N=100,
