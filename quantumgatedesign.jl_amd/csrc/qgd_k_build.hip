@@ -37,10 +37,11 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
 // The same with the coefficient vector passed BY VALUE in the kernel arguments (up to QGD_PCOF_KERNARG doubles):
 // an evaluation then starts with this kernel instead of with a 1.4 KB host-to-device copy packet and the gap
 // behind it (2.9 + 6 us on the timeline of one cnot3 evaluation).
-struct PcofArg { double v[QGD_PCOF_KERNARG]; };
+template <int NMAX> struct PcofArg { double v[NMAX]; };      // (the launch cost grows with the argument size: 3 sizes)
+template <int NMAX>
 __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
-                         const PcofArg pcof, double *__restrict__ tab, int nt, int m,
+                         const PcofArg<NMAX> pcof, double *__restrict__ tab, int nt, int m,
                          int n_ops, double *__restrict__ scal, int *__restrict__ status)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -341,6 +342,17 @@ static int launch_build_LR64(const qgdk_ctx *c)
     return 0;
 }
 
+template <int NMAX>
+static int launch_tables_arg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    PcofArg<NMAX> arg;
+    memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
+    int total = c->nt * (c->m + 1) * c->n_ops * 2;
+    hipLaunchKernelGGL((k_tables_arg<NMAX>), dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
+                       c->poff, arg, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int qgdk_tables(const qgdk_ctx *c, const double *pcof)
@@ -353,13 +365,10 @@ int qgdk_tables(const qgdk_ctx *c, const double *pcof)
 
 int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
 {
-    if (n_pcof > QGD_PCOF_KERNARG) return (int)hipErrorInvalidValue;
-    PcofArg arg;
-    memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
-    int total = c->nt * (c->m + 1) * c->n_ops * 2;
-    hipLaunchKernelGGL(k_tables_arg, dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
-                       c->poff, arg, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
-    return (int)hipGetLastError();
+    if (n_pcof <= 64) return launch_tables_arg<64>(c, pcof_host, n_pcof);
+    if (n_pcof <= 192) return launch_tables_arg<192>(c, pcof_host, n_pcof);
+    if (n_pcof <= QGD_PCOF_KERNARG) return launch_tables_arg<QGD_PCOF_KERNARG>(c, pcof_host, n_pcof);
+    return (int)hipErrorInvalidValue;
 }
 
 int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt, const double *qt)
