@@ -382,7 +382,7 @@ static int launch_build_ell_nw(const qgdk_ctx *c)
 template <int M>
 static int launch_build_ell(const qgdk_ctx *c)
 {
-    static const bool narrow = getenv("QGD_BUILD_ELL_NARROW") != nullptr;
+    const bool narrow = getenv("QGD_BUILD_ELL_NARROW") != nullptr;      // (comparison path; not static so that tests can switch it)
     return narrow ? launch_build_ell_nw<M, 4>(c) : launch_build_ell_nw<M, 8>(c);
 }
 

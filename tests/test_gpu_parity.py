@@ -233,6 +233,25 @@ def test_graph_replay_matches_plain_launches(qgd, which, monkeypatch):
     qgd.clear_cache()
 
 
+@pytest.mark.parametrize("switch", ["QGD_ELL_ROW_PACKED", "QGD_BUILD_ELL_NARROW"])
+def test_sparse_kernel_comparison_paths(qgd, switch, monkeypatch):
+    """The alternatives kept beside the default sparse kernels -- row-packed ELL slots instead of diagonal-ordered
+    ones, 16-column build workgroups instead of 32-column ones -- give the same gradient (cnot3 order 8, guarded
+    two-qutrit problem order 6) as the numpy statement of the algorithm."""
+    monkeypatch.setenv(switch, "1")
+    qgd.clear_cache()
+    for which, order in (("cnot3", 8), ("guarded", 6)):
+        prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+        Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+        ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        assert dp.operator_path()[0] == "sparse"
+        grad, _ = dp.discrete_adjoint(pcof)
+        dp.close()
+        assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max(), which
+    qgd.clear_cache()
+
+
 @pytest.mark.parametrize("n_basis,force_copy", [(10, True), (300, False)])
 def test_pcof_upload_paths(qgd, n_basis, force_copy, monkeypatch):
     """pcof travels in the kernel arguments of k_tables when it fits (<= 448 coefficients) and through a device
