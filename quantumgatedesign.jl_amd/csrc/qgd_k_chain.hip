@@ -649,7 +649,7 @@ static int launch_chain(const ChainArgs &a, hipStream_t stream)
     // the matrix-matrix chains (block propagators) pair up column groups when one group per
     // workgroup would need more than one workgroup per CU: half the L2 traffic for the step
     // matrices at the same MFMA time; small grids keep one group per workgroup (shorter steps)
-    if (MODE == 0 && a.ngroups % 2 == 0 && (long long)a.nblocks * a.ngroups > 256) return launch_chain_ng<MODE, 2>(a, stream);
+    if (MODE == 0 && a.ngroups % 2 == 0 && (long long)a.nblocks * a.ngroups > 256) return launch_chain_ng<MODE, 2>(a, stream);   // (one group per workgroup, two workgroups per CU: the same within 2 %)
     return launch_chain_ng<MODE, 1>(a, stream);
 }
 
