@@ -88,6 +88,16 @@ def measured_traffic(phase):
     return (2.0 * f + w) * 1024.0
 
 
+def measured_mfma_util(phase):
+    """MFMA pipe utilisation of the phase's kernel from the committed counter pass (profiles/r01_v11_pmc_mfma_cnot3.json:
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_v11_pmc_mfma_cnot3.json")
+    kern = KERNEL_OF_PHASE.get(phase, "").replace("void ", "")
+    if not kern or not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("kernels", {}).get(kern, {}).get("mfma_util")
+
+
 def cpu_baseline(qgd, orc, seconds_target=12.0):
     """Oracle ('port' of the reference CPU path) on a bounded sample: the same cnot3 problem and
     controls at dt=1 with fewer steps, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19),
@@ -305,7 +315,7 @@ def main():
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
                        "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom).replace("void ", ""), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": measured_traffic(dom),
+                         "frac": achieved / peak, "traffic": measured_traffic(dom), "mfma_pipe_busy_pmc": measured_mfma_util(dom),
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
