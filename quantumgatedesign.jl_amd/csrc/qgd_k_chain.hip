@@ -830,6 +830,50 @@ __global__ __launch_bounds__(256) void k_lambda(const double *__restrict__ LinvT
     }
 }
 
+// the same with the size at compile time (Np <= 64): the 2 * Np/4 fragment loads of a wave are all issued before the
+// first MFMA needs one (the run-time loop above waits for a global round trip per k-step)
+template <int NPC>
+__global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ LinvT, const double *__restrict__ yhist,
+                                                  double *__restrict__ lam, int cp, double *__restrict__ zero_a, int n_a,
+                                                  double *__restrict__ zero_b, int n_b)
+{
+    {
+        const int gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const int gsz = gridDim.x * gridDim.y * blockDim.x;
+        for (int e = gid; e < n_a; e += gsz) zero_a[e] = 0.0;
+        for (int e = gid; e < n_b; e += gsz) zero_b[e] = 0.0;
+    }
+    __shared__ double ys[NPC * 16];
+    const int n = blockIdx.y + 1, grp = blockIdx.x;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)NPC * PWc, pl = (size_t)NPC * NPC;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const double *Tre = LinvT + (size_t)n * 2 * pl, *Tim = Tre + pl;
+    double are[NPC / 4], aim[NPC / 4];
+    const bool live = wave * 16 < NPC;
+    if (live) {
+        const int arow = wave * 16 + c16;
+        #pragma unroll
+        for (int i = 0; i < NPC / 4; i++) { are[i] = Tre[arow + NPC * (4 * i + kk)]; aim[i] = Tim[arow + NPC * (4 * i + kk)]; }
+    }
+    for (int e = threadIdx.x; e < NPC * 16; e += blockDim.x)
+        ys[e] = yhist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    if (!live) return;
+    d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+    #pragma unroll
+    for (int i = 0; i < NPC / 4; i++) {
+        double b1, b2;
+        panel_b(ys + (size_t)(4 * i + kk) * 16, c16, b1, b2);
+        acc0 = MFMA(are[i], b1, acc0);
+        acc1 = MFMA(-aim[i], b2, acc1);          // (Linv^H)(row,k) = conj(Linv(k,row))
+    }
+    #pragma unroll
+    for (int r = 0; r < 4; r++)
+        lam[(size_t)n * hstep + (size_t)(wave * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = acc0[r] + acc1[r];
+}
+
 extern "C" {
 
 static inline bool chain_is_fast(const qgdk_ctx *c) { return c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64; }
@@ -1141,6 +1185,16 @@ int qgdk_forcing_sweep(const qgdk_ctx *c)
 int qgdk_lambda(const qgdk_ctx *c)
 {
     if (c->dense_gemm && !c->use_sparse && c->nt > 1) return qgdk_dense_lambda(c);
+#define CALL_LC(N) hipLaunchKernelGGL((k_lambda_c<N>), dim3(c->cp / 8, c->nt - 1), dim3(256), 0, c->stream, c->LinvT, c->yhist, c->lam, \
+                                      c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof)
+    if (c->nt > 1) switch (c->Np) {
+        case 16: CALL_LC(16); return (int)hipGetLastError();
+        case 32: CALL_LC(32); return (int)hipGetLastError();
+        case 48: CALL_LC(48); return (int)hipGetLastError();
+        case 64: CALL_LC(64); return (int)hipGetLastError();
+        default: break;
+    }
+#undef CALL_LC
     size_t shm = (size_t)c->Np * 16 * sizeof(double);
     hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
                        c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof);
