@@ -492,12 +492,13 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
 // slot of an LDS row is XOR-ed with row%4 so that the four k-rows of a B fragment fall in different banks.
 // 8 waves, wave w owns row blocks w*RBW .. w*RBW+RBW-1; A fragments of step k4+1 are in flight while
 // the MFMAs of step k4 issue.  Two barriers per step (a step is >= 25 us of MFMA time at these sizes).
-template <int MODE, int RBW>
+template <int MODE, int RBW, int NGT>
 __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
 {
     constexpr bool ADJ = (MODE >= 2);
     extern __shared__ double cur[];
-    const int Np = a.Np, nrb = Np >> 4, ngt = (a.ngroups + 3) >> 2;
+    constexpr int TW = 16 * NGT;                         // doubles per state row of the tile
+    const int Np = a.Np, nrb = Np >> 4, ngt = (a.ngroups + NGT - 1) / NGT;
     int b, ct;
     if (MODE == 0) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; b = xcd + 8 * (slot / ngt); ct = slot % ngt; }
     else { b = blockIdx.x / ngt; ct = blockIdx.x % ngt; }
@@ -509,14 +510,14 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
     const int c16 = lane & 15, kk = lane >> 4;
     // B operand [-Bim | Bre]; the adjoint's A fragment is loaded un-conjugated, the sign goes here
     const int sign_hi = ((c16 < 8) != ADJ) ? (int)0x80000000 : 0;
-    for (int e = tid; e < Np * 64; e += blockDim.x) {
-        const int row = e >> 6, g = (e >> 4) & 3, c = e & 15, grp = ct * 4 + g;
+    for (int e = tid; e < Np * TW; e += blockDim.x) {
+        const int row = e / TW, g = (e >> 4) % NGT, c = e & 15, grp = ct * NGT + g;
         double v = 0.0;
         if (grp < a.ngroups) {
             if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
             else if (MODE != 2) v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
         }
-        cur[(size_t)row * 64 + ((g ^ (row & 3)) << 4) + c] = v;
+        cur[(size_t)row * TW + ((g ^ (row & (NGT - 1))) << 4) + c] = v;
     }
     __syncthreads();
     int rb[RBW];
@@ -526,11 +527,11 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
         const int n = ADJ ? e0 - 1 - st : s0 + st;
         const int nout = ADJ ? n : n + 1;
         const double *Pn = chain_matrix(a, n);
-        d4 acc[RBW][4];
+        d4 acc[RBW][NGT];
         #pragma unroll
         for (int r = 0; r < RBW; r++)
             #pragma unroll
-            for (int g = 0; g < 4; g++) acc[r][g] = (d4){0, 0, 0, 0};
+            for (int g = 0; g < NGT; g++) acc[r][g] = (d4){0, 0, 0, 0};
         int arow[RBW];
         #pragma unroll
         for (int r = 0; r < RBW; r++) arow[r] = (rb[r] < nrb ? rb[r] : 0) * 16 + c16;
@@ -545,10 +546,10 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
             const int kn = (k0 + 8 < Np) ? k0 + 8 : k0;
             #pragma unroll
             for (int r = 0; r < RBW; r++) chain_a_raw<ADJ>(Pn, Np, arow[r], kn + kk, n2re[r], n2im[r]);
-            const double *brow = cur + (size_t)(k0 + kk) * 64 + c16;
+            const double *brow = cur + (size_t)(k0 + kk) * TW + c16;
             #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const double b1 = brow[(g ^ kk) << 4];
+            for (int g = 0; g < NGT; g++) {
+                const double b1 = brow[(g ^ (kk & (NGT - 1))) << 4];
                 const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);
                 const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);
                 const double b2 = __hiloint2double(hi ^ sign_hi, lo);
@@ -566,8 +567,8 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
         for (int r = 0; r < RBW; r++) {
             if (rb[r] >= nrb) continue;
             #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int grp = ct * 4 + g;
+            for (int g = 0; g < NGT; g++) {
+                const int grp = ct * NGT + g;
                 if (grp >= a.ngroups) continue;
                 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
                     double v = acc[r][g][e];
                     const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16;
                     if (ADJ) v += a.forcing[a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho];
-                    cur[(size_t)row * 64 + ((g ^ kk) << 4) + c16] = v;
+                    cur[(size_t)row * TW + ((g ^ (kk & (NGT - 1))) << 4) + c16] = v;
                     if (MODE == 1 || MODE == 3) a.out[ho] = v;
                 }
             }
@@ -585,10 +586,10 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
     if (MODE == 0 || MODE == 2) {
         const size_t pl = (size_t)Np * Np;
         double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
-        for (int e = tid; e < Np * 64; e += blockDim.x) {
-            const int row = e >> 6, g = (e >> 4) & 3, c = e & 15, grp = ct * 4 + g;
+        for (int e = tid; e < Np * TW; e += blockDim.x) {
+            const int row = e / TW, g = (e >> 4) % NGT, c = e & 15, grp = ct * NGT + g;
             if (grp >= a.ngroups) continue;
-            const double v = cur[(size_t)row * 64 + ((g ^ (row & 3)) << 4) + c];
+            const double v = cur[(size_t)row * TW + ((g ^ (row & (NGT - 1))) << 4) + c];
             if (MODE == 0) {
                 const int col = grp * 8 + (c & 7);
                 pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)Np * col] = v;
@@ -600,25 +601,38 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
     }
 }
 
-template <int MODE>
-static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
+// Tile width: 4 column groups per workgroup stream the step matrix once per 32 columns -- the right choice when
+// there are more tiles than CUs (config 5: 32 blocks x 8 tiles).  When there are not, the step time of ONE workgroup
+// is what counts and narrower tiles put more CUs on the same chain (N = 100, 32 columns, 54 blocks: one 4-group tile
+// per block is 54 workgroups at 10.5 us per step, four 1-group tiles are 216 at 1.5 us).
+template <int MODE, int NGT>
+static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
 {
-    const int ngt = (a.ngroups + 3) / 4, nrb = a.Np / 16;
+    const int ngt = (a.ngroups + NGT - 1) / NGT, nrb = a.Np / 16;
     const int nwg = (MODE == 0) ? 8 * ngt * ((a.nblocks + 7) / 8) : a.nblocks * ngt;
-    const size_t shm = (size_t)a.Np * 64 * sizeof(double);
+    const size_t shm = (size_t)a.Np * 16 * NGT * sizeof(double);
     if (nwg <= 0) return 0;
-#define CALL_CD(R) do { SET_LDS_ONCE((k_chain_dense<MODE, R>), shm); \
-        hipLaunchKernelGGL((k_chain_dense<MODE, R>), dim3(nwg), dim3(512), shm, stream, a); } while (0)
+#define CALL_CD(R) do { SET_LDS_ONCE((k_chain_dense<MODE, R, NGT>), shm); \
+        hipLaunchKernelGGL((k_chain_dense<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); } while (0)
     if (nrb <= 8) CALL_CD(1); else if (nrb <= 16) CALL_CD(2); else CALL_CD(3);
 #undef CALL_CD
     return (int)hipGetLastError();
+}
+
+template <int MODE>
+static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
+{
+    const long long cus = 256;
+    if ((long long)a.nblocks * a.ngroups <= 2 * cus) return launch_chain_dense_w<MODE, 1>(a, stream);
+    if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= 2 * cus) return launch_chain_dense_w<MODE, 2>(a, stream);
+    return launch_chain_dense_w<MODE, 4>(a, stream);
 }
 
 // the dense chain pays when a tile of 4 groups is (nearly) full and the state tile fits in LDS
 static bool chain_is_dense(const ChainArgs &a)
 {
     const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;     // (comparison path; a getenv per launch is noise at these sizes)
-    return !off && a.Np > 64 && a.Np <= 288 && a.ngroups >= 3;
+    return !off && a.Np > 64 && a.Np <= 288;
 }
 
 template <int MODE, int NG>
