@@ -594,10 +594,17 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
     const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
     double *W = scratch + (size_t)blockIdx.x * panel;
     const double *Ln = L + (size_t)n * panel;
+#ifdef QGD_INVB_PROFILE
+    long long pt[8] = {0,0,0,0,0,0,0,0}, pl_ = clock64();
+#define IBP(i) do { const long long n_ = clock64(); pt[i] += n_ - pl_; pl_ = n_; } while (0)
+#else
+#define IBP(i) do { } while (0)
+#endif
     for (size_t e = t; e < panel; e += nth) W[e] = Ln[e];
     for (int r = t; r < Np; r += nth) used[r] = 0;
     __syncthreads();
 
+    IBP(0);
     for (int p0 = 0; p0 < Np; p0 += NB) {
         // ---- 1. the 16 panel columns into LDS
         for (int e = t; e < Np * NB; e += nth) {
@@ -606,6 +613,7 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
             Fre[e] = W[o]; Fim[e] = W[o + 8];
         }
         __syncthreads();
+        IBP(1);
         // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
         for (int s = 0; s < NB; s++) {
             double best = -1.0; int bi = 0;
@@ -646,9 +654,11 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
             }
             __syncthreads();
         }
+        IBP(2);
         // ---- 3. the 16 pivot rows (their values before the block step) as B operand
         for (int e = t; e < NB * PW; e += nth) Bp[e] = W[(size_t)rho[p0 + e / PW] * PW + (e % PW)];
         __syncthreads();
+        IBP(3);
         // ---- 4. rank-16 block step, tile by tile: M += A M[P,:], A = multipliers (minus identity on the
         //         pivot rows); the pivot columns then take the multipliers (the in-place inverse entries)
         const int ngroups = Np / 8, gp = p0 >> 3;
@@ -680,6 +690,7 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
             for (int r = 0; r < 4; r++) W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16] = acc[r];
         }
         __syncthreads();
+        IBP(4);
     }
     // A^-1[rinv[x]][rho[j]] = M[x][j]
     double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
@@ -691,6 +702,10 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
         T[i * Np + c] = re; T[pl + i * Np + c] = im;
         A[i + Np * c] = re; A[pl + i + Np * c] = im;
     }
+    IBP(5);
+#ifdef QGD_INVB_PROFILE
+    if (blockIdx.x == 0 && t == 0) printf("invb cycles: load %lld, panel cols %lld, pivots %lld, pivot rows %lld, update %lld, output %lld\n", pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
 }
 
 static inline size_t inverse_blocked_lds(int Np)
