@@ -470,7 +470,9 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
                                       c->ops, c->tab, Af, c->Np, c->n_ops, c->m)
     DISPATCH_NOPS(c->n_ops, CALL_AF)
 #undef CALL_AF
-    const int grid = dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt);     // Np/8 >= 9 column groups here
+    // Np/8 >= 9 column groups here.  (64-row tiles <1,4>, to have 6.3 rounds of workgroups instead of 3.14 at config 5,
+    //  were slower: 7.95 vs 7.2 ms for the six levels.)
+    const int grid = dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt);
     for (int j = 0; j < c->m; j++)
         hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->cw, c->Np, c->m,
                            c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
