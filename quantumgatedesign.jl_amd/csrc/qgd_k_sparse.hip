@@ -32,6 +32,7 @@ __device__ __forceinline__ void cfma(c2 &acc, const c2 a, const c2 x)
 // assemble A_d(t_n) = K - iS, d = 0..nd-1, over the union pattern into LDS:
 // As[(d*Z + e)*64 + r] = (K, -S).  One (entry, row) pair per thread: the operator values are
 // fetched once and combined with the coefficients of every derivative order.
+template <int NOPS = -1>       // NOPS >= 0: the operator count at compile time (no exec-masked branch around each load)
 __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ ell_val,
                                              const double *__restrict__ tab, int n, int m, int nd,
                                              int n_ops, int Z, int Np, int tid, int nth)
@@ -45,8 +46,8 @@ __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ 
         kv[0] = live ? ell_val[at] : 0.0;
         sv[0] = live ? ell_val[per + at] : 0.0;
         #pragma unroll
-        for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {
-            const bool on = live && o < n_ops;
+        for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+            const bool on = live && NOPS_ON(NOPS, o, n_ops);
             kv[o + 1] = on ? ell_val[(size_t)(2 + 2 * o) * per + at] : 0.0;
             sv[o + 1] = on ? ell_val[(size_t)(3 + 2 * o) * per + at] : 0.0;
         }
@@ -54,8 +55,8 @@ __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ 
             const double *t = tab + (((size_t)n * (m + 1) + d) * n_ops) * 2;
             double K = (d == 0) ? kv[0] : 0.0, S = (d == 0) ? sv[0] : 0.0;
             #pragma unroll
-            for (int o = 0; o < QGD_MAX_OPS_DEV; o++) {
-                if (o < n_ops) { K = __builtin_fma(t[2 * o + 1], kv[o + 1], K); S = __builtin_fma(t[2 * o], sv[o + 1], S); }
+            for (int o = 0; o < NOPS_LIM(NOPS); o++) {
+                if (NOPS_ON(NOPS, o, n_ops)) { K = __builtin_fma(t[2 * o + 1], kv[o + 1], K); S = __builtin_fma(t[2 * o], sv[o + 1], S); }
             }
             As[(d * Z + e) * 64 + r] = (c2){K, -S};
         }
@@ -69,7 +70,7 @@ __device__ __forceinline__ void assemble_ell(c2 *As, const double *__restrict__ 
 // Source-major like the dense kernel: when D_i is complete its contributions to every later
 // level are accumulated at once, so D_i's neighbour rows are read from LDS once.
 // ---------------------------------------------------------------------------
-template <int M, int NW>
+template <int M, int NW, int NOPS>
 __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restrict__ ell_col,
                                                       const uint8_t *__restrict__ ell_inv,
                                                       const double *__restrict__ ell_val,
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
     const uint32_t slots = active ? *reinterpret_cast<const uint32_t *>(ell_inv + (size_t)r * Np + c0) : 0xffffffffu;
-    assemble_ell(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
+    assemble_ell<NOPS>(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
     SP_PROF(0);
     c2 T[M][4], Lacc[4], Racc[4];
     #pragma unroll
@@ -230,7 +231,7 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
         for (int j = 1; j <= M; j++)
             g[j - 1][c] = (c2){cw[2 * j] * lx.re - cw[2 * j + 1] * ln.re, cw[2 * j] * lx.im - cw[2 * j + 1] * ln.im};
     }
-    if (M > 1) assemble_ell(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
+    if (M > 1) assemble_ell<NOPS>(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
     SP_PROF(16);
     for (int item = tid; item < Z * 64; item += 256) {
         const int rr = item & 63, e = item >> 6;
@@ -369,13 +370,13 @@ static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 // default: 46.5 us on the 551-point benchmark grid against 49.8 us for NW = 4 (16 columns, 48 KB, three per CU,
 // QGD_BUILD_ELL_NARROW=1) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.
 // (Before the LDS accesses were 16-byte aligned both took 63 us, bound by bank conflicts.)
-template <int M, int NW>
+template <int M, int NW, int NOPS>
 static int launch_build_ell_nw(const qgdk_ctx *c)
 {
     const size_t shm = lds_build_ell(M, c->ell_z, NW);
-    SET_LDS_ONCE((k_build_LR_ell<M, NW>), shm);
-    hipLaunchKernelGGL((k_build_LR_ell<M, NW>), dim3(c->nt, (c->Np + 4 * NW - 1) / (4 * NW)), dim3(64 * NW), shm, c->stream, c->ell_col,
-                       c->ell_inv, c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
+    SET_LDS_ONCE((k_build_LR_ell<M, NW, NOPS>), shm);
+    hipLaunchKernelGGL((k_build_LR_ell<M, NW, NOPS>), dim3(c->nt, (c->Np + 4 * NW - 1) / (4 * NW)), dim3(64 * NW), shm, c->stream,
+                       c->ell_col, c->ell_inv, c->ell_val, c->tab, c->L, c->R, c->cw, c->Np, c->n_ops, c->ell_z);
     return (int)hipGetLastError();
 }
 
@@ -383,7 +384,11 @@ template <int M>
 static int launch_build_ell(const qgdk_ctx *c)
 {
     const bool narrow = getenv("QGD_BUILD_ELL_NARROW") != nullptr;      // (comparison path; not static so that tests can switch it)
-    return narrow ? launch_build_ell_nw<M, 4>(c) : launch_build_ell_nw<M, 8>(c);
+    if (narrow) return launch_build_ell_nw<M, 4, -1>(c);
+#define CALL_BE(N) return launch_build_ell_nw<M, 8, N>(c)
+    DISPATCH_NOPS(c->n_ops, CALL_BE)
+#undef CALL_BE
+    return 0;
 }
 
 template <int M, int NOPS>
