@@ -66,7 +66,7 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
     return model
 
 
-KERNEL_OF_PHASE = {"build_LR": "void k_build_LR_ell<4, 8>", "inverse": "void k_inverse_mfma<64>", "propagator": "k_propagator",
+KERNEL_OF_PHASE = {"build_LR": "void k_build_LR_ell<4, 8, 3>", "inverse": "void k_inverse_mfma<64>", "propagator": "k_propagator",
                    "lambda": "k_lambda", "guard": "k_guard_diag"}
 PMC_PROFILE = "r01_v11_pmc_fetch_write.json"
 
