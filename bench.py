@@ -66,64 +66,109 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
     return model
 
 
-KERNEL_OF_PHASE = {"build_LR": "void k_build_LR_ell<4, 8, 3>", "inverse": "void k_inverse_mfma<64>", "propagator": "k_propagator",
+KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_mfma", "propagator": "k_propagator",
                    "lambda": "k_lambda", "guard": "k_guard_diag"}
-PMC_PROFILE = "r01_v11_pmc_fetch_write.json"
+PMC_PROFILE = "r02_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
+PMC_MFMA_PROFILE = "r02_pmc_mfma_cnot3.json"
+
+
+def _lookup_kernel(table, kern):
+    """Value of the first key of `table` that names kernel `kern` (keys are full demangled names with template
+    arguments, e.g. 'void k_build_LR_ell<4, 8, 3>'; `kern` is the bare kernel name)."""
+    for key, val in (table or {}).items():
+        bare = key.replace("void ", "")
+        if bare == kern or bare.startswith(kern + "<") or bare.startswith(kern + "("):
+            return key, val
+    return None, None
 
 
 def measured_traffic(phase):
     """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes
     (profiles/PMC_PROFILE: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this same command;
     on gfx950 FETCH_SIZE counts half of a wide coalesced read, so it is doubled --
-    MI355X_MICROARCH.md 'HBM').  None when no profile of that kernel is committed."""
+    MI355X_MICROARCH.md 'HBM').  (None, None) when no profile of that kernel is committed."""
     path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     kern = KERNEL_OF_PHASE.get(phase)
     if not kern or not os.path.exists(path):
-        return None
+        return None, None
     d = json.load(open(path))
-    f = d.get("FETCH_SIZE_KB_mean_per_launch", {}).get(kern)
-    w = d.get("WRITE_SIZE_KB_mean_per_launch", {}).get(kern)
+    _, f = _lookup_kernel(d.get("FETCH_SIZE_KB_mean_per_launch"), kern)
+    _, w = _lookup_kernel(d.get("WRITE_SIZE_KB_mean_per_launch"), kern)
     if f is None or w is None:
-        return None
-    return (2.0 * f + w) * 1024.0
+        return None, None
+    return (2.0 * f + w) * 1024.0, "profiles/" + PMC_PROFILE
 
 
 def measured_mfma_util(phase):
-    """MFMA pipe utilisation of the phase's kernel from the committed counter pass (profiles/r01_v11_pmc_mfma_cnot3.json:
+    """MFMA pipe utilisation of the phase's kernel from the committed counter pass (profiles/PMC_MFMA_PROFILE:
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_v11_pmc_mfma_cnot3.json")
-    kern = KERNEL_OF_PHASE.get(phase, "").replace("void ", "")
+    path = os.path.join(ROOT, "profiles", PMC_MFMA_PROFILE)
+    kern = KERNEL_OF_PHASE.get(phase, "")
     if not kern or not os.path.exists(path):
         return None
-    return json.load(open(path)).get("kernels", {}).get(kern, {}).get("mfma_util")
+    _, v = _lookup_kernel(json.load(open(path)).get("kernels"), kern)
+    return None if v is None else v.get("mfma_util")
 
 
-def cpu_baseline(qgd, orc, seconds_target=12.0):
-    """Oracle ('port' of the reference CPU path) on a bounded sample: the same cnot3 problem and
-    controls at dt=1 with fewer steps, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19),
-    columns in parallel as the reference's Threads.@threads (forward_evolution.jl:48,332)."""
+def _oracle_rate(qgd, orc, make_case, order, threads, sparse, seconds_target, probe_steps=6):
+    """timesteps/s of the oracle's full discrete_adjoint on a bounded sample: `probe_steps` steps to size the sample,
+    then as many steps as fit in `seconds_target` (at most the full grid)."""
+    orc.set_num_threads(threads)
+    orc.set_sparse_operators(sparse)
+    try:
+        prob, ctrl, pcof, target, full = make_case(probe_steps)
+        t0 = time.time()
+        orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+        per_step = (time.time() - t0) / probe_steps
+        nsample = int(max(probe_steps, min(full, seconds_target / per_step)))
+        prob, ctrl, pcof, target, full = make_case(nsample)
+        t0 = time.time()
+        _, _, _, _, st = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+        el = time.time() - t0
+    finally:
+        orc.set_sparse_operators(False)
+    return {"value": nsample / el, "unit": "timesteps/s", "cores": threads, "operators": "CSC" if sparse else "dense",
+            "timesteps": nsample, "of": full, "seconds": round(el, 2),
+            "gmres_iters_fwd": round(st.fwd_gmres_iters, 1), "gmres_iters_adj": round(st.adj_gmres_iters, 1)}
+
+
+def cpu_baseline(qgd, orc, seconds_target=10.0):
+    """Oracle ('port' of the reference CPU path; Julia is not in the image) on bounded samples of the same
+    workload: cnot3 order 8 at dt=1, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19), columns in parallel
+    as the reference's Threads.@threads (forward_evolution.jl:48,332), gradient accumulation serial
+    (eval_grad_discrete_adjoint.jl:148-157).  The headline object is the 8-thread dense-operator figure (regression.jl:30
+    builds dense operators); `variants` adds what BASELINE.md section 2 lists: one thread (the author's cluster runs,
+    cnot3_optimize_gate.sb:7), CSC operators (DispersiveProblem's default sparse_rep=true), and C2 (cnot2, order 8)."""
     import numpy as np
+    import cases
     cores = os.cpu_count() or 1
     threads = min(8, cores)
-    orc.set_num_threads(threads)
-    nsample = 12
-    prob, ctrl, pcof, target = workload(qgd, nsample, float(nsample))
-    prob.gmres_abstol = prob.gmres_reltol = 1e-12
-    t0 = time.time()
-    orc.discrete_adjoint(prob, ctrl, pcof, target, order=8)
-    per_step = (time.time() - t0) / nsample
-    nsample = int(max(12, min(400, seconds_target / per_step)))
-    prob, ctrl, pcof, target = workload(qgd, nsample, float(nsample))
-    prob.gmres_abstol = prob.gmres_reltol = 1e-12
-    t0 = time.time()
-    _, _, _, _, st = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8, return_all=True)
-    el = time.time() - t0
+
+    def cnot3(nsteps):
+        prob, ctrl, pcof, target = workload(qgd, nsteps, float(nsteps))
+        prob.gmres_abstol = prob.gmres_reltol = 1e-12
+        return prob, ctrl, pcof, target, 550
+
+    def cnot2(nsteps):       # examples/cnot2_optimization.jl:10-47 (tf = nsteps: the script's dt = 1)
+        prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=nsteps, tf=float(nsteps), amp=1e-2)
+        prob.gmres_abstol = prob.gmres_reltol = 1e-12
+        return prob, ctrl, pcof, target, 100
+
+    head = _oracle_rate(qgd, orc, cnot3, 8, threads, False, seconds_target)
+    variants = {}
+    for name, case, th, sp, budget in (("cnot3_dense_1thread", cnot3, 1, False, 4.0), ("cnot3_csc_%dthreads" % threads, cnot3, threads, True, 4.0),
+                                       ("cnot3_csc_1thread", cnot3, 1, True, 4.0), ("cnot2_order8_csc_1thread", cnot2, 1, True, 2.0),
+                                       ("cnot2_order8_csc_4threads", cnot2, min(4, cores), True, 2.0)):
+        try:
+            variants[name] = _oracle_rate(qgd, orc, case, 8, th, sp, budget)
+        except Exception as exc:          # a variant must never cost the headline line
+            variants[name] = {"error": repr(exc)}
     return {
-        "value": nsample / el, "unit": "timesteps/s", "cores": threads, "kind": "port",
-        "sample": f"cnot3 order 8, dt=1, {nsample} of 550 timesteps, all 8 columns, GMRES tol 1e-12, "
+        "value": head["value"], "unit": "timesteps/s", "cores": threads, "kind": "port",
+        "sample": f"cnot3 order 8, dt=1, {head['timesteps']} of 550 timesteps, all 8 columns, dense operators, GMRES tol 1e-12, "
                   f"{threads} threads over columns (gradient accumulation serial as in the reference); "
-                  f"mean GMRES iterations fwd {st.fwd_gmres_iters:.1f} adj {st.adj_gmres_iters:.1f}",
-        "seconds": el,
+                  f"mean GMRES iterations fwd {head['gmres_iters_fwd']} adj {head['gmres_iters_adj']}",
+        "seconds": head["seconds"], "host_cores": cores, "variants": variants,
     }
 
 
@@ -151,13 +196,26 @@ def large_n_case(qgd, np, steps=3):
         grad, _ = dp.discrete_adjoint(pcof)
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / steps
+    # the number is only worth printing if the gradient is right: centred-difference directional derivative of
+    # infidelity + guard penalty (objective ~ -3e4 with the un-normalised random U0 as target: eps 1e-3)
+    d = np.random.default_rng(1).standard_normal(len(pcof)); d /= np.linalg.norm(d)
+    eps = 1e-3
+
+    def obj(p):
+        a, b, g = dp.eval_forward(p)
+        return 1 - (a * a + b * b) / prob.N_ess_levels ** 2 + g
+
+    fd = (obj(pcof + eps * d) - obj(pcof - eps * d)) / (2 * eps)
+    fd_rel = abs(fd - grad @ d) / abs(fd)
+    assert np.isfinite(grad).all() and fd_rel < 1e-6, f"C5 gradient check failed: adjoint {grad @ d}, centred difference {fd}"
     dp.close()
     gemms = m * (m - 1) // 2 + m + 4.0 * nsteps / (nsteps + 1) + 3 + m * (m - 1) // 2 + n_ops * m
     tflop = 8.0 * N ** 3 * gemms * (nsteps + 1) / 1e12
     return {"workload": f"C5 synthetic: N={N}, {c} columns, {n_ops} control operators, order {order}, nsteps={nsteps}",
             "timesteps_per_s": nsteps / sec, "ms_per_evaluation": sec * 1e3, "executed_tflop_per_evaluation": tflop,
             "bound": "mfma", "achieved": tflop / sec, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": tflop / sec / PEAK_FP64_MATRIX_TFLOPS, "grad_norm": float(np.linalg.norm(grad))}
+            "frac": tflop / sec / PEAK_FP64_MATRIX_TFLOPS, "grad_norm": float(np.linalg.norm(grad)),
+            "gradient_vs_central_difference_rel": fd_rel}
 
 
 def main():
@@ -171,6 +229,20 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started bare with --gpus N: become the launcher of N ranks (one process per GPU) BEFORE anything touches the
+        # GPU in this process (device_count() does not initialise it), and pass the children's output through.
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to print a "
+                     f"{have}-GPU number under n_gpus={args.gpus}")
+        port = os.environ.get("MASTER_PORT", "29517")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import numpy as np
     import torch   # first: so that one HIP runtime (torch's) serves both torch and libqgd_hip
     import torch.distributed as dist
@@ -179,6 +251,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and not args.force_dist:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     use_dist = world > 1 or args.force_dist
     if use_dist:
         torch.cuda.set_device(local_rank)
@@ -286,6 +360,34 @@ def main():
         barrier()
         fwd_elapsed = time.perf_counter() - t1
 
+    # The reference-shaped call: optimize_gate hands discrete_adjoint! its preallocated state_history, lambda_history
+    # and adjoint_forcing on every iteration (ipopt_optimal_control.jl:207-214, :304-330).  The same evaluation with
+    # the three arrays downloaded in the reference layout (31.6 MB), registered (pinned) once as INTEGRATION.md's shim
+    # does, and unregistered (pageable).  Reported beside `value`, never as `value`.
+    with_hist = None
+    if not use_dist:
+        try:
+            n2, m1, ntp, cc = prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions
+            with_hist = {"bytes_per_evaluation": 8 * (n2 * m1 * ntp * cc + 2 * n2 * ntp * cc)}
+            for label, pinned in (("pinned", True), ("pageable", False)):
+                hist = np.zeros((n2, m1, ntp, cc), order="F"); lam = np.zeros((n2, m1, ntp, cc), order="F")
+                forc = np.zeros((n2, ntp, cc), order="F")
+                if pinned:
+                    for a in (hist, lam, forc):
+                        dp.pin(a)
+                dp.set_timing(0)
+                dp.discrete_adjoint(pcof, False, hist, lam, forc)
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    g_h, _ = dp.discrete_adjoint(pcof, False, hist, lam, forc)
+                barrier()
+                with_hist[label + "_ms_per_step"] = (time.perf_counter() - t2) / args.steps * 1e3
+                assert np.abs(g_h - grad).max() <= 1e-12 * np.abs(grad).max()
+                del hist, lam, forc
+        except Exception as exc:
+            with_hist = {"error": repr(exc)}
+
     if rank == 0:
         for k in phase_ms:
             phase_ms[k] /= nsamp
@@ -304,6 +406,7 @@ def main():
             peak, unit = PEAK_HBM_GBS, "GB/s"
         # N > 1: ONE evaluation is spread over the ranks by time windows (strong scaling)
         total_timesteps = args.nsteps * args.steps
+        traffic, traffic_source = measured_traffic(dom)
         out = {
             "metric": "forward+adjoint timesteps/sec, cnot3 order-8 fp64",
             "value": total_timesteps / elapsed, "unit": "timesteps/s",
@@ -314,12 +417,14 @@ def main():
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
                        "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
-            "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom).replace("void ", ""), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": measured_traffic(dom), "mfma_pipe_busy_pmc": measured_mfma_util(dom),
+            "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
             "weak_in_time": weak,
+            "with_history_ms_per_step": None if not with_hist else with_hist.get("pinned_ms_per_step"),
+            "with_history": with_hist,
             "forward_only_timesteps_per_s": (total_timesteps / fwd_elapsed) if fwd_elapsed else None,
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),

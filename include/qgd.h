@@ -67,6 +67,20 @@ typedef struct qgd_problem_desc {
 /* SchrodingerProb constructor + validation.  On failure *out is NULL and
  * qgd_last_error(NULL) holds the message. */
 int qgd_create(const qgd_problem_desc *desc, qgd_handle *out);
+
+/* The same constructor for sparse operators: SchrodingerProb accepts SparseMatrixCSC
+ * (src/SchrodingerProb.jl:24-31; DispersiveProblem defaults to sparse_rep=true,
+ * src/ProblemConstructors/multi_qudit_systems.jl:118-162).  A qgd_csc is the three arrays of a
+ * SparseMatrixCSC{Float64,Int64} (colptr: n+1 entries; rowval, nzval: nnz entries) with
+ * index_base = 1 (Julia) or 0 (scipy).  desc->system_sym .. asym_ops are ignored; u0, v0, guard stay
+ * dense.  The operators feed the sparse (ELL) kernels directly; stored zeros are kept out of the pattern. */
+typedef struct qgd_csc {
+    const int64_t *colptr, *rowval;
+    const double *nzval;
+    int32_t index_base, reserved;
+} qgd_csc;
+int qgd_create_csc(const qgd_problem_desc *desc, const qgd_csc *system_sym, const qgd_csc *system_asym,
+                   const qgd_csc *sym_ops /* n_ops */, const qgd_csc *asym_ops /* n_ops */, qgd_handle *out);
 void qgd_destroy(qgd_handle h);
 const char *qgd_last_error(qgd_handle h);
 int qgd_abi_version(void);
@@ -106,8 +120,10 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof,
 
 /* discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160): gradient of
  * infidelity + guard penalty (no ridge term, as the reference).  With
- * history_precomputed != 0 the forward sweep of the last qgd_eval_forward is
- * reused (ipopt_optimal_control.jl:297-308).  Optional outputs (nullable):
+ * history_precomputed != 0 the forward sweep of the last evaluation is reused
+ * (ipopt_optimal_control.jl:297-308) -- the device's own copy of it, and only when
+ * it was computed from this same pcof (otherwise the sweep is redone); uv_history
+ * is an output in both cases.  Optional outputs (nullable):
  *   uv_history      [2N, 1+m, 1+nsteps, n_cols]
  *   lambda_history  [2N, 1+m, 1+nsteps, n_cols]  (column j=0 filled: the only one
  *                   the reference consumes, eval_grad_discrete_adjoint.jl:604)
@@ -116,6 +132,15 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof,
 int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
                          int32_t history_precomputed, double *grad, double *uv_history,
                          double *lambda_history, double *adjoint_forcing, double *out3);
+
+/* Host buffers of the optional outputs.  The reference's optimize_gate allocates state_history, lambda_history and
+ * adjoint_forcing once and hands the same arrays to discrete_adjoint! on every iteration
+ * (src/ipopt_optimal_control.jl:223-241, :304-330).  Registering such an array pins it, so that the downloads run at
+ * PCIe speed beside the adjoint sweep; unregistered buffers work too (pageable copies).  A registered
+ * lambda_history is zero-filled once, at its first use: the library only ever writes its j = 0 columns.
+ * Unregister before the array is freed. */
+int qgd_register_host_buffer(qgd_handle h, void *ptr, size_t bytes);
+int qgd_unregister_host_buffer(qgd_handle h, void *ptr);
 
 /* eval_adjoint (src/forward_evolution.jl:300-315, per column :352-483): backward sweep from a
  * caller-given terminal lambda_N [2N, n_cols] with optional forcing [2N, 1+nsteps, n_cols];

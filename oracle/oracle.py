@@ -50,8 +50,21 @@ class _Prob(C.Structure):
         ("gmres_abstol", C.c_double), ("gmres_reltol", C.c_double),
         ("system_sym", C.c_void_p), ("system_asym", C.c_void_p),
         ("sym_ops", C.c_void_p), ("asym_ops", C.c_void_p),
-        ("u0", C.c_void_p), ("v0", C.c_void_p), ("guard", C.c_void_p),
+        ("u0", C.c_void_p), ("v0", C.c_void_p), ("guard", C.c_void_p), ("csc", C.c_void_p),
     ]
+
+
+class _Csc(C.Structure):
+    _fields_ = [("colptr", C.c_void_p), ("rowval", C.c_void_p), ("nzval", C.c_void_p)]
+
+
+_SPARSE = False
+
+
+def set_sparse_operators(on: bool):
+    """Operators as SparseMatrixCSC (the reference's DispersiveProblem default, sparse_rep=true) instead of dense."""
+    global _SPARSE
+    _SPARSE = bool(on)
 
 
 class _Stats(C.Structure):
@@ -97,9 +110,22 @@ class Problem:
         # sym_ops[k] stored as C-contiguous transpose == column-major original
         if precond is None:
             precond = 1 if getattr(prob, "preconditioner_type", "") == "DiagonalHamiltonianPreconditioner" else 0
+        csc_ptr = None
+        if _SPARSE:
+            from scipy.sparse import csc_matrix
+            mats = [prob.system_sym, prob.system_asym, *prob.sym_operators, *prob.asym_operators]
+            self.csc_arrays = []
+            self.csc = (_Csc * len(mats))()
+            for i, a in enumerate(mats):
+                sp = csc_matrix(np.asarray(a))
+                arrs = (sp.indptr.astype(np.int64), sp.indices.astype(np.int64), sp.data.astype(np.float64))
+                self.csc_arrays.append(arrs)
+                self.csc[i] = _Csc(_ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]))
+            csc_ptr = C.cast(self.csc, C.c_void_p)
         self.c = _Prob(prob.N_tot_levels, prob.N_operators, prob.N_initial_conditions, prob.N_ess_levels,
                        prob.nsteps, precond, prob.tf, prob.gmres_abstol, prob.gmres_reltol,
-                       *[_ptr(self.bufs[k]) for k in ("system_sym", "system_asym", "sym_ops", "asym_ops", "u0", "v0", "guard")])
+                       *[_ptr(self.bufs[k]) for k in ("system_sym", "system_asym", "sym_ops", "asym_ops", "u0", "v0", "guard")],
+                       csc_ptr)
         self.N = prob.N_tot_levels
         self.n_cols = prob.N_initial_conditions
         self.nsteps = prob.nsteps

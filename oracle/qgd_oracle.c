@@ -280,6 +280,16 @@ static void gemv_acc(int n, double alpha, const double *A, const double *x, doub
     }
 }
 
+/* the same with a SparseMatrixCSC operand (SparseArrays' mul!: one pass over the stored entries, column by column) */
+static void spmv_acc(int n, double alpha, const qo_csc *A, const double *x, double *y)
+{
+    if (alpha == 0.0) return;
+    for (int j = 0; j < n; j++) {
+        const double ax = alpha * x[j];
+        for (int64_t e = A->colptr[j]; e < A->colptr[j + 1]; e++) y[A->rowval[e]] += A->nzval[e] * ax;
+    }
+}
+
 static int64_t g_applies = 0;
 
 void qo_apply_hamiltonian(const qo_prob *pr, const double *pvals, const double *qvals, int ld,
@@ -289,6 +299,28 @@ void qo_apply_hamiltonian(const qo_prob *pr, const double *pvals, const double *
     const double af = use_adjoint ? -1.0 : 1.0;
     const double *in_re = in, *in_im = in + N;
     double *out_re = out, *out_im = out + N;
+    if (pr->csc) {      /* sparse_rep = true: the same sixteen mul! calls on SparseMatrixCSC operands */
+        const qo_csc *ssym = pr->csc, *sasym = pr->csc + 1;
+        if (d == 0) {
+            spmv_acc(N, af, sasym, in_re, out_re);
+            spmv_acc(N, af, ssym, in_im, out_re);
+            spmv_acc(N, af, sasym, in_im, out_im);
+            spmv_acc(N, -af, ssym, in_re, out_im);
+        }
+        for (int k = 0; k < pr->n_ops; k++) {
+            const qo_csc *sym = pr->csc + 2 + k, *asym = pr->csc + 2 + pr->n_ops + k;
+            const double p = pvals[d + (size_t)k * ld], q = qvals[d + (size_t)k * ld];
+            spmv_acc(N, af * q, asym, in_re, out_re);
+            spmv_acc(N, af * p, sym, in_im, out_re);
+            spmv_acc(N, af * q, asym, in_im, out_im);
+            spmv_acc(N, -af * p, sym, in_re, out_im);
+        }
+#ifdef QO_COUNT_APPLIES
+        #pragma omp atomic
+        g_applies++;
+#endif
+        return;
+    }
     if (d == 0) {
         gemv_acc(N, af, pr->system_asym, in_re, out_re);
         gemv_acc(N, af, pr->system_sym, in_im, out_re);

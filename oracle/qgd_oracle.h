@@ -77,7 +77,16 @@ typedef struct qo_prob {
     const double *sym_ops, *asym_ops;        /* n_ops x (N x N) */
     const double *u0, *v0;                   /* N x n_cols */
     const double *guard;                     /* 2N x 2N */
+    /* Optional sparse operators (SparseMatrixCSC, the reference's default sparse_rep=true of DispersiveProblem,
+       src/ProblemConstructors/multi_qudit_systems.jl:118-162): 2 + 2 n_ops matrices in the order system_sym,
+       system_asym, sym_ops[0..], asym_ops[0..], 0-based indices.  NULL = dense mul! as above. */
+    const struct qo_csc *csc;
 } qo_prob;
+
+typedef struct qo_csc {
+    const int64_t *colptr, *rowval;
+    const double *nzval;
+} qo_csc;
 
 typedef struct qo_stats {
     double fwd_gmres_iters;   /* mean iterations per step per column */

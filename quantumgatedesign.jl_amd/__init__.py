@@ -14,7 +14,7 @@ from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_pr
                        create_initial_conditions, create_gate, basis_state, lowering_operators_system,
                        control_ops, multi_qudit_hamiltonian_dispersive, cnot2_problem, cnot3_problem,
                        multi_qudit_hamiltonian_jayne, JaynesCummingsProblem, rotating_frame_qubit, dahlquist_problem)
-from .evolution import (DeviceProblem, device_problem, clear_cache, eval_forward, eval_forward_, eval_adjoint, eval_grad_forced, eval_grad_finite_difference, discrete_adjoint,
+from .evolution import (DeviceProblem, device_problem, clear_cache, release, eval_forward, eval_forward_, eval_adjoint, eval_grad_forced, eval_grad_finite_difference, discrete_adjoint,
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)
 from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup

@@ -22,6 +22,7 @@ EXPORTS = [
     "qgd_set_partition", "qgd_get_partition", "qgd_set_stream", "qgd_exchange_buffer",
     "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
     "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
+    "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc",
 ]
 
 
@@ -33,6 +34,12 @@ class ProblemDesc(C.Structure):
         ("asym_ops", C.c_void_p), ("u0", C.c_void_p), ("v0", C.c_void_p), ("guard", C.c_void_p),
         ("device", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class CSC(C.Structure):
+    """qgd_csc of include/qgd.h."""
+    _fields_ = [("colptr", C.c_void_p), ("rowval", C.c_void_p), ("nzval", C.c_void_p),
+                ("index_base", C.c_int32), ("reserved", C.c_int32)]
 
 
 class QGDError(RuntimeError):
@@ -67,6 +74,8 @@ def lib():
     L.qgd_last_error.restype = C.c_char_p
     L.qgd_last_error.argtypes = [C.c_void_p]
     L.qgd_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
+    L.qgd_create_csc.argtypes = [C.POINTER(ProblemDesc), C.POINTER(CSC), C.POINTER(CSC), C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_void_p)]
     L.qgd_destroy.argtypes = [C.c_void_p]
     L.qgd_destroy.restype = None
     L.qgd_set_nsteps.argtypes = [C.c_void_p, C.c_int32, C.c_double]
@@ -94,6 +103,8 @@ def lib():
     L.qgd_set_operator_path.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_get_operator_path.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_eval_adjoint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_register_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.qgd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -11,7 +11,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .evolution import eval_forward
+from .evolution import eval_forward, release
 
 
 def richardson_extrap_sol(A_h, A_2h, order):
@@ -39,6 +39,15 @@ def get_histories(prob, controls, pcof, N_iterations, orders=(2, 4, 6, 8, 10), m
     base = prob.nsteps if base_nsteps is None else int(base_nsteps)
     work = prob.copy()
     ret = OrderedDict()
+    try:
+        return _run_histories(work, controls, pcof, N_iterations, orders, min_error_limit, max_error_limit, base,
+                              nsteps_change_factor, start_iteration, filename, say, ret)
+    finally:
+        release(work)      # one device grid per order, sized for the finest time grid: give them back now
+
+
+def _run_histories(work, controls, pcof, N_iterations, orders, min_error_limit, max_error_limit, base,
+                   nsteps_change_factor, start_iteration, filename, say, ret):
     for order in orders:
         summary = dict(order=order, nsteps=[], step_sizes=[], elapsed_times=[], histories=[], richardson_errors=[])
         ret[f"Order {order} (QGD)"] = summary

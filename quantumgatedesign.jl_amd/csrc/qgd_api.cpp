@@ -54,6 +54,19 @@ struct qgd_handle_s {
     // kernels and the ~6 us per dependent dispatch is spent on the device side, not in hipLaunchKernel; the
     // instantiation costs several ms once.  Captured on the third eligible call, dropped by every entry point
     // that changes buffers, sizes or options.
+    // reference-layout outputs (uv_history, lambda_history, adjoint_forcing): re-laid out on the device
+    // (qgd_k_layout.hip) into staging buffers and copied out on a second stream, so that the download of the
+    // state history overlaps the adjoint sweep.  Host buffers the caller registered (qgd_register_host_buffer)
+    // are pinned: the copies then run at PCIe speed.
+    struct HostReg { void *host; size_t bytes; bool zeroed; };
+    std::vector<HostReg> regs;
+    std::vector<void *> stage_bufs;
+    double *stage_hist = nullptr, *stage_lam = nullptr, *stage_f = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_ready = nullptr;
+    std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
+    std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
+    bool copies_pending = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_calls = 0;
@@ -130,6 +143,7 @@ int alloc_grid(qgd_handle h)
     free_pool(h->grid_bufs);
     free_pool(h->forced_bufs); h->forced_key = 0;
     free_pool(h->forcing_bufs); h->forcing_key = 0;
+    free_pool(h->stage_bufs); h->stage_hist = h->stage_lam = h->stage_f = nullptr;
     // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
     //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
     {
@@ -252,27 +266,91 @@ int alloc_grid(qgd_handle h)
     return QGD_OK;
 }
 
-// real history panel(s) -> Julia layout [2N, 1+m, nt, c]
+#define K_TRY(h, expr)                                                                         \
+    do {                                                                                       \
+        int e__ = (expr);                                                                      \
+        if (e__ != 0)                                                                          \
+            return fail((h), QGD_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__)); \
+    } while (0)
+
+qgd_handle_s::HostReg *find_reg(qgd_handle h, const void *p, size_t bytes)
+{
+    for (auto &r : h->regs)
+        if ((const char *)p >= (const char *)r.host && (const char *)p + bytes <= (const char *)r.host + r.bytes) return &r;
+    return nullptr;
+}
+
+int copy_side(qgd_handle h)
+{
+    if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->ev_ready) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    return QGD_OK;
+}
+
+// the copy stream takes over from the compute stream at this point of the launch sequence
+int hand_over(qgd_handle h)
+{
+    HIP_TRY(h, hipEventRecord(h->ev_ready, h->k.stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->ev_ready, 0));
+    h->copies_pending = true;
+    return QGD_OK;
+}
+
+int finish_copies(qgd_handle h)
+{
+    if (h->copies_pending) { HIP_TRY(h, hipStreamSynchronize(h->copy_stream)); h->copies_pending = false; }
+    return QGD_OK;
+}
+
+// state history: panels hist [nt][Np][2cp] (j = 0) and dpsi [nt][m][Np][2cp] (j = 1..m) -> the reference's
+// uv_history[2N, 1+m, nt, c] (forward_evolution.jl:42-44).  Asynchronous: finish_copies() before returning.
 int copy_history_out(qgd_handle h, double *uv_history)
 {
     qgdk_ctx &k = h->k;
-    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, nt = k.nt, m = k.m;
-    std::vector<double> h0(nt * hstep), hd(nt * m * hstep);
-    HIP_TRY(h, hipMemcpyAsync(h0.data(), k.hist, h0.size() * sizeof(double), hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(h, hipMemcpyAsync(hd.data(), k.dpsi, hd.size() * sizeof(double), hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(h, hipStreamSynchronize(k.stream));
-    const size_t N = k.N, n2 = 2 * N;
-    for (size_t col = 0; col < (size_t)k.c; col++)
-        for (size_t n = 0; n < nt; n++)
-            for (size_t j = 0; j <= m; j++) {
-                const double *src = (j == 0) ? h0.data() + n * hstep : hd.data() + (n * m + (j - 1)) * hstep;
-                double *dst = uv_history + ((col * nt + n) * (m + 1) + j) * n2;
-                for (size_t i = 0; i < N; i++) {
-                    size_t o = panel_index((int)i, (int)col, (int)PWc);
-                    dst[i] = src[o];
-                    dst[N + i] = src[o + 8];
-                }
-            }
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N;
+    const size_t total = n2 * (m + 1) * nt * k.c;
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (!h->stage_hist && (rc = dev_alloc(h, h->stage_bufs, &h->stage_hist, total))) return rc;
+    const long long dcol = (long long)(nt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
+    K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, h->stage_hist, dcol, dn, dj, 0, (int)nt, 1, 0, k.stream));
+    K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream));
+    if ((rc = hand_over(h))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(uv_history, h->stage_hist, total * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    return QGD_OK;
+}
+
+// one panel per time point (lambda, adjoint forcing) -> [2N, J, nt, c] with only Taylor index 0 written
+// (J = 1: adjoint_forcing; J = 1+m: lambda_history, whose other columns are zero)
+int copy_panels_out(qgd_handle h, const double *panels, double **stage, double *out, size_t J, int n_first)
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, n2 = 2 * (size_t)k.N;
+    const size_t compact = n2 * nt * k.c;
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (!*stage) {
+        if ((rc = dev_alloc(h, h->stage_bufs, stage, compact))) return rc;
+        HIP_TRY(h, hipMemsetAsync(*stage, 0, compact * sizeof(double), k.stream));     // time points below n_first stay zero
+    }
+    K_TRY(h, qgdk_layout(&k, panels, (long long)hstep, 0, *stage, (long long)(nt * n2), (long long)n2, 0, n_first, (int)nt - n_first, 1, 0, k.stream));
+    if ((rc = hand_over(h))) return rc;
+    if (J == 1) {
+        HIP_TRY(h, hipMemcpyAsync(out, *stage, compact * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+        return QGD_OK;
+    }
+    qgd_handle_s::HostReg *reg = find_reg(h, out, compact * J * sizeof(double));
+    if (reg) {      // pinned destination: strided copy of the j = 0 columns; the rest is zero-filled once
+        if (!reg->zeroed) { memset(out, 0, compact * J * sizeof(double)); reg->zeroed = true; }
+        HIP_TRY(h, hipMemcpy2DAsync(out, J * n2 * sizeof(double), *stage, n2 * sizeof(double), n2 * sizeof(double), nt * k.c,
+                                    hipMemcpyDeviceToHost, h->copy_stream));
+        return QGD_OK;
+    }
+    h->scatter_tmp.resize(compact);
+    HIP_TRY(h, hipMemcpyAsync(h->scatter_tmp.data(), *stage, compact * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+    memset(out, 0, compact * J * sizeof(double));
+    for (size_t r = 0; r < nt * (size_t)k.c; r++) memcpy(out + r * J * n2, h->scatter_tmp.data() + r * n2, n2 * sizeof(double));
     return QGD_OK;
 }
 
@@ -287,13 +365,6 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
     HIP_TRY(h, hipMemcpyAsync(h->pcof_dev, src, sizeof(double) * n_pcof, hipMemcpyHostToDevice, h->k.stream));
     return QGD_OK;
 }
-
-#define K_TRY(h, expr)                                                                         \
-    do {                                                                                       \
-        int e__ = (expr);                                                                      \
-        if (e__ != 0)                                                                          \
-            return fail((h), QGD_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e__)); \
-    } while (0)
 
 // forward, part 1: everything that needs no other rank (tables .. block propagators)
 int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
@@ -361,7 +432,9 @@ int run_forward(qgd_handle h, const double *pcof, int n_pcof)
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
     int rc = forward_begin(h, pcof, n_pcof);
     if (rc) return rc;
-    return forward_end(h);
+    if ((rc = forward_end(h))) return rc;
+    if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
+    return QGD_OK;
 }
 
 int check_status(qgd_handle h)
@@ -390,7 +463,8 @@ int fetch_results(qgd_handle h, double *grad, double *out3)
     HIP_TRY(h, hipStreamSynchronize(k.stream));      // (spinning on hipStreamQuery instead: no difference, 359 us either way)
     int st;
     memcpy(&st, h->host_out + np + 4, sizeof(int));
-    if (st) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
+    // (host_out[np + 3]: the same flag as a double, summed over the ranks of a time-partitioned evaluation)
+    if (st || h->host_out[np + 3] != 0.0) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
     if (grad) memcpy(grad, h->host_out, np * sizeof(double));
     if (out3) memcpy(out3, h->host_out + np, 3 * sizeof(double));
     return QGD_OK;
@@ -600,12 +674,49 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     return QGD_OK;
 }
 
+int qgd_create_csc(const qgd_problem_desc *d, const qgd_csc *ssym, const qgd_csc *sasym, const qgd_csc *sym_ops,
+                   const qgd_csc *asym_ops, qgd_handle *out)
+{
+    if (out) *out = nullptr;
+    if (!d || !out || !ssym || !sasym || (d->n_ops > 0 && (!sym_ops || !asym_ops))) return fail(nullptr, QGD_ERR_ARGUMENT, "null argument");
+    if (d->N < 1 || d->n_ops < 0) return fail(nullptr, QGD_ERR_ARGUMENT, "N, n_cols must be positive and n_ops non-negative");
+    const size_t N = (size_t)d->N, nn = N * N, n_ops = (size_t)d->n_ops;
+    std::vector<double> dense((2 + 2 * n_ops) * nn, 0.0);
+    auto expand = [&](const qgd_csc &a, double *dst) -> bool {
+        if (!a.colptr || (a.index_base != 0 && a.index_base != 1)) return false;
+        const int64_t b = a.index_base;
+        if (a.colptr[0] != b) return false;
+        for (size_t j = 0; j < N; j++) {
+            if (a.colptr[j + 1] < a.colptr[j]) return false;
+            for (int64_t e = a.colptr[j] - b; e < a.colptr[j + 1] - b; e++) {
+                if (!a.rowval || !a.nzval) return false;
+                const int64_t i = a.rowval[e] - b;
+                if (i < 0 || i >= (int64_t)N) return false;
+                dst[(size_t)i + N * j] += a.nzval[e];
+            }
+        }
+        return true;
+    };
+    bool ok = expand(*ssym, dense.data()) && expand(*sasym, dense.data() + nn);
+    for (size_t o = 0; o < n_ops && ok; o++)
+        ok = expand(sym_ops[o], dense.data() + (2 + o) * nn) && expand(asym_ops[o], dense.data() + (2 + n_ops + o) * nn);
+    if (!ok) return fail(nullptr, QGD_ERR_ARGUMENT, "malformed CSC operator (colptr/rowval out of range or index_base not 0/1)");
+    qgd_problem_desc dd = *d;
+    dd.system_sym = dense.data(); dd.system_asym = dense.data() + nn;
+    dd.sym_ops = dense.data() + 2 * nn; dd.asym_ops = dense.data() + (2 + n_ops) * nn;
+    return qgd_create(&dd, out);
+}
+
 void qgd_destroy(qgd_handle h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
     drop_graph(h);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    for (auto &r : h->regs) (void)hipHostUnregister(r.host);
+    free_pool(h->stage_bufs);
     free_pool(h->static_bufs); free_pool(h->grid_bufs); free_pool(h->basis_bufs); free_pool(h->forced_bufs); free_pool(h->forcing_bufs);
     for (auto &p : h->phases) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     if (h->host_out) (void)hipHostFree(h->host_out);
@@ -651,7 +762,7 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     qgdk_ctx &k = h->k;
     free_pool(h->basis_bufs);
     free_pool(h->forced_bufs); h->forced_key = 0;
-    h->have_basis = false;
+    h->have_basis = false; h->forward_valid = false; h->derivs_valid = false; h->fwd_pcof.clear();
     k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr; if (h->status_static) k.status = h->status_static;
     h->ncoef.assign(k.n_ops, 0); h->poff.assign(k.n_ops, 0); h->goff.assign(k.n_ops, 0);
     size_t total = 0; int np = 0, ncmax = 0;
@@ -726,9 +837,9 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
         { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
         h->derivs_valid = true;
     }
-    if ((rc = fetch_results(h, nullptr, out3))) return rc;
     if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
-    return QGD_OK;
+    if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
+    return finish_copies(h);
 }
 
 int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32_t history_precomputed,
@@ -767,6 +878,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             HIP_TRY(h, hipGraphLaunch(h->graph_exec, k.stream));
             HIP_TRY(h, hipStreamSynchronize(k.stream));
             h->forward_valid = true;
+            h->fwd_pcof.assign(pcof, pcof + n_pcof);
             h->derivs_valid = qgdk_gradient_needs_derivs(&k) != 0;
             const size_t np = (size_t)k.n_pcof;
             int st;
@@ -777,45 +889,31 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             return QGD_OK;
         }
     }
-    if (history_precomputed) {
-        if (!h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+    struct CopyGuard { qgd_handle h; ~CopyGuard() { (void)finish_copies(h); } } guard{h};   // no copy outlives the call
+    // history_precomputed: the reference differentiates the history it is GIVEN with the pcof it is given
+    // (eval_grad_discrete_adjoint.jl:118-124).  The device keeps its own copy of the last forward sweep; it is
+    // reused only when it was computed from this very pcof, otherwise the sweep is simply redone.
+    if (history_precomputed && !h->forward_valid)
+        return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+    const bool reuse = history_precomputed && (pcof ? ((size_t)n_pcof == h->fwd_pcof.size() && n_pcof > 0 &&
+                                                       !memcmp(pcof, h->fwd_pcof.data(), sizeof(double) * n_pcof))
+                                                    : h->fwd_pcof.empty());
+    if (reuse) {
         // the terminal right-hand side may not have been written if the target was set later
         { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
     } else {
         if ((rc = run_forward(h, pcof, n_pcof))) return rc;
     }
+    if (uv_history) {   // the download of the state history runs beside the adjoint sweep
+        if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+        if ((rc = copy_history_out(h, uv_history))) return rc;
+    }
     if ((rc = adjoint_begin(h))) return rc;
     if ((rc = adjoint_end(h))) return rc;
-    if (uv_history && !h->derivs_valid) {   // the fused gradient kernel keeps the derivatives on chip
-        PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true;
-    }
+    if (lambda_history && (rc = copy_panels_out(h, k.lam, &h->stage_lam, lambda_history, (size_t)k.m + 1, 1))) return rc;
+    if (adjoint_forcing && (rc = copy_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
     if ((rc = fetch_results(h, grad, out3))) return rc;
-    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
-    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, nt = k.nt, N = k.N, n2 = 2 * N, m = k.m;
-    if (lambda_history) {
-        std::vector<double> l(nt * hstep);
-        HIP_TRY(h, hipMemcpy(l.data(), k.lam, l.size() * sizeof(double), hipMemcpyDeviceToHost));
-        memset(lambda_history, 0, sizeof(double) * n2 * (m + 1) * nt * k.c);
-        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 1; n < nt; n++) {
-            double *dst = lambda_history + ((col * nt + n) * (m + 1)) * n2;
-            for (size_t i = 0; i < N; i++) {
-                size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
-                dst[i] = l[o]; dst[N + i] = l[o + 8];
-            }
-        }
-    }
-    if (adjoint_forcing) {
-        std::vector<double> f(nt * hstep);
-        HIP_TRY(h, hipMemcpy(f.data(), k.forcing, f.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) {
-            double *dst = adjoint_forcing + (col * nt + n) * n2;
-            for (size_t i = 0; i < N; i++) {
-                size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
-                dst[i] = f[o]; dst[N + i] = f[o + 8];
-            }
-        }
-    }
-    return QGD_OK;
+    return finish_copies(h);
 }
 
 int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, const double *forcing,
@@ -864,9 +962,9 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
         K_TRY(h, qgdk_forcing_add_derivs(&k));     // w_j = D_j w_0 + E_j
         h->derivs_valid = false;
     }
-    if ((rc = fetch_results(h, nullptr, out3))) return rc;
     if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
-    return QGD_OK;
+    if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
+    return finish_copies(h);
 }
 
 int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad)
@@ -1136,6 +1234,31 @@ int qgd_dist_finish(qgd_handle h, double *grad, double *out3)
     if (!h) return QGD_ERR_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     return fetch_results(h, grad, out3);
+}
+
+int qgd_register_host_buffer(qgd_handle h, void *ptr, size_t bytes)
+{
+    if (!h || !ptr || !bytes) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (find_reg(h, ptr, bytes)) return QGD_OK;
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, QGD_ERR_NO_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    h->regs.push_back({ptr, bytes, false});
+    return QGD_OK;
+}
+
+int qgd_unregister_host_buffer(qgd_handle h, void *ptr)
+{
+    if (!h || !ptr) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (size_t i = 0; i < h->regs.size(); i++)
+        if (h->regs[i].host == ptr) {
+            if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+            (void)hipHostUnregister(ptr);
+            h->regs.erase(h->regs.begin() + i);
+            return QGD_OK;
+        }
+    return fail(h, QGD_ERR_ARGUMENT, "buffer was not registered");
 }
 
 int qgd_set_operator_path(qgd_handle h, int32_t mode)

@@ -397,10 +397,14 @@ __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, 
                                                   const int32_t *__restrict__ ncoef,
                                                   const int32_t *__restrict__ poff,
                                                   const double *__restrict__ sigma,
-                                                  double *__restrict__ grad, int nt, int m, int n_ops)
+                                                  double *__restrict__ grad, int nt, int m, int n_ops,
+                                                  const int *__restrict__ status, double *__restrict__ scal)
 {
     // grid (time chunks, n_ops, coefficient tiles of 64); thread = (coefficient, time sub-slot)
     __shared__ double red[4][64];
+    // the singularity flag also travels as a double in the spare scalar slot, INSIDE the range the ranks all-reduce:
+    // every rank of a time-partitioned evaluation then fails together (qgd_dist_finish)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && *status) scal[3] = 1.0;
     const int k = blockIdx.y;
     const int nc = ncoef[k];
     const int l = blockIdx.z * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
@@ -514,7 +518,7 @@ int qgdk_gradient(const qgdk_ctx *c)
 int qgdk_contract(const qgdk_ctx *c)
 {
     hipLaunchKernelGGL(k_contract, dim3((c->nt + CT_CHUNK - 1) / CT_CHUNK, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
-                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops);
+                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops, c->status, c->scal);
     return (int)hipGetLastError();
 }
 

@@ -28,8 +28,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
-// hipFuncSetAttribute once per kernel instantiation (it is a host-side driver call)
-#define SET_LDS_ONCE(fn, bytes) do { static size_t done_ = 0; if ((size_t)(bytes) > done_) { HIPCHK(hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); done_ = (bytes); } } while (0)
+// hipFuncSetAttribute once per kernel instantiation AND device (it is a host-side driver call and the attribute is
+// per device; handles on several GPUs may live in one process).  The record is atomic: two host threads driving
+// separate handles at worst both make the call.
+#include <atomic>
+#define QGD_MAX_DEVICES 16
+#define SET_LDS_ONCE(fn, bytes) do { static std::atomic<size_t> done_[QGD_MAX_DEVICES]; int dev_ = 0; (void)hipGetDevice(&dev_); \
+    std::atomic<size_t> &d_ = done_[(unsigned)dev_ % QGD_MAX_DEVICES]; \
+    if ((size_t)(bytes) > d_.load(std::memory_order_acquire)) { HIPCHK(hipFuncSetAttribute((const void *)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); d_.store((bytes), std::memory_order_release); } } while (0)
 
 // B-operand pair for one 4-deep k-step out of a panel row (LDS or global):
 // b1 = [Bre|Bim], b2 = [-Bim|Bre]

@@ -31,6 +31,18 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _check_out(a, shape, name):
+    """Output arrays go to the C ABI as bare pointers: the shape, dtype and memory order the library will
+    write must be exactly what it is given (the reference raises a DimensionMismatch here)."""
+    if a is None:
+        return None
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.shape != tuple(shape) or not a.flags.f_contiguous \
+            or not a.flags.writeable:
+        raise ValueError(f"{name} must be a writable float64 Fortran-ordered array of shape {tuple(shape)}; got "
+                         f"{getattr(a, 'dtype', type(a))} {getattr(a, 'shape', None)}")
+    return a
+
+
 def complex_to_real(x):
     """state_vector_helpers.jl:72-74."""
     x = np.asarray(x)
@@ -46,7 +58,9 @@ def real_to_complex(x):
 class DeviceProblem:
     """One qgd handle: a SchrodingerProb resident on one GPU for one Hermite order."""
 
-    def __init__(self, prob, order: int, device: int = 0):
+    def __init__(self, prob, order: int, device: int = 0, csc: bool = False):
+        """``csc=True`` hands the operators to the library as SparseMatrixCSC triples (qgd_create_csc), the
+        form DispersiveProblem(sparse_rep=true) produces in the reference."""
         self.lib = _lib.lib()
         self.N = prob.N_tot_levels
         self.c = prob.N_initial_conditions
@@ -65,7 +79,22 @@ class DeviceProblem:
                              _vp(bufs["ssym"]), _vp(bufs["sasym"]), _vp(bufs["sym"]), _vp(bufs["asym"]),
                              _vp(bufs["u0"]), _vp(bufs["v0"]), _vp(bufs["guard"]), device, 0)
         h = C.c_void_p()
-        rc = self.lib.qgd_create(C.byref(d), C.byref(h))
+        if csc:
+            from scipy.sparse import csc_matrix
+            keep = []
+
+            def triple(a):
+                sp = csc_matrix(np.asarray(a))
+                arrs = (sp.indptr.astype(np.int64), sp.indices.astype(np.int64), sp.data.astype(np.float64))
+                keep.append(arrs)
+                return _lib.CSC(_vp(arrs[0]), _vp(arrs[1]), _vp(arrs[2]), 0, 0)
+
+            ssym, sasym = triple(prob.system_sym), triple(prob.system_asym)
+            syms = (_lib.CSC * max(self.n_ops, 1))(*[triple(o) for o in prob.sym_operators])
+            asyms = (_lib.CSC * max(self.n_ops, 1))(*[triple(o) for o in prob.asym_operators])
+            rc = self.lib.qgd_create_csc(C.byref(d), C.byref(ssym), C.byref(sasym), syms, asyms, C.byref(h))
+        else:
+            rc = self.lib.qgd_create(C.byref(d), C.byref(h))
         _lib.check(None, rc)
         self.h = h
         self._finalizer = weakref.finalize(self, self.lib.qgd_destroy, h)
@@ -83,7 +112,12 @@ class DeviceProblem:
         self._basis_key = None
 
     def set_target(self, target):
-        t = complex_to_real(target) if np.iscomplexobj(target) or np.asarray(target).shape[0] == self.N else _f(target)
+        target = np.asarray(target)
+        if target.ndim != 2 or target.shape[1] != self.c or target.shape[0] not in (self.N, 2 * self.N) \
+                or (np.iscomplexobj(target) and target.shape[0] != self.N):
+            raise ValueError(f"target must be [{self.N}, {self.c}] (complex or real) or the stacked real form "
+                             f"[{2 * self.N}, {self.c}]; got {target.shape}")
+        t = complex_to_real(target) if target.shape[0] == self.N else _f(target)
         key = t.tobytes()
         if key != self._target_key:
             _lib.check(self.h, self.lib.qgd_set_target(self.h, _vp(t)))
@@ -115,7 +149,30 @@ class DeviceProblem:
         _lib.check(self.h, self.lib.qgd_set_control_tables(self.h, _vp(p), _vp(q)))
 
     # -- evaluation --------------------------------------------------------
+    def _hist_shape(self):
+        return (2 * self.N, self.m + 1, self.nsteps + 1, self.c)
+
+    def pin(self, array):
+        """Register (pin) an output array that will be handed to discrete_adjoint / eval_forward repeatedly
+        (qgd_register_host_buffer): its downloads then run at PCIe speed.  Unpinned when the array dies."""
+        if not isinstance(array, np.ndarray) or array.dtype != np.float64 or not array.flags.f_contiguous:
+            raise ValueError("only float64 Fortran-ordered arrays can be pinned")
+        key = (array.ctypes.data, array.nbytes)
+        pins = self.__dict__.setdefault("_pins", {})
+        if key in pins:
+            return array
+        _lib.check(self.h, self.lib.qgd_register_host_buffer(self.h, C.c_void_p(key[0]), key[1]))
+        lib, h, fin = self.lib, self.h, self._finalizer
+
+        def unpin(ptr=key[0]):
+            pins.pop(key, None)
+            if fin.alive:
+                lib.qgd_unregister_host_buffer(h, C.c_void_p(ptr))
+        pins[key] = weakref.finalize(array, unpin)
+        return array
+
     def eval_forward(self, pcof=None, uv_history=None):
+        _check_out(uv_history, self._hist_shape(), "uv_history")
         out3 = np.zeros(3)
         pc = None if pcof is None else np.ascontiguousarray(pcof, dtype=np.float64)
         _lib.check(self.h, self.lib.qgd_eval_forward(
@@ -138,6 +195,9 @@ class DeviceProblem:
             if rc:
                 _lib.check(self.h, rc)
             return io[1].copy(), io[2].copy()
+        _check_out(uv_history, self._hist_shape(), "history")
+        _check_out(lambda_history, self._hist_shape(), "lambda_history")
+        _check_out(adjoint_forcing, (2 * self.N, self.nsteps + 1, self.c), "adjoint_forcing")
         pc = np.ascontiguousarray(pcof, dtype=np.float64)
         grad = np.zeros(len(pc))
         out3 = np.zeros(3)
@@ -191,6 +251,7 @@ class DeviceProblem:
         want = (2 * self.N, self.m, self.nsteps + 1, self.c)
         if forcing.shape != want:
             raise ValueError(f"forcing must have shape {want}")
+        _check_out(uv_history, self._hist_shape(), "uv_history")
         out3 = np.zeros(3)
         _lib.check(self.h, self.lib.qgd_eval_forward_forced(self.h, _vp(pcof), len(pcof), _vp(forcing),
                                                              None if uv_history is None else _vp(uv_history), _vp(out3)))
@@ -229,23 +290,52 @@ class DeviceProblem:
 _cache: dict = {}
 
 
+def _fingerprint(prob):
+    """Cheap digest of the fields a handle copies to the device at creation (operators, initial
+    conditions, guard): a prob mutated in place gets a fresh handle instead of a stale device copy."""
+    import zlib
+    h = 0
+    for a in (prob.system_sym, prob.system_asym, prob.u0, prob.v0, prob.guard_subspace_projector,
+              *prob.sym_operators, *prob.asym_operators):
+        a = np.asarray(a)
+        h = zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1), h) ^ hash(a.shape)
+    return (h, prob.N_tot_levels, prob.N_initial_conditions, prob.N_ess_levels, prob.N_operators)
+
+
+def _evict(key):
+    ent = _cache.pop(key, None)
+    if ent is not None:
+        ent[1].close()
+
+
 def device_problem(prob, order: int, device: int = 0) -> DeviceProblem:
+    """The handle of (prob, order) -- created on first use, released when ``prob`` is garbage-collected
+    (or by release(prob) / clear_cache()), re-created when prob's operators or initial conditions changed."""
     key = (id(prob), int(order), device)
     ent = _cache.get(key)
-    if ent is not None and ent[0]() is prob:
+    fp = _fingerprint(prob)
+    if ent is not None and ent[0]() is prob and ent[2] == fp:
         dp = ent[1]
         if dp.nsteps != prob.nsteps or dp.tf != prob.tf:
             dp.set_nsteps(prob.nsteps, prob.tf)
         return dp
+    if ent is not None:
+        _evict(key)
     dp = DeviceProblem(prob, order, device)
-    _cache[key] = (weakref.ref(prob), dp)
+    _cache[key] = (weakref.ref(prob), dp, fp)
+    weakref.finalize(prob, _evict, key)
     return dp
 
 
+def release(prob):
+    """Close every cached handle of ``prob`` (all orders, all devices)."""
+    for key in [k for k, ent in _cache.items() if k[0] == id(prob) and ent[0]() is prob]:
+        _evict(key)
+
+
 def clear_cache():
-    for _, dp in list(_cache.values()):
-        dp.close()
-    _cache.clear()
+    for key in list(_cache):
+        _evict(key)
 
 
 # ---------------------------------------------------------------------------

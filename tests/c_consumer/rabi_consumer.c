@@ -1,0 +1,120 @@
+/* A plain C consumer of include/qgd.h -- the header, not a hand-copied ctypes/Julia struct, is the contract.
+ *
+ * Builds the reference's Rabi oscillator (src/ProblemConstructors/rabi_oscillator.jl:7-22: H = [[0, p+iq],[p-iq, 0]],
+ * U0 = I), and checks
+ *   1. the SchrodingerProb validation (a non-antisymmetric operator is an argument error with the reference's message);
+ *   2. qgd_eval_forward with explicit control tables: |Omega| = 1/2, tf = pi is a SWAP
+ *      (test/OptimizationTests/optimization_rabi_osc_SWAP.jl:18-39), to 1e-10;
+ *   3. qgd_discrete_adjoint with a two-coefficient control basis (p = theta_0, q = theta_1) against centred
+ *      differences of the infidelity from qgd_eval_forward (the reference's adjoint-vs-FD contract,
+ *      test/GradientTests/compare_gradients.jl:47-65), to 1e-7 relative;
+ *   4. the same problem through qgd_create_csc gives the same gradient.
+ * Exit code 0 and "C_CONSUMER_OK" on success; 3 when there is no GPU (the library has no CPU path).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qgd.h"
+
+#define NL 2
+#define NC 2
+#define ORDER 8
+#define M (ORDER / 2)
+#define NSTEPS 20
+#define NT (NSTEPS + 1)
+
+static int die(const char *what, qgd_handle h, int rc)
+{
+    fprintf(stderr, "%s failed: code %d: %s\n", what, rc, qgd_last_error(h));
+    return rc == QGD_ERR_NO_DEVICE ? 3 : 1;
+}
+
+static double infidelity_of(const double *out3) { return 1.0 - (out3[0] * out3[0] + out3[1] * out3[1]) / (NL * NL); }
+
+int main(void)
+{
+    const double pi = 3.14159265358979323846;
+    /* column-major 2x2: a + a^T and a - a^T with a = [[0,1],[0,0]] */
+    double zero[4] = {0, 0, 0, 0}, sym[4] = {0, 1, 1, 0}, asym[4] = {0, -1, 1, 0}, bad[4] = {0, 1, 1, 0};
+    double u0[4] = {1, 0, 0, 1}, v0[4] = {0, 0, 0, 0};
+    qgd_problem_desc d;
+    memset(&d, 0, sizeof d);
+    d.N = NL; d.n_cols = NC; d.n_ops = 1; d.n_ess = NL; d.order = ORDER; d.nsteps = NSTEPS; d.tf = pi;
+    d.system_sym = zero; d.system_asym = zero; d.sym_ops = sym; d.asym_ops = bad; d.u0 = u0; d.v0 = v0;
+    d.guard = NULL; d.device = 0;
+    qgd_handle h = NULL;
+    int rc;
+
+    if (qgd_abi_version() != QGD_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 1; }
+    /* 1. validation comes before any device work */
+    rc = qgd_create(&d, &h);
+    if (rc != QGD_ERR_ARGUMENT || h != NULL || !strstr(qgd_last_error(NULL), "not anti-symmetric")) {
+        fprintf(stderr, "validation: expected QGD_ERR_ARGUMENT, got %d (%s)\n", rc, qgd_last_error(NULL));
+        return 1;
+    }
+    d.asym_ops = asym;
+    if ((rc = qgd_create(&d, &h))) return die("qgd_create", NULL, rc);
+
+    /* 2. SWAP: tables[(1+M), n_ops, NT] column-major, p = 1/2, q = 0, all derivatives 0 */
+    static double pt[(1 + M) * NT], qt[(1 + M) * NT];
+    for (int n = 0; n < NT; n++) pt[(1 + M) * n] = 0.5;
+    if ((rc = qgd_set_control_tables(h, pt, qt))) return die("qgd_set_control_tables", h, rc);
+    static double hist[2 * NL * (1 + M) * NT * NC];
+    double out3[3];
+    if ((rc = qgd_eval_forward(h, NULL, 0, hist, out3))) return die("qgd_eval_forward", h, rc);
+    for (int col = 0; col < NC; col++)
+        for (int i = 0; i < NL; i++) {
+            const double *w = hist + ((size_t)(col * NT + NSTEPS) * (1 + M)) * 2 * NL;   /* [2N, 1+M, NT, NC], j = 0 */
+            const double p2 = w[i] * w[i] + w[NL + i] * w[NL + i], want = (i != col) ? 1.0 : 0.0;
+            if (fabs(p2 - want) > 1e-10) { fprintf(stderr, "SWAP: |psi[%d,%d]|^2 = %.15g\n", i, col, p2); return 1; }
+        }
+
+    /* 3. gradient: basis Gp[n][d][l], Gq[n][d][l], n_coeff = 2: p = theta_0, q = theta_1 (constant in time) */
+    static double Gp[NT * (1 + M) * 2], Gq[NT * (1 + M) * 2];
+    for (int n = 0; n < NT; n++) { Gp[(n * (1 + M)) * 2 + 0] = 1.0; Gq[(n * (1 + M)) * 2 + 1] = 1.0; }
+    const int32_t ncoef[1] = {2};
+    const double *gp[1] = {Gp}, *gq[1] = {Gq};
+    if ((rc = qgd_set_control_basis(h, ncoef, gp, gq))) return die("qgd_set_control_basis", h, rc);
+    double target[2 * NL * NC] = {0, 0, 0, -1, 0, 0, -1, 0};   /* [Re; Im] of -i * SWAP, column-major 4 x 2 */
+    if ((rc = qgd_set_target(h, target))) return die("qgd_set_target", h, rc);
+    double theta[2] = {0.4, 0.1}, grad[2], fd[2];
+    if ((rc = qgd_discrete_adjoint(h, theta, 2, 0, grad, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint", h, rc);
+    const double infid0 = infidelity_of(out3);
+    for (int l = 0; l < 2; l++) {
+        const double eps = 1e-5;
+        double tp[2] = {theta[0], theta[1]}, tm[2] = {theta[0], theta[1]}, op[3], om[3];
+        tp[l] += eps; tm[l] -= eps;
+        if ((rc = qgd_eval_forward(h, tp, 2, NULL, op))) return die("qgd_eval_forward(+)", h, rc);
+        if ((rc = qgd_eval_forward(h, tm, 2, NULL, om))) return die("qgd_eval_forward(-)", h, rc);
+        fd[l] = (infidelity_of(op) - infidelity_of(om)) / (2 * eps);
+        if (fabs(fd[l] - grad[l]) > 1e-7 * fmax(1.0, fabs(fd[l]))) {
+            fprintf(stderr, "gradient[%d]: adjoint %.12g, centred difference %.12g\n", l, grad[l], fd[l]);
+            return 1;
+        }
+    }
+    /* at theta = (1/2, 0) the gate is the target: infidelity 0 */
+    double opt[2] = {0.5, 0.0}, g2[2];
+    if ((rc = qgd_discrete_adjoint(h, opt, 2, 0, g2, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(opt)", h, rc);
+    if (fabs(infidelity_of(out3)) > 1e-10) { fprintf(stderr, "infidelity at the optimum: %.3e\n", infidelity_of(out3)); return 1; }
+
+    /* 4. the CSC constructor (Julia's 1-based SparseMatrixCSC arrays) */
+    const int64_t cp_zero[3] = {1, 1, 1}, cp_off[3] = {1, 2, 3}, rv_off[2] = {2, 1};
+    const double nz_sym[2] = {1, 1}, nz_asym[2] = {-1, 1};
+    qgd_csc zs = {cp_zero, NULL, NULL, 1, 0}, s1 = {cp_off, rv_off, nz_sym, 1, 0}, a1 = {cp_off, rv_off, nz_asym, 1, 0};
+    qgd_handle hc = NULL;
+    if ((rc = qgd_create_csc(&d, &zs, &zs, &s1, &a1, &hc))) return die("qgd_create_csc", NULL, rc);
+    if ((rc = qgd_set_control_basis(hc, ncoef, gp, gq))) return die("qgd_set_control_basis(csc)", hc, rc);
+    if ((rc = qgd_set_target(hc, target))) return die("qgd_set_target(csc)", hc, rc);
+    double gc[2];
+    if ((rc = qgd_discrete_adjoint(hc, theta, 2, 0, gc, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(csc)", hc, rc);
+    if (fabs(gc[0] - grad[0]) > 1e-13 || fabs(gc[1] - grad[1]) > 1e-13 || fabs(infidelity_of(out3) - infid0) > 1e-13) {
+        fprintf(stderr, "CSC handle differs: %.15g %.15g vs %.15g %.15g\n", gc[0], gc[1], grad[0], grad[1]);
+        return 1;
+    }
+    qgd_destroy(hc);
+    qgd_destroy(h);
+    printf("infidelity(0.4, 0.1) = %.12f  grad = [%.12f, %.12f]  fd = [%.12f, %.12f]\nC_CONSUMER_OK\n", infid0, grad[0], grad[1], fd[0], fd[1]);
+    return 0;
+}

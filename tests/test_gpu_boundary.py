@@ -1,0 +1,144 @@
+"""GPU tests of the drop-in boundary itself: a C consumer of include/qgd.h, the CSC constructor, the
+registered (pinned) output buffers of the reference-shaped discrete_adjoint! call, argument validation."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_c_consumer(tmpdir):
+    csrc = os.path.join(ROOT, "quantumgatedesign.jl_amd", "csrc")
+    exe = os.path.join(str(tmpdir), "rabi_consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_consumer", "rabi_consumer.c"), "-o", exe,
+                           "-L", csrc, "-lqgd_hip", f"-Wl,-rpath,{csrc}", "-Wl,-rpath-link,/opt/rocm/lib", "-lm"])
+    return exe
+
+
+def test_c_consumer_of_the_header(tmp_path):
+    """tests/c_consumer/rabi_consumer.c, compiled by gcc against include/qgd.h and linked to libqgd_hip.so: Rabi SWAP
+    closed form, adjoint vs centred differences, CSC constructor -- no Python, no ctypes struct in between."""
+    exe = build_c_consumer(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "C_CONSUMER_OK" in res.stdout
+
+
+@pytest.mark.parametrize("which,order", [("cnot2", 4), ("cnot3", 8)])
+def test_csc_constructor_matches_dense(qgd, which, order):
+    """qgd_create_csc (SparseMatrixCSC triples, SchrodingerProb.jl:24-31) against qgd_create on the same operators."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    out = []
+    for csc in (False, True):
+        dp = qgd.DeviceProblem(prob, order, csc=csc)
+        dp.set_controls(ctrl); dp.set_target(target)
+        out.append(dp.discrete_adjoint(pcof))
+        assert dp.operator_path()[0] == "sparse"
+        dp.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_registered_outputs_match_pageable(qgd, orc):
+    """The reference-shaped call discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, ...) as optimize_gate
+    makes it (ipopt_optimal_control.jl:304-330), with the three output arrays registered (pinned: device re-layout +
+    asynchronous copies beside the adjoint sweep, strided copy of the j = 0 columns of lambda_history) and not
+    registered: identical arrays, and both equal to the oracle's."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=24, tf=24.0)
+    order = 8
+    orc.set_converged_terminal(True)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    finally:
+        orc.set_converged_terminal(False)
+    dp = qgd.device_problem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    res = {}
+    for pinned in (False, True):
+        hist = np.full(h_ref.shape, np.nan, order="F"); lam = np.full(h_ref.shape, np.nan, order="F")
+        forcing = np.full(f_ref.shape, np.nan, order="F")
+        if pinned:
+            for a in (hist, lam, forcing):
+                dp.pin(a)
+            lam[...] = 0.0     # (a registered lambda_history is zero-filled by the library at its first use only)
+        for rep in range(2):   # the second call reuses the staging buffers and the registrations
+            grad, out3 = dp.discrete_adjoint(pcof + (0.0 if rep else 1e-3), False, hist, lam, forcing)
+        res[pinned] = (grad, hist, lam, forcing)
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+    grad, hist, lam, forcing = res[True]
+    assert np.abs(hist - h_ref).max() <= 1e-11 * max(1.0, np.abs(h_ref).max())
+    assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-11 * max(1.0, np.abs(lam_ref[:, 0]).max())
+    assert not lam[:, 1:].any()
+    assert np.abs(forcing - f_ref).max() <= 1e-11
+    assert np.abs(grad - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
+    del hist, lam, forcing, res      # unpins
+    qgd.clear_cache()
+
+
+def test_history_precomputed_is_tied_to_its_pcof(qgd):
+    """history_precomputed=True after a forward sweep with a DIFFERENT pcof must not differentiate the stale sweep
+    (the reference uses the history it is given together with the pcof it is given): the device redoes the sweep."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd)
+    dp = qgd.device_problem(prob, 4)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g_a, o_a = dp.discrete_adjoint(pcof)
+    pcof_b = pcof * 1.5
+    g_b, o_b = dp.discrete_adjoint(pcof_b)
+    dp.eval_forward(pcof_b)
+    g, o = dp.discrete_adjoint(pcof, history_precomputed=True)       # the sweep on the device belongs to pcof_b
+    assert np.allclose(g, g_a, rtol=0, atol=1e-14) and np.allclose(o, o_a, rtol=0, atol=1e-14)
+    g, o = dp.discrete_adjoint(pcof_b, history_precomputed=True)     # now it matches: reused
+    assert np.allclose(g, g_b, rtol=0, atol=1e-14) and np.allclose(o, o_b, rtol=0, atol=1e-14)
+    qgd.clear_cache()
+
+
+def test_output_array_validation(qgd):
+    """Wrong dtype / order / shape of an output array is a ValueError before anything reaches the C ABI
+    (the reference raises a DimensionMismatch); a target with the wrong row count likewise."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=10, tf=10.0)
+    order = 4
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    grad = np.zeros(len(pcof))
+    for bad in (np.zeros(shape, order="C"), np.zeros(shape, dtype=np.float32, order="F"),
+                np.zeros((shape[0], shape[1], shape[2] // 2, shape[3]), order="F")):
+        with pytest.raises(ValueError):
+            qgd.discrete_adjoint_(grad, bad, None, None, prob, ctrl, pcof, target, order=order)
+        with pytest.raises(ValueError):
+            qgd.discrete_adjoint_(grad, None, bad, None, prob, ctrl, pcof, target, order=order)
+    with pytest.raises(ValueError):
+        qgd.discrete_adjoint_(grad, None, None, np.zeros((shape[0], shape[2], shape[3] + 1), order="F"), prob, ctrl, pcof,
+                              target, order=order)
+    with pytest.raises(ValueError):
+        qgd.discrete_adjoint(prob, ctrl, pcof, target[:2], order=order)     # N_ess-row target
+    qgd.clear_cache()
+
+
+def test_handle_cache_follows_the_problem(qgd):
+    """The handle cache releases a prob's device grids when the prob dies and notices in-place mutation of its
+    operators / initial conditions (a stale device copy would silently answer for the old problem)."""
+    import gc
+    from qgd_amd import evolution
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=10, tf=10.0)
+    g0 = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=4)
+    assert any(k[0] == id(prob) for k in evolution._cache)
+    prob.u0[0, 0] = 0.5                                  # mutate in place
+    g1 = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=4)
+    assert np.abs(g1 - g0).max() > 1e-6
+    fresh = prob.copy()
+    g2 = qgd.discrete_adjoint(fresh, ctrl, pcof, target, order=4)
+    assert np.allclose(g1, g2, rtol=0, atol=1e-14)
+    n_before = len(evolution._cache)
+    del fresh
+    gc.collect()
+    assert len(evolution._cache) == n_before - 1
+    work = prob.copy()
+    qgd.get_histories(work, ctrl, pcof, 2, orders=(2, 4), quiet=True)      # closes the handles it created
+    assert len(evolution._cache) == n_before - 1
+    qgd.clear_cache()

@@ -4,6 +4,7 @@ the C-ABI library loads and exports every symbol include/qgd.h declares."""
 import ctypes as C
 import math
 import os
+import sys
 import re
 
 import numpy as np
@@ -190,6 +191,32 @@ def test_no_silent_cpu_fallback(qgd):
     with pytest.raises(qgd._lib.QGDError) as ei:
         qgd.DeviceProblem(prob, 3)          # odd order: ArgumentError before any device work
     assert ei.value.code == qgd._lib.QGD_ERR_ARGUMENT
+
+
+def test_c_consumer_compiles_against_the_header(tmp_path):
+    """tests/c_consumer/rabi_consumer.c is C99 compiled with -Wall -Wextra -Werror against include/qgd.h and linked to
+    libqgd_hip.so.  Without a GPU it must get as far as the SchrodingerProb validation (which needs no device) and
+    then stop with the library's no-device error (exit code 3) -- never compute on the CPU."""
+    import subprocess
+    import torch
+    from test_gpu_boundary import build_c_consumer
+    exe = build_c_consumer(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() == 0:
+        assert res.returncode == 3, res.stdout + res.stderr
+        assert "no HIP device" in res.stderr
+    else:
+        assert res.returncode == 0 and "C_CONSUMER_OK" in res.stdout, res.stdout + res.stderr
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` started bare must launch N ranks or fail loudly -- never print a 1-GPU number."""
+    import subprocess
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode != 0 and "refusing" in res.stderr and "metric" not in res.stdout
 
 
 def test_oracle_is_not_imported_by_the_package(qgd):

@@ -162,3 +162,18 @@ def test_reference_terminal_solve_stalls(qgd, orc):
     rel = lambda g: np.abs(g - exact).max() / np.abs(exact).max()
     assert rel(g_conv) < 1e-12
     assert 1e-9 < rel(g_faithful) < 1e-3
+
+
+def test_csc_operators_equal_dense(qgd, orc):
+    """The oracle's SparseMatrixCSC operator mode (the reference's DispersiveProblem default sparse_rep=true,
+    multi_qudit_systems.jl:118-162; used by bench.py's CPU-baseline variants) performs the same additions in the same
+    order over the stored entries: identical histories and gradient."""
+    prob, ctrl, pcof, target = cases.guarded_case(qgd, nsteps=6, tf=3.0)
+    out = []
+    for sp in (False, True):
+        orc.set_sparse_operators(sp)
+        try:
+            out.append(orc.discrete_adjoint(prob, ctrl, pcof, target, order=6, return_all=True))
+        finally:
+            orc.set_sparse_operators(False)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
