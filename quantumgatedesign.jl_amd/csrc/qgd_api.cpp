@@ -20,7 +20,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct Phase { const char *name; hipEvent_t e0, e1; bool used; };
+struct Phase { const char *name; int slot; hipEvent_t e0, e1; bool used; };
 
 }  // namespace
 
@@ -67,6 +67,17 @@ struct qgd_handle_s {
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
     std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
     bool copies_pending = false;
+    double *lambda_out = nullptr;       // lambda_history of the evaluation in flight (copied out right after the lambda phase)
+    // Time-chunk pipeline of the front of an evaluation (sparse path, N = 64).  build_LR, inverse+propagator and the
+    // block products are each latency-bound launches that leave most CUs idle at their tails, and time point n of one
+    // needs only time points n-1, n of the one before: the grid is cut into pipe_chunks groups of scan blocks; the
+    // build kernels run back to back on the main stream, and chunk i's inverse + block products run on side stream i
+    // as soon as its build is done -- beside the build of chunk i+1 and the inverses of the other chunks.
+    // QGD_PIPE_CHUNKS=1 turns it off.
+    enum { MAX_CHUNKS = 8 };
+    int pipe_chunks = getenv("QGD_PIPE_CHUNKS") ? atoi(getenv("QGD_PIPE_CHUNKS")) : 1;
+    hipStream_t pipe_stream[MAX_CHUNKS] = {};
+    hipEvent_t pipe_built[MAX_CHUNKS] = {}, pipe_done[MAX_CHUNKS] = {};
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_calls = 0;
@@ -118,22 +129,24 @@ double hermite_coefficient(int j, int p, int q) { return factorial(p) * factoria
 
 inline size_t panel_index(int row, int col, int PWc) { return (size_t)row * PWc + (col >> 3) * 16 + (col & 7); }
 
+// One event pair per (phase, slot): the pieces of a phase that the time-chunk pipeline launches on its side streams
+// are bracketed separately (slot = chunk) and qgd_get_timings adds them up.
 struct PhaseTimer {
-    qgd_handle h; size_t idx; bool on;
-    PhaseTimer(qgd_handle h_, const char *name) : h(h_), idx(0), on(h_->timing)
+    qgd_handle h; size_t idx; bool on; hipStream_t stream;
+    PhaseTimer(qgd_handle h_, const char *name, hipStream_t s = nullptr, int slot = 0) : h(h_), idx(0), on(h_->timing), stream(s ? s : h_->k.stream)
     {
         if (on && !h->timing_only.empty() && h->timing_only != name) on = false;
         if (!on) return;
-        for (idx = 0; idx < h->phases.size(); idx++) if (!strcmp(h->phases[idx].name, name)) break;
+        for (idx = 0; idx < h->phases.size(); idx++) if (!strcmp(h->phases[idx].name, name) && h->phases[idx].slot == slot) break;
         if (idx == h->phases.size()) {
-            Phase p{name, nullptr, nullptr, false};
+            Phase p{name, slot, nullptr, nullptr, false};
             (void)hipEventCreate(&p.e0); (void)hipEventCreate(&p.e1);
             h->phases.push_back(p);
         }
         h->phases[idx].used = true;
-        (void)hipEventRecord(h->phases[idx].e0, h->k.stream);
+        (void)hipEventRecord(h->phases[idx].e0, stream);
     }
-    ~PhaseTimer() { if (on) (void)hipEventRecord(h->phases[idx].e1, h->k.stream); }
+    ~PhaseTimer() { if (on) (void)hipEventRecord(h->phases[idx].e1, stream); }
 };
 
 int alloc_grid(qgd_handle h)
@@ -385,13 +398,57 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
     }
     if (!pcof) {   // (with pcof, k_tables clears them)
         HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));
-        HIP_TRY(h, hipMemsetAsync(k.status, 0, sizeof(int), k.stream));
+        HIP_TRY(h, hipMemsetAsync(k.status, 0, 2 * sizeof(int), k.stream));
     }
-    { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
-    { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
-    if (qgdk_propagator_is_fused(&k)) { K_TRY(h, qgdk_propagator(&k)); }   // k_inverse_mfma formed P_n already
-    else { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
-    { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
+    const int C = std::min<int>(h->pipe_chunks, qgd_handle_s::MAX_CHUNKS);
+    const bool piped = C > 1 && k.Np == 64 && k.use_sparse && qgdk_propagator_is_fused(&k) && k.scan_blocks >= 2 * C &&
+                       !(h->timing && h->timing_only.empty());      // (a full per-phase breakdown is taken on the serial path)
+    if (piped) {
+        const int B = k.scan_blocks, S = k.nt - 1;
+        const size_t pl = (size_t)k.Np * k.Np, panel = 2 * pl;
+        for (int i = 0; i < C; i++) {
+            if (!h->pipe_stream[i]) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[i], hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_built[i], hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_done[i], hipEventDisableTiming));
+            }
+            const int b0 = (int)((long long)B * i / C), b1 = (int)((long long)B * (i + 1) / C);
+            const int s_lo = std::min(S, b0 * k.scan_blen), s_hi = std::min(S, b1 * k.scan_blen);
+            if (s_hi <= s_lo) continue;
+            // build: time points (s_lo, s_hi] (and point 0 with the first chunk).  The launchers index everything by the
+            // time point: a context whose per-time-point arrays start at n0 and whose grid has `cnt` points does the piece.
+            {
+                const int n0 = (i == 0) ? 0 : s_lo + 1, cnt = s_hi - n0 + 1;
+                qgdk_ctx kb = k;
+                kb.tab += (size_t)n0 * (k.m + 1) * std::max(k.n_ops, 1) * 2; kb.L += (size_t)n0 * panel; kb.R += (size_t)n0 * panel;
+                kb.nt = cnt;
+                PhaseTimer t(h, "build_LR", k.stream, i);
+                K_TRY(h, qgdk_build_LR(&kb));
+            }
+            HIP_TRY(h, hipEventRecord(h->pipe_built[i], k.stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->pipe_stream[i], h->pipe_built[i], 0));
+            // inverse + propagator of the matrices n in (s_lo, s_hi]: L_n^-1 and P_{n-1} = L_n^-1 R_{n-1}
+            {
+                qgdk_ctx ki = k;
+                ki.stream = h->pipe_stream[i];
+                ki.L += (size_t)s_lo * panel; ki.R += (size_t)s_lo * panel; ki.LinvT += (size_t)s_lo * 2 * pl;
+                ki.LinvA += (size_t)s_lo * 2 * pl; ki.Pr += (size_t)s_lo * panel; ki.Pc += (size_t)s_lo * 2 * pl;
+                ki.nt = s_hi - s_lo + 1;
+                PhaseTimer t(h, "inverse", ki.stream, i);
+                K_TRY(h, qgdk_inverse(&ki));
+            }
+            { PhaseTimer t(h, "sweep_forward", h->pipe_stream[i], i); K_TRY(h, qgdk_forward_blocks_range(&k, b0, b1, h->pipe_stream[i])); }
+            HIP_TRY(h, hipEventRecord(h->pipe_done[i], h->pipe_stream[i]));
+        }
+        for (int i = 0; i < C; i++) HIP_TRY(h, hipStreamWaitEvent(k.stream, h->pipe_done[i], 0));
+        { PhaseTimer t(h, "sweep_forward", k.stream, C); K_TRY(h, qgdk_forward_blocks_upper(&k)); }
+    } else {
+        { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
+        { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
+        if (qgdk_propagator_is_fused(&k)) { K_TRY(h, qgdk_propagator(&k)); }   // k_inverse_mfma formed P_n already
+        else { PhaseTimer t(h, "propagator"); K_TRY(h, qgdk_propagator(&k)); }
+        { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
+    }
     h->forward_valid = false;
     h->derivs_valid = false;
     return QGD_OK;
@@ -422,6 +479,11 @@ int adjoint_end(qgd_handle h)
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
     { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+    if (h->lambda_out) {      // its download runs beside the gradient kernels
+        double *out = h->lambda_out; h->lambda_out = nullptr;
+        int rc = copy_panels_out(h, k.lam, &h->stage_lam, out, (size_t)k.m + 1, 1);
+        if (rc) return rc;
+    }
     if (!h->derivs_valid && qgdk_gradient_needs_derivs(&k)) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
     { PhaseTimer t(h, "gradient"); K_TRY(h, qgdk_gradient(&k)); }
     return QGD_OK;
@@ -714,6 +776,11 @@ void qgd_destroy(qgd_handle h)
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
     drop_graph(h);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (int i = 0; i < qgd_handle_s::MAX_CHUNKS; i++) {
+        if (h->pipe_stream[i]) { (void)hipStreamSynchronize(h->pipe_stream[i]); (void)hipStreamDestroy(h->pipe_stream[i]); }
+        if (h->pipe_built[i]) (void)hipEventDestroy(h->pipe_built[i]);
+        if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
+    }
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     for (auto &r : h->regs) (void)hipHostUnregister(r.host);
     free_pool(h->stage_bufs);
@@ -908,10 +975,13 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
         if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
         if ((rc = copy_history_out(h, uv_history))) return rc;
     }
-    if ((rc = adjoint_begin(h))) return rc;
-    if ((rc = adjoint_end(h))) return rc;
-    if (lambda_history && (rc = copy_panels_out(h, k.lam, &h->stage_lam, lambda_history, (size_t)k.m + 1, 1))) return rc;
+    // (the guard forcing is final once the forward sweep is: eval_grad_discrete_adjoint.jl:732-752)
     if (adjoint_forcing && (rc = copy_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
+    if ((rc = adjoint_begin(h))) return rc;
+    h->lambda_out = lambda_history;
+    rc = adjoint_end(h);
+    h->lambda_out = nullptr;
+    if (rc) return rc;
     if ((rc = fetch_results(h, grad, out3))) return rc;
     return finish_copies(h);
 }
@@ -1113,11 +1183,18 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     if (s == "L" || s == "R" || s == "Linv" || s == "P") need = nt * N * N * 2;
     else if (s == "sigma") need = nt * (size_t)k.n_ops * k.m * 2;
     else if (s == "tables") need = nt * (size_t)(k.m + 1) * k.n_ops * 2;
+    else if (s == "repivoted") need = 1;
     else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
     if (needed) *needed = need;
     if (!out) return QGD_OK;
     if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
     HIP_TRY(h, hipStreamSynchronize(k.stream));
+    if (s == "repivoted") {     // workgroups of the last inverse launch whose static-pivot attempt was redone with partial pivoting
+        int v[2] = {0, 0};
+        HIP_TRY(h, hipMemcpy(v, k.status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        out[0] = (double)v[1];
+        return QGD_OK;
+    }
     if (s == "sigma") { HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
     if (s == "tables") { HIP_TRY(h, hipMemcpy(out, k.tab, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
     memset(out, 0, need * sizeof(double));
@@ -1295,13 +1372,23 @@ int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, in
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->k.stream);
     int cnt = 0;
-    for (auto &p : h->phases) {
+    for (size_t i = 0; i < h->phases.size(); i++) {
+        auto &p = h->phases[i];
         if (!p.used) continue;
+        bool first = true;        // the pieces of one phase (slots of the time-chunk pipeline) are reported as their sum
+        for (size_t j = 0; j < i; j++) if (h->phases[j].used && !strcmp(h->phases[j].name, p.name)) first = false;
+        if (!first) continue;
         if (cnt < cap && names && ms) {
             names[cnt] = p.name;
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, p.e0, p.e1) != hipSuccess) t = -1.f;
-            ms[cnt] = t;
+            float tot = 0.f;
+            for (size_t j = i; j < h->phases.size(); j++) {
+                auto &q = h->phases[j];
+                if (!q.used || strcmp(q.name, p.name)) continue;
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, q.e0, q.e1) != hipSuccess) { tot = -1.f; break; }
+                tot += t;
+            }
+            ms[cnt] = tot;
         }
         cnt++;
     }

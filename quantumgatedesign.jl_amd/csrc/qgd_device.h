@@ -88,6 +88,8 @@ int qgdk_propagator(const qgdk_ctx *c);
 int qgdk_propagator_is_fused(const qgdk_ctx *c);
 int qgdk_forward_blocks(const qgdk_ctx *c);
 int qgdk_forward_finish(const qgdk_ctx *c);
+int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t stream);
+int qgdk_forward_blocks_upper(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
 int qgdk_guard_is_fused(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < 4) scal[gid] = 0.0;            // objective scalars and the singularity flag start at zero
     if (gid == 4) *status = 0;
+    if (gid == 5) status[1] = 0;          // workgroups of the inverse that fell back to partial pivoting
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
     double s = 0.0;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < 4) scal[gid] = 0.0;
     if (gid == 4) *status = 0;
+    if (gid == 5) status[1] = 0;          // workgroups of the inverse that fell back to partial pivoting
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
     double s = 0.0;

@@ -938,6 +938,42 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
     return 0;
 }
 
+// forward, part 1 in pieces (time-chunk pipeline of qgd_api.cpp): the block propagators of blocks [b0, b1) on `stream`;
+// then the levels above them (super-blocks, window product) on the context's stream
+int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t stream)
+{
+    const size_t pl2 = (size_t)2 * c->Np * c->Np;
+    const int B = c->scan_blocks, S = c->nt - 1;
+    const int s_lo = b0 * c->scan_blen, s_hi = (b1 * c->scan_blen < S) ? b1 * c->scan_blen : S;
+    if (b1 <= b0 || s_hi <= s_lo) return 0;
+    ChainArgs a{};
+    a.Np = c->Np; a.cp = c->cp; a.S = s_hi - s_lo; a.Pmat = c->Pc + (size_t)s_lo * pl2;
+    a.PiC = c->PiX + (size_t)b0 * pl2; a.PiR = c->PiX + ((size_t)B + b0) * pl2;
+    a.nblocks = b1 - b0; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    return launch_chain<0>(a, stream);
+}
+
+int qgdk_forward_blocks_upper(const qgdk_ctx *c)
+{
+    const size_t pl2 = (size_t)2 * c->Np * c->Np;
+    const int B = c->scan_blocks, B2 = c->scan_blocks2, g = c->scan_g;
+    int rc;
+    if (B2 > 1) {      // super-block propagators from the block propagators
+        ChainArgs a2{};
+        a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
+        a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+    }
+    if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
+        ChainArgs r{};
+        r.Np = c->Np; r.cp = c->cp; r.ngroups = c->Np / 8; r.nblocks = 1;
+        if (B2 > 1) { r.S = B2; r.blen = B2; r.Pmat = c->PiC2; } else { r.S = B; r.blen = B; r.Pmat = c->PiX; }
+        r.PiC = c->RX + (size_t)c->part_rank * rx_chunk(c); r.PiR = r.PiC + pl2;
+        if ((rc = launch_chain<0>(r, c->stream))) return rc;
+    }
+    return 0;
+}
+
 // forward, part 2 (after the all-gather of RX): state at the window start, at the super-block and block
 // starts, then the history of the own blocks
 int qgdk_forward_finish(const qgdk_ctx *c)

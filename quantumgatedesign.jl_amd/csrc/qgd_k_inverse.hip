@@ -564,6 +564,323 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 }
 
 // ---------------------------------------------------------------------------
+// K2 (Np = 64, default): the same blocked Gauss-Jordan + fused propagator, NM matrices per workgroup with
+// ALIGNED phases, static pivots first.
+//
+// What k_inverse_mfma loses (profiles/r01_v13: 0.28 of the fp64 MFMA peak, 64 x ~790-cycle pivot steps per matrix):
+// on gfx950 an f64 MFMA holds the SIMD's fp64 pipe for 64 cycles, so a wave that shares its SIMD with another
+// workgroup's burst of rank-4 updates issues about ONE vector instruction per MFMA -- and the serial pivot chain of a
+// matrix is ~200 dependent vector instructions per panel.  Three independent workgroups per CU interleave their
+// phases at random, so most pivot chains run beside somebody's MFMA burst.  Here the NM matrices that share a CU
+// live in ONE workgroup (NM x 4 waves; matrix i's waves on SIMDs 0..3, its panel wave on SIMD i) and every
+// barrier is common: all panel chains run at the same time on different SIMDs with no MFMA in flight, then all
+// waves issue their rank-4 updates together.
+//
+// Static pivots: L(t_n) = sum_j c_j (-dt)^j D_j is strongly diagonally dominant for the reference's physical models
+// (diagonal drift, small couplings: src/ProblemConstructors/multi_qudit_systems.jl), so the first attempt takes the
+// diagonal as pivot -- no DPP max-scan, no readlane of the winner, pivot ROWS known in advance: they are published
+// together with the panel columns (2 barriers per panel instead of 3) and the output permutation is the identity.
+// Every multiplier is checked against a modulus of 8 (partial pivoting guarantees 1); when any matrix of the
+// workgroup exceeds it (or meets a zero pivot) the workgroup reloads its matrices and repeats the elimination with
+// partial pivoting, exactly as k_inverse_mfma does.  Singular matrices raise `status` from the pivoted pass only.
+// ---------------------------------------------------------------------------
+#define INV_GROWTH2 64.0
+
+#ifdef QGD_INVM_PROFILE      // scripts/ubench/inverse_multi_bench.hip: cycles of workgroup 0 / thread 0 per phase
+__device__ unsigned long long g_invm_prof[16];
+#define INVM_PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_invm_prof[i] += (unsigned long long)(now_ - prof_last); prof_last = now_; } } while (0)
+#define INVM_PROF_DECL long long &prof_last,
+#define INVM_PROF_ARG prof_last,
+#else
+#define INVM_PROF(i) do { } while (0)
+#define INVM_PROF_DECL
+#define INVM_PROF_ARG
+#endif
+
+template <int NP, bool STATIC>
+__device__ __forceinline__ bool gj_panels(INVM_PROF_DECL d4 (&M)[NP / 8], double *__restrict__ work, int *__restrict__ rho,
+                                          int *__restrict__ rinv, const int w, const int lane, const int pw,
+                                          int *__restrict__ status)
+{
+    constexpr int NG = NP / 8, PW = 2 * NP;
+    constexpr int O_PROW = 0, O_G = O_PROW + 8 * PW, O_F = O_G + 16 * NP;
+    double *Prow = work + O_PROW;                       // [2][4][PW]   pivot rows (B operand), by panel parity
+    double *Gm = work + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
+    double *Fm = work + O_F;                            // [2][NP][4]   panel columns re/im
+    const int c16 = lane & 15, kk = lane >> 4;
+    bool used = lane >= NP;                             // panel wave, pivoted pass: this lane's row has been a pivot row
+    bool bad = false;
+    for (int pn = 0; pn < NP / 4; pn++) {
+        const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
+        double *Gre = Gm + par * 8 * NP, *Gim = Gre + 4 * NP;
+        double *Pr = Prow + par * 4 * PW;
+        // ---- 1. publish the panel columns; static pass: and the pivot rows p0..p0+3 (rows 16w+kk+4r: wave p0/16,
+        //         register (p0/4)%4, lanes kk = 0..3)
+        {
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                double *dst = Fm + (c16 < 8 ? 0 : 4 * NP);
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) dst[(16 * w + kk + 4 * r) * 4 + s] = M[g][r];
+                    }
+                }
+            }
+        }
+        if (STATIC && w == (p0 >> 4)) {
+            const int rsel = (p0 >> 2) & 3;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r == rsel) {
+                    #pragma unroll
+                    for (int g = 0; g < NG; g++) Pr[kk * PW + 16 * g + c16] = M[g][r];
+                }
+            }
+        }
+        INVM_PROF(1);
+        lds_barrier();
+        INVM_PROF(2);
+        // ---- 2. the panel wave of this matrix: in-place Gauss-Jordan on the NP x 4 panel, lane = row
+        if (w == pw) {
+            double xr[4], xi[4];
+            const int lrow = (lane < NP) ? lane : 0;
+            #pragma unroll
+            for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                int pr;
+                if (STATIC) pr = p0 + s;
+                else {
+                    const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
+                    unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
+                    key = wave_max_u32(key);
+                    pr = 63 - (int)(key & 63u);
+                    if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
+                    used = used || (lane == pr);
+                }
+                double yr[4], yi[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
+                const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
+                const double ir = yr[s] * den, ii = -yi[s] * den;
+                const double fr = xr[s], fi = xi[s];
+                if (STATIC) {      // |multiplier|^2 of every other row; NaN (zero pivot) counts as too large
+                    const double m2 = (fr * fr + fi * fi) * den;
+                    bad = bad || (lane != pr && lane < NP && !(m2 <= INV_GROWTH2));
+                }
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double rr = (q == s) ? ir : yr[q] * ir - yi[q] * ii;      // scaled pivot row
+                    const double ri = (q == s) ? ii : yr[q] * ii + yi[q] * ir;
+                    const double br = (q == s) ? 0.0 : xr[q], bi = (q == s) ? 0.0 : xi[q];
+                    xr[q] = (lane == pr) ? rr : br - (fr * rr - fi * ri);
+                    xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
+                }
+            }
+            if (lane < NP) {
+                #pragma unroll
+                for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
+            }
+        }
+        INVM_PROF(3);
+        lds_barrier();
+        INVM_PROF(4);
+        // ---- 3. pivoted pass: the owners of the pivot rows publish them as the B operand of the block step
+        if (!STATIC) {
+            const int s0 = rho[p0], s1 = rho[p0 + 1], s2 = rho[p0 + 2], s3 = rho[p0 + 3];
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = 16 * w + kk + 4 * r;
+                const int ps = (x == s0) ? 0 : (x == s1) ? 1 : (x == s2) ? 2 : (x == s3) ? 3 : -1;
+                if (ps >= 0) {
+                    #pragma unroll
+                    for (int g = 0; g < NG; g++) Pr[ps * PW + 16 * g + c16] = M[g][r];
+                }
+            }
+            lds_barrier();
+        }
+        // ---- 4. rank-4 block step on the MFMA, then the pivot columns take the multipliers
+        {
+            const int arow = 16 * w + c16;
+            const int prow = STATIC ? p0 + kk : rho[p0 + kk];
+            const double are = Gre[arow * 4 + kk] - ((arow == prow) ? 1.0 : 0.0);
+            const double aim = Gim[arow * 4 + kk];
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double b1, b2;
+                panel_b(Pr + kk * PW + 16 * g, c16, b1, b2);
+                M[g] = MFMA(are, b1, M[g]);
+                M[g] = MFMA(aim, b2, M[g]);
+            }
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                const double *src = (c16 < 8) ? Gre : Gim;
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) M[g][r] = src[(16 * w + kk + 4 * r) * 4 + s];
+                    }
+                }
+            }
+        }
+        INVM_PROF(5);
+        // no barrier here: the next panel writes F (last read before barrier 2) and the buffers read above
+        // (G, Prow) alternate with the panel parity
+    }
+    return __any(bad);
+}
+
+template <int NP, int NM, int WPE = NM>
+__global__ __launch_bounds__(NP * 4 * NM) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void k_inverse_multi(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                     double *__restrict__ Pr, double *__restrict__ Pc, int n0, int n_end, int try_static,
+                     int *__restrict__ status, int *__restrict__ repivoted)
+{
+    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
+    constexpr int WORK = 8 * PW + 16 * NP + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
+    __shared__ double smem_all[NM][SM];
+    __shared__ int rho_all[NM][NP], rinv_all[NM][NP];
+    __shared__ int redo;
+    const int wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // (wave-uniform: addresses stay in SGPRs)
+    const int mat = wg / NW, w = wg % NW, t = threadIdx.x - mat * NTH;       // t: thread index within the matrix
+    const int c16 = lane & 15, kk = lane >> 4;
+    int n = n0 + (int)blockIdx.x * NM + mat;
+    const bool valid = n < n_end;                       // (a workgroup past the end repeats the last matrix, without stores)
+    if (!valid) n = n_end - 1;
+    double *smem = smem_all[mat];
+    int *rho = rho_all[mat], *rinv = rinv_all[mat];
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const double *Ln = L + (size_t)n * panel;
+    const int pw = mat % NW;                            // panel waves of the matrices of a workgroup sit on different SIMDs
+
+    d4 M[NG];
+#ifdef QGD_INVM_PROFILE
+    long long prof_last = clock64();
+#endif
+    if (threadIdx.x == 0) redo = 0;
+    // attempt 0: static pivots (skipped when try_static == 0); attempt 1: partial pivoting.  ONE copy of the load in
+    // the code: two copies let the compiler keep the first M alive for the second attempt (64 more registers, spills).
+    for (int attempt = try_static ? 0 : 1; attempt < 2; attempt++) {
+        #pragma unroll
+        for (int g = 0; g < NG; g++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
+        INVM_PROF(0);
+        if (attempt == 0) {
+            __syncthreads();
+            const bool bad = gj_panels<NP, true>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, pw, status);
+            if (w == pw && bad && lane == 0) redo = 1;
+            __syncthreads();
+            if (!redo) {
+                if (t < NP) { rho[t] = t; rinv[t] = t; }
+                break;
+            }
+            if (threadIdx.x == 0 && repivoted) atomicAdd(repivoted, 1);    // some multiplier was too large: start over
+        } else {
+            (void)gj_panels<NP, false>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, pw, status);
+        }
+    }
+    __syncthreads();
+    INVM_PROF(6);
+    // ---- output (as k_inverse_mfma).  A^-1[rinv[x]][rho[j]] = M[x][j] goes through LDS one plane at a time (real
+    // parts, then imaginary parts): each staged plane is written out as LinvT (left operand of lambda = L^-H y) and is at
+    // once the A operand of one half of the step propagator P_{n-1} = L_n^-1 R_{n-1} = Are [Rre|Rim] + Aim [-Rim|Rre]
+    // (forward_evolution.jl:181-220, the implicit solve done for all right-hand sides).  For the product wave w owns the
+    // column groups 2w, 2w+1 of P over all rows: R is read once.
+    double *T = LinvT + (size_t)n * 2 * pl;
+    const double *Rn = R + (size_t)(n - 1) * panel;
+    int orow[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) orow[r] = rinv[16 * w + kk + 4 * r] * LDP;
+    constexpr int NRT = NP / 16, GPW = NG / NW;            // row tiles, column groups per wave
+    d4 acc[NRT][GPW];
+    #pragma unroll
+    for (int rt = 0; rt < NRT; rt++)
+        #pragma unroll
+        for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = (d4){0, 0, 0, 0};
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((c16 >> 3) == pass) {
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int oc = rho[8 * g + (c16 & 7)];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) smem[orow[r] + oc] = M[g][r];
+            }
+        }
+        lds_barrier();
+        INVM_PROF(7);
+        if (valid) {   // (buffer-addressed: descriptor and the constant part of the offset in SGPRs, no 64-bit vector adds)
+            const __amdgpu_buffer_rsrc_t rT = buffer_of(T + pass * pl);
+            #pragma unroll
+            for (int q = 0; q < NP * NP / NTH; q++) {
+                const int e = t + q * NTH;
+                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
+            }
+        }
+        INVM_PROF(8);
+        #pragma unroll 4
+        for (int ks = 0; ks < NP / 4; ks++) {
+            const int k = 4 * ks + kk;
+            double bf[GPW];
+            #pragma unroll
+            for (int gg = 0; gg < GPW; gg++) {
+                const double *row = Rn + (size_t)k * PW + 16 * (GPW * w + gg);
+                if (pass == 0) bf[gg] = row[c16];
+                else { const double v = row[c16 ^ 8]; bf[gg] = (c16 < 8) ? -v : v; }
+            }
+            #pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const double af = smem[(16 * rt + c16) * LDP + k];
+                #pragma unroll
+                for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
+            }
+        }
+        INVM_PROF(9);
+        lds_barrier();
+        INVM_PROF(10);
+    }
+    // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
+    // column-major planes (left operand of the forward sweep) through LDS
+    double *Prn = Pr + (size_t)(n - 1) * panel, *Pcn = Pc + (size_t)(n - 1) * 2 * pl;
+    if (valid) {
+        #pragma unroll
+        for (int rt = 0; rt < NRT; rt++)
+            #pragma unroll
+            for (int gg = 0; gg < GPW; gg++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    Prn[(size_t)(16 * rt + kk + 4 * r) * PW + 16 * (GPW * w + gg) + c16] = acc[rt][gg][r];
+    }
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((c16 >> 3) == pass) {
+            #pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+                #pragma unroll
+                for (int gg = 0; gg < GPW; gg++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        smem[(8 * (GPW * w + gg) + (c16 & 7)) * LDP + 16 * rt + kk + 4 * r] = acc[rt][gg][r];   // [col][row]
+        }
+        lds_barrier();
+        if (valid) {
+            const __amdgpu_buffer_rsrc_t rC = buffer_of(Pcn + pass * pl);
+            #pragma unroll
+            for (int q = 0; q < NP * NP / NTH; q++) {
+                const int e = t + q * NTH;
+                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rC, t * 8, q * NTH * 8);
+            }
+        }
+        lds_barrier();
+    }
+    INVM_PROF(11);
+}
+
+// ---------------------------------------------------------------------------
 // K2 (any Np > 64 whose panels fit in LDS, Np <= 288): blocked Gauss-Jordan with the matrix in an
 // HBM/L2 work slab (panel layout) and 16 pivots per panel.  The same scheme as k_inverse_mfma --
 // implicit pivoting, the pivoted in-place elimination of the Np x 16 panel yields the multipliers,
@@ -799,6 +1116,19 @@ int qgdk_inverse(const qgdk_ctx *c)
     case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 64:   // blocked elimination with MFMA rank-4 updates (the register-blocked VALU kernel measured 0.22 ms)
+        // QGD_INV_STATIC=1: k_inverse_multi (static pivots first, partial pivoting when a multiplier exceeds 8), one matrix
+        // per workgroup and three workgroups per CU; QGD_INV_MULTI=2|3: that many matrices per workgroup with aligned
+        // phases; with QGD_INV_PIVOTED=1 no static attempt.  Comparison paths: in the cnot3 evaluation none of them beats
+        // k_inverse_mfma (347 us per evaluation against 351 static, 354 three aligned matrices, 389 two).
+        if (!getenv("QGD_INVERSE_VALU") && (getenv("QGD_INV_STATIC") || getenv("QGD_INV_MULTI"))) {
+            const char *mm = getenv("QGD_INV_MULTI");
+            const int nm = mm ? atoi(mm) : 1, st = getenv("QGD_INV_PIVOTED") ? 0 : 1;
+#define CALL_IM(NM, WPE) hipLaunchKernelGGL((k_inverse_multi<64, NM, WPE>), dim3((nmat + NM - 1) / NM), dim3(256 * NM), 0, c->stream, c->L, c->R, \
+                                            c->LinvT, c->Pr, c->Pc, 1, nmat + 1, st, c->status, c->status + 1)
+            if (nm == 3) CALL_IM(3, 3); else if (nm == 2) CALL_IM(2, 2); else CALL_IM(1, 3);
+#undef CALL_IM
+            return (int)hipGetLastError();
+        }
         if (!getenv("QGD_INVERSE_VALU")) {
             hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status
 #ifdef QGD_INV_PROFILE

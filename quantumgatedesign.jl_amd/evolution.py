@@ -235,6 +235,8 @@ class DeviceProblem:
         if name in ("L", "R", "Linv", "P"):
             z = out.reshape(nt, self.N, self.N, 2)
             return z[..., 0] + 1j * z[..., 1]
+        if name == "repivoted":
+            return int(out[0])
         if name == "sigma":
             return out.reshape(nt, self.n_ops, self.m, 2)
         return out.reshape(nt, self.m + 1, self.n_ops, 2)
