@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libqgd_hip.so")
+# QGD_LIB_PATH: an alternative build of the same library (e.g. one compiled with the in-kernel cycle stamps on)
+LIB_PATH = os.environ.get("QGD_LIB_PATH") or os.path.join(CSRC, "libqgd_hip.so")
 
 QGD_OK, QGD_ERR_ARGUMENT, QGD_ERR_NO_DEVICE, QGD_ERR_STATE, QGD_ERR_UNSUPPORTED, QGD_ERR_NUMERIC = range(6)
 

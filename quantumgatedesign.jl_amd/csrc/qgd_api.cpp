@@ -255,7 +255,8 @@ int alloc_grid(qgd_handle h)
     const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
     if (need > 150 * 1024 || Np > 64) {      // (the blocked kernel for Np > 64 always works in a slab)
         k.inv_batch = 512;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.inv_scratch, (size_t)k.inv_batch * 2 * pl))) return rc;
+        // (work slab + the 64 pivot rows of a super-step of k_inverse_blocked2, per workgroup)
+        if ((rc = dev_alloc(h, h->grid_bufs, &k.inv_scratch, (size_t)k.inv_batch * (2 * pl + 64 * 2 * Np)))) return rc;
     } else {
         k.inv_batch = 0; k.inv_scratch = nullptr;
     }

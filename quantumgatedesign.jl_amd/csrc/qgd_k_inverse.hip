@@ -1025,6 +1025,264 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// K2 (64 < Np <= 288, default): the same blocked Gauss-Jordan with TWO block levels.  k_inverse_blocked streams the whole
+// work slab (2 Np^2 doubles, 1 MB at Np = 256) through the accumulators once per 16 pivots: 6.4 GB per launch at config
+// 5 against 0.6 GB algorithmic (PMC, profiles/r01_v8_pmc_c5.json), and it is HBM-bound there.  Block Gauss-Jordan has the
+// same form for any block size -- M += (G - E_P) M[P,:], G = the in-place result of eliminating the pivot columns -- so
+// the 16-pivot steps are applied to the 64 columns of a SUPER-PANEL only (that is the in-place elimination of an
+// Np x 64 panel), and the columns outside it get one rank-64 update per super-panel: the slab is streamed Np/64 times
+// instead of Np/16.  The rank-64 update keeps the A operand of a row block (16 rows x 64 pivots) in registers over all
+// column groups; its B operand, the 64 pivot rows as they were before the super-step, is copied to a scratch area
+// behind the slab first (the rows are overwritten in place by their own tiles).
+// ---------------------------------------------------------------------------
+#define INVB_SB 64
+// [-Bim | Bre] from [Bre | Bim]: rotate the 16-lane row by 8 and negate lanes 0..7 (as swap8_signed of qgd_k_dense.hip)
+__device__ __forceinline__ double swap8_signed_inv(double b1, int sign_hi)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);
+    return __hiloint2double(hi ^ sign_hi, lo);
+}
+__global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restrict__ L,
+                                                          double *__restrict__ LinvA,
+                                                          double *__restrict__ LinvT,
+                                                          double *__restrict__ scratch, int Np, int n0,
+                                                          int *__restrict__ status)
+{
+    constexpr int NB = INVB_NB, SB = INVB_SB;
+    extern __shared__ double smem[];
+    const int PW = 2 * Np;
+    double *Fre = smem, *Fim = Fre + (size_t)Np * NB;          // panel columns -> multipliers
+    double *Bp = Fim + (size_t)Np * NB;                         // [NB][2*SB] pivot rows of the inner step (super-panel columns only)
+    double *fre = Bp + (size_t)NB * 2 * SB, *fim = fre + Np;    // column s of the panel before the step
+    double *yrow = fim + Np;                                    // [2*NB] scaled pivot row
+    double *redv = yrow + 2 * NB;                               // [8]
+    int *redi = reinterpret_cast<int *>(redv + 8);              // [8]
+    int *rho = redi + 8, *rinv = rho + Np, *used = rinv + Np;
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, nth = blockDim.x, wave = t >> 6, lane = t & 63, nw = nth >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    double *W = scratch + (size_t)blockIdx.x * (panel + (size_t)SB * PW);
+    double *Bg = W + panel;                                      // [SB][PW] pivot rows of the super-step (old values)
+    const double *Ln = L + (size_t)n * panel;
+#ifdef QGD_INVB_PROFILE
+    long long pt[8] = {0,0,0,0,0,0,0,0}, pl_ = clock64();
+#define IB2(i) do { const long long n_ = clock64(); pt[i] += n_ - pl_; pl_ = n_; } while (0)
+#else
+#define IB2(i) do { } while (0)
+#endif
+    // (no copy of L into the slab: every element is READ from L until the step that first writes it -- the columns of
+    //  super-panel 0 until its first inner update, the other columns until the first rank-64 update -- and from the slab after)
+    for (int r = t; r < Np; r += nth) used[r] = 0;
+    __syncthreads();
+    IB2(0);
+
+    for (int q0 = 0; q0 < Np; q0 += SB) {
+        const int sbw = (Np - q0 < SB) ? Np - q0 : SB;          // pivots of this super-panel (a multiple of 16)
+        const int g_lo = q0 >> 3, sg = sbw >> 3;                // its column groups: g_lo .. g_lo + sg - 1
+        for (int p0 = q0; p0 < q0 + sbw; p0 += NB) {
+            const double *Ws = (p0 == 0) ? Ln : W;              // source of the super-panel's columns in this step
+            // ---- 1. the 16 panel columns into LDS
+            for (int e = t; e < Np * NB; e += nth) {
+                const int r = e / NB, col = p0 + (e % NB);
+                const size_t o = (size_t)r * PW + (col >> 3) * 16 + (col & 7);
+                Fre[e] = Ws[o]; Fim[e] = Ws[o + 8];
+            }
+            __syncthreads();
+            IB2(1);
+            // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
+            for (int s = 0; s < NB; s++) {
+                double best = -1.0; int bi = 0;
+                for (int r = t; r < Np; r += nth) {
+                    const double a = Fre[r * NB + s], b = Fim[r * NB + s];
+                    fre[r] = a; fim[r] = b;
+                    const double v = a * a + b * b;
+                    if (!used[r] && v > best) { best = v; bi = r; }
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ob = __shfl_down(best, off);
+                    const int oi = __shfl_down(bi, off);
+                    if (ob > best) { best = ob; bi = oi; }
+                }
+                if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
+                __syncthreads();
+                int pr = redi[0]; double pb = redv[0];
+                for (int w = 1; w < nw; w++) if (redv[w] > pb) { pb = redv[w]; pr = redi[w]; }
+                if (t < NB) {                                    // scaled pivot row (the pivot entry becomes 1/pivot)
+                    const double a = fre[pr], b = fim[pr];
+                    const double den = 1.0 / (a * a + b * b), ir = a * den, ii = -b * den;
+                    const double x = Fre[pr * NB + t], y = Fim[pr * NB + t];
+                    yrow[t] = (t == s) ? ir : x * ir - y * ii;
+                    yrow[NB + t] = (t == s) ? ii : x * ii + y * ir;
+                }
+                if (t == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; used[pr] = 1; if (!(pb > 0.0)) *status = 1; }
+                __syncthreads();
+                for (int e = t; e < Np * NB; e += nth) {
+                    const int r = e / NB, q = e % NB;
+                    const double rr = yrow[q], ri = yrow[NB + q];
+                    if (r == pr) { Fre[e] = rr; Fim[e] = ri; }
+                    else {
+                        const double f1 = fre[r], f2 = fim[r];
+                        const double br = (q == s) ? 0.0 : Fre[e], bi2 = (q == s) ? 0.0 : Fim[e];
+                        Fre[e] = br - (f1 * rr - f2 * ri);
+                        Fim[e] = bi2 - (f1 * ri + f2 * rr);
+                    }
+                }
+                __syncthreads();
+            }
+            IB2(2);
+            // ---- 3. the 16 pivot rows (their values before the step), super-panel columns only, as B operand
+            for (int e = t; e < NB * 2 * sbw; e += nth) {
+                const int k = e / (2 * sbw), c = e % (2 * sbw);
+                Bp[k * 2 * SB + c] = Ws[(size_t)rho[p0 + k] * PW + 16 * g_lo + c];
+            }
+            __syncthreads();
+            IB2(3);
+            // ---- 4. rank-16 step on the columns of the super-panel; the pivot columns then take the multipliers
+            const int gp = p0 >> 3;
+            // (four column groups of a row block at a time: independent accumulators, one A operand, 16 loads in flight)
+            const int sq = (sg + 3) >> 2;
+            for (int ti = wave; ti < (Np / 16) * sq; ti += nw) {
+                const int rb = ti / sq, gq = (ti % sq) * 4;
+                const int arow = 16 * rb + c16;
+                d4 acc[4];
+                int gi[4]; bool ok[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ok[q] = gq + q < sg;
+                    gi[q] = ok[q] ? gq + q : gq;
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) acc[q][r] = Ws[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * (g_lo + gi[q]) + c16];
+                }
+                #pragma unroll
+                for (int ks = 0; ks < NB / 4; ks++) {
+                    const int sidx = 4 * ks + kk;
+                    const double are = Fre[arow * NB + sidx] - ((arow == rho[p0 + sidx]) ? 1.0 : 0.0);
+                    const double aim = Fim[arow * NB + sidx];
+                    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        double b1, b2;
+                        panel_b(Bp + (size_t)sidx * 2 * SB + 16 * gi[q], c16, b1, b2);
+                        acc[q] = MFMA(are, b1, acc[q]);
+                        acc[q] = MFMA(aim, b2, acc[q]);
+                    }
+                }
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int g = g_lo + gi[q];
+                    if (g == gp || g == gp + 1) {
+                        const int sidx = 8 * (g - gp) + (c16 & 7);
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = 16 * rb + kk + 4 * r;
+                            acc[q][r] = (c16 < 8) ? Fre[row * NB + sidx] : Fim[row * NB + sidx];
+                        }
+                    }
+                    if (ok[q]) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16] = acc[q][r];
+                    }
+                }
+            }
+            __syncthreads();
+            IB2(4);
+        }
+        if (sbw == Np) break;                                   // one super-panel covers the matrix: nothing outside it
+        const double *Wo = (q0 == 0) ? Ln : W;                  // the outside columns have not been written before the first rank-64 update
+        // ---- 5. the sbw pivot rows of the super-step as they are now in the OUTSIDE columns (untouched so far)
+        #pragma unroll 8
+        for (int e = t; e < sbw * PW; e += nth) {
+            const int k = e / PW, c = e % PW;
+            if ((c >> 4) < g_lo || (c >> 4) >= g_lo + sg) Bg[(size_t)k * PW + c] = Wo[(size_t)rho[q0 + k] * PW + c];
+        }
+        __syncthreads();
+        IB2(5);
+        // ---- 6. rank-sbw update of the outside columns: M += (G - E_P) M_old[P,:], G = the super-panel's columns
+        const int nks = sbw >> 2;
+        for (int rb = wave; rb < Np / 16; rb += nw) {
+            const int arow = 16 * rb + c16;
+            double are[SB / 4], aim[SB / 4];
+            #pragma unroll
+            for (int ks = 0; ks < SB / 4; ks++) {
+                if (ks < nks) {
+                    const int sidx = 4 * ks + kk, col = q0 + sidx;
+                    const size_t o = (size_t)arow * PW + (col >> 3) * 16 + (col & 7);
+                    are[ks] = W[o] - ((arow == rho[q0 + sidx]) ? 1.0 : 0.0);
+                    aim[ks] = W[o + 8];
+                } else { are[ks] = 0.0; aim[ks] = 0.0; }
+            }
+            // four outside column groups at a time (independent accumulators); the B operand of step ks+2 is in flight
+            // while the 8 MFMAs of step ks issue; [-Bim | Bre] by a DPP row rotation instead of a second load
+            const int nout = Np / 8 - sg, sign_hi = (c16 < 8) ? (int)0x80000000 : 0;
+            for (int o0 = 0; o0 < nout; o0 += 4) {
+                int go[4]; bool ok[4];
+                d4 acc[4];
+                const double *bp[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ok[q] = o0 + q < nout;
+                    const int o = ok[q] ? o0 + q : o0;
+                    go[q] = (o < g_lo) ? o : o + sg;
+                    bp[q] = Bg + (size_t)kk * PW + 16 * go[q] + c16;
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) acc[q][r] = Wo[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * go[q] + c16];
+                }
+                double b0[4], b1[4], b2[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) { b0[q] = bp[q][0]; b1[q] = bp[q][(size_t)((nks > 1) ? 4 : 0) * PW]; }
+                #pragma unroll
+                for (int ks = 0; ks < SB / 4; ks++) {
+                    if (ks < nks) {
+                        const int kn = (ks + 2 < nks) ? ks + 2 : nks - 1;
+                        #pragma unroll
+                        for (int q = 0; q < 4; q++) b2[q] = bp[q][(size_t)kn * 4 * PW];
+                        #pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const double bs = swap8_signed_inv(b0[q], sign_hi);
+                            acc[q] = MFMA(are[ks], b0[q], acc[q]);
+                            acc[q] = MFMA(aim[ks], bs, acc[q]);
+                        }
+                        #pragma unroll
+                        for (int q = 0; q < 4; q++) { b0[q] = b1[q]; b1[q] = b2[q]; }
+                    }
+                }
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (ok[q]) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * go[q] + c16] = acc[q][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        IB2(6);
+    }
+    // A^-1[rinv[x]][rho[j]] = M[x][j]
+    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
+    #pragma unroll 8
+    for (size_t e = t; e < pl; e += nth) {
+        const int x = e / Np, j = e % Np;
+        const size_t o = (size_t)x * PW + (j >> 3) * 16 + (j & 7);
+        const double re = W[o], im = W[o + 8];
+        const size_t i = rinv[x], c = rho[j];
+        T[i * Np + c] = re; T[pl + i * Np + c] = im;
+        A[i + Np * c] = re; A[pl + i + Np * c] = im;
+    }
+    IB2(7);
+#ifdef QGD_INVB_PROFILE
+    if (blockIdx.x == 0 && t == 0) printf("invb2 cycles: load %lld, panel cols %lld, pivots %lld, pivot rows %lld, inner update %lld, outer rows %lld, outer update %lld, output %lld\n", pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
+#endif
+#undef IB2
+}
+
+static inline size_t inverse_blocked2_lds(int Np)
+{
+    return ((size_t)2 * Np * INVB_NB + (size_t)INVB_NB * 2 * INVB_SB + 2 * Np + 2 * INVB_NB + 8) * sizeof(double) + (size_t)(8 + 3 * Np) * sizeof(int);
+}
+
 static inline size_t inverse_blocked_lds(int Np)
 {
     return ((size_t)2 * Np * INVB_NB + (size_t)INVB_NB * 2 * Np + 2 * Np + 2 * INVB_NB + 8) * sizeof(double) + (size_t)(8 + 3 * Np) * sizeof(int);
@@ -1138,6 +1396,16 @@ int qgdk_inverse(const qgdk_ctx *c)
         }
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
+    }
+    if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {
+        const size_t shm = inverse_blocked2_lds(c->Np);      // two block levels: 64-column super-panels
+        HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+            const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+            hipLaunchKernelGGL(k_inverse_blocked2, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch,
+                               c->Np, n0, c->status);
+        }
+        return (int)hipGetLastError();
     }
     if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED")) {
         const size_t shm = inverse_blocked_lds(c->Np);
