@@ -172,6 +172,39 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
     }
 
 
+C5_GRAD_NORM_1GPU = 3454.7659605167805     # |grad| of the C5 workload on one GPU (profiles/r02_bench.json): what a partitioned run must reproduce
+
+
+def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3):
+    """The same C5 evaluation spread over the ranks by time windows (strong scaling: the configuration where the
+    windows can pay); every rank holds the reduced gradient, rank 0 reports."""
+    import torch
+    import torch.distributed as dist
+    N, n_ops, nsteps, order = 256, 4, 200, 12
+    prob = qgd.construct_rand_prob(N, n_ops, tf=2.0, nsteps=nsteps, scale=1.0 / N)
+    ctrl = [qgd.FortranBSplineControl(16, 20, prob.tf) for _ in range(n_ops)]
+    pcof = np.random.default_rng(5).random(qgd.get_number_of_control_parameters(ctrl))
+    target = prob.u0 + 1j * prob.v0
+    back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
+                             stream=torch.cuda.current_stream().cuda_stream)
+    dp = qgd.TimePartitioned(back, qgd.TorchComm())
+    back.set_timing(0)
+    dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        grad, _ = dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    tm = torch.tensor([time.perf_counter() - t0], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    sec = float(tm.item()) / steps
+    back.close()
+    gn = float(np.linalg.norm(grad))
+    return {"workload": f"C5 synthetic: N={N}, 256 columns, {n_ops} control operators, order {order}, nsteps={nsteps}, "
+                        f"time windows over {world} GPUs", "scaling": "strong", "timesteps_per_s": nsteps / sec,
+            "ms_per_evaluation": sec * 1e3, "grad_norm": gn, "grad_norm_rel_diff_vs_1gpu": abs(gn - C5_GRAD_NORM_1GPU) / C5_GRAD_NORM_1GPU}
+
+
 def large_n_case(qgd, np, steps=3):
     """BASELINE.json configs[4] (C5: random dense SchrodingerProb, N=256, 256 columns, 4 control operators,
     order 12, tf=2, nsteps=200) -- the configuration where the MFMA roofline is the binding one.
@@ -227,6 +260,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true", help="skip the secondary C5 (N=256) measurement")
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, the product path) or gloo "
+                                                      "(plumbing check of the multi-process protocol; collectives staged through the host)")
+    ap.add_argument("--oversubscribe", action="store_true", help="let several ranks share a GPU (test boxes with one GPU; with --backend gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -235,7 +271,7 @@ def main():
         import subprocess
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (args.oversubscribe and have >= 1):
             sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to print a "
                      f"{have}-GPU number under n_gpus={args.gpus}")
         port = os.environ.get("MASTER_PORT", "29517")
@@ -254,12 +290,16 @@ def main():
     if world != max(args.gpus, 1) and not args.force_dist:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     use_dist = world > 1 or args.force_dist
+    if args.oversubscribe:
+        local_rank %= max(torch.cuda.device_count(), 1)
     if use_dist:
+        import datetime
         torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            kw = dict(device_id=torch.device("cuda", local_rank)) if args.backend == "nccl" else {}
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
     n_gpus = max(world, 1)
 
     qgd = import_package()
@@ -318,7 +358,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     # N > 1, beside the strong-scaling `value`: the same evaluation on a time grid that grows with the rank count
@@ -341,7 +381,7 @@ def main():
             for _ in range(args.steps):
                 dpw.discrete_adjoint(pcof_w)
             barrier()
-            tw = torch.tensor([time.perf_counter() - t2], device="cuda", dtype=torch.float64)
+            tw = torch.tensor([time.perf_counter() - t2], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             weak = {"nsteps": nsteps_w, "value": nsteps_w * args.steps / float(tw.item()), "unit": "timesteps/s",
                     "ms_per_step": float(tw.item()) / args.steps * 1e3, "scaling": "weak"}
@@ -388,6 +428,14 @@ def main():
         except Exception as exc:
             with_hist = {"error": repr(exc)}
 
+    # N > 1: C5 under the same partition (every rank takes part; secondary number, must never cost the headline one)
+    large_dist = None
+    if use_dist and world > 1 and not args.no_large_n:
+        try:
+            large_dist = large_n_partitioned(qgd, np, rank, world, local_rank)
+        except Exception as exc:
+            large_dist = {"error": repr(exc)}
+
     if rank == 0:
         for k in phase_ms:
             phase_ms[k] /= nsamp
@@ -416,7 +464,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
-                       "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"},
+                       "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"
+                                      + ("" if args.backend == "nccl" else f" ({args.backend} backend, host-staged: plumbing check, not a measurement)")},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work},
@@ -432,6 +481,8 @@ def main():
         if not use_dist and not args.no_large_n:
             dp.close()
             out["large_n"] = large_n_case(qgd, np)
+        if large_dist is not None:
+            out["large_n"] = large_dist
         if not args.no_cpu_baseline:
             orc = import_oracle()
             out["cpu_baseline"] = cpu_baseline(qgd, orc)

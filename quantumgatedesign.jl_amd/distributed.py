@@ -102,11 +102,26 @@ class TorchComm:
         import torch.distributed as dist
         self.dist, self.group = dist, group
 
+    def _host_staged(self, t):
+        # gloo has no device collectives for every op: a plumbing-check backend stages through the host
+        return self.dist.get_backend(self.group) == "gloo" and getattr(t, "is_cuda", False)
+
     def all_gather(self, whole, own):
         # in place: `own` is this rank's chunk of `whole` (NCCL/RCCL in-place all-gather layout)
+        if self._host_staged(whole):
+            import torch
+            host = torch.empty(whole.shape, dtype=whole.dtype)
+            self.dist.all_gather_into_tensor(host, own.cpu(), group=self.group)
+            whole.copy_(host)
+            return
         self.dist.all_gather_into_tensor(whole, own, group=self.group)
 
     def all_reduce(self, whole):
+        if self._host_staged(whole):
+            host = whole.cpu()
+            self.dist.all_reduce(host, group=self.group)
+            whole.copy_(host)
+            return
         self.dist.all_reduce(whole, group=self.group)
 
 

@@ -1,16 +1,24 @@
 """Per-rank device time of the time-partitioned evaluation, all ranks in one process on one GPU
-(collectives = device copies, not timed): what each rank would spend computing at world = 1, 2, 4, 8."""
+(collectives = device copies, not timed): what each rank would spend computing at world = 1, 2, 4, 8.
+    python scripts/partition_timing.py          cnot3 headline (N=64, 8 columns, order 8, 550 steps)
+    python scripts/partition_timing.py c5       BASELINE.json configs[4] (N=256, 256 columns, order 12, 200 steps)"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import torch, numpy as np
 from __graft_entry__ import import_package
 qgd = import_package()
 import cases
-prob, target = qgd.cnot3_problem(nsteps=550, tf=550.0)
-ctrl = cases.cnot3_controls(qgd, prob)
-pcof = (np.random.default_rng(0).random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
+C5 = len(sys.argv) > 1 and sys.argv[1] == "c5"
+if C5:
+    prob, ctrl, pcof, _ = cases.synthetic_case(qgd, N=256, c=256, n_ops=4, nsteps=200, tf=2.0)
+    target, order = prob.u0 + 1j * prob.v0, 12
+else:
+    prob, target = qgd.cnot3_problem(nsteps=550, tf=550.0)
+    ctrl = cases.cnot3_controls(qgd, prob)
+    pcof = (np.random.default_rng(0).random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
+    order = 8
 for world in (1, 2, 4, 8):
-    backs = [qgd.DeviceBackend(prob, 8, ctrl, target, r, world) for r in range(world)]
+    backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, world) for r in range(world)]
     grp = qgd.LocalGroup(backs)
     for b in backs:   # serialise the ranks (they share this one GPU): per-rank event times then mean what they say
         for name in ("forward_begin", "forward_end", "adjoint_begin", "adjoint_end"):

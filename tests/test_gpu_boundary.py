@@ -142,3 +142,28 @@ def test_handle_cache_follows_the_problem(qgd):
     qgd.get_histories(work, ctrl, pcof, 2, orders=(2, 4), quiet=True)      # closes the handles it created
     assert len(evolution._cache) == n_before - 1
     qgd.clear_cache()
+
+
+def test_bench_two_processes_share_the_gpu():
+    """`python bench.py --gpus 2` as the driver starts it (bare: it launches two ranks itself), here with two PROCESSES
+    on the one GPU of the test box and the gloo backend (collectives staged through the host: RCCL refuses two ranks on
+    one device).  Every step of the multi-process protocol is real -- rendezvous, one handle per process, the two
+    all-gathers and the all-reduce on the library's exchange buffers -- only the transport differs from the product
+    path.  The partitioned gradient must equal the single-process one, for cnot3 and for C5."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--nsteps", "120"]
+    env = dict(os.environ, MASTER_PORT="29631")
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--no-large-n"] + common, capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--oversubscribe"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert abs(j2["grad_norm"] - j1["grad_norm"]) <= 1e-11 * j1["grad_norm"]
+    assert abs(j2["infidelity"] - j1["infidelity"]) <= 1e-12
+    assert "error" not in j2["large_n"], j2["large_n"]
+    assert j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10
+    assert j2["weak_in_time"] is None or "error" not in j2["weak_in_time"], j2["weak_in_time"]
