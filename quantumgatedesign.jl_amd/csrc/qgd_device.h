@@ -118,10 +118,11 @@ int qgdk_dense_derivs(const qgdk_ctx *c);
 int qgdk_dense_gradient(const qgdk_ctx *c);
 int qgdk_dense_lambda(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
+int qgdk_derivs_sparse(const qgdk_ctx *c);
 /* qgd_k_layout.hip: panels [n][j][Np][2cp] -> reference layout dst[col][n][j][2N] (to_panels = 0) or back */
 int qgdk_layout(const qgdk_ctx *c, const double *panels, long long src_n, long long src_j, double *ref,
                 long long dst_col, long long dst_n, long long dst_j, int n0, int n_cnt, int j_cnt,
-                int to_panels, hipStream_t stream);
+                int to_panels, hipStream_t stream, int max_workgroups);
 #ifdef __cplusplus
 }
 #endif

@@ -358,6 +358,65 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
     SP_PROF(22);
 }
 
+// ---------------------------------------------------------------------------
+// Stage derivatives w_1..w_m of the stored states (compute_derivatives!, hermite.jl:56-101) for the uv_history output:
+//   (j+1) w_{j+1} = sum_{i<=j} A_{j-i} w_i,  A_d(t_n) assembled once per workgroup into LDS (ELL), lane = row,
+// two columns per thread -- the "sources" half of k_gradpoint_ell, writing the panels dpsi[n][j-1] instead of inner
+// products.  (The MFMA kernel k_derivs took 141 us on the cnot3 grid for what is 7 entries per row.)
+// ---------------------------------------------------------------------------
+template <int M, int NOPS>
+__global__ __launch_bounds__(256) void k_derivs_ell(const int32_t *__restrict__ ell_col, const double *__restrict__ ell_val,
+                                                    const double *__restrict__ tab, const double *__restrict__ hist,
+                                                    double *__restrict__ dpsi, int Np, int cp, int n_ops, int Z)
+{
+    constexpr int PS = 9;
+    extern __shared__ __attribute__((aligned(16))) double smem_raw[];
+    c2 *As = reinterpret_cast<c2 *>(smem_raw);          // [M][Z][64]
+    c2 *buf = As + (size_t)M * Z * 64;                  // [64][PS]   the current source
+    int *Ecol = reinterpret_cast<int *>(buf + 64 * PS); // [Z][64]
+    const int grp = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, r = tid & 63, cl = 2 * w;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const bool live = r < Np;
+    const size_t o0 = (size_t)(live ? r : 0) * PWc + grp * 16 + cl;
+    c2 ps[2];
+    #pragma unroll
+    for (int c = 0; c < 2; c++)
+        ps[c] = live ? (c2){hist[(size_t)n * hstep + o0 + c], hist[(size_t)n * hstep + o0 + c + 8]} : (c2){0.0, 0.0};
+    assemble_ell<NOPS>(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, 256);
+    for (int item = tid; item < Z * 64; item += 256) {
+        const int rr = item & 63, e = item >> 6;
+        Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
+    }
+    c2 T[M + 1][2];
+    #pragma unroll
+    for (int q = 0; q <= M; q++) { T[q][0] = (c2){0.0, 0.0}; T[q][1] = (c2){0.0, 0.0}; }
+    #pragma unroll
+    for (int i = 0; i < M; i++) {
+        __syncthreads();                                // (first pass: also orders the prologue's LDS writes)
+        buf[r * PS + cl] = ps[0]; buf[r * PS + cl + 1] = ps[1];
+        __syncthreads();
+        _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
+            const c2 *src = buf + (size_t)Ecol[e * 64 + r] * PS + cl;
+            const c2 x0 = src[0], x1 = src[1];
+            #pragma unroll
+            for (int d = 0; d + i + 1 <= M; d++) {
+                const c2 a = As[(d * Z + e) * 64 + r];
+                cfma(T[i + d + 1][0], a, x0); cfma(T[i + d + 1][1], a, x1);
+            }
+        }
+        const double inv = 1.0 / (double)(i + 1);
+        ps[0] = (c2){T[i + 1][0].re * inv, T[i + 1][0].im * inv};
+        ps[1] = (c2){T[i + 1][1].re * inv, T[i + 1][1].im * inv};
+        if (live) {
+            double *dst = dpsi + ((size_t)n * M + i) * hstep + o0;
+            dst[0] = ps[0].re; dst[1] = ps[1].re; dst[8] = ps[0].im; dst[9] = ps[1].im;
+        }
+    }
+}
+static size_t lds_derivs_ell(int M, int Z) { return ((size_t)M * Z * 64 + 64 * 9) * 16 + (size_t)Z * 64 * 4; }
+
 static size_t lds_build_ell(int M, int Z, int NW) { return ((size_t)M * Z * 64 + 64 * (4 * NW + 1)) * 16 + (size_t)Z * 64 * 4; }
 static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 {
@@ -411,6 +470,25 @@ static int launch_grad_ell(const qgdk_ctx *c)
     return 0;
 }
 
+template <int M, int NOPS>
+static int launch_derivs_ell_n(const qgdk_ctx *c)
+{
+    const size_t shm = lds_derivs_ell(M, c->ell_z);
+    SET_LDS_ONCE((k_derivs_ell<M, NOPS>), shm);
+    hipLaunchKernelGGL((k_derivs_ell<M, NOPS>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ell_col, c->ell_val, c->tab,
+                       c->hist, c->dpsi, c->Np, c->cp, c->n_ops, c->ell_z);
+    return (int)hipGetLastError();
+}
+
+template <int M>
+static int launch_derivs_ell(const qgdk_ctx *c)
+{
+#define CALL_DE(N) return launch_derivs_ell_n<M, N>(c)
+    DISPATCH_NOPS(c->n_ops, CALL_DE)
+#undef CALL_DE
+    return 0;
+}
+
 #define DISPATCH_M(m, FN) \
     switch (m) { case 1: return FN<1>(c); case 2: return FN<2>(c); case 3: return FN<3>(c); case 4: return FN<4>(c); \
                  case 5: return FN<5>(c); case 6: return FN<6>(c); case 7: return FN<7>(c); case 8: return FN<8>(c); \
@@ -436,5 +514,6 @@ int qgdk_sparse_profile(unsigned long long *out32, int reset)
 
 int qgdk_build_LR_sparse(const qgdk_ctx *c) { DISPATCH_M(c->m, launch_build_ell) }
 int qgdk_gradient_sparse(const qgdk_ctx *c) { DISPATCH_M(c->m, launch_grad_ell) }
+int qgdk_derivs_sparse(const qgdk_ctx *c) { DISPATCH_M(c->m, launch_derivs_ell) }
 
 } // extern "C"

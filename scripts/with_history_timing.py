@@ -1,0 +1,22 @@
+"""The reference-shaped call discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, ...) on the cnot3 headline
+problem with the three output arrays registered: ms per evaluation (QGD_ZEROCOPY_WGS selects the writer: 0 = device
+staging + copies, n = n persistent workgroups writing into the registered host memory)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from __graft_entry__ import import_package
+import bench
+qgd = import_package()
+prob, ctrl, pcof, target = bench.workload(qgd, 550, 550.0)
+dp = qgd.DeviceProblem(prob, 8); dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(0)
+g0, _ = dp.discrete_adjoint(pcof)
+hist = dp.pin(np.zeros((128, 5, 551, 8), order="F")); lam = dp.pin(np.zeros((128, 5, 551, 8), order="F"))
+forc = dp.pin(np.zeros((128, 551, 8), order="F"))
+for _ in range(3): dp.discrete_adjoint(pcof, False, hist, lam, forc)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): g, _ = dp.discrete_adjoint(pcof, False, hist, lam, forc)
+torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 20
+h2 = np.zeros((128, 5, 551, 8), order="F"); dp.eval_forward(pcof, h2)
+print("QGD_ZEROCOPY_WGS=%s: %.3f ms per evaluation with history; grad diff %.1e, history diff %.1e" %
+      (os.environ.get("QGD_ZEROCOPY_WGS", "default"), el * 1e3, np.abs(g - g0).max(), np.abs(h2 - hist).max()))
