@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--nsteps", type=int, default=550, help="timesteps of the workload (tf = nsteps, dt = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true", help="skip the secondary C5 (N=256) measurement")
+    ap.add_argument("--no-with-history", action="store_true", help="skip the secondary measurement with the three output arrays "
+                                                                   "(profiling runs: keeps the kernel statistics to the headline evaluation)")
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, the product path) or gloo "
                                                       "(plumbing check of the multi-process protocol; collectives staged through the host)")
@@ -405,7 +407,7 @@ def main():
     # the three arrays downloaded in the reference layout (31.6 MB), registered (pinned) once as INTEGRATION.md's shim
     # does, and unregistered (pageable).  Reported beside `value`, never as `value`.
     with_hist = None
-    if not use_dist:
+    if not use_dist and not args.no_with_history:
         try:
             n2, m1, ntp, cc = prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions
             with_hist = {"bytes_per_evaluation": 8 * (n2 * m1 * ntp * cc + 2 * n2 * ntp * cc)}

@@ -323,8 +323,8 @@ int finish_copies(qgd_handle h)
 // zero-copy 1.41 / 1.15 / 1.01 / 0.96 / 0.96 ms with 8 / 16 / 32 / 64 / 128 workgroups -- the copies win, so 0 is the default.
 int zerocopy_wgs()
 {
-    static const int v = getenv("QGD_ZEROCOPY_WGS") ? atoi(getenv("QGD_ZEROCOPY_WGS")) : 0;
-    return v;
+    const char *e = getenv("QGD_ZEROCOPY_WGS");
+    return e ? atoi(e) : 0;
 }
 
 int copy_history_out(qgd_handle h, double *uv_history)

@@ -45,11 +45,14 @@ def test_csc_constructor_matches_dense(qgd, which, order):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_registered_outputs_match_pageable(qgd, orc):
+@pytest.mark.parametrize("zerocopy", [None, "16"])
+def test_registered_outputs_match_pageable(qgd, orc, zerocopy, monkeypatch):
     """The reference-shaped call discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, ...) as optimize_gate
     makes it (ipopt_optimal_control.jl:304-330), with the three output arrays registered (pinned: device re-layout +
     asynchronous copies beside the adjoint sweep, strided copy of the j = 0 columns of lambda_history) and not
     registered: identical arrays, and both equal to the oracle's."""
+    if zerocopy:        # the comparison path: persistent workgroups write the registered (mapped) arrays in place
+        monkeypatch.setenv("QGD_ZEROCOPY_WGS", zerocopy)
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=24, tf=24.0)
     order = 8
     orc.set_converged_terminal(True)
