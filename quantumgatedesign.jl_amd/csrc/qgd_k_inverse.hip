@@ -1084,54 +1084,76 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
         const int g_lo = q0 >> 3, sg = sbw >> 3;                // its column groups: g_lo .. g_lo + sg - 1
         for (int p0 = q0; p0 < q0 + sbw; p0 += NB) {
             const double *Ws = (p0 == 0) ? Ln : W;              // source of the super-panel's columns in this step
-            // ---- 1. the 16 panel columns into LDS
-            for (int e = t; e < Np * NB; e += nth) {
-                const int r = e / NB, col = p0 + (e % NB);
-                const size_t o = (size_t)r * PW + (col >> 3) * 16 + (col & 7);
-                Fre[e] = Ws[o]; Fim[e] = Ws[o + 8];
+            // ---- 1. the 16 panel columns into REGISTERS: thread t keeps the elements (r, q) = (t/16 + 32 k, t%16), k < KMAX,
+            //         for the 16 pivot steps of the panel (k_inverse_blocked keeps them in LDS: 64 LDS operations per thread
+            //         and pivot step, three barriers; here ~20 and two)
+            constexpr int KMAX = 9;                              // Np <= 288
+            const int q = t & 15, r0 = t >> 4;
+            double xr[KMAX], xi[KMAX];
+            #pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const int r = r0 + 32 * k, col = p0 + q;
+                const bool ok = r < Np;
+                const size_t o = (size_t)(ok ? r : 0) * PW + (col >> 3) * 16 + (col & 7);
+                xr[k] = ok ? Ws[o] : 0.0; xi[k] = ok ? Ws[o + 8] : 0.0;
             }
-            __syncthreads();
             IB2(1);
             // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
             for (int s = 0; s < NB; s++) {
-                double best = -1.0; int bi = 0;
-                for (int r = t; r < Np; r += nth) {
-                    const double a = Fre[r * NB + s], b = Fim[r * NB + s];
-                    fre[r] = a; fim[r] = b;
-                    const double v = a * a + b * b;
-                    if (!used[r] && v > best) { best = v; bi = r; }
+                if (q == s) {                                    // column s of the panel, for everybody
+                    #pragma unroll
+                    for (int k = 0; k < KMAX; k++) { const int r = r0 + 32 * k; if (r < Np) { fre[r] = xr[k]; fim[r] = xi[k]; } }
                 }
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ob = __shfl_down(best, off);
-                    const int oi = __shfl_down(bi, off);
-                    if (ob > best) { best = ob; bi = oi; }
-                }
-                if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
                 __syncthreads();
-                int pr = redi[0]; double pb = redv[0];
-                for (int w = 1; w < nw; w++) if (redv[w] > pb) { pb = redv[w]; pr = redi[w]; }
-                if (t < NB) {                                    // scaled pivot row (the pivot entry becomes 1/pivot)
+                // pivot = largest modulus among the unused rows, found by every wave for itself (no cross-wave exchange);
+                // ties go to the lowest row so that all waves agree
+                // (one 32-bit key per row: the upper bits of |x|^2 with the low 9 bits replaced by 511 - row, so that a DPP
+                //  max-scan yields the arg-max -- pivot = largest modulus compared on 23 bits, ties to the lowest row)
+                unsigned key = 0;
+                for (int r = lane; r < Np; r += 64) {
+                    const double a = fre[r], b = fim[r];
+                    const unsigned mag = (unsigned)__double2hiint(a * a + b * b);
+                    const unsigned kr = used[r] ? 0u : ((mag & ~511u) | (unsigned)(511 - r));
+                    key = kr > key ? kr : key;
+                }
+                key = wave_max_u32(key);
+                const int pr = 511 - (int)(key & 511u);
+                const bool nonsingular = (key >> 9) != 0;
+                double f1[KMAX], f2[KMAX];                       // column s at my rows: the multipliers of this step
+                #pragma unroll
+                for (int k = 0; k < KMAX; k++) { const int r = r0 + 32 * k; f1[k] = (r < Np) ? fre[r] : 0.0; f2[k] = (r < Np) ? fim[r] : 0.0; }
+                {                                                // the owners of row pr publish it scaled (the pivot entry becomes 1/pivot)
                     const double a = fre[pr], b = fim[pr];
-                    const double den = 1.0 / (a * a + b * b), ir = a * den, ii = -b * den;
-                    const double x = Fre[pr * NB + t], y = Fim[pr * NB + t];
-                    yrow[t] = (t == s) ? ir : x * ir - y * ii;
-                    yrow[NB + t] = (t == s) ? ii : x * ii + y * ir;
-                }
-                if (t == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; used[pr] = 1; if (!(pb > 0.0)) *status = 1; }
-                __syncthreads();
-                for (int e = t; e < Np * NB; e += nth) {
-                    const int r = e / NB, q = e % NB;
-                    const double rr = yrow[q], ri = yrow[NB + q];
-                    if (r == pr) { Fre[e] = rr; Fim[e] = ri; }
-                    else {
-                        const double f1 = fre[r], f2 = fim[r];
-                        const double br = (q == s) ? 0.0 : Fre[e], bi2 = (q == s) ? 0.0 : Fim[e];
-                        Fre[e] = br - (f1 * rr - f2 * ri);
-                        Fim[e] = bi2 - (f1 * ri + f2 * rr);
+                    const double den = fast_rcp(a * a + b * b), ir = a * den, ii = -b * den;
+                    #pragma unroll
+                    for (int k = 0; k < KMAX; k++) {
+                        if (r0 + 32 * k == pr) {
+                            yrow[q] = (q == s) ? ir : xr[k] * ir - xi[k] * ii;
+                            yrow[NB + q] = (q == s) ? ii : xr[k] * ii + xi[k] * ir;
+                        }
                     }
                 }
+                if (t == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if (!nonsingular) *status = 1; }
                 __syncthreads();
+                if (t == 0) used[pr] = 1;                        // (read again only after the next step's barrier)
+                const double rr = yrow[q], ri = yrow[NB + q];
+                #pragma unroll
+                for (int k = 0; k < KMAX; k++) {
+                    if (r0 + 32 * k == pr) { xr[k] = rr; xi[k] = ri; }
+                    else {
+                        const double br = (q == s) ? 0.0 : xr[k], bi2 = (q == s) ? 0.0 : xi[k];
+                        xr[k] = br - (f1[k] * rr - f2[k] * ri);
+                        xi[k] = bi2 - (f1[k] * ri + f2[k] * rr);
+                    }
+                }
             }
+            // the factored panel (multipliers / inverse entries) into LDS: the A operand of the updates
+            #pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const int r = r0 + 32 * k;
+                if (r < Np) { Fre[r * NB + q] = xr[k]; Fim[r * NB + q] = xi[k]; }
+            }
+            __syncthreads();
             IB2(2);
             // ---- 3. the 16 pivot rows (their values before the step), super-panel columns only, as B operand
             for (int e = t; e < NB * 2 * sbw; e += nth) {
@@ -1260,17 +1282,39 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
         __syncthreads();
         IB2(6);
     }
-    // A^-1[rinv[x]][rho[j]] = M[x][j]
+    // A^-1[i][c] = M[rho[i]][rinv[c]].  Tiles of 32 x 64 go through LDS: the slab is gathered (rows rho[i], columns
+    // rinv[c]: scattered inside a row, L1-friendly) and BOTH outputs are written in runs of consecutive doubles --
+    // LinvT row-major, LinvA column-major.  (Scattering the slab straight into the two outputs, as k_inverse_blocked does,
+    // writes LinvA 8 bytes per 64-byte line: 0.85 M of the kernel's 5 M cycles at Np = 256.)
     double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
-    #pragma unroll 8
-    for (size_t e = t; e < pl; e += nth) {
-        const int x = e / Np, j = e % Np;
-        const size_t o = (size_t)x * PW + (j >> 3) * 16 + (j & 7);
-        const double re = W[o], im = W[o + 8];
-        const size_t i = rinv[x], c = rho[j];
-        T[i * Np + c] = re; T[pl + i * Np + c] = im;
-        A[i + Np * c] = re; A[pl + i + Np * c] = im;
-    }
+    double *tre = smem, *tim = smem + 32 * 65;
+    for (int i0 = 0; i0 < Np; i0 += 32)
+        for (int c0 = 0; c0 < Np; c0 += 64) {
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = t + k * 512, il = idx >> 6, cl = idx & 63;
+                const int i = i0 + il, c = c0 + cl;
+                if (i < Np && c < Np) {
+                    const int jj = rinv[c];
+                    const size_t o = (size_t)rho[i] * PW + (jj >> 3) * 16 + (jj & 7);
+                    tre[il * 65 + cl] = W[o]; tim[il * 65 + cl] = W[o + 8];
+                }
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = t + k * 512;
+                {
+                    const int il = idx >> 6, cl = idx & 63, i = i0 + il, c = c0 + cl;
+                    if (i < Np && c < Np) { T[(size_t)i * Np + c] = tre[il * 65 + cl]; T[pl + (size_t)i * Np + c] = tim[il * 65 + cl]; }
+                }
+                {
+                    const int cl = idx >> 5, il = idx & 31, i = i0 + il, c = c0 + cl;
+                    if (i < Np && c < Np) { A[(size_t)i + (size_t)Np * c] = tre[il * 65 + cl]; A[pl + (size_t)i + (size_t)Np * c] = tim[il * 65 + cl]; }
+                }
+            }
+            __syncthreads();
+        }
     IB2(7);
 #ifdef QGD_INVB_PROFILE
     if (blockIdx.x == 0 && t == 0) printf("invb2 cycles: load %lld, panel cols %lld, pivots %lld, pivot rows %lld, inner update %lld, outer rows %lld, outer update %lld, output %lld\n", pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
