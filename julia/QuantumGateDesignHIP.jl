@@ -10,6 +10,7 @@ using QuantumGateDesign
 import QuantumGateDesign: SchrodingerProb, eval_forward!, discrete_adjoint!,
                           get_number_of_control_parameters, eval_grad_p_derivative!,
                           eval_grad_q_derivative!
+using SparseArrays: SparseMatrixCSC, sparse
 
 const libqgd = joinpath(@__DIR__, "..", "quantumgatedesign.jl_amd", "csrc", "libqgd_hip.so")
 
@@ -22,11 +23,17 @@ struct ProblemDesc            # qgd_problem_desc, include/qgd.h
     device::Int32; reserved::Int32
 end
 
+struct CSC                    # qgd_csc, include/qgd.h: the three arrays of a SparseMatrixCSC{Float64,Int64}
+    colptr::Ptr{Int64}; rowval::Ptr{Int64}; nzval::Ptr{Float64}
+    index_base::Int32; reserved::Int32
+end
+
 mutable struct DeviceProblem
     handle::Ptr{Cvoid}
     order::Int
     nsteps::Int
     basis_key::UInt
+    pinned::Vector{Any}      # output arrays registered with the handle (kept alive until unregistered)
 end
 
 function check(h, rc)
@@ -35,29 +42,58 @@ function check(h, rc)
     rc == 1 ? throw(ArgumentError(msg)) : error("qgd error $rc: $msg")
 end
 
-"One handle per (prob, order); dense column-major copies are made for the call only."
+"One handle per (prob, order).  Operators stored as SparseMatrixCSC (DispersiveProblem's default, sparse_rep=true)
+go to the library as they are (qgd_create_csc: colptr/rowval/nzval, 1-based); dense ones as column-major copies made
+for the call only."
 function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
     N = prob.N_tot_levels
-    ssym, sasym = Matrix{Float64}(prob.system_sym), Matrix{Float64}(prob.system_asym)
-    sym = reduce(hcat, [vec(Matrix{Float64}(op)) for op in prob.sym_operators]; init=zeros(N*N, 0))
-    asym = reduce(hcat, [vec(Matrix{Float64}(op)) for op in prob.asym_operators]; init=zeros(N*N, 0))
     u0, v0 = Matrix{Float64}(reshape(prob.u0, N, :)), Matrix{Float64}(reshape(prob.v0, N, :))
     W = Matrix{Float64}(prob.guard_subspace_projector)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve ssym sasym sym asym u0 v0 W begin
-        d = ProblemDesc(N, size(u0, 2), prob.N_operators, prob.N_ess_levels, order, prob.nsteps, prob.tf,
-                        pointer(ssym), pointer(sasym), pointer(sym), pointer(asym),
-                        pointer(u0), pointer(v0), pointer(W), device, 0)
-        rc = ccall((:qgd_create, libqgd), Cint, (Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), d, h)
+    if prob.system_sym isa SparseMatrixCSC
+        mats = SparseMatrixCSC{Float64,Int64}[prob.system_sym, prob.system_asym, prob.sym_operators..., prob.asym_operators...]
+        GC.@preserve mats u0 v0 W begin
+            csc = [CSC(pointer(a.colptr), pointer(a.rowval), pointer(a.nzval), 1, 0) for a in mats]
+            nop = prob.N_operators
+            d = ProblemDesc(N, size(u0, 2), nop, prob.N_ess_levels, order, prob.nsteps, prob.tf,
+                            C_NULL, C_NULL, C_NULL, C_NULL, pointer(u0), pointer(v0), pointer(W), device, 0)
+            rc = ccall((:qgd_create_csc, libqgd), Cint,
+                       (Ref{ProblemDesc}, Ref{CSC}, Ref{CSC}, Ptr{CSC}, Ptr{CSC}, Ref{Ptr{Cvoid}}),
+                       d, csc[1], csc[2], pointer(csc, 3), pointer(csc, 3 + nop), h)
+        end
+    else
+        ssym, sasym = Matrix{Float64}(prob.system_sym), Matrix{Float64}(prob.system_asym)
+        sym = reduce(hcat, [vec(Matrix{Float64}(op)) for op in prob.sym_operators]; init=zeros(N*N, 0))
+        asym = reduce(hcat, [vec(Matrix{Float64}(op)) for op in prob.asym_operators]; init=zeros(N*N, 0))
+        GC.@preserve ssym sasym sym asym u0 v0 W begin
+            d = ProblemDesc(N, size(u0, 2), prob.N_operators, prob.N_ess_levels, order, prob.nsteps, prob.tf,
+                            pointer(ssym), pointer(sasym), pointer(sym), pointer(asym),
+                            pointer(u0), pointer(v0), pointer(W), device, 0)
+            rc = ccall((:qgd_create, libqgd), Cint, (Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), d, h)
+        end
     end
     check(C_NULL, rc)
-    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0))
+    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0), Any[])
     finalizer(x -> ccall((:qgd_destroy, libqgd), Cvoid, (Ptr{Cvoid},), x.handle), dp)
     return dp
 end
 
-"Control basis G[n,d,l] = d/dpcof_l (p^(d)(t_n)/d!) from the package's own eval_grad_*_derivative!
-(all in-scope controls are linear in pcof).  C-ordered [nt][m+1][N_coeff] == Julia Array (N_coeff, m+1, nt)."
+"Pin an output array that is handed to hip_discrete_adjoint! on every iteration (optimize_gate allocates
+state_history, lambda_history and adjoint_forcing once, src/ipopt_optimal_control.jl:207-214): its download then
+runs at PCIe speed beside the adjoint sweep.  The array is kept alive by the handle."
+function pin!(dp::DeviceProblem, a::Array{Float64})
+    any(x -> x === a, dp.pinned) && return a
+    check(dp.handle, ccall((:qgd_register_host_buffer, libqgd), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+          dp.handle, a, sizeof(a)))
+    push!(dp.pinned, a)
+    return a
+end
+
+"Control basis G[n,d,l] = d/dpcof_l (p^(d)(t_n)/d!) from the package's own eval_grad_*_derivative!.
+The device path is exact only for controls that are LINEAR in pcof (every family the package ships is:
+B-splines with or without carriers, GRAPE, Hermite); AbstractControl is an open protocol
+(src/Controls/Control.jl:6-27), so linearity is probed -- the Jacobian must not depend on pcof -- and a
+non-linear control is refused instead of silently computing G(pcof)*pcof."
 function set_controls!(dp::DeviceProblem, prob, controls, pcof)
     key = hash((objectid(controls), prob.nsteps, prob.tf))
     key == dp.basis_key && return
@@ -66,7 +102,15 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
     for k in 1:prob.N_operators
         c = controls[k]; nc = c.N_coeff; push!(ncoef, nc)
         gp, gq = zeros(nc, m + 1, nt), zeros(nc, m + 1, nt)
-        lp = QuantumGateDesign.get_control_vector_slice(pcof, controls, k)
+        lp = Vector{Float64}(QuantumGateDesign.get_control_vector_slice(pcof, controls, k))
+        probe, g1, g2 = lp .+ 0.37 .* (1 .+ abs.(lp)), zeros(nc), zeros(nc)
+        for n in (0, div(nt, 3), nt - 1), d in 0:m            # linearity probe at three time points
+            for (f!) in (eval_grad_p_derivative!, eval_grad_q_derivative!)
+                f!(g1, c, n * dt, lp, d); f!(g2, c, n * dt, probe, d)
+                maximum(abs.(g1 .- g2)) <= 1e-12 * max(1.0, maximum(abs.(g1))) ||
+                    throw(ArgumentError("control $k is not linear in its coefficients: the device path needs a pcof-independent basis (use qgd_set_control_tables for the forward sweep only)"))
+            end
+        end
         for n in 0:nt-1, d in 0:m
             eval_grad_p_derivative!(view(gp, :, 1 + d, 1 + n), c, n * dt, lp, d)
             eval_grad_q_derivative!(view(gq, :, 1 + d, 1 + n), c, n * dt, lp, d)
@@ -82,15 +126,30 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
     dp.basis_key = key
 end
 
-const _cache = IdDict{Any,DeviceProblem}()
+# Handle cache: at most MAX_HANDLES (a cnot3 handle holds ~300 MB of device memory), least recently used first out;
+# keyed by the prob OBJECT, so a copy(prob) gets its own handle and release!(prob) frees it explicitly.
+const MAX_HANDLES = 4
+const _cache = Vector{Tuple{Any,Int,DeviceProblem}}()
 function device_problem(prob, order)
-    dp = get!(() -> DeviceProblem(prob, order), _cache, (prob, order))
+    i = findfirst(e -> e[1] === prob && e[2] == order, _cache)
+    if i === nothing
+        length(_cache) >= MAX_HANDLES && finalize(popfirst!(_cache)[3])
+        push!(_cache, (prob, order, DeviceProblem(prob, order)))
+    else
+        push!(_cache, splice!(_cache, i))
+    end
+    dp = _cache[end][3]
     if dp.nsteps != prob.nsteps      # scripts mutate prob.nsteps (examples/cnot3_optimize_gate.jl:51-52)
         check(dp.handle, ccall((:qgd_set_nsteps, libqgd), Cint, (Ptr{Cvoid}, Int32, Float64), dp.handle, prob.nsteps, prob.tf))
         dp.nsteps = prob.nsteps; dp.basis_key = UInt(0)
     end
     return dp
 end
+release!(prob) = foreach(e -> finalize(e[3]), splice!(_cache, findall(e -> e[1] === prob, _cache)))
+
+"infidelity + guard penalty of the last evaluation from the three scalars the device returns
+(infidelity_real, guard_penalty_real: src/infidelity.jl:7-18, :56-96) -- no state history needed on the host."
+objective_terms(out3, N_ess) = (1 - (out3[1]^2 + out3[2]^2) / N_ess^2, out3[3])
 
 "Drop-in for eval_forward!(uv_history, prob, controls, pcof; order) -- src/forward_evolution.jl:33-70."
 function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, controls, pcof::Vector{Float64}; order::Int=2)
@@ -99,23 +158,46 @@ function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, 
     out3 = zeros(3)
     check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
           (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pcof, length(pcof), uv_history, out3))
-    return nothing
+    return out3
+end
+
+"The objective without the history: what optimize_gate's eval_f needs (INTEGRATION.md section 2, variant B)."
+function hip_objective(prob::SchrodingerProb, controls, pcof::Vector{Float64}, target; order::Int=2)
+    dp = device_problem(prob, order)
+    set_controls!(dp, prob, controls, pcof)
+    tr = Matrix{Float64}(vcat(real(target), imag(target)))
+    check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
+    out3 = zeros(3)
+    check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
+          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pcof, length(pcof), C_NULL, out3))
+    return objective_terms(out3, prob.N_ess_levels)
 end
 
 "Drop-in for discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target;
 order, history_precomputed) -- src/eval_grad_discrete_adjoint.jl:107-160."
-function hip_discrete_adjoint!(grad::Vector{Float64}, history::Array{Float64,4}, lambda_history::Array{Float64,4},
-        adjoint_forcing::Array{Float64,3}, prob::SchrodingerProb, controls, pcof::Vector{Float64},
-        target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false)
+function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float64,4},Nothing},
+        lambda_history::Union{Array{Float64,4},Nothing}, adjoint_forcing::Union{Array{Float64,3},Nothing},
+        prob::SchrodingerProb, controls, pcof::Vector{Float64},
+        target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false, cost_type=:Infidelity)
+    cost_type == :Infidelity || throw(ArgumentError("the device path implements cost_type=:Infidelity only"))
     dp = device_problem(prob, order)
     set_controls!(dp, prob, controls, pcof)
+    shape = (prob.real_system_size, 1 + div(order, 2), 1 + prob.nsteps, prob.N_initial_conditions)
+    for a in (history, lambda_history)
+        a === nothing || size(a) == shape || throw(DimensionMismatch("history arrays must be $shape, got $(size(a))"))
+    end
+    adjoint_forcing === nothing || size(adjoint_forcing) == (shape[1], shape[3], shape[4]) || throw(DimensionMismatch("adjoint_forcing"))
+    foreach(a -> a === nothing || pin!(dp, a), (history, lambda_history, adjoint_forcing))
+    ptr(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))       # as eval_grad_discrete_adjoint.jl:126
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
     out3 = zeros(3)
-    check(dp.handle, ccall((:qgd_discrete_adjoint, libqgd), Cint,
-          (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-          dp.handle, pcof, length(pcof), history_precomputed, grad, history, lambda_history, adjoint_forcing, out3))
-    return grad
+    GC.@preserve history lambda_history adjoint_forcing begin
+        check(dp.handle, ccall((:qgd_discrete_adjoint, libqgd), Cint,
+              (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              dp.handle, pcof, length(pcof), history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), out3))
+    end
+    return grad, objective_terms(out3, prob.N_ess_levels)     # (gradient; (infidelity, guard penalty) of this pcof)
 end
 
 """
