@@ -175,7 +175,7 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
 C5_GRAD_NORM_1GPU = 3454.7659605167805     # |grad| of the C5 workload on one GPU (profiles/r02_bench.json): what a partitioned run must reproduce
 
 
-def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3):
+def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3, shard="time"):
     """The same C5 evaluation spread over the ranks by time windows (strong scaling: the configuration where the
     windows can pay); every rank holds the reduced gradient, rank 0 reports."""
     import torch
@@ -185,9 +185,12 @@ def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3):
     ctrl = [qgd.FortranBSplineControl(16, 20, prob.tf) for _ in range(n_ops)]
     pcof = np.random.default_rng(5).random(qgd.get_number_of_control_parameters(ctrl))
     target = prob.u0 + 1j * prob.v0
-    back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
-                             stream=torch.cuda.current_stream().cuda_stream)
-    dp = qgd.TimePartitioned(back, qgd.TorchComm())
+    if shard == "columns":
+        back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        dp = qgd.ColumnSharded(back, qgd.TorchComm())
+    else:
+        back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        dp = qgd.TimePartitioned(back, qgd.TorchComm())
     back.set_timing(0)
     dp.discrete_adjoint(pcof)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -201,7 +204,7 @@ def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3):
     back.close()
     gn = float(np.linalg.norm(grad))
     return {"workload": f"C5 synthetic: N={N}, 256 columns, {n_ops} control operators, order {order}, nsteps={nsteps}, "
-                        f"time windows over {world} GPUs", "scaling": "strong", "timesteps_per_s": nsteps / sec,
+                        f"{'time windows' if shard == 'time' else 'column blocks'} over {world} GPUs", "scaling": "strong", "timesteps_per_s": nsteps / sec,
             "ms_per_evaluation": sec * 1e3, "grad_norm": gn, "grad_norm_rel_diff_vs_1gpu": abs(gn - C5_GRAD_NORM_1GPU) / C5_GRAD_NORM_1GPU}
 
 
@@ -264,6 +267,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, the product path) or gloo "
                                                       "(plumbing check of the multi-process protocol; collectives staged through the host)")
+    ap.add_argument("--shard", default="time", choices=["time", "columns"],
+                    help="N > 1: how ONE evaluation is split over the ranks -- time windows (default: 2 all-gathers + 1 all-reduce) or the "
+                         "reference's thread axis, blocks of initial-condition columns (2 all-reduces; the step matrices are built on every rank)")
     ap.add_argument("--oversubscribe", action="store_true", help="let several ranks share a GPU (test boxes with one GPU; with --backend gloo)")
     args = ap.parse_args()
 
@@ -309,9 +315,14 @@ def main():
     order = 8
     if use_dist:
         # time-partitioned: one problem spread over the ranks (strong scaling), DESIGN.md "Multi-GPU"
-        back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
-                                 stream=torch.cuda.current_stream().cuda_stream)
-        dp = qgd.TimePartitioned(back, qgd.TorchComm())
+        if args.shard == "columns":
+            back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank,
+                                     stream=torch.cuda.current_stream().cuda_stream)
+            dp = qgd.ColumnSharded(back, qgd.TorchComm())
+        else:
+            back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
+                                     stream=torch.cuda.current_stream().cuda_stream)
+            dp = qgd.TimePartitioned(back, qgd.TorchComm())
         dp.timings, dp.close, dp.set_timing = back.timings, back.close, back.set_timing
     else:
         dp = qgd.DeviceProblem(prob, order, device=0)
@@ -367,7 +378,7 @@ def main():
     # (nsteps = 550 per GPU, dt unchanged), i.e. per-GPU work fixed -- where a 0.44 ms evaluation has no more
     # per-rank latency to give, this is what the time-window partition is for.  Reported as `weak_in_time`.
     weak = None
-    if use_dist and (world > 1 or os.environ.get("QGD_BENCH_WEAK")):
+    if use_dist and args.shard == "time" and (world > 1 or os.environ.get("QGD_BENCH_WEAK")):
         try:
             dp.close()
             nsteps_w = args.nsteps * world
@@ -434,7 +445,7 @@ def main():
     large_dist = None
     if use_dist and world > 1 and not args.no_large_n:
         try:
-            large_dist = large_n_partitioned(qgd, np, rank, world, local_rank)
+            large_dist = large_n_partitioned(qgd, np, rank, world, local_rank, shard=args.shard)
         except Exception as exc:
             large_dist = {"error": repr(exc)}
 
@@ -466,7 +477,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
-                       "parallelism": "1 GPU" if n_gpus == 1 else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"
+                       "parallelism": "1 GPU" if n_gpus == 1 else (f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation" if args.shard == "time"
+                                                                   else f"column blocks over {n_gpus} GPUs, 2 all-reduces per evaluation")
                                       + ("" if args.backend == "nccl" else f" ({args.backend} backend, host-staged: plumbing check, not a measurement)")},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),

@@ -181,7 +181,8 @@ int qgd_get_partition(qgd_handle h, int32_t *out8);
 int qgd_set_stream(qgd_handle h, void *hip_stream);
 /* which: 0 window propagators, per rank [planes | panel] of the product of its step matrices
  * (all-gather, 4 N^2 doubles per rank), 1 window affine parts of the adjoint, per rank [phi | y_N]
- * (all-gather), 2 gradient + {<w,R>, <w,T>, guard, 0} (all-reduce sum).  Sizes in doubles. */
+ * (all-gather), 2 gradient + {<w,R>, <w,T>, guard, 0} (all-reduce sum), 3 the three scalars alone (column shards).
+ * Sizes in doubles. */
 int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *total_doubles,
                         size_t *own_offset, size_t *own_doubles);
 int qgd_dist_forward_begin(qgd_handle h, const double *pcof, int32_t n_pcof);
@@ -189,6 +190,17 @@ int qgd_dist_forward_end(qgd_handle h);
 int qgd_dist_adjoint_begin(qgd_handle h);
 int qgd_dist_adjoint_end(qgd_handle h);
 int qgd_dist_finish(qgd_handle h, double *grad, double *out3);
+
+/* ---- column-sharded evaluation over several GPUs (one handle per rank) -- the reference's own parallel axis
+ * (Threads.@threads over initial conditions, src/forward_evolution.jl:48,332).  Each rank creates its handle from ITS
+ * columns of u0, v0 and of the target, with the GLOBAL n_ess.  Only the overlaps in the terminal condition couple the
+ * columns (infidelity.jl:13-17).  Sequence per evaluation, on every rank:
+ *   qgd_cols_forward -> all_reduce_sum(buffer 3: <w_N,R>, <w_N,T>, guard)
+ *   qgd_cols_adjoint(h, rank == 0) -> all_reduce_sum(buffer 2: gradient + scalars) -> qgd_dist_finish
+ * (keep_scalars != 0 on exactly one rank: the scalars are already global when the second reduction sums them).
+ * The step matrices are built on every rank; see DESIGN.md section 6 for when this split pays. */
+int qgd_cols_forward(qgd_handle h, const double *pcof, int32_t n_pcof);
+int qgd_cols_adjoint(qgd_handle h, int32_t keep_scalars);
 
 /* Per-phase device time of the last evaluation (HIP events), milliseconds.
  * names/ms hold up to cap entries; returns the number of phases through *n. */

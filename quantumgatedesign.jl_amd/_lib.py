@@ -23,7 +23,7 @@ EXPORTS = [
     "qgd_set_partition", "qgd_get_partition", "qgd_set_stream", "qgd_exchange_buffer",
     "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
     "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
-    "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc",
+    "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc", "qgd_cols_forward", "qgd_cols_adjoint",
 ]
 
 
@@ -104,6 +104,8 @@ def lib():
     L.qgd_set_operator_path.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_get_operator_path.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_eval_adjoint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qgd_cols_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.qgd_cols_adjoint.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_register_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.qgd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L

@@ -1297,6 +1297,9 @@ int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *tot
     } else if (which == 2) {   // gradient + scalars, all-reduce(sum)
         if (!k.redbuf) return fail(h, QGD_ERR_STATE, "no control basis set");
         *dev_ptr = k.redbuf; *total_doubles = (size_t)k.n_pcof + 4; *own_offset = 0; *own_doubles = (size_t)k.n_pcof + 4;
+    } else if (which == 3) {   // column shards: the three objective scalars at the turnaround, all-reduce(sum)
+        if (!k.redbuf) return fail(h, QGD_ERR_STATE, "no control basis set");
+        *dev_ptr = k.scal; *total_doubles = 3; *own_offset = 0; *own_doubles = 3;
     } else return fail(h, QGD_ERR_ARGUMENT, "unknown exchange buffer");
     return QGD_OK;
 }
@@ -1364,6 +1367,38 @@ int qgd_unregister_host_buffer(qgd_handle h, void *ptr)
             return QGD_OK;
         }
     return fail(h, QGD_ERR_ARGUMENT, "buffer was not registered");
+}
+
+// ---------------------------------------------------------------------------
+// Column-sharded evaluation: the reference's own parallel axis (Threads.@threads over initial conditions,
+// src/forward_evolution.jl:48,332) and the split BASELINE.json's north star sketches.  Every rank's handle is built
+// from ITS columns of u0, v0 and the target, with the global N_ess.  Everything is independent per column except the
+// overlaps <w_N,R>, <w_N,T> in the terminal condition (global sums, infidelity.jl:13-17): one all-reduce of three
+// scalars at the turnaround, one of [grad | scalars] at the end.  The propagator build is replicated on every rank --
+// that is why time windows are the default split.
+// ---------------------------------------------------------------------------
+int qgd_cols_forward(qgd_handle h, const double *pcof, int32_t n_pcof)
+{
+    if (!h || !pcof) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called first");
+    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called first");
+    return run_forward(h, pcof, n_pcof);        // scal = this rank's <w,R>, <w,T>, guard: exchange buffer 3
+}
+
+int qgd_cols_adjoint(qgd_handle h, int32_t keep_scalars)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    qgdk_ctx &k = h->k;
+    if (!h->forward_valid) return fail(h, QGD_ERR_STATE, "no forward evaluation to differentiate");
+    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal_given(&k)); }      // y_N from the all-reduced overlaps
+    int rc;
+    if ((rc = adjoint_begin(h))) return rc;
+    if ((rc = adjoint_end(h))) return rc;
+    // the final all-reduce sums [grad | scalars]; the scalars are global already: all ranks but one contribute zeros
+    if (!keep_scalars) HIP_TRY(h, hipMemsetAsync(k.scal, 0, 3 * sizeof(double), k.stream));
+    return QGD_OK;
 }
 
 int qgd_set_operator_path(qgd_handle h, int32_t mode)

@@ -93,6 +93,7 @@ int qgdk_forward_blocks_upper(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
 int qgdk_guard_is_fused(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
+int qgdk_terminal_given(const qgdk_ctx *c);   /* y_N from the overlaps already in scal (column shards) */
 int qgdk_adjoint_blocks(const qgdk_ctx *c);
 int qgdk_adjoint_finish(const qgdk_ctx *c);
 int qgdk_apply_LH(const qgdk_ctx *c);

@@ -760,14 +760,14 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
                                                   double *__restrict__ scal, int Np, int cp, int nt,
                                                   int n_ess, int have_target, int write_y,
                                                   double *__restrict__ y2, double *__restrict__ y3,
-                                                  double *__restrict__ y4)
+                                                  double *__restrict__ y4, int given_ab)
 {
     __shared__ double red[32];
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
     const size_t hstep = (size_t)Np * PWc;
     const double *w = hist + (size_t)(nt - 1) * hstep;
     double a = 0.0, b = 0.0;
-    if (have_target) {
+    if (have_target && !given_ab) {
         for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
             const int col = e % PWc;
             const int c16 = col & 15;
@@ -783,7 +783,10 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
     __syncthreads();
     a = 0.0; b = 0.0;
     for (int q = 0; q < nw; q++) { a += red[q]; b += red[16 + q]; }
-    if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
+    // column shards: the overlaps are GLOBAL sums over all columns (infidelity.jl:13-17); after the ranks' all-reduce
+    // they are in scal and the terminal condition is formed from them, not from this rank's columns
+    if (given_ab) { a = scal[0]; b = scal[1]; }
+    else if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
     if (!write_y) return;
     const double sc = 2.0 / ((double)n_ess * (double)n_ess);
     double *y = yhist + (size_t)(nt - 1) * hstep;
@@ -1059,13 +1062,16 @@ int qgdk_guard_kernel(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
-int qgdk_terminal(const qgdk_ctx *c, int write_y)
+static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab);
+int qgdk_terminal(const qgdk_ctx *c, int write_y) { return launch_terminal(c, write_y, 0); }
+int qgdk_terminal_given(const qgdk_ctx *c) { return launch_terminal(c, 1, 1); }
+static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;     // y_N for the other ranks
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
-                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep);
+                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab);
     return (int)hipGetLastError();
 }
 

@@ -94,6 +94,56 @@ class DeviceBackend:
         self.dp.close()
 
 
+class ColumnBackend:
+    """One rank's share of a SchrodingerProb under the COLUMN split (the reference's thread axis,
+    src/forward_evolution.jl:48,332): a contiguous block of the initial-condition columns of u0, v0 and of the
+    target; operators, controls and the whole time grid are replicated."""
+
+    def __init__(self, prob, order, controls, target, rank, world, device=0, stream=None):
+        c = prob.N_initial_conditions
+        if world > c:
+            raise ValueError(f"{world} ranks for {c} initial conditions: a rank would own no column")
+        lo, hi = rank * c // world, (rank + 1) * c // world
+        sub = prob.copy()
+        sub.u0 = np.asfortranarray(prob.u0[:, lo:hi]); sub.v0 = np.asfortranarray(prob.v0[:, lo:hi])
+        sub.N_initial_conditions = hi - lo          # N_ess_levels stays the global one
+        self.columns, self.rank, self.world = (lo, hi), rank, world
+        self.dp = DeviceProblem(sub, order, device)
+        self.lib, self.h = self.dp.lib, self.dp.h
+        if stream is not None:
+            _lib.check(self.h, self.lib.qgd_set_stream(self.h, C.c_void_p(stream)))
+        self.dp.set_controls(controls)
+        target = np.asarray(target)
+        self.dp.set_target(target[:, lo:hi])
+        self.n_pcof = self.dp.n_pcof
+
+    exchange_buffer = DeviceBackend.exchange_buffer
+
+    def forward(self, pcof):
+        pc = np.ascontiguousarray(pcof, dtype=np.float64)
+        _lib.check(self.h, self.lib.qgd_cols_forward(self.h, _vp(pc), len(pc)))
+
+    def adjoint(self):
+        _lib.check(self.h, self.lib.qgd_cols_adjoint(self.h, 1 if self.rank == 0 else 0))
+
+    finish, timings, set_timing, close = DeviceBackend.finish, DeviceBackend.timings, DeviceBackend.set_timing, DeviceBackend.close
+
+
+class ColumnSharded:
+    """discrete_adjoint! with the columns spread over the ranks: two small all-reduces per evaluation."""
+
+    def __init__(self, backend, comm):
+        self.b, self.comm = backend, comm
+
+    def discrete_adjoint(self, pcof):
+        b = self.b
+        b.forward(pcof)
+        self.comm.all_reduce(b.exchange_buffer(3)[0])       # <w_N,R>, <w_N,T>, guard: global before the terminal condition
+        b.adjoint()
+        self.comm.all_reduce(b.exchange_buffer(2)[0])       # gradient (+ the scalars, kept by rank 0 only)
+        return b.finish()
+
+
 class TorchComm:
     """Collectives of one evaluation through torch.distributed (backend "nccl" = RCCL on ROCm,
     "gloo" on CPU)."""
@@ -159,8 +209,24 @@ class LocalGroup:
                 if whole_dst.data_ptr() != whole_src.data_ptr():
                     whole_dst[off:off + own_src.numel()].copy_(own_src)
 
+    def _reduce(self, which):
+        wholes = [b.exchange_buffer(which)[0] for b in self.backends]
+        total = wholes[0].clone()
+        for w in wholes[1:]:
+            total += w
+        for w in wholes:
+            w.copy_(total)
+
     def discrete_adjoint(self, pcof):
         bs = self.backends
+        if isinstance(bs[0], ColumnBackend):
+            for b in bs:
+                b.forward(pcof)
+            self._reduce(3)
+            for b in bs:
+                b.adjoint()
+            self._reduce(2)
+            return [b.finish() for b in bs]
         for b in bs:
             b.forward_begin(pcof)
         self._gather(0)

@@ -147,7 +147,8 @@ def test_handle_cache_follows_the_problem(qgd):
     qgd.clear_cache()
 
 
-def test_bench_two_processes_share_the_gpu():
+@pytest.mark.parametrize("shard", ["time", "columns"])
+def test_bench_two_processes_share_the_gpu(shard):
     """`python bench.py --gpus 2` as the driver starts it (bare: it launches two ranks itself), here with two PROCESSES
     on the one GPU of the test box and the gloo backend (collectives staged through the host: RCCL refuses two ranks on
     one device).  Every step of the multi-process protocol is real -- rendezvous, one handle per process, the two
@@ -159,7 +160,7 @@ def test_bench_two_processes_share_the_gpu():
     env = dict(os.environ, MASTER_PORT="29631")
     one = subprocess.run([sys.executable, bench, "--gpus", "1", "--no-large-n"] + common, capture_output=True, text=True, timeout=600, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--oversubscribe"] + common,
+    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--shard", shard] + common,
                          capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
@@ -170,3 +171,30 @@ def test_bench_two_processes_share_the_gpu():
     assert "error" not in j2["large_n"], j2["large_n"]
     assert j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10
     assert j2["weak_in_time"] is None or "error" not in j2["weak_in_time"], j2["weak_in_time"]
+
+
+@pytest.mark.parametrize("which,order,world", [("cnot2", 4, 2), ("cnot2", 8, 4), ("guarded", 6, 2), ("cnot3", 8, 2), ("cnot3", 8, 8),
+                                               ("synthetic", 12, 2), ("synthetic", 4, 3)])
+def test_column_sharded_matches_single_gpu(qgd, which, order, world):
+    """The column split (the reference's own parallel axis, Threads.@threads over initial conditions,
+    src/forward_evolution.jl:48,332; the form BASELINE.json's north star sketches): every rank owns a block of the
+    columns of u0, v0 and the target, two small all-reduces per evaluation.  All ranks inside one process on the one
+    GPU (the collectives become device sums); gradient and scalars must equal the unsharded evaluation."""
+    import torch
+    if which == "synthetic":
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=100, c=24, nsteps=12, tf=0.3)
+    else:
+        prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g_ref, o_ref = dp.discrete_adjoint(pcof)
+    dp.close()
+    stream = torch.cuda.current_stream().cuda_stream
+    backs = [qgd.ColumnBackend(prob, order, ctrl, target, r, world, device=0, stream=stream) for r in range(world)]
+    assert sum(b.columns[1] - b.columns[0] for b in backs) == prob.N_initial_conditions
+    for rep in range(2):
+        for g, o in qgd.LocalGroup(backs).discrete_adjoint(pcof):
+            assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+            assert np.abs(o - o_ref).max() <= 1e-12 * max(1.0, np.abs(o_ref).max())
+    for b in backs:
+        b.close()
