@@ -392,7 +392,7 @@ static int launch_gradpoint64_m(const qgdk_ctx *c)
 // (the "grad_slice .-= contrib" of eval_grad_discrete_adjoint.jl:642-643)
 // grid: (ceil(nc_max/64), n_ops, NSPLIT); atomicAdd over the time splits.
 // ---------------------------------------------------------------------------
-#define CT_CHUNK 16
+#define CT_CHUNK 8
 __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
                                                   const int32_t *__restrict__ ncoef,
                                                   const int32_t *__restrict__ poff,

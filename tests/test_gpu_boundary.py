@@ -42,7 +42,8 @@ def test_csc_constructor_matches_dense(qgd, which, order):
         out.append(dp.discrete_adjoint(pcof))
         assert dp.operator_path()[0] == "sparse"
         dp.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # (to rounding, not bitwise: the contraction kernel adds its time chunks with atomics, in whatever order they finish)
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-14 * np.abs(out[0][0]).max() and np.allclose(out[0][1], out[1][1], rtol=1e-14, atol=1e-15)
 
 
 @pytest.mark.parametrize("zerocopy", [None, "16"])
@@ -73,8 +74,9 @@ def test_registered_outputs_match_pageable(qgd, orc, zerocopy, monkeypatch):
         for rep in range(2):   # the second call reuses the staging buffers and the registrations
             grad, out3 = dp.discrete_adjoint(pcof + (0.0 if rep else 1e-3), False, hist, lam, forcing)
         res[pinned] = (grad, hist, lam, forcing)
-    for a, b in zip(res[False], res[True]):
+    for a, b in zip(res[False][1:], res[True][1:]):      # the three arrays: the same kernels produced them, only the transport differs
         assert np.array_equal(a, b)
+    assert np.abs(res[False][0] - res[True][0]).max() <= 1e-14 * np.abs(res[True][0]).max()    # (gradient: atomics, any order)
     grad, hist, lam, forcing = res[True]
     assert np.abs(hist - h_ref).max() <= 1e-11 * max(1.0, np.abs(h_ref).max())
     assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-11 * max(1.0, np.abs(lam_ref[:, 0]).max())
