@@ -292,15 +292,25 @@ class DeviceProblem:
 _cache: dict = {}
 
 
+try:
+    from xxhash import xxh3_64_intdigest as _digest          # ~10 GB/s
+except ImportError:                                           # pragma: no cover
+    from zlib import crc32 as _digest
+
+
 def _fingerprint(prob):
-    """Cheap digest of the fields a handle copies to the device at creation (operators, initial
-    conditions, guard): a prob mutated in place gets a fresh handle instead of a stale device copy."""
-    import zlib
+    """Digest of the fields a handle copies to the device at creation (operators, initial conditions,
+    guard): a prob mutated in place gets a fresh handle instead of a stale device copy.  Arrays up to 1 MB are
+    hashed whole, larger ones through 65536 evenly spaced elements (the digest runs on every reference-shaped
+    call: ~40 us for a cnot3 problem)."""
     h = 0
     for a in (prob.system_sym, prob.system_asym, prob.u0, prob.v0, prob.guard_subspace_projector,
               *prob.sym_operators, *prob.asym_operators):
         a = np.asarray(a)
-        h = zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1), h) ^ hash(a.shape)
+        flat = a.reshape(-1, order="A") if (a.flags.f_contiguous or a.flags.c_contiguous) else np.ascontiguousarray(a).reshape(-1)
+        if flat.nbytes > (1 << 20):
+            flat = np.ascontiguousarray(flat[:: max(1, flat.size // 65536)])
+        h = (h * 1000003) ^ _digest(flat.view(np.uint8).data) ^ hash(a.shape)
     return (h, prob.N_tot_levels, prob.N_initial_conditions, prob.N_ess_levels, prob.N_operators)
 
 
