@@ -175,3 +175,41 @@ class NumpyBackend:
     def finish(self):
         r = self.red.numpy()
         return r[:self.n_pcof].copy(), r[self.n_pcof:self.n_pcof + 3].copy()
+
+
+
+class NumpyColumnBackend:
+    """numpy stand-in for quantumgatedesign.jl_amd.distributed.ColumnBackend (TEST INFRASTRUCTURE): a block of the
+    initial-condition columns per rank, the same two exchange buffers (3: the overlap scalars, 2: [grad | scalars])."""
+
+    def __init__(self, qgd, prob, order, controls, target, rank, world):
+        c = prob.N_initial_conditions
+        lo, hi = rank * c // world, (rank + 1) * c // world
+        self.sub = prob.copy()
+        self.sub.u0 = np.asfortranarray(prob.u0[:, lo:hi]); self.sub.v0 = np.asfortranarray(prob.v0[:, lo:hi])
+        self.sub.N_initial_conditions = hi - lo
+        self.order, self.rank = order, rank
+        self.target = np.asarray(target, dtype=complex)[:, lo:hi]
+        self.Gp, self.Gq, self.off = qgd.control_basis(controls, prob.nsteps, prob.tf, order // 2)
+        self.n_pcof = sum(g.shape[2] for g in self.Gp)
+        self.red = torch.zeros(self.n_pcof + 4, dtype=torch.float64)
+
+    def exchange_buffer(self, which):
+        whole = self.red[self.n_pcof:self.n_pcof + 3] if which == 3 else self.red
+        return whole, whole
+
+    def forward(self, pcof):
+        self.pcof = np.asarray(pcof, dtype=float)
+        ref = pp.evaluate(self.sub, self.Gp, self.Gq, self.off, self.pcof, self.target, self.order)
+        self.red[self.n_pcof:self.n_pcof + 3] = torch.tensor([ref["overlap"][0], ref["overlap"][1], ref["guard"]])
+
+    def adjoint(self):
+        a, b = float(self.red[self.n_pcof]), float(self.red[self.n_pcof + 1])
+        ref = pp.evaluate(self.sub, self.Gp, self.Gq, self.off, self.pcof, self.target, self.order, overlap=(a, b))
+        self.red[:self.n_pcof] = torch.from_numpy(ref["grad"])
+        if self.rank != 0:
+            self.red[self.n_pcof:self.n_pcof + 3] = 0.0
+
+    def finish(self):
+        r = self.red.numpy()
+        return r[:self.n_pcof].copy(), r[self.n_pcof:self.n_pcof + 3].copy()

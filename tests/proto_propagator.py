@@ -56,8 +56,9 @@ def build_LR(Ac, m, dt):
     return L, R, D
 
 
-def evaluate(prob, Gp, Gq, offsets, pcof, target, order):
-    """Full forward + adjoint + gradient.  Returns dict of every intermediate."""
+def evaluate(prob, Gp, Gq, offsets, pcof, target, order, overlap=None):
+    """Full forward + adjoint + gradient.  Returns dict of every intermediate.  ``overlap=(a, b)``: form the terminal
+    condition from these (global) overlaps instead of the ones of prob's own columns (column-sharded evaluation)."""
     m = order // 2
     N, c, nsteps = prob.N_tot_levels, prob.N_initial_conditions, prob.nsteps
     dt = prob.tf / nsteps
@@ -82,8 +83,9 @@ def evaluate(prob, Gp, Gq, offsets, pcof, target, order):
     ovl = np.sum(np.conj(T) * psi[-1])                              # <w,R> + i<w,T>
     a, b = ovl.real, ovl.imag
     infid = 1 - (a * a + b * b) / prob.N_ess_levels ** 2
+    ga, gb = (a, b) if overlap is None else overlap
     y = np.zeros((nt, N, c), dtype=complex)
-    y[-1] = (2 / prob.N_ess_levels ** 2) * (a + 1j * b) * T + fc[-1]  # a*R + b*T with T=[Rim;-Rre] <-> -i*R
+    y[-1] = (2 / prob.N_ess_levels ** 2) * (ga + 1j * gb) * T + fc[-1]  # a*R + b*T with T=[Rim;-Rre] <-> -i*R
     for n in range(nsteps - 1, 0, -1):
         y[n] = P[n].conj().T @ y[n + 1] + fc[n]
     lam = np.zeros_like(y)

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import cases
 import proto_propagator as pp
-from numpy_backend import NumpyBackend, partition
+from numpy_backend import NumpyBackend, NumpyColumnBackend, partition
 
 
 def _free_port():
@@ -52,6 +52,36 @@ def test_gloo_time_partition(qgd, which, nsteps, order, world):
         assert np.abs(grad - ref["grad"]).max() <= 1e-12 * np.abs(ref["grad"]).max()
         assert abs(out3[0] ** 2 + out3[1] ** 2 - (a * a + b * b)) < 1e-12
         assert abs(out3[2] - ref["guard"]) < 1e-12
+
+
+def _worker_cols(rank, world, port, which, nsteps, order, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import import_package
+        qgd = import_package()
+        prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=nsteps / 2.0)
+        back = NumpyColumnBackend(qgd, prob, order, ctrl, target, rank, world)
+        out[rank] = qgd.ColumnSharded(back, qgd.TorchComm()).discrete_adjoint(pcof)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which,nsteps,order,world", [("cnot2", 30, 4, 2), ("guarded", 24, 6, 2), ("cnot2", 20, 8, 4)])
+def test_gloo_column_shards(qgd, which, nsteps, order, world):
+    """The column split (ColumnSharded + TorchComm: all-reduce of the three overlap scalars at the turnaround, all-reduce
+    of [grad | scalars] at the end) under gloo, against the unsharded numpy statement."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_cols, args=(world, _free_port(), which, nsteps, order, out), nprocs=world, join=True)
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=nsteps / 2.0)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    a, b = ref["overlap"]
+    for r in range(world):
+        grad, out3 = out[r]
+        assert np.abs(grad - ref["grad"]).max() <= 1e-12 * np.abs(ref["grad"]).max()
+        assert abs(out3[0] - a) < 1e-12 and abs(out3[1] - b) < 1e-12 and abs(out3[2] - ref["guard"]) < 1e-12
 
 
 def test_partition_rule_covers_the_grid():
