@@ -19,8 +19,8 @@ for _ in range(40): g, o = dp.discrete_adjoint(pcof)
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 40
 print("%%-40s %%.1f us  grad_norm %%.12f" %% (os.environ.get("TAG"), el * 1e6, np.linalg.norm(g)))
 ''' % (ROOT, ROOT)
-settings = [dict(), dict(QGD_INV_PIVOTED="1"), dict(QGD_INV_OLD="1"), dict(QGD_INV_MULTI="3"), dict(QGD_INV_MULTI="2"),
-            dict(QGD_PIPE_CHUNKS="2"), dict(QGD_PIPE_CHUNKS="3"), dict(QGD_PIPE_CHUNKS="2", QGD_INV_OLD="1"), dict(), dict(QGD_INV_OLD="1")]
+settings = [dict(), dict(QGD_GRAPH="1"), dict(QGD_INV_STATIC="1"), dict(QGD_INV_STATIC="1", QGD_INV_PIVOTED="1"), dict(QGD_INV_MULTI="3"), dict(QGD_INV_MULTI="2"),
+            dict(QGD_PIPE_CHUNKS="2"), dict(QGD_PIPE_CHUNKS="3"), dict(), dict(QGD_GRAPH="1")]
 for extra in settings:
     env = dict(os.environ, TAG=" ".join(f"{k}={v}" for k, v in extra.items()) or "default", **extra)
     subprocess.run([sys.executable, "-c", CODE], env=env)

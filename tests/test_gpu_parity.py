@@ -701,3 +701,27 @@ def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
     assert dp.intermediate("repivoted") > 0
     assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
     dp.close()
+
+
+@pytest.mark.parametrize("c", [20, 64])
+def test_cnot3_many_columns(qgd, c):
+    """The sparse N=64 path with more initial conditions than one MFMA tile (the whole 64-dimensional basis, and a
+    ragged 20): several column groups per time point in the sweeps, the gradient scalars summed over groups."""
+    prob, ctrl, pcof, _ = cases.cnot3_case(qgd, nsteps=30, tf=30.0)
+    U0 = np.eye(64, c)
+    prob.u0 = np.asfortranarray(U0); prob.v0 = np.asfortranarray(np.zeros((64, c)))
+    prob.N_initial_conditions = c
+    target = cases.rand_target(prob, seed=c)
+    order = 8
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    assert dp.operator_path()[0] == "sparse"
+    hist = np.zeros((128, order // 2 + 1, prob.nsteps + 1, c), order="F")
+    grad, out3 = dp.discrete_adjoint(pcof, False, hist)
+    dp.close()
+    assert close(hist, pp.history_real(ref["ws"]), 1e-11)
+    assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
+    a, b = ref["overlap"]          # the statement's overlap is sum conj(R) psi = <w,R> - i <w,T>  (T = [R_im; -R_re], infidelity.jl:13-17)
+    assert abs(out3[0] - a) < 1e-11 and abs(out3[1] + b) < 1e-11 and abs(out3[2] - ref["guard"]) < 1e-11
