@@ -360,8 +360,8 @@ def main():
     nsamp = 0
     for i in range(args.steps):
         # the event pair around the dominant kernel costs ~20 us per evaluation (it drains the queue between two
-        # kernels): it brackets every 4th step of the timed region, the kernel's duration is the mean of those
-        sample = (i % 4 == 0)
+        # kernels): it brackets every 8th step of the timed region, the kernel's duration is the mean of those
+        sample = (i % 8 == 0)
         dp.set_timing(2 if sample else 0, dom_raw)
         grad, out3 = dp.discrete_adjoint(pcof)
         if sample:
