@@ -395,6 +395,9 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             const int lrow = (lane < NP) ? lane : 0;
             #pragma unroll
             for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
+#ifdef QGD_INV_KO_CHAIN
+            if (lane == 0) { for (int s = 0; s < 4; s++) { rho[p0 + s] = p0 + s; rinv[p0 + s] = p0 + s; } }
+#else
             #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
@@ -418,6 +421,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                     xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
                 }
             }
+#endif
             if (lane < NP) {
                 #pragma unroll
                 for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
@@ -508,6 +512,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
             }
         }
+#ifndef QGD_INV_KO_PRODUCT      // (knock-out experiments of scripts/ubench/inverse_bench.hip: timing only, wrong results)
         #pragma unroll 4
         for (int ks = 0; ks < NP / 4; ks++) {
             const int k = 4 * ks + kk;
@@ -525,6 +530,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
             }
         }
+#endif
         lds_barrier();
     }
     // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
