@@ -67,6 +67,7 @@ struct qgd_handle_s {
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
     std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
     bool copies_pending = false;
+    bool defer_terminal = false;        // a full gradient evaluation: the overlaps and y_N ride in the first adjoint launch
     double *lambda_out = nullptr;       // lambda_history of the evaluation in flight (copied out right after the lambda phase)
     // Time-chunk pipeline of the front of an evaluation (sparse path, N = 64).  build_LR, inverse+propagator and the
     // block products are each latency-bound launches that leave most CUs idle at their tails, and time point n of one
@@ -486,7 +487,7 @@ int forward_end(qgd_handle h)
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
     if (!qgdk_guard_is_fused(&k)) { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }   // else: done by the history pass
-    if (k.part_rank == k.part_world - 1) {   // the rank that owns the final time
+    if (k.part_rank == k.part_world - 1 && !h->defer_terminal) {   // the rank that owns the final time
         PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target));
     }
     h->forward_valid = true;
@@ -496,7 +497,10 @@ int forward_end(qgd_handle h)
 int adjoint_begin(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
+    k.fuse_terminal = h->defer_terminal ? 1 : 0;     // (the forward sweep left the terminal condition to this launch)
+    h->defer_terminal = false;
     { PhaseTimer t(h, "sweep_adjoint"); K_TRY(h, qgdk_adjoint_blocks(&k)); }
+    k.fuse_terminal = 0;
     return QGD_OK;
 }
 
@@ -955,6 +959,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(k.stream, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok) {
+                h->defer_terminal = qgdk_terminal_can_fuse(&k) != 0;
                 rc = run_forward(h, pcof, n_pcof);
                 if (!rc) rc = adjoint_begin(h);
                 if (!rc) rc = adjoint_end(h);
@@ -982,7 +987,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             return QGD_OK;
         }
     }
-    struct CopyGuard { qgd_handle h; ~CopyGuard() { (void)finish_copies(h); } } guard{h};   // no copy outlives the call
+    struct CopyGuard { qgd_handle h; ~CopyGuard() { (void)finish_copies(h); h->defer_terminal = false; } } guard{h};   // no copy (and no deferred terminal condition) outlives the call
     // history_precomputed: the reference differentiates the history it is GIVEN with the pcof it is given
     // (eval_grad_discrete_adjoint.jl:118-124).  The device keeps its own copy of the last forward sweep; it is
     // reused only when it was computed from this very pcof, otherwise the sweep is simply redone.
@@ -995,7 +1000,9 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
         // the terminal right-hand side may not have been written if the target was set later
         { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
     } else {
-        if ((rc = run_forward(h, pcof, n_pcof))) return rc;
+        h->defer_terminal = k.have_target && qgdk_terminal_can_fuse(&k) != 0;
+        rc = run_forward(h, pcof, n_pcof);
+        if (rc) { h->defer_terminal = false; return rc; }
     }
     if (uv_history) {   // the download of the state history runs beside the adjoint sweep
         if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }

@@ -17,6 +17,7 @@ typedef struct qgdk_ctx {
     // sparse-operator path (qgd_k_sparse.hip): ELL over the union pattern of all operators, and
     // one ELL list per control operator.  Padding entries point at the row itself with value 0.
     int use_sparse, ell_z, op_z;
+    int fuse_terminal;  // set for one call of qgdk_adjoint_blocks: its first launch carries the terminal condition (k_terminal's work)
     int32_t *ell_col;   // [ell_z][Np]
     uint8_t *ell_inv;   // [Np][Np]: slot of column c in row r of the union pattern, 0xff when absent
     double *ell_val;    // [(2+2 n_ops)][ell_z][Np]   planes in the order of `ops`
@@ -92,6 +93,7 @@ int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t str
 int qgdk_forward_blocks_upper(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
 int qgdk_guard_is_fused(const qgdk_ctx *c);
+int qgdk_terminal_can_fuse(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
 int qgdk_terminal_given(const qgdk_ctx *c);   /* y_N from the overlaps already in scal (column shards) */
 int qgdk_adjoint_blocks(const qgdk_ctx *c);

@@ -58,7 +58,18 @@ struct ChainArgs {
     const double *fs_G; const int64_t *fs_goff; const int32_t *fs_ncoef, *fs_poff;
     const double *fs_gf;                         // adjoint forcing f_n [nt][Np][2*cp_state]: guard part = -<f_n, s_n>
     double *fs_gacc;                             // [n_pcof] guard sums
+    // MODE 2, t_on: ONE extra workgroup (the last of the grid) does the work of k_terminal -- overlaps <w_N,R>, <w_N,T>
+    // and y_N -- beside the affine parts of the blocks, which do not need it: the adjoint sweep starts one launch earlier
+    int t_on, t_nt, t_ness, t_have_target;
+    const double *t_hist, *t_target, *t_forcing;
+    double *t_yhist, *t_scal, *t_y2, *t_y3, *t_y4;
 };
+
+__device__ __forceinline__ void terminal_block(const double *__restrict__ hist, const double *__restrict__ target,
+                                               const double *__restrict__ forcing, double *__restrict__ yhist,
+                                               double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
+                                               int write_y, double *__restrict__ y2, double *__restrict__ y3,
+                                               double *__restrict__ y4, int given_ab);
 
 __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
 {
@@ -149,6 +160,11 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     constexpr int NRB = NP / 16, NT = CHAIN_NT(MODE), KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
+    if (MODE == 2 && a.t_on && blockIdx.x == gridDim.x - 1) {      // the extra workgroup: k_terminal's work
+        terminal_block(a.t_hist, a.t_target, a.t_forcing, a.t_yhist, a.t_scal, NP, a.cp, a.t_nt, a.t_ness, a.t_have_target, 1,
+                       a.t_y2, a.t_y3, a.t_y4, 0);
+        return;
+    }
     int b, grp0;
     {
         ChainArgs a2 = a; a2.ngroups = a.ngroups / NG;
@@ -640,7 +656,7 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
 {
     const bool fast = (a.Np == 16 || a.Np == 32 || a.Np == 48 || a.Np == 64) && a.ngroups % NG == 0;
     const int ng = fast ? a.ngroups / NG : a.ngroups;
-    const int nwg = (MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng;
+    const int nwg = ((MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng) + ((MODE == 2 && fast && a.t_on) ? 1 : 0);
     if (nwg <= 0) return 0;
     switch (fast ? a.Np : 0) {
     case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE, NG>), dim3(nwg), dim3(16 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
@@ -753,14 +769,13 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
 // eval_grad_discrete_adjoint.jl:22-40).  Single workgroup.
 //   scal[0] = <w_N,R>, scal[1] = <w_N,T>;  y_N = (2/Ness^2)(a R + b T) + f_N
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hist,
-                                                  const double *__restrict__ target,
-                                                  const double *__restrict__ forcing,
-                                                  double *__restrict__ yhist,
-                                                  double *__restrict__ scal, int Np, int cp, int nt,
-                                                  int n_ess, int have_target, int write_y,
-                                                  double *__restrict__ y2, double *__restrict__ y3,
-                                                  double *__restrict__ y4, int given_ab)
+// the overlaps and the terminal condition of the adjoint (infidelity.jl:7-18; eval_grad_discrete_adjoint.jl:1-67 in the
+// variable y = L^T lambda): one workgroup, any size up to 1024 threads
+__device__ __forceinline__ void terminal_block(const double *__restrict__ hist, const double *__restrict__ target,
+                                               const double *__restrict__ forcing, double *__restrict__ yhist,
+                                               double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
+                                               int write_y, double *__restrict__ y2, double *__restrict__ y3,
+                                               double *__restrict__ y4, int given_ab)
 {
     __shared__ double red[32];
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
@@ -889,6 +904,19 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
     #pragma unroll
     for (int r = 0; r < 4; r++)
         lam[(size_t)n * hstep + (size_t)(wave * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = acc0[r] + acc1[r];
+}
+
+
+__global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hist,
+                                                  const double *__restrict__ target,
+                                                  const double *__restrict__ forcing,
+                                                  double *__restrict__ yhist,
+                                                  double *__restrict__ scal, int Np, int cp, int nt,
+                                                  int n_ess, int have_target, int write_y,
+                                                  double *__restrict__ y2, double *__restrict__ y3,
+                                                  double *__restrict__ y4, int given_ab)
+{
+    terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab);
 }
 
 extern "C" {
@@ -1041,6 +1069,7 @@ int qgdk_forward_finish(const qgdk_ctx *c)
 }
 
 int qgdk_guard_is_fused(const qgdk_ctx *c) { return guard_is_fused(c) ? 1 : 0; }
+int qgdk_terminal_can_fuse(const qgdk_ctx *c) { return chain_is_fast(c) && !getenv("QGD_TERMINAL_KERNEL"); }
 
 int qgdk_guard(const qgdk_ctx *c)
 {
@@ -1085,6 +1114,13 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     ChainArgs a{};
     a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = c->phiX;
     a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
+    if (c->fuse_terminal && chain_is_fast(c)) {          // y_N and the overlaps by an extra workgroup of this launch
+        const size_t hstep = (size_t)c->Np * 2 * c->cp;
+        a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target;
+        a.t_hist = c->hist; a.t_target = c->target; a.t_forcing = c->forcing; a.t_yhist = c->yhist; a.t_scal = c->scal;
+        a.t_y2 = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
+        a.t_y3 = c->bndY + (size_t)c->scan_blocks * hstep; a.t_y4 = c->bndY2 + (size_t)c->scan_blocks2 * hstep;
+    }
     if ((rc = launch_chain<2>(a, c->stream))) return rc;
     if (B2 > 1) {      // affine parts of the super-blocks (their propagators PiR2 come from the forward sweep)
         ChainArgs a2{};
