@@ -907,6 +907,42 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
 }
 
 
+// the same in two launches of many workgroups, for panels of >= 32768 elements: partial overlaps by atomics, then y_N
+__global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__ w, const double *__restrict__ target,
+                                                      double *__restrict__ scal, int hstep, int PWc)
+{
+    __shared__ double red[8];
+    double a = 0.0, b = 0.0;
+    for (int e = blockIdx.x * 2048 + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * 2048); e += 256) {
+        const int c16 = (e % PWc) & 15;
+        const double tp = target[e ^ 8];
+        a += w[e] * target[e];
+        b += (c16 < 8) ? w[e] * tp : -w[e] * tp;
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&scal[0], red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(&scal[1], red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_terminal_y(const double *__restrict__ target, const double *__restrict__ f,
+                                                    const double *__restrict__ scal, double *__restrict__ y,
+                                                    double *__restrict__ y2, double *__restrict__ y3, double *__restrict__ y4,
+                                                    int hstep, int PWc, int n_ess)
+{
+    const double a = scal[0], b = scal[1], sc = 2.0 / ((double)n_ess * (double)n_ess);
+    for (int e = blockIdx.x * 2048 + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * 2048); e += 256) {
+        const int c16 = (e % PWc) & 15;
+        const double tv = target[e], tp = target[e ^ 8];
+        const double Tv = (c16 < 8) ? tp : -tp;
+        const double v = sc * (a * tv + b * Tv) + f[e];
+        y[e] = v; y2[e] = v; y3[e] = v; y4[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hist,
                                                   const double *__restrict__ target,
                                                   const double *__restrict__ forcing,
@@ -1098,6 +1134,20 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;     // y_N for the other ranks
+    if (hstep >= 32768 && !getenv("QGD_TERMINAL_ONE_WG")) {
+        // large panels (config 5: 131072 elements): one workgroup took 177 us; many workgroups, two launches
+        const int nwg = (int)((hstep + 2047) / 2048);
+        const double *w = c->hist + (size_t)(c->nt - 1) * hstep;
+        if (!given_ab) {
+            HIPCHK(hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
+            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(nwg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp);
+        }
+        if (write_y)
+            hipLaunchKernelGGL(k_terminal_y, dim3(nwg), dim3(256), 0, c->stream, c->target, c->forcing + (size_t)(c->nt - 1) * hstep,
+                               c->scal, c->yhist + (size_t)(c->nt - 1) * hstep, slot, c->bndY + (size_t)c->scan_blocks * hstep,
+                               c->bndY2 + (size_t)c->scan_blocks2 * hstep, (int)hstep, 2 * c->cp, c->n_ess);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab);
