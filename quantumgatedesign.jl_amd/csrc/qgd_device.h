@@ -65,6 +65,10 @@ typedef struct qgdk_ctx {
     // second scan level over the block propagators: scan_blocks2 super-blocks of scan_g blocks
     int scan_blocks2, scan_g;
     double *PiC2, *PiR2, *phi2, *bnd2, *bndY2;
+    // forward history pass over sub-blocks (N <= 64, one rank): stored running products of the block chains (Hmid:
+    // [B][sub_n] after 3, 6, ... steps) and of the level-2 chains (Qmid: [B2][g-2] after 2 .. g-1 blocks)
+    int sub_hist, sub_n;
+    double *Hmid, *Qmid;
     int part_rank, part_world, n_off, nt_glob;
     // forced (forward-sensitivity) gradient, qgd_k_forced.hip: basis responses and sensitivity scan buffers
     double *fs_BR, *fs_BL;   // [nt][n_ops*2*m][Np][2cp]

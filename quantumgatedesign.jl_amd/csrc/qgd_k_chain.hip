@@ -58,6 +58,17 @@ struct ChainArgs {
     const double *fs_G; const int64_t *fs_goff; const int32_t *fs_ncoef, *fs_poff;
     const double *fs_gf;                         // adjoint forcing f_n [nt][Np][2*cp_state]: guard part = -<f_n, s_n>
     double *fs_gacc;                             // [n_pcof] guard sums
+    // MODE 0, mid_every > 0: the running product is also stored after k = mid_first, mid_first + mid_every, ... (< block
+    // length) matrices, planes layout, at mid_out + ((size_t)b * mid_n + (k - mid_first) / mid_every) * 2 Np^2.
+    // MODE 1, sub_T > 0 (forward history pass over SUB-blocks): `nblocks` counts sub-blocks, sub_T per block of blen steps,
+    // sub_len steps each; sub-block t >= 1 of block b starts from the block's start state advanced by ONE step with the
+    // stored product sub_H[b * sub_n + t - 1] (the first t * sub_len step matrices of the block).  pre_Q: the prefix
+    // products of the blocks inside a super-block stored by the level-2 scan, pre_Q[j * pre_Qn + i - 2] = product of the
+    // first i >= 2 blocks of super-block j: the block-level prefix of the history pass is then ONE step instead of i.
+    // Together: <= B2 + 1 + 1 + sub_len dependent steps instead of B2 + g + blen, on sub_T times as many CUs.
+    double *mid_out; int mid_every, mid_n, mid_first;
+    int sub_T, sub_len, sub_n, pre_Qn;
+    const double *sub_H, *pre_Q;
     // MODE 2, t_on: ONE extra workgroup (the last of the grid) does the work of k_terminal -- overlaps <w_N,R>, <w_N,T>
     // and y_N -- beside the affine parts of the blocks, which do not need it: the adjoint sweep starts one launch earlier
     int t_on, t_nt, t_ness, t_have_target;
@@ -172,7 +183,12 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         grp0 *= NG;
     }
     if (b >= a.nblocks) return;
-    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const bool subs = (MODE == 1) && a.sub_T > 0;        // b counts sub-blocks: block bb, sub-block tsub
+    const int bb = subs ? b / a.sub_T : b, tsub = subs ? b % a.sub_T : 0;
+    const int blk_end = ((bb + 1) * a.blen < a.S) ? (bb + 1) * a.blen : a.S;
+    const int s0 = bb * a.blen + (subs ? tsub * a.sub_len : 0);
+    const int e0 = subs ? ((s0 + a.sub_len < blk_end) ? s0 + a.sub_len : blk_end) : blk_end;
+    if (subs && s0 >= blk_end) return;                   // (a short last block has fewer sub-blocks)
     const int PWc = (MODE == 0) ? 2 * NP : 2 * a.cp;
     const size_t hstep = (size_t)NP * PWc;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -187,24 +203,37 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     const int nsteps = (e0 > s0) ? e0 - s0 : 0;
     double pen = 0.0;                                     // guard penalty of the states this thread handles
     // prefix segments (MODE 1/3): counts and first indices for this block
-    int pcnt[3] = {0, 0, 0}, pfirst[3] = {0, 0, 0}, npfx = 0;
+    int pcnt[4] = {0, 0, 0, 0}, pfirst[4] = {0, 0, 0, 0}, npfx = 0;
+    const double *pfix[4] = {nullptr, nullptr, nullptr, nullptr};   // a segment of ONE step with this stored product
+    const size_t pl2_ = (size_t)2 * NP * NP;
     if ((MODE == 1 || MODE == 3) && a.npre > 0) {
         bool have1 = false;
         for (int q = 0; q < a.npre; q++) have1 = have1 || (a.pre_kind[q] == 1);
-        const int j = have1 ? b / a.pre_g : 0;
-        const int ej = have1 ? (((j + 1) * a.pre_g < a.nblocks) ? (j + 1) * a.pre_g : a.nblocks) : a.nblocks;
+        const int nblk = subs ? a.nblocks / a.sub_T : a.nblocks;
+        const int j = have1 ? bb / a.pre_g : 0;
+        const int ej = have1 ? (((j + 1) * a.pre_g < nblk) ? (j + 1) * a.pre_g : nblk) : nblk;
         for (int q = 0; q < a.npre; q++) {
             const int kind = a.pre_kind[q];
             if (!ADJ) {
                 pfirst[q] = (kind == 2 && have1) ? j * a.pre_g : 0;
-                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? j : b - pfirst[q];
+                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? j : bb - pfirst[q];
+                if (MODE == 1 && kind == 2 && a.pre_Q && have1 && pcnt[q] >= 1) {   // the stored block-prefix product
+                    const int i = pcnt[q];
+                    pfix[q] = (i == 1) ? a.pre_P[q] + (size_t)pfirst[q] * pl2_ : a.pre_Q + ((size_t)j * a.pre_Qn + (i - 2)) * pl2_;
+                    pcnt[q] = 1;
+                }
             } else {    // descending: first = highest index
                 pfirst[q] = (kind == 0) ? a.pre_rank_count - 1 : (kind == 1) ? a.pre_B2 - 1 : ej - 1;
-                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? a.pre_B2 - 1 - j : ej - 1 - b;
+                pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? a.pre_B2 - 1 - j : ej - 1 - bb;
             }
             if (pcnt[q] < 0) pcnt[q] = 0;
             npfx += pcnt[q];
         }
+    }
+    int npre_eff = ((MODE == 1 || MODE == 3) ? a.npre : 0);
+    if (subs && tsub > 0) {                               // from the block's start state to this sub-block's: one step
+        pfix[npre_eff] = a.sub_H + ((size_t)bb * a.sub_n + (tsub - 1)) * pl2_;
+        pcnt[npre_eff] = 1; npfx += 1; npre_eff++;
     }
     const int total = npfx + nsteps;
 
@@ -253,9 +282,10 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             q = __builtin_amdgcn_readfirstlane(q);
             n = __builtin_amdgcn_readfirstlane(ADJ ? pfirst[q] - sl : pfirst[q] + sl);
             const size_t pl2 = (size_t)2 * NP * NP;
-            Pn = a.pre_pm_bpr[q] ? a.pre_P[q] + (size_t)(n / a.pre_pm_bpr[q]) * a.pre_pm_chunk[q] + (size_t)(n % a.pre_pm_bpr[q]) * pl2
-                                 : a.pre_P[q] + (size_t)n * pl2;
-            fsrc = a.pre_f[q]; fbpr = a.pre_f_bpr[q];
+            if (pfix[q]) Pn = pfix[q];
+            else Pn = a.pre_pm_bpr[q] ? a.pre_P[q] + (size_t)(n / a.pre_pm_bpr[q]) * a.pre_pm_chunk[q] + (size_t)(n % a.pre_pm_bpr[q]) * pl2
+                                      : a.pre_P[q] + (size_t)n * pl2;
+            if (q < a.npre) { fsrc = a.pre_f[q]; fbpr = a.pre_f_bpr[q]; }
         }
         // Addresses = buffer descriptor on the step's matrix (SGPRs) + a per-lane byte offset computed once + constants:
         // no vector ALU per load.  While the other team runs its burst of f64 MFMAs, a wave on the same SIMD gets about
@@ -347,6 +377,18 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         CH_STAMP(2);
         lds_barrier(); done++;                            // the next team starts; the rest is off the critical path
         CH_STAMP(3);
+        if (MODE == 0 && a.mid_every > 0) {              // the running product of the first st+1 matrices, for the sub-block history pass
+            const int kdone = st + 1;
+            if (kdone >= a.mid_first && kdone < total && (kdone - a.mid_first) % a.mid_every == 0) {
+                const size_t pl = (size_t)NP * NP;
+                double *pc = a.mid_out + ((size_t)b * a.mid_n + (kdone - a.mid_first) / a.mid_every) * 2 * pl + (c16 >= 8 ? pl : 0);
+                #pragma unroll
+                for (int g = 0; g < NG; g++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        pc[(size_t)(rb * 16 + kk + 4 * r) + (size_t)NP * ((grp0 + g) * 8 + (c16 & 7))] = res[g][r];
+            }
+        }
         if (((MODE == 1 || MODE == 3) && mainstep) || (MODE == 5 && a.out)) {
             const __amdgpu_buffer_rsrc_t rO = buffer_of(a.out + (size_t)nout * hstep + (size_t)grp0 * 16);
             #pragma unroll
@@ -957,6 +999,7 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
 
 extern "C" {
 
+#define QGD_SUB_LEN 3      /* steps per sub-block of the forward history pass */
 static inline bool chain_is_fast(const qgdk_ctx *c) { return c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64; }
 
 // diagonal guard projector + compiled-size sweeps: k_chain_fast<.,1,.> does the guard work
@@ -988,11 +1031,13 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
     a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pc;
     a.PiC = c->PiX; a.PiR = c->PiX + (size_t)B * pl2;
     a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    if (c->sub_hist) { a.mid_out = c->Hmid; a.mid_every = QGD_SUB_LEN; a.mid_first = QGD_SUB_LEN; a.mid_n = c->sub_n; }
     if ((rc = launch_chain<0>(a, c->stream))) return rc;
     if (B2 > 1) {      // super-block propagators from the block propagators
         ChainArgs a2{};
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if (c->sub_hist && g > 2) { a2.mid_out = c->Qmid; a2.mid_every = 1; a2.mid_first = 2; a2.mid_n = g - 2; }
         if ((rc = launch_chain<0>(a2, c->stream))) return rc;
     }
     if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
@@ -1017,6 +1062,7 @@ int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t str
     a.Np = c->Np; a.cp = c->cp; a.S = s_hi - s_lo; a.Pmat = c->Pc + (size_t)s_lo * pl2;
     a.PiC = c->PiX + (size_t)b0 * pl2; a.PiR = c->PiX + ((size_t)B + b0) * pl2;
     a.nblocks = b1 - b0; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
+    if (c->sub_hist) { a.mid_out = c->Hmid + (size_t)b0 * c->sub_n * pl2; a.mid_every = QGD_SUB_LEN; a.mid_first = QGD_SUB_LEN; a.mid_n = c->sub_n; }
     return launch_chain<0>(a, stream);
 }
 
@@ -1029,6 +1075,7 @@ int qgdk_forward_blocks_upper(const qgdk_ctx *c)
         ChainArgs a2{};
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if (c->sub_hist && g > 2) { a2.mid_out = c->Qmid; a2.mid_every = 1; a2.mid_first = 2; a2.mid_n = g - 2; }
         if ((rc = launch_chain<0>(a2, c->stream))) return rc;
     }
     if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
@@ -1062,6 +1109,11 @@ int qgdk_forward_finish(const qgdk_ctx *c)
         if (B2 > 1) { s3.pre_kind[q] = 1; s3.pre_P[q] = c->PiC2; q++; }
         if (B > 1) { s3.pre_kind[q] = 2; s3.pre_P[q] = c->PiX; q++; }
         s3.npre = q; s3.pre_g = g; s3.pre_B2 = B2;
+        if (c->sub_hist) {   // sub-blocks of QGD_SUB_LEN steps on their own workgroups, prefixes through the stored products
+            s3.sub_T = c->sub_n + 1; s3.sub_len = QGD_SUB_LEN; s3.sub_n = c->sub_n; s3.sub_H = c->Hmid;
+            s3.nblocks = B * s3.sub_T;
+            if (B2 > 1 && g > 2) { s3.pre_Q = c->Qmid; s3.pre_Qn = g - 2; }
+        }
         if (guard_is_fused(c)) {
             s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
             s3.n_off = c->n_off; s3.nt_glob = c->nt_glob; s3.count_first = (c->n_off == 0) ? 1 : 0; s3.dt = c->dt; s3.tf = c->tf;
