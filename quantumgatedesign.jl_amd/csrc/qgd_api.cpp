@@ -232,7 +232,7 @@ int alloc_grid(qgd_handle h)
         if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY2, (nb2 + 1) * hstep))) return rc;
         // sub-block history pass (qgd_k_chain.hip): only with compiled-size chains, one rank, blocks of at least 6 steps
         k.sub_hist = 0; k.sub_n = 0; k.Hmid = k.Qmid = nullptr;
-        if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.part_world == 1 && k.scan_blen >= 6 && !getenv("QGD_HIST_WHOLE_BLOCKS")) {
+        if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blen >= 6 && !getenv("QGD_HIST_WHOLE_BLOCKS")) {
             k.sub_hist = 1; k.sub_n = (k.scan_blen + 2) / 3 - 1;      // stored products after 3, 6, ... steps
             if ((rc = dev_alloc(h, h->grid_bufs, &k.Hmid, nb * (size_t)k.sub_n * 2 * pl))) return rc;
             if ((rc = dev_alloc(h, h->grid_bufs, &k.Qmid, (nb2 + 1) * (size_t)std::max(k.scan_g, 2) * 2 * pl))) return rc;

@@ -174,7 +174,7 @@ def test_full_size_properties(qgd):
 
 
 @pytest.mark.parametrize("which,nsteps,world", [("cnot2", 100, 2), ("cnot2", 100, 4), ("guarded", 90, 3), ("cnot3", 64, 2),
-                                                ("cnot3", 96, 8)])
+                                                ("cnot3", 96, 8), ("cnot3", 400, 2), ("cnot3", 550, 3), ("guarded", 420, 2)])
 def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
     """The multi-GPU algorithm (time windows per rank, two all-gathers and one all-reduce per
     evaluation) with all ranks inside this process on the one GPU: gradient and scalars must equal
