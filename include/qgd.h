@@ -126,7 +126,8 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof,
  * is an output in both cases.  Optional outputs (nullable):
  *   uv_history      [2N, 1+m, 1+nsteps, n_cols]
  *   lambda_history  [2N, 1+m, 1+nsteps, n_cols]  (column j=0 filled: the only one
- *                   the reference consumes, eval_grad_discrete_adjoint.jl:604)
+ *                   the reference consumes, eval_grad_discrete_adjoint.jl:604;
+ *                   all 1+m columns after qgd_set_lambda_derivatives(h, 1))
  *   adjoint_forcing [2N, 1+nsteps, n_cols]       (:732-752)
  */
 int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
@@ -142,10 +143,18 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
 int qgd_register_host_buffer(qgd_handle h, void *ptr, size_t bytes);
 int qgd_unregister_host_buffer(qgd_handle h, void *ptr);
 
+/* The derivative columns lambda_history[:, 2:end, :, :] as the reference leaves them: eval_adjoint! stores, beside
+ * lambda_n, the m adjoint derivatives the explicit side of step n was built from (src/forward_evolution.jl:427-433,
+ * :471-480; compute_adjoint_derivatives!, src/hermite.jl:284-305) -- evaluated with the controls at t_{n-1} for time
+ * index n >= 2 and at t_1 for n = 1; index 0 is never written.  Nothing downstream reads them
+ * (eval_grad_discrete_adjoint.jl:604 takes column 1 only), so they are off by default: on != 0 makes
+ * qgd_discrete_adjoint and qgd_eval_adjoint fill them too (one more kernel, and 1+m times the lambda download). */
+int qgd_set_lambda_derivatives(qgd_handle h, int32_t on);
+
 /* eval_adjoint (src/forward_evolution.jl:300-315, per column :352-483): backward sweep from a
  * caller-given terminal lambda_N [2N, n_cols] with optional forcing [2N, 1+nsteps, n_cols];
  * lambda_history [2N, 1+m, 1+nsteps, n_cols] receives lambda_n in column j=0 (time index 0 stays
- * zero, as in the reference). */
+ * zero, as in the reference), and the derivative columns after qgd_set_lambda_derivatives(h, 1). */
 int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const double *terminal_condition,
                      const double *forcing, double *lambda_history);
 

@@ -174,11 +174,14 @@ function hip_objective(prob::SchrodingerProb, controls, pcof::Vector{Float64}, t
 end
 
 "Drop-in for discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target;
-order, history_precomputed) -- src/eval_grad_discrete_adjoint.jl:107-160."
+order, history_precomputed) -- src/eval_grad_discrete_adjoint.jl:107-160.  `lambda_derivatives=true` also fills
+lambda_history[:, 2:end, :, :] the way eval_adjoint! leaves it (src/forward_evolution.jl:427-433); nothing in the package
+reads those columns, so the default keeps them zero and the download small."
 function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float64,4},Nothing},
         lambda_history::Union{Array{Float64,4},Nothing}, adjoint_forcing::Union{Array{Float64,3},Nothing},
         prob::SchrodingerProb, controls, pcof::Vector{Float64},
-        target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false, cost_type=:Infidelity)
+        target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false, cost_type=:Infidelity,
+        lambda_derivatives::Bool=false)
     cost_type == :Infidelity || throw(ArgumentError("the device path implements cost_type=:Infidelity only"))
     dp = device_problem(prob, order)
     set_controls!(dp, prob, controls, pcof)
@@ -191,6 +194,7 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
     ptr(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))       # as eval_grad_discrete_adjoint.jl:126
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
+    check(dp.handle, ccall((:qgd_set_lambda_derivatives, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, lambda_derivatives))
     out3 = zeros(3)
     GC.@preserve history lambda_history adjoint_forcing begin
         check(dp.handle, ccall((:qgd_discrete_adjoint, libqgd), Cint,

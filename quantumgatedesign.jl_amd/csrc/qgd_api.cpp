@@ -62,6 +62,9 @@ struct qgd_handle_s {
     std::vector<HostReg> regs;
     std::vector<void *> stage_bufs;
     double *stage_hist = nullptr, *stage_lam = nullptr, *stage_f = nullptr;
+    // qgd_set_lambda_derivatives: the m derivative columns of lambda_history as the reference leaves them
+    bool lambda_derivs = false;
+    double *dlam = nullptr, *dlam_scratch = nullptr, *stage_lam_full = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_ready = nullptr;
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
@@ -158,6 +161,7 @@ int alloc_grid(qgd_handle h)
     free_pool(h->forced_bufs); h->forced_key = 0;
     free_pool(h->forcing_bufs); h->forcing_key = 0;
     free_pool(h->stage_bufs); h->stage_hist = h->stage_lam = h->stage_f = nullptr;
+    h->dlam = h->dlam_scratch = h->stage_lam_full = nullptr;
     // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
     //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
     {
@@ -401,6 +405,32 @@ int copy_panels_out(qgd_handle h, const double *panels, double **stage, double *
     return QGD_OK;
 }
 
+// lambda_history with its derivative columns (qgd_set_lambda_derivatives): lam [nt][Np][2cp] (j = 0) and
+// dlam [nt][m][Np][2cp] (k_adjoint_derivs, j = 1..m) -> [2N, 1+m, nt, c] for time indices 1 .. nt-1; index 0 stays
+// zero, as in the reference (forward_evolution.jl:414-480).  Asynchronous: finish_copies() before returning.
+int copy_lambda_full_out(qgd_handle h, double *out)
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N;
+    const size_t total = n2 * (m + 1) * nt * k.c;
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (!h->dlam) {
+        if ((rc = dev_alloc(h, h->stage_bufs, &h->dlam, nt * std::max<size_t>(m, 1) * hstep))) return rc;
+        if ((m + 1) * (size_t)k.Np * 16 * sizeof(double) > 150 * 1024 &&
+            (rc = dev_alloc(h, h->stage_bufs, &h->dlam_scratch, (nt - 1) * (size_t)(k.cp / 8) * (m + 1) * k.Np * 16))) return rc;
+        if ((rc = dev_alloc(h, h->stage_bufs, &h->stage_lam_full, total))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->stage_lam_full, 0, total * sizeof(double), k.stream));
+    }
+    { PhaseTimer t(h, "lambda_derivs"); K_TRY(h, qgdk_adjoint_derivs(&k, h->dlam, h->dlam_scratch)); }
+    const long long dcol = (long long)(nt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
+    K_TRY(h, qgdk_layout(&k, k.lam, (long long)hstep, 0, h->stage_lam_full, dcol, dn, dj, 1, (int)nt - 1, 1, 0, k.stream, 0));
+    K_TRY(h, qgdk_layout(&k, h->dlam, (long long)(m * hstep), (long long)hstep, h->stage_lam_full + n2, dcol, dn, dj, 1, (int)nt - 1, (int)m, 0, k.stream, 0));
+    if ((rc = hand_over(h))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, h->stage_lam_full, total * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+    return QGD_OK;
+}
+
 int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 {
     if (n_pcof != h->k.n_pcof) return fail(h, QGD_ERR_ARGUMENT, "length of pcof does not match the control basis");
@@ -518,7 +548,7 @@ int adjoint_end(qgd_handle h)
     { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
     if (h->lambda_out) {      // its download runs beside the gradient kernels
         double *out = h->lambda_out; h->lambda_out = nullptr;
-        int rc = copy_panels_out(h, k.lam, &h->stage_lam, out, (size_t)k.m + 1, 1);
+        int rc = h->lambda_derivs ? copy_lambda_full_out(h, out) : copy_panels_out(h, k.lam, &h->stage_lam, out, (size_t)k.m + 1, 1);
         if (rc) return rc;
     }
     if (!h->derivs_valid && qgdk_gradient_needs_derivs(&k)) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
@@ -1166,6 +1196,13 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
     { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
     { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
     if ((rc = check_status(h))) return rc;
+    if (h->lambda_derivs) {      // the reference's derivative columns too (forward_evolution.jl:427-433, :471-480)
+        HIP_TRY(h, hipMemcpyAsync(k.lam + (nt - 1) * hstep, lamN.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+        rc = copy_lambda_full_out(h, lambda_history);
+        const int rc2 = finish_copies(h);
+        h->forward_valid = false;
+        return rc ? rc : rc2;
+    }
     std::vector<double> l(nt * hstep);
     HIP_TRY(h, hipMemcpy(l.data(), k.lam, l.size() * sizeof(double), hipMemcpyDeviceToHost));
     memset(lambda_history, 0, sizeof(double) * n2 * (m + 1) * nt * k.c);
@@ -1431,6 +1468,14 @@ int qgd_get_operator_path(qgd_handle h, int32_t *out3)
 {
     if (!h || !out3) return QGD_ERR_ARGUMENT;
     out3[0] = h->k.use_sparse ? 2 : 1; out3[1] = h->k.ell_z; out3[2] = h->k.op_z;
+    return QGD_OK;
+}
+
+int qgd_set_lambda_derivatives(qgd_handle h, int32_t on)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    h->lambda_derivs = (on != 0);
+    for (auto &r : h->regs) r.zeroed = false;      // columns 1..m of a registered lambda_history change meaning
     return QGD_OK;
 }
 

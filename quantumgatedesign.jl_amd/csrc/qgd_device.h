@@ -109,6 +109,7 @@ int qgdk_gradient(const qgdk_ctx *c);
 int qgdk_contract(const qgdk_ctx *c);
 int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
+int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch);
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);
 size_t qgdk_forced_lds(int Np, int m);

@@ -427,6 +427,69 @@ __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, 
 }
 
 // ---------------------------------------------------------------------------
+// Derivative columns of lambda_history (optional output, qgd_set_lambda_derivatives).  The reference's eval_adjoint!
+// stores, beside lambda_n, the m "adjoint derivatives" it built the explicit side of step n from
+// (forward_evolution.jl:427-433; compute_adjoint_derivatives!, hermite.jl:284-305, a tree recursion of
+// 2^j - 1 Hamiltonian applications per order).  They are w_j = D_j(t)^T lambda_n with the D_j of K9, so the
+// reverse sweep of that recursion gives them in j(j+1)/2 applications:
+//   g_j = lambda_n;  k = j..1, i = 0..k-1:  g_i -= (1/k) A_{k-1-i}(t) g_k   (A^T = -A);   w_j = g_0
+// The reference evaluates the controls at t_{n-1} for time index n >= 2 and at t_1 for n = 1 (:423, :472); index 0
+// is never written.  One workgroup per (time point, column group); dlam: [nt][m][Np][2cp].
+// ---------------------------------------------------------------------------
+template <int NOPS>
+__global__ __launch_bounds__(256) void k_adjoint_derivs(const double *__restrict__ ops,
+                                                        const double *__restrict__ tab,
+                                                        const double *__restrict__ lam,
+                                                        double *__restrict__ dlam, int Np, int cp,
+                                                        int n_ops, int m, double *__restrict__ gpanels)
+{
+    extern __shared__ double lds_panels[];              // g_0 .. g_m
+    const int n = blockIdx.y + 1, grp = blockIdx.x;
+    const int tn = (n >= 2) ? n - 1 : 1;
+    double *smem = gpanels ? gpanels + ((size_t)blockIdx.y * gridDim.x + grp) * (size_t)(m + 1) * Np * 16 : lds_panels;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t ps = (size_t)Np * 16;
+    for (int j = 1; j <= m; j++) {
+        for (int e = threadIdx.x; e < Np * 16; e += blockDim.x) {
+            smem[(size_t)j * ps + e] = lam[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+            for (int i = 0; i < j; i++) smem[(size_t)i * ps + e] = 0.0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int k = j; k >= 1; k--) {
+            const double *src = smem + (size_t)k * ps;
+            const double inv = 1.0 / (double)k;
+            for (int rb = wave; rb * 16 < Np; rb += nw) {         // a wave owns its rows of every target panel
+                const int arow = rb * 16 + c16;
+                for (int i = 0; i < k; i++) {
+                    OpCoef cf;
+                    load_coef(cf, tab, tn, k - 1 - i, m, n_ops);
+                    d4 acc = (d4){0, 0, 0, 0};
+                    for (int k0 = 0; k0 < Np; k0 += 4) {
+                        double are, aim, b1, b2;
+                        assembled_a<NOPS>(ops, Np, n_ops, cf, arow, k0 + kk, are, aim);
+                        panel_b(src + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                        acc = MFMA(are, b1, acc);
+                        acc = MFMA(aim, b2, acc);
+                    }
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) smem[(size_t)i * ps + (size_t)(rb * 16 + kk + 4 * r) * 16 + c16] -= acc[r] * inv;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < Np * 16; e += blockDim.x)
+            dlam[(((size_t)n * m + (j - 1)) * Np + (e >> 4)) * PWc + grp * 16 + (e & 15)] = smem[e];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Test hook: out = (+/-) A_d(t_n) * in for a panel of columns (apply_hamiltonian!,
 // hermite.jl:556-588, batched over all initial-condition columns).
 // ---------------------------------------------------------------------------
@@ -530,6 +593,21 @@ int qgdk_apply(const qgdk_ctx *c, const double *in, double *out, int n, int d, d
                                       c->cp, c->n_ops, c->m, n, d, sign)
     DISPATCH_NOPS(c->n_ops, CALL_AP)
 #undef CALL_AP
+    return (int)hipGetLastError();
+}
+
+// dlam[n][j-1] = D_j(t_{max(n-1,1)})^T lambda_n for n = 1 .. nt-1 (k_adjoint_derivs); scratch: (m+1) panels per workgroup
+// in HBM when they do not fit in LDS, else null
+int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch)
+{
+    if (c->nt < 2 || c->m < 1) return 0;
+    size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
+    if (scratch) shm = 0;
+#define CALL_AD(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_derivs<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_adjoint_derivs<N>), dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->ops, c->tab, c->lam, dlam, \
+                           c->Np, c->cp, c->n_ops, c->m, scratch); } while (0)
+    DISPATCH_NOPS(c->n_ops, CALL_AD)
+#undef CALL_AD
     return (int)hipGetLastError();
 }
 

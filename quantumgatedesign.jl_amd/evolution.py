@@ -219,6 +219,12 @@ class DeviceProblem:
                                                      None if fo is None else _vp(fo), _vp(lam)))
         return lam
 
+    def set_lambda_derivatives(self, on=True):
+        """Fill ``lambda_history[:, 1:, :, :]`` as the reference leaves it (forward_evolution.jl:427-433, :471-480):
+        the adjoint derivatives of lambda_n with the controls at t_{n-1} (t_1 for n = 1).  Off by default -- nothing
+        reads these columns, and they make the lambda download 1+m times as large."""
+        _lib.check(self.h, self.lib.qgd_set_lambda_derivatives(self.h, 1 if on else 0))
+
     def apply_hamiltonian(self, w, time_index=0, derivative_order=0, use_adjoint=False):
         w = _f(w).reshape(2 * self.N, self.c, order="F")
         out = np.zeros_like(w, order="F")
@@ -421,13 +427,19 @@ def eval_grad_finite_difference(prob, controls, pcof, target, dpcof=1e-5, order=
     return grad
 
 
-def eval_adjoint(prob, controls, pcof, terminal_condition, order=2, forcing=None):
+def eval_adjoint(prob, controls, pcof, terminal_condition, order=2, forcing=None, lambda_derivatives=False):
     """QuantumGateDesign.eval_adjoint (forward_evolution.jl:300-315), used by the reference's scripts
     (examples/cnot2_optimization.jl:56, regression.jl:49): lambda history ``[2N, 1+order/2, 1+nsteps, c]``
-    from a given terminal condition; column j=0 holds lambda_n (the only column the package consumes)."""
+    from a given terminal condition; column j=0 holds lambda_n (the only column the package consumes);
+    ``lambda_derivatives=True`` also fills the derivative columns the reference leaves there."""
     dp = device_problem(prob, order)
     dp.set_controls(controls)
-    return dp.eval_adjoint(pcof, terminal_condition, forcing)
+    dp.set_lambda_derivatives(lambda_derivatives)
+    try:
+        return dp.eval_adjoint(pcof, terminal_condition, forcing)
+    finally:
+        if lambda_derivatives:
+            dp.set_lambda_derivatives(False)
 
 
 def infidelity_real(psi, target, N_ess):
@@ -465,14 +477,21 @@ def guard_penalty_real(history, dt, T, W):
 
 
 def discrete_adjoint_(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target,
-                      order=2, cost_type="Infidelity", history_precomputed=False):
-    """discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160)."""
+                      order=2, cost_type="Infidelity", history_precomputed=False, lambda_derivatives=False):
+    """discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160).  ``lambda_derivatives=True``: columns 1..m of
+    ``lambda_history`` as the reference leaves them (default: zeros; only column 0 is ever consumed)."""
     if cost_type not in ("Infidelity", ":Infidelity"):
         raise NotImplementedError("only cost_type=:Infidelity is implemented (the reference marks the others untested)")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
     dp.set_target(target)
-    g, _ = dp.discrete_adjoint(pcof, history_precomputed, history, lambda_history, adjoint_forcing)
+    if lambda_derivatives:
+        dp.set_lambda_derivatives(True)
+    try:
+        g, _ = dp.discrete_adjoint(pcof, history_precomputed, history, lambda_history, adjoint_forcing)
+    finally:
+        if lambda_derivatives:
+            dp.set_lambda_derivatives(False)
     grad[:] = g
     return grad
 

@@ -34,6 +34,26 @@ def test_large_n_kernels_vs_oracle(qgd, orc, N, c, n_ops, nsteps, order):
     qgd.clear_cache()
 
 
+@pytest.mark.parametrize("N,c,n_ops,nsteps,order", [(80, 4, 2, 6, 12), (180, 9, 2, 4, 12)])
+def test_large_n_lambda_derivative_columns(qgd, orc, N, c, n_ops, nsteps, order):
+    """qgd_set_lambda_derivatives beyond N = 64 (the second case keeps the m+1 work panels of k_adjoint_derivs in HBM:
+    7 x 192 x 16 doubles do not fit in LDS) against the oracle's tree recursion (hermite.jl:225-305)."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=nsteps, tf=0.05 * nsteps, seed=N)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    orc.set_converged_terminal(True)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    finally:
+        orc.set_converged_terminal(False)
+    lam = np.zeros(h_ref.shape, order="F")
+    grad = np.zeros_like(g_ref)
+    qgd.discrete_adjoint_(grad, None, lam, None, prob, ctrl, pcof, target, order=order, lambda_derivatives=True)
+    for j in range(order // 2 + 1):
+        assert np.abs(lam[:, j] - lam_ref[:, j]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, j]).max()), j
+    assert np.abs(grad - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
+    qgd.clear_cache()
+
+
 def c5_problem(qgd, nsteps, tf):
     """BASELINE.json configs[4] / SURVEY 8(d) C5: N=256=(4,4,4,4), 256 columns (U0 random complex N x N, N_ess = N),
     4 control operators, dense rand+rand^T / rand-rand^T entries scaled 1/N, degree-16 B-splines with 20 basis

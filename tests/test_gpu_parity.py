@@ -352,6 +352,61 @@ def test_eval_adjoint_vs_oracle(qgd, orc, which, order):
     qgd.clear_cache()
 
 
+@pytest.mark.parametrize("order", [2, 4, 8, 10])
+def test_lambda_history_derivative_columns(qgd, orc, order):
+    """lambda_history[:, 1:, :, :] as the reference leaves it (forward_evolution.jl:427-433, :471-480: the adjoint
+    derivatives of compute_adjoint_derivatives!, hermite.jl:284-305, with the controls at t_{n-1}, t_1 for n = 1, time
+    index 0 never written) -- the opt-in output of qgd_set_lambda_derivatives against the oracle's tree recursion, through
+    discrete_adjoint! and through eval_adjoint; and the default, which leaves those columns zero."""
+    for name, prob, ctrl, pcof, target in cases.gradient_cases(qgd):
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+        lam = np.full(h_ref.shape, np.nan, order="F")
+        grad = np.zeros_like(g_ref)
+        qgd.discrete_adjoint_(grad, None, lam, None, prob, ctrl, pcof, target, order=order, lambda_derivatives=True)
+        assert np.abs(lam_ref[:, 1:]).max() > 0 and not np.abs(lam_ref[:, :, 0]).any()
+        for j in range(order // 2 + 1):
+            assert np.abs(lam[:, j] - lam_ref[:, j]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, j]).max()), (name, order, j)
+        assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max()
+        lam0 = np.full(h_ref.shape, np.nan, order="F")
+        qgd.discrete_adjoint_(grad, None, lam0, None, prob, ctrl, pcof, target, order=order)
+        assert not np.abs(lam0[:, 1:]).any() and np.array_equal(lam0[:, 0], lam[:, 0])
+    prob, ctrl, pcof, target = cases.guarded_case(qgd)
+    rng = np.random.default_rng(order)
+    n2, c, nt = prob.real_system_size, prob.N_initial_conditions, prob.nsteps + 1
+    term = rng.standard_normal((n2, c))
+    forcing = 0.1 * rng.standard_normal((n2, nt, c))
+    ref = orc.eval_adjoint(prob, ctrl, pcof, term, order=order, forcing=forcing)
+    got = qgd.eval_adjoint(prob, ctrl, pcof, term, order=order, forcing=forcing, lambda_derivatives=True)
+    for j in range(order // 2 + 1):
+        assert np.abs(got[:, j] - ref[:, j]).max() <= 1e-10 * max(1.0, np.abs(ref[:, j]).max()), j
+    qgd.clear_cache()
+
+
+def test_lambda_history_derivative_columns_cnot3(qgd, orc):
+    """The same on the headline problem (sparse-operator path, N = 64, order 8), with a registered lambda_history."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd)
+    orc.set_converged_terminal(True)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8, return_all=True)
+    finally:
+        orc.set_converged_terminal(False)
+    dp = qgd.DeviceProblem(prob, 8)
+    dp.set_controls(ctrl); dp.set_target(target)
+    lam = dp.pin(np.zeros(h_ref.shape, order="F"))
+    g0, _ = dp.discrete_adjoint(pcof, False, None, lam)          # default first: zeros in the derivative columns
+    assert not np.abs(lam[:, 1:]).any()
+    dp.set_lambda_derivatives(True)
+    g1, _ = dp.discrete_adjoint(pcof, False, None, lam)
+    for j in range(5):
+        assert np.abs(lam[:, j] - lam_ref[:, j]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, j]).max()), j
+    dp.set_lambda_derivatives(False)                              # and back: the registered array is cleared again
+    g2, _ = dp.discrete_adjoint(pcof, False, None, lam)
+    assert not np.abs(lam[:, 1:]).any() and close(lam[:, 0], lam_ref[:, 0], 1e-10)
+    assert np.abs(g1 - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max() and np.abs(g1 - g0).max() <= 1e-13 * np.abs(g0).max()
+    del lam
+    dp.close()
+
+
 @pytest.mark.parametrize("older_kernels", [False, True])
 def test_large_n_fallback_paths(qgd, older_kernels, monkeypatch):
     """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12 -- vs the numpy statement
