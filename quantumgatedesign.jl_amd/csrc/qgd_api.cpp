@@ -170,6 +170,7 @@ int alloc_grid(qgd_handle h)
         int B0 = (int)std::lround(std::pow((double)S, 2.0 / 3.0));
         if (S < 24) B0 = 1;
         if (B0 > 64) B0 = 64;
+        if (getenv("QGD_SCAN_B0")) B0 = atoi(getenv("QGD_SCAN_B0"));      // (tuning experiments)
         if (B0 < 1) B0 = 1;
         if (k.Np > 64 && k.Np <= 288) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile
             const int ngt = std::max(k.Np / 32, k.cp / 32);
@@ -193,6 +194,7 @@ int alloc_grid(qgd_handle h)
         k.dt = k.tf / S;
         if (k.scan_blocks > 8) {
             int B2 = (int)std::lround(std::sqrt(2.0 * k.scan_blocks));
+            if (getenv("QGD_SCAN_B2")) B2 = std::max(1, atoi(getenv("QGD_SCAN_B2")));
             k.scan_g = (k.scan_blocks + B2 - 1) / B2;
             k.scan_blocks2 = (k.scan_blocks + k.scan_g - 1) / k.scan_g;
         } else { k.scan_blocks2 = 1; k.scan_g = k.scan_blocks; }
