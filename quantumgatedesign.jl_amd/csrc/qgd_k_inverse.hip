@@ -570,6 +570,199 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 }
 
 // ---------------------------------------------------------------------------
+// K2 (Np = 64, comparison path QGD_INV_AUGMENTED=1): the same elimination on the AUGMENTED matrix [L_n | R_{n-1}].  The row
+// operations that turn L into the identity turn R into P_{n-1} = L_n^-1 R_{n-1}, so the step propagator comes out of
+// the rank-4 block steps themselves (8 more column groups per step, same A operand) instead of a separate product
+// phase behind the elimination (k_inverse_mfma: 256 MFMAs per wave at 42 % of the pipe, the A operand re-read from
+// the LDS staging plane, R streamed from global inside the loop).  With implicit pivoting row rho(i) of the
+// augmented matrix ends as the equation of unknown i:  P[i][j] = MR[rho(i)][j].
+// Measured (scripts/ubench/inverse_bench.hip -DKERNEL=k_inverse_aug): SLOWER -- 67.0 / 98.7 / 117.2 / 123.7 us for
+// 256 / 512 / 550 / 768 matrices against 64.8 / 91.1 / 108.7 / 117.9: the 16 extra MFMAs lengthen each of the 16
+// barrier-delimited block steps, in which the four waves of a matrix move in lockstep, by more than the free-running
+// product phase behind the elimination costs -- that phase overlaps with the other workgroups of the CU, the block
+// steps do not.
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_inverse_aug(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                   double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status)
+{
+    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, PW2 = 2 * PW, LDP = NP + 1;
+    constexpr int O_PROW = 0, O_G = O_PROW + 8 * PW2, O_F = O_G + 16 * NP,
+                  WORK = O_F + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
+    __shared__ double smem[SM];
+    __shared__ int rho[NP], rinv[NP];                   // rho[p] = row of the p-th pivot
+    double *Prow = smem + O_PROW;                       // [2][4][2 PW]  pivot rows of [M | MR] (B operand), by panel parity
+    double *Gm = smem + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
+    double *Fm = smem + O_F;                            // [2][NP][4]    panel columns re/im
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
+    const double *Ln = L + (size_t)n * panel, *Rn = R + (size_t)(n - 1) * panel;
+
+    d4 M[NG], MR[NG];
+    #pragma unroll
+    for (int g = 0; g < NG; g++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
+    #pragma unroll
+    for (int g = 0; g < NG; g++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) MR[g][r] = Rn[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
+    bool used = lane >= NP;
+    const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
+
+    for (int pn = 0; pn < NP / 4; pn++) {
+        const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
+        double *Gre = Gm + par * 8 * NP, *Gim = Gre + 4 * NP;
+        double *Pw = Prow + par * 4 * PW2;
+        // ---- 1. publish the panel columns
+        {
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                double *dst = Fm + (c16 < 8 ? 0 : 4 * NP);
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) dst[(16 * w + kk + 4 * r) * 4 + s] = M[g][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. one wave: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row (as k_inverse_mfma)
+        if (w == pw) {
+            __builtin_amdgcn_s_setprio(1);
+            double xr[4], xi[4];
+            const int lrow = (lane < NP) ? lane : 0;
+            #pragma unroll
+            for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
+                unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
+                key = wave_max_u32(key);
+                const int pr = 63 - (int)(key & 63u);
+                if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
+                used = used || (lane == pr);
+                double yr[4], yi[4];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
+                const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
+                const double ir = yr[s] * den, ii = -yi[s] * den;
+                const double fr = xr[s], fi = xi[s];
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double rr = (q == s) ? ir : yr[q] * ir - yi[q] * ii;      // scaled pivot row
+                    const double ri = (q == s) ? ii : yr[q] * ii + yi[q] * ir;
+                    const double br = (q == s) ? 0.0 : xr[q], bi = (q == s) ? 0.0 : xi[q];
+                    xr[q] = (lane == pr) ? rr : br - (fr * rr - fi * ri);
+                    xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
+                }
+            }
+            if (lane < NP) {
+                #pragma unroll
+                for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+        // ---- 3. the owners of the pivot rows publish them (both halves) as the B operand of the block step
+        {
+            const int s0 = rho[p0], s1 = rho[p0 + 1], s2 = rho[p0 + 2], s3 = rho[p0 + 3];
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = 16 * w + kk + 4 * r;
+                const int ps = (x == s0) ? 0 : (x == s1) ? 1 : (x == s2) ? 2 : (x == s3) ? 3 : -1;
+                if (ps >= 0) {
+                    #pragma unroll
+                    for (int g = 0; g < NG; g++) { Pw[ps * PW2 + 16 * g + c16] = M[g][r]; Pw[ps * PW2 + PW + 16 * g + c16] = MR[g][r]; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 4. rank-4 block step on the MFMA over [M | MR], then the pivot columns take the multipliers
+        {
+            const int arow = 16 * w + c16;
+            const double are = Gre[arow * 4 + kk] - ((arow == rho[p0 + kk]) ? 1.0 : 0.0);
+            const double aim = Gim[arow * 4 + kk];
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double b1, b2;
+                panel_b(Pw + kk * PW2 + 16 * g, c16, b1, b2);
+                M[g] = MFMA(are, b1, M[g]);
+                M[g] = MFMA(aim, b2, M[g]);
+            }
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                double b1, b2;
+                panel_b(Pw + kk * PW2 + PW + 16 * g, c16, b1, b2);
+                MR[g] = MFMA(are, b1, MR[g]);
+                MR[g] = MFMA(aim, b2, MR[g]);
+            }
+            const int s = (c16 & 7) - q0;
+            if (s >= 0 && s < 4) {
+                const double *src = (c16 < 8) ? Gre : Gim;
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g == gp) {
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) M[g][r] = src[(16 * w + kk + 4 * r) * 4 + s];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- output.  P[rinv[x]][j] = MR[x][j]: the row-major panel (left operand of the adjoint sweep as P^H) straight
+    // from the registers, the stores in flight under the staging of the other three results
+    int prow[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) prow[r] = rinv[16 * w + kk + 4 * r];
+    {
+        double *Prn = Pr + (size_t)(n - 1) * panel;
+        #pragma unroll
+        for (int g = 0; g < NG; g++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) Prn[(size_t)prow[r] * PW + 16 * g + c16] = MR[g][r];
+    }
+    // A^-1[rinv[x]][rho[j]] = M[x][j] (LinvT, left operand of lambda = L^-H y) and the column-major planes of P (left
+    // operand of the forward sweep) go through LDS one plane at a time
+    double *T = LinvT + (size_t)n * 2 * pl, *Pcn = Pc + (size_t)(n - 1) * 2 * pl;
+    #pragma unroll
+    for (int plane = 0; plane < 4; plane++) {
+        const int pass = plane & 1;
+        if ((c16 >> 3) == pass) {
+            if (plane < 2) {
+                #pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const int oc = rho[8 * g + (c16 & 7)];
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) smem[prow[r] * LDP + oc] = M[g][r];
+                }
+            } else {
+                #pragma unroll
+                for (int g = 0; g < NG; g++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) smem[(8 * g + (c16 & 7)) * LDP + prow[r]] = MR[g][r];      // [col][row]
+            }
+        }
+        lds_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t rT = buffer_of((plane < 2 ? T : Pcn) + pass * pl);
+            #pragma unroll
+            for (int q = 0; q < NP * NP / NTH; q++) {
+                const int e = t + q * NTH;
+                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2 (Np = 64, default): the same blocked Gauss-Jordan + fused propagator, NM matrices per workgroup with
 // ALIGNED phases, static pivots first.
 //
@@ -1435,6 +1628,10 @@ int qgdk_inverse(const qgdk_ctx *c)
                                             c->LinvT, c->Pr, c->Pc, 1, nmat + 1, st, c->status, c->status + 1)
             if (nm == 3) CALL_IM(3, 3); else if (nm == 2) CALL_IM(2, 2); else CALL_IM(1, 3);
 #undef CALL_IM
+            return (int)hipGetLastError();
+        }
+        if (!getenv("QGD_INVERSE_VALU") && getenv("QGD_INV_AUGMENTED")) {    // elimination of [L | R] (comparison path: 117 against 109 us for 550 matrices)
+            hipLaunchKernelGGL((k_inverse_aug<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
             return (int)hipGetLastError();
         }
         if (!getenv("QGD_INVERSE_VALU")) {

@@ -4,6 +4,11 @@
 // Prints the mean launch time over 50 launches of nmat matrices, the max |Linv*L - I|, and (with
 // -DQGD_INV_PROFILE) the cycles one workgroup spent in each phase of the blocked elimination.
 #include "../../quantumgatedesign.jl_amd/csrc/qgd_k_inverse.hip"
+#ifndef KERNEL
+#define KERNEL k_inverse_mfma      // -DKERNEL=k_inverse_aug: the augmented elimination
+#endif
+#define STR2(x) #x
+#define STR(x) STR2(x)
 #include <cstdio>
 #include <vector>
 #include <complex>
@@ -34,7 +39,7 @@ int main(int argc, char **argv)
 #ifdef QGD_INV_PROFILE
         hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS, dprof);
 #else
-        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS);
+        hipLaunchKernelGGL((KERNEL<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS);
 #endif
     };
     for (int i = 0; i < 5; i++) launch();
@@ -44,7 +49,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < 50; i++) launch();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("k_inverse_mfma<64>: %d matrices, %.2f us per launch (%s)\n", nmat, ms / 50 * 1e3, hipGetErrorString(hipGetLastError()));
+    printf(STR(KERNEL) "<64>: %d matrices, %.2f us per launch (%s)\n", nmat, ms / 50 * 1e3, hipGetErrorString(hipGetLastError()));
     // check matrix 1 (blockIdx 0)
     std::vector<double> T(2 * pl);
     hipMemcpy(T.data(), dT + 2 * pl, 2 * pl * 8, hipMemcpyDeviceToHost);

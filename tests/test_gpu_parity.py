@@ -719,13 +719,14 @@ def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
     measurements).  k_inverse_multi (QGD_INV_STATIC=1) tries the diagonal as pivot first (L(t_n) of the dispersive models
     is strongly diagonally dominant) and redoes a matrix with partial pivoting when a multiplier exceeds 8.  cnot3: no
     matrix falls back and the result equals the partially-pivoted k_inverse_mfma to rounding, as do the aligned
-    multi-matrix workgroups and the time-chunk pipeline over side streams; a drift that makes the diagonal of L vanish:
+    multi-matrix workgroups, the time-chunk pipeline over side streams and the elimination of the augmented [L | R]
+    (k_inverse_aug: the propagator out of the block steps instead of a product phase); a drift that makes the diagonal of L vanish:
     matrices DO fall back and the result still matches the numpy statement (the fallback is exercised, not just present)."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
     res = {}
     for tag, env in (("static", {"QGD_INV_STATIC": "1"}), ("pivoted", {"QGD_INV_STATIC": "1", "QGD_INV_PIVOTED": "1"}),
                      ("multi3", {"QGD_INV_MULTI": "3"}), ("multi2", {"QGD_INV_MULTI": "2"}), ("old", {}),
-                     ("piped", {"QGD_PIPE_CHUNKS": "2"})):
+                     ("piped", {"QGD_PIPE_CHUNKS": "2"}), ("augmented", {"QGD_INV_AUGMENTED": "1"})):
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         dp = qgd.DeviceProblem(prob, 8)
@@ -735,7 +736,7 @@ def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
         for k_ in env:
             monkeypatch.delenv(k_)
     assert res["static"][2] == 0 and res["multi3"][2] == 0
-    for tag in ("pivoted", "multi3", "multi2", "old", "piped"):
+    for tag in ("pivoted", "multi3", "multi2", "old", "piped", "augmented"):
         assert np.abs(res[tag][0] - res["static"][0]).max() <= 1e-12 * np.abs(res["static"][0]).max(), tag
         assert np.abs(res[tag][3] - res["static"][3]).max() <= 1e-12 * np.abs(res["static"][3]).max(), tag
         assert np.abs(res[tag][4] - res["static"][4]).max() <= 1e-12, tag
