@@ -134,10 +134,11 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
             Racc[c].re = __builtin_fma(cR, Di[c].re, Racc[c].re); Racc[c].im = __builtin_fma(cR, Di[c].im, Racc[c].im);
         }
         if (i == M) break;
-        if (i > 1) __syncthreads();                     // the previous source has been consumed
+        // (a wave reads only the columns it wrote: the exchange is among its own lanes, no workgroup barrier)
+        wave_lds_fence();                               // the previous source has been consumed
         #pragma unroll
         for (int c = 0; c < 4; c++) Ds[r * DS + cl + c] = Di[c];
-        __syncthreads();
+        wave_lds_fence();
         if (active) {
             // (an explicit one-entry-ahead prefetch of the neighbour row and operator values was measured: 66.5 vs
             //  62.9 us -- the loop is not waiting on LDS latency)
@@ -245,11 +246,13 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
     }
     SP_PROF(17);
     // ---- G passes: g_i += -(1/j) A_{j-1-i} g_j (A^H = -A), i = 1..j-1, j = m..2
+    __syncthreads();                                    // the lists and A_d(t_n) are in LDS
+    // (from here on a wave reads only the two columns of `buf` it wrote itself: the exchange is among its own lanes)
     #pragma unroll
     for (int j = M; j >= 2; j--) {
-        if (j < M) __syncthreads();                     // the previous right operand has been consumed
+        wave_lds_fence();                               // the previous right operand has been consumed
         buf[r * PS + cl] = g[j - 1][0]; buf[r * PS + cl + 1] = g[j - 1][1];
-        __syncthreads();
+        wave_lds_fence();
         c2 t[M][2];
         #pragma unroll
         for (int q = 0; q < M; q++) { t[q][0] = (c2){0.0, 0.0}; t[q][1] = (c2){0.0, 0.0}; }
@@ -283,9 +286,9 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
         for (int d = 0; d < M; d++) { sp[o][d] = 0.0; sq[o][d] = 0.0; }
     #pragma unroll
     for (int i = 0; i < M; i++) {
-        __syncthreads();                                // first pass: also orders the prologue's LDS writes
+        wave_lds_fence();
         buf[r * PS + cl] = ps[0]; buf[r * PS + cl + 1] = ps[1];
-        __syncthreads();
+        wave_lds_fence();
         if (i + 1 < M) {
             _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
                 const c2 *src = buf + (size_t)Ecol[e * 64 + r] * PS + cl;
@@ -392,11 +395,12 @@ __global__ __launch_bounds__(256) void k_derivs_ell(const int32_t *__restrict__ 
     c2 T[M + 1][2];
     #pragma unroll
     for (int q = 0; q <= M; q++) { T[q][0] = (c2){0.0, 0.0}; T[q][1] = (c2){0.0, 0.0}; }
+    __syncthreads();                                    // the list and A_d(t_n) are in LDS
     #pragma unroll
     for (int i = 0; i < M; i++) {
-        __syncthreads();                                // (first pass: also orders the prologue's LDS writes)
+        wave_lds_fence();                               // (a wave reads only the two columns it wrote)
         buf[r * PS + cl] = ps[0]; buf[r * PS + cl + 1] = ps[1];
-        __syncthreads();
+        wave_lds_fence();
         _Pragma("unroll 1") for (int e = 0; e < Z; e++) {
             const c2 *src = buf + (size_t)Ecol[e * 64 + r] * PS + cl;
             const c2 x0 = src[0], x1 = src[1];

@@ -75,6 +75,15 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exchange through LDS among the lanes of ONE wave (a wave that writes its own columns of a slab and then reads other
+// rows of the same columns): the LDS executes a wave's instructions in order, so no s_barrier is needed -- only the
+// compiler must keep the order.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Buffer-addressed 8-byte load / store: address = descriptor base (SGPRs, wave-uniform) + soff (SGPR or constant)
 // + voff (one VGPR byte offset per lane).  No vector ALU instruction is needed to form the address.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
