@@ -21,4 +21,4 @@ from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup, 
 from .optimize import optimize_gate, OptimizationHistory, read_optimization_history
 from .convergence import (get_histories, richardson_extrap_rel_err, richardson_extrap_sol, observed_orders,
                           save_histories, load_histories)
-from . import _lib
+from . import _lib, jld2io

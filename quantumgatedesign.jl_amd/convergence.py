@@ -2,7 +2,7 @@
 src/Tests/test_convergence.jl:20-146 (``get_histories``) and :233-250 (Richardson extrapolation):
 the report generator the reference uses for its accuracy-versus-time plots, driven here by the
 device ``eval_forward``.  Results are plain dictionaries of numpy arrays; ``save_histories`` /
-``load_histories`` store them as ``.npz`` (the reference writes JLD2, which needs Julia).
+``load_histories`` store them as JLD2/HDF5 (a ``.jld2`` name: ``jld2io``, through libhdf5) or as ``.npz``.
 """
 from __future__ import annotations
 
@@ -11,6 +11,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import jld2io
 from .evolution import eval_forward, release
 
 
@@ -88,6 +89,14 @@ def observed_orders(summary):
 
 
 def save_histories(ret, filename):
+    """The dictionary of get_histories on disk.  ``.jld2``: one group per "Order k (QGD)" summary with the reference's
+    keys (src/Tests/test_convergence.jl:60-81; ``histories`` as a Vector of 4-d arrays), written through libhdf5
+    (``jld2io``) -- JLD2 itself stores each summary as a serialised Dict object, which only Julia can produce; the keys
+    and array encodings inside are the same.  Other names: a flat ``.npz``."""
+    if jld2io.is_jld2_name(filename):
+        jld2io.save(filename, {name: {k: (list(v) if k == "histories" else np.asarray(v)) for k, v in summary.items()}
+                               for name, summary in ret.items()})
+        return
     flat = {}
     for name, summary in ret.items():
         for key, val in summary.items():
@@ -100,6 +109,11 @@ def save_histories(ret, filename):
 
 
 def load_histories(filename):
+    if jld2io.is_jld2_name(filename):
+        ret = OrderedDict()
+        for name, summary in jld2io.load(filename).items():
+            ret[name] = {k: (list(v) if k == "histories" else (v.tolist() if isinstance(v, np.ndarray) else v)) for k, v in summary.items()}
+        return ret
     data = np.load(filename if str(filename).endswith(".npz") else str(filename) + ".npz")
     ret = OrderedDict()
     for full in data.files:

@@ -16,6 +16,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from . import jld2io
 from .controls import get_number_of_control_parameters
 from .evolution import device_problem
 
@@ -39,9 +40,29 @@ class OptimizationHistory:
     FIELDS = ("iter_count", "ipopt_obj_value", "wall_time", "pcof", "grad_pcof", "analytic_obj_value",
               "infidelity", "guard_penalty", "ridge_penalty")
 
-    def write(self, filename):
-        """write(obj::OptimizationHistory, filename) (src/ipopt_optimal_control.jl:74-86): the same nine
-        keys, as a numpy ``.npz`` archive (the reference writes JLD2, which needs Julia)."""
+    def as_dict(self):
+        """The nine keys with the Julia types of the reference's struct: Vector{Int64}, Vector{Float64} and, for
+        ``pcof`` / ``grad_pcof``, Vector{Vector{Float64}} (a list of arrays)."""
+        out = {}
+        for k in self.FIELDS:
+            v = getattr(self, k)
+            if k in ("pcof", "grad_pcof"):
+                out[k] = [np.asarray(x, dtype=np.float64) for x in v]
+            else:
+                out[k] = np.asarray(v, dtype=np.int64 if k == "iter_count" else np.float64)
+        return out
+
+    def write(self, filename, setup=None):
+        """write(obj::OptimizationHistory, filename) (src/ipopt_optimal_control.jl:74-86): the same nine top-level
+        keys.  A name ending in ``.jld2`` gives a JLD2/HDF5 file (``jld2io``: written through libhdf5, the layout
+        ``read_optimization_history`` of the reference loads with ``JLD2.load``), with ``setup`` as the ``Setup`` group
+        of :223-241; any other name a numpy ``.npz`` archive."""
+        if jld2io.is_jld2_name(filename):
+            data = self.as_dict()
+            if setup:
+                data = dict(Setup=setup, **data)
+            jld2io.save(filename, data)
+            return
         np.savez(filename, **{k: np.asarray(getattr(self, k)) for k in self.FIELDS})
 
     def __repr__(self):
@@ -53,7 +74,12 @@ class OptimizationHistory:
 
 
 def read_optimization_history(filename):
-    """read_optimization_history (src/ipopt_optimal_control.jl:91-104) for the ``.npz`` written above."""
+    """read_optimization_history (src/ipopt_optimal_control.jl:91-104): from a JLD2/HDF5 file (a ``.jld2`` name; also
+    one written by the reference -- its nine keys are plain arrays and reference arrays) or the ``.npz`` written above."""
+    if jld2io.is_jld2_name(filename):
+        data = jld2io.load(filename)
+        return OptimizationHistory(**{k: [np.asarray(x) for x in data[k]] if k in ("pcof", "grad_pcof") else list(np.asarray(data[k]))
+                                      for k in OptimizationHistory.FIELDS})
     data = np.load(filename if str(filename).endswith(".npz") else str(filename) + ".npz")
     return OptimizationHistory(**{k: list(data[k]) for k in OptimizationHistory.FIELDS})
 
@@ -78,6 +104,20 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
     hist = OptimizationHistory()
     last = {}
     t0 = time.time()
+    # the one-time entries of the result file (update_jld2, :223-241); the problem and the controls are Julia structs
+    # there -- here the plain fields that define them
+    setup = dict(target=np.asarray(target, dtype=np.complex128), ridge_penalty_strength=float(ridge_penalty_strength),
+                 max_cpu_time=float(max_cpu_time), pcof_init=pcof_init, order=int(order),
+                 schrodinger_prob=dict(tf=float(schro_prob.tf), nsteps=int(schro_prob.nsteps),
+                                       N_ess_levels=int(schro_prob.N_ess_levels), N_guard_levels=int(schro_prob.N_guard_levels),
+                                       N_tot_levels=int(schro_prob.N_tot_levels), N_operators=int(schro_prob.N_operators),
+                                       u0=np.asarray(schro_prob.u0), v0=np.asarray(schro_prob.v0)),
+                 controls=dict(N_coeff=np.asarray([c.N_coeff for c in (controls if isinstance(controls, (list, tuple)) else [controls])]),
+                               kinds=", ".join(type(c).__name__ for c in (controls if isinstance(controls, (list, tuple)) else [controls]))))
+    if pcof_L is not None:
+        setup["pcof_L"] = np.broadcast_to(np.asarray(pcof_L, float), (N_coeff,)).copy()
+    if pcof_U is not None:
+        setup["pcof_U"] = np.broadcast_to(np.asarray(pcof_U, float), (N_coeff,)).copy()
 
     def fun(pcof):
         grad, out3 = dp.discrete_adjoint(pcof)                                       # :257-268, :304
@@ -100,7 +140,7 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
         if print_level >= 5:
             print(f"iter {len(hist):4d}  objective {last['obj']:.6e}  infidelity {last['infid']:.6e}  guard {last['guard']:.3e}")
         if filename is not None:                                                    # update_jld2, :223-241
-            hist.write(filename)
+            hist.write(filename, setup)
         if last["obj"] < 1e-7:
             raise _Stop
 
@@ -125,5 +165,5 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
         hist.infidelity.append(last["infid"]); hist.guard_penalty.append(last["guard"])
         hist.ridge_penalty.append(last["ridge"])
     if filename is not None:
-        hist.write(filename)
+        hist.write(filename, setup)
     return hist

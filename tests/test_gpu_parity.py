@@ -314,10 +314,11 @@ def test_cnot3_gradient_all_orders(qgd, order):
     qgd.clear_cache()
 
 
-def test_optimize_gate_rabi_swap(qgd):
+def test_optimize_gate_rabi_swap(qgd, tmp_path):
     """The reference's end-to-end test (test/OptimizationTests/optimization_rabi_osc_SWAP.jl:18-39):
     from 25 starts around the analytic optimum, optimize_gate(order=8, ridge 0) must return
-    pcof ~ [0.5, 0] with rtol 5e-4 (Julia isapprox on the vector norm)."""
+    pcof ~ [0.5, 0] with rtol 5e-4 (Julia isapprox on the vector norm).  One run also writes the result file of
+    update_jld2 (src/ipopt_optimal_control.jl:223-241) and reads it back."""
     prob = qgd.construct_rabi_prob(tf=np.pi, nsteps=20)
     control = qgd.GRAPEControl(1, prob.tf)
     target = np.array([[0.0, 1.0], [1.0, 0.0]])
@@ -332,6 +333,14 @@ def test_optimize_gate_rabi_swap(qgd):
             assert hist.analytic_obj_value[-1] < 1e-6
             if abs(q0) < 1e-12:
                 assert np.linalg.norm(final - opt) <= 5e-4 * 0.5, (p0, q0, final)
+    if qgd.jld2io.available():
+        f = tmp_path / "rabi_swap.jld2"
+        hist = qgd.optimize_gate(prob, control, np.array([0.45, 0.05]), target, order=8, ridge_penalty_strength=0,
+                                 print_level=0, filename=f)
+        back = qgd.read_optimization_history(f)
+        assert len(back) == len(hist) and np.array_equal(back.pcof[-1], hist.pcof[-1]) and back.infidelity == hist.infidelity
+        setup = qgd.jld2io.load(f)["Setup"]
+        assert setup["order"] == 8 and np.array_equal(setup["target"], target) and setup["schrodinger_prob"]["nsteps"] == 20
     qgd.clear_cache()
 
 

@@ -259,6 +259,53 @@ def test_richardson_and_history_io(qgd, tmp_path):
     assert len(g) == 3 and np.array_equal(g.pcof[2], h.pcof[2]) and g.infidelity == h.infidelity
 
 
+def test_jld2_files(qgd, tmp_path):
+    """the result files in the reference's format.  ``.jld2`` names go through libhdf5 (jld2io): a
+    valid HDF5 file of the 1.8 generation (superblock 2) behind the 512-byte JLD2 user block, the nine keys of
+    write(obj::OptimizationHistory, filename) (src/ipopt_optimal_control.jl:74-86) with the HDF5 types JLD2 gives
+    Vector{Int64}, Vector{Float64} and Vector{Vector{Float64}} (object references), the Setup group of :223-241, complex
+    matrices as {re, im} compounds with Julia's (column-major) dimension order -- checked with h5dump where the image
+    has it, and read back."""
+    import shutil
+    import subprocess
+    jl = qgd.jld2io
+    if not jl.available():
+        pytest.skip("no libhdf5 in this image")
+    h = qgd.OptimizationHistory()
+    for i in range(3):
+        h.iter_count.append(i); h.ipopt_obj_value.append(1.0 / (i + 1)); h.wall_time.append(0.1 * i)
+        h.pcof.append(np.full(4, i, float)); h.grad_pcof.append(np.full(4, -i, float))
+        h.analytic_obj_value.append(1.0 / (i + 1)); h.infidelity.append(0.5 / (i + 1))
+        h.guard_penalty.append(0.0); h.ridge_penalty.append(0.01 * i)
+    target = np.arange(6).reshape(3, 2) * (1 + 0.5j)
+    f = tmp_path / "opt.jld2"
+    h.write(f, dict(order=8, ridge_penalty_strength=1e-2, target=target, note="swap gate"))
+    raw = open(f, "rb").read(600)
+    assert raw.startswith(b"HDF5-based Julia Data Format, version ") and raw[512:520] == b"\x89HDF\r\n\x1a\n" and raw[520] == 2
+    g = qgd.read_optimization_history(f)
+    assert g.iter_count == [0, 1, 2] and g.infidelity == h.infidelity and np.array_equal(g.grad_pcof[2], h.grad_pcof[2])
+    d = jl.load(f)
+    assert d["Setup"]["order"] == 8 and d["Setup"]["note"] == "swap gate" and np.array_equal(d["Setup"]["target"], target)
+    dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(dump):
+        txt = subprocess.run([dump, "-H", str(f)], capture_output=True, text=True, check=True).stdout
+        one = " ".join(txt.split())
+        assert 'DATASET "iter_count" { DATATYPE H5T_STD_I64LE DATASPACE SIMPLE { ( 3 ) / ( 3 ) }' in one
+        assert 'DATASET "pcof" { DATATYPE H5T_REFERENCE { H5T_STD_REF_OBJECT } DATASPACE SIMPLE { ( 3 ) / ( 3 ) }' in one
+        # a 3 x 2 Julia matrix: HDF5 dimensions reversed
+        assert 'DATASET "target" { DATATYPE H5T_COMPOUND { H5T_IEEE_F64LE "re"; H5T_IEEE_F64LE "im"; } DATASPACE SIMPLE { ( 2, 3 )' in one
+    # the convergence dictionaries (src/Tests/test_convergence.jl:60-81)
+    ret = {"Order 4 (QGD)": dict(order=4, nsteps=[10, 20], step_sizes=[0.1, 0.05], elapsed_times=[1.0, 2.0],
+                                 histories=[np.random.default_rng(0).random((4, 3, 5, 2)), np.ones((4, 3, 5, 2))],
+                                 richardson_errors=[float("nan"), 1e-3])}
+    qgd.save_histories(ret, tmp_path / "conv.jld2")
+    back = qgd.load_histories(tmp_path / "conv.jld2")["Order 4 (QGD)"]
+    assert back["nsteps"] == [10, 20] and back["order"] == 4 and np.isnan(back["richardson_errors"][0])
+    assert np.array_equal(back["histories"][0], ret["Order 4 (QGD)"]["histories"][0])
+    with pytest.raises(TypeError):
+        jl.save(tmp_path / "bad.jld2", dict(x=None))
+
+
 def _quad_piece_sum(D1, tf, coeffs, t):
     """bspline2 (src/Controls/bspline_control.jl:139-165), restated term by term for one time."""
     dtknot = tf / (D1 - 2); width = 3 * dtknot
