@@ -109,7 +109,7 @@ def optimize_gate(schro_prob, controls, pcof_init, target, order=4, pcof_L=None,
     setup = dict(target=np.asarray(target, dtype=np.complex128), ridge_penalty_strength=float(ridge_penalty_strength),
                  max_cpu_time=float(max_cpu_time), pcof_init=pcof_init, order=int(order),
                  schrodinger_prob=dict(tf=float(schro_prob.tf), nsteps=int(schro_prob.nsteps),
-                                       N_ess_levels=int(schro_prob.N_ess_levels), N_guard_levels=int(schro_prob.N_guard_levels),
+                                       N_ess_levels=int(schro_prob.N_ess_levels),
                                        N_tot_levels=int(schro_prob.N_tot_levels), N_operators=int(schro_prob.N_operators),
                                        u0=np.asarray(schro_prob.u0), v0=np.asarray(schro_prob.v0)),
                  controls=dict(N_coeff=np.asarray([c.N_coeff for c in (controls if isinstance(controls, (list, tuple)) else [controls])]),
