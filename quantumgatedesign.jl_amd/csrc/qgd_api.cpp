@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -326,7 +327,26 @@ int hand_over(qgd_handle h)
 
 int finish_copies(qgd_handle h)
 {
-    if (h->copies_pending) { HIP_TRY(h, hipStreamSynchronize(h->copy_stream)); h->copies_pending = false; }
+    if (h->copies_pending) {
+        // (spinning on hipStreamQuery, or on an event recorded behind the copies: no difference, 0.94 ms either way)
+        HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+        h->copies_pending = false;
+    }
+    return QGD_OK;
+}
+
+// Device-to-host download on the copy stream.  A plain hipMemcpyAsync into REGISTERED host memory runs as a blit kernel
+// (__amd_rocclr_copyBuffer): its waves fill the CUs and starve the adjoint chain kernels beside it (15 -> 410 us for the
+// first of them on cnot3), which delays lambda and leaves the PCIe link idle at the end of the evaluation.  The same
+// bytes as a pitched (rows x row_bytes, pitch = row_bytes) copy go through the DMA engine and leave the CUs alone.
+// QGD_COPY_BLIT=1 keeps the plain copy.
+int download(qgd_handle h, void *dst, const void *src, size_t row_bytes, size_t rows)
+{
+    static const bool blit = getenv("QGD_COPY_BLIT") != nullptr;
+    if (blit || rows <= 1 || !find_reg(h, dst, row_bytes * rows))
+        HIP_TRY(h, hipMemcpyAsync(dst, src, row_bytes * rows, hipMemcpyDeviceToHost, h->copy_stream));
+    else
+        HIP_TRY(h, hipMemcpy2DAsync(dst, row_bytes, src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, h->copy_stream));
     return QGD_OK;
 }
 
@@ -361,8 +381,7 @@ int copy_history_out(qgd_handle h, double *uv_history)
     K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, h->stage_hist, dcol, dn, dj, 0, (int)nt, 1, 0, k.stream, 0));
     K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream, 0));
     if ((rc = hand_over(h))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(uv_history, h->stage_hist, total * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-    return QGD_OK;
+    return download(h, uv_history, h->stage_hist, n2 * (m + 1) * sizeof(double), nt * k.c);
 }
 
 // one panel per time point (lambda, adjoint forcing) -> [2N, J, nt, c] with only Taylor index 0 written
@@ -390,8 +409,7 @@ int copy_panels_out(qgd_handle h, const double *panels, double **stage, double *
     K_TRY(h, qgdk_layout(&k, panels, (long long)hstep, 0, *stage, (long long)(nt * n2), (long long)n2, 0, n_first, (int)nt - n_first, 1, 0, k.stream, 0));
     if ((rc = hand_over(h))) return rc;
     if (J == 1) {
-        HIP_TRY(h, hipMemcpyAsync(out, *stage, compact * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-        return QGD_OK;
+        return download(h, out, *stage, n2 * sizeof(double), nt * k.c);
     }
     if (reg) {      // pinned destination: strided copy of the j = 0 columns; the rest is zero-filled once
         if (!reg->zeroed) { memset(out, 0, compact * J * sizeof(double)); reg->zeroed = true; }
@@ -429,8 +447,7 @@ int copy_lambda_full_out(qgd_handle h, double *out)
     K_TRY(h, qgdk_layout(&k, k.lam, (long long)hstep, 0, h->stage_lam_full, dcol, dn, dj, 1, (int)nt - 1, 1, 0, k.stream, 0));
     K_TRY(h, qgdk_layout(&k, h->dlam, (long long)(m * hstep), (long long)hstep, h->stage_lam_full + n2, dcol, dn, dj, 1, (int)nt - 1, (int)m, 0, k.stream, 0));
     if ((rc = hand_over(h))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out, h->stage_lam_full, total * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
-    return QGD_OK;
+    return download(h, out, h->stage_lam_full, n2 * (m + 1) * sizeof(double), nt * k.c);
 }
 
 int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
@@ -1026,6 +1043,13 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
             return QGD_OK;
         }
     }
+    // QGD_HOST_TRACE=1: host-side time stamps of the stages of this call (us since entry) on stderr
+    static const bool host_trace = getenv("QGD_HOST_TRACE") != nullptr;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (host_trace) fprintf(stderr, "[qgd host] %-22s %8.1f us\n", what,
+                                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count());
+    };
     struct CopyGuard { qgd_handle h; ~CopyGuard() { (void)finish_copies(h); h->defer_terminal = false; } } guard{h};   // no copy (and no deferred terminal condition) outlives the call
     // history_precomputed: the reference differentiates the history it is GIVEN with the pcof it is given
     // (eval_grad_discrete_adjoint.jl:118-124).  The device keeps its own copy of the last forward sweep; it is
@@ -1043,19 +1067,28 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
         rc = run_forward(h, pcof, n_pcof);
         if (rc) { h->defer_terminal = false; return rc; }
     }
-    if (uv_history) {   // the download of the state history runs beside the adjoint sweep
+    stamp("forward launched");
+    // The downloads run on the copy stream beside the adjoint sweep and are what bounds this form of the call (PCIe):
+    // the guard forcing goes first -- it is final once the forward sweep is (eval_grad_discrete_adjoint.jl:732-752) and
+    // keeps the link busy while the stage derivatives of the state history are still being computed and laid out
+    if (adjoint_forcing && (rc = copy_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
+    stamp("forcing copy issued");
+    if (uv_history) {
         if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
         if ((rc = copy_history_out(h, uv_history))) return rc;
     }
-    // (the guard forcing is final once the forward sweep is: eval_grad_discrete_adjoint.jl:732-752)
-    if (adjoint_forcing && (rc = copy_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
+    stamp("history copy issued");
     if ((rc = adjoint_begin(h))) return rc;
     h->lambda_out = lambda_history;
     rc = adjoint_end(h);
     h->lambda_out = nullptr;
     if (rc) return rc;
+    stamp("adjoint launched");
     if ((rc = fetch_results(h, grad, out3))) return rc;
-    return finish_copies(h);
+    stamp("results fetched");
+    rc = finish_copies(h);
+    stamp("copies finished");
+    return rc;
 }
 
 int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, const double *forcing,

@@ -20,3 +20,12 @@ torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 20
 h2 = np.zeros((128, 5, 551, 8), order="F"); dp.eval_forward(pcof, h2)
 print("QGD_ZEROCOPY_WGS=%s: %.3f ms per evaluation with history; grad diff %.1e, history diff %.1e" %
       (os.environ.get("QGD_ZEROCOPY_WGS", "default"), el * 1e3, np.abs(g - g0).max(), np.abs(h2 - hist).max()))
+# where the time of one call goes: the bare C entry point against the Python wrapper around it
+import ctypes as C
+vp = lambda a: a.ctypes.data_as(C.c_void_p)
+pc = np.ascontiguousarray(pcof); grad = np.zeros(len(pc)); out3 = np.zeros(3)
+args = (dp.h, vp(pc), len(pc), 0, vp(grad), vp(hist), vp(lam), vp(forc), vp(out3))
+for _ in range(3): dp.lib.qgd_discrete_adjoint(*args)
+t0 = time.perf_counter()
+for _ in range(20): dp.lib.qgd_discrete_adjoint(*args)
+print("bare qgd_discrete_adjoint with the three arrays: %.3f ms per call" % ((time.perf_counter() - t0) / 20 * 1e3))
