@@ -134,6 +134,18 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof,
                          int32_t history_precomputed, double *grad, double *uv_history,
                          double *lambda_history, double *adjoint_forcing, double *out3);
 
+/* cost_type of discrete_adjoint! / eval_grad_forced (src/eval_grad_discrete_adjoint.jl:26-35,
+ * src/eval_grad_forced.jl:155-165): what the final state is measured by.  :Infidelity (default) is the gate
+ * infidelity against the target; :Tracking is 0.5 |w_N - target|^2 and :Norm is 0.5 |w_N|^2 over the stacked real
+ * states of all columns (the reference marks both untested; here they are tested like :Infidelity -- adjoint against
+ * forced and centred differences, and against the oracle).  With a cost type other than :Infidelity the scalars
+ * out3 of qgd_eval_forward / qgd_discrete_adjoint are { cost, 0, guard penalty }.  Anything else: QGD_ERR_ARGUMENT
+ * (the reference throws "Invalid cost type"). */
+#define QGD_COST_INFIDELITY 0
+#define QGD_COST_TRACKING   1
+#define QGD_COST_NORM       2
+int qgd_set_cost_type(qgd_handle h, int32_t cost_type);
+
 /* Host buffers of the optional outputs.  The reference's optimize_gate allocates state_history, lambda_history and
  * adjoint_forcing once and hands the same arrays to discrete_adjoint! on every iteration
  * (src/ipopt_optimal_control.jl:223-241, :304-330).  Registering such an array pins it, so that the downloads run at

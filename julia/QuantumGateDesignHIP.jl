@@ -173,6 +173,12 @@ function hip_objective(prob::SchrodingerProb, controls, pcof::Vector{Float64}, t
     return objective_terms(out3, prob.N_ess_levels)
 end
 
+"cost_type as in src/eval_grad_discrete_adjoint.jl:26-35; anything else throws like the reference."
+function set_cost_type!(dp, cost_type)
+    code = cost_type == :Infidelity ? 0 : cost_type == :Tracking ? 1 : cost_type == :Norm ? 2 : throw("Invalid cost type: $cost_type")
+    check(dp.handle, ccall((:qgd_set_cost_type, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, code))
+end
+
 "Drop-in for discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target;
 order, history_precomputed) -- src/eval_grad_discrete_adjoint.jl:107-160.  `lambda_derivatives=true` also fills
 lambda_history[:, 2:end, :, :] the way eval_adjoint! leaves it (src/forward_evolution.jl:427-433); nothing in the package
@@ -182,9 +188,9 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
         prob::SchrodingerProb, controls, pcof::Vector{Float64},
         target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false, cost_type=:Infidelity,
         lambda_derivatives::Bool=false)
-    cost_type == :Infidelity || throw(ArgumentError("the device path implements cost_type=:Infidelity only"))
     dp = device_problem(prob, order)
     set_controls!(dp, prob, controls, pcof)
+    set_cost_type!(dp, cost_type)
     shape = (prob.real_system_size, 1 + div(order, 2), 1 + prob.nsteps, prob.N_initial_conditions)
     for a in (history, lambda_history)
         a === nothing || size(a) == shape || throw(DimensionMismatch("history arrays must be $shape, got $(size(a))"))
@@ -201,24 +207,28 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
               (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
               dp.handle, pcof, length(pcof), history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), out3))
     end
-    return grad, objective_terms(out3, prob.N_ess_levels)     # (gradient; (infidelity, guard penalty) of this pcof)
+    set_cost_type!(dp, :Infidelity)
+    # (gradient; (infidelity, guard penalty) of this pcof -- with :Tracking / :Norm out3 is (cost, 0, guard penalty))
+    return grad, (cost_type == :Infidelity ? objective_terms(out3, prob.N_ess_levels) : (out3[1], out3[3]))
 end
 
 """
-    hip_eval_grad_forced(prob, controls, pcof, target; order=2)
+    hip_eval_grad_forced(prob, controls, pcof, target; order=2, cost_type=:Infidelity)
 
 Drop-in for `eval_grad_forced` (src/eval_grad_forced.jl:17-60): the gradient by forward
 sensitivities, all control parameters in one device call.
 """
 function hip_eval_grad_forced(prob::SchrodingerProb, controls, pcof::Vector{Float64},
-        target::AbstractMatrix{<:Number}; order::Int=2)
+        target::AbstractMatrix{<:Number}; order::Int=2, cost_type=:Infidelity)
     dp = device_problem(prob, order)
     set_controls!(dp, prob, controls, pcof)
+    set_cost_type!(dp, cost_type)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
     grad = zeros(length(pcof))
     check(dp.handle, ccall((:qgd_eval_grad_forced, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}),
           dp.handle, pcof, length(pcof), grad))
+    set_cost_type!(dp, :Infidelity)
     return grad
 end
 

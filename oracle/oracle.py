@@ -174,6 +174,15 @@ def set_converged_terminal(on: bool):
     lib().qo_set_converged_terminal(1 if on else 0)
 
 
+COST_TYPES = {"Infidelity": 0, ":Infidelity": 0, "Tracking": 1, ":Tracking": 1, "Norm": 2, ":Norm": 2}
+
+
+def set_cost_type(cost_type="Infidelity"):
+    """cost_type of discrete_adjoint / eval_grad_forced / eval_grad_finite_difference (a process-wide switch like the
+    one above; eval_grad_discrete_adjoint.jl:26-35)."""
+    lib().qo_set_cost_type(COST_TYPES[cost_type])
+
+
 def coefficient(j, p, q):
     return lib().qo_coefficient(j, p, q)
 

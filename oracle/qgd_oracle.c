@@ -28,6 +28,12 @@ void qo_set_num_threads(int n) { g_threads = n; }
 static int g_converged_terminal = 0;
 void qo_set_converged_terminal(int on) { g_converged_terminal = on; }
 
+/* cost_type of discrete_adjoint / eval_grad_forced / eval_grad_finite_difference
+ * (eval_grad_discrete_adjoint.jl:26-35, eval_grad_forced.jl:155-165, eval_grad_finite_difference.jl:48-59):
+ * 0 :Infidelity (default), 1 :Tracking (0.5 |w_N - target|^2), 2 :Norm (0.5 |w_N|^2). */
+static int g_cost_type = 0;
+void qo_set_cost_type(int type) { g_cost_type = type; }
+
 static double factorial_d(int n) { double f = 1.0; for (int i = 2; i <= n; i++) f *= i; return f; }
 static double binomial_d(int n, int k) { return factorial_d(n) / (factorial_d(k) * factorial_d(n - k)); }
 
@@ -842,6 +848,8 @@ int qo_compute_terminal_condition(const qo_prob *pr, const qo_control *const *co
             rhs[i]     = sc * (dR * r[i]     + dT * r[N + i]);
             rhs[N + i] = sc * (dR * r[N + i] - dT * r[i]);
         }
+        if (g_cost_type == 1) for (int i = 0; i < n2; i++) rhs[i] = -(final_state[i + (size_t)c * n2] - r[i]);   /* :29-30 */
+        if (g_cost_type == 2) for (int i = 0; i < n2; i++) rhs[i] = -final_state[i + (size_t)c * n2];            /* :31-32 */
         if (forcing_end) for (int i = 0; i < n2; i++) rhs[i] += forcing_end[i + (size_t)c * n2];
         gmres_solve(&ws, lhs_adjoint_apply, &h, NULL, x, rhs, pr->gmres_abstol, pr->gmres_reltol, maxiter);
         memcpy(terminal_out + (size_t)c * n2, x, sizeof(double) * n2);
@@ -1032,6 +1040,14 @@ int qo_eval_grad_forced(const qo_prob *pr, const qo_control *const *controls, co
                 for (int i = 0; i < N; i++) { pR += p[i] * r[i] + p[N + i] * r[N + i]; pT += p[i] * r[N + i] - p[N + i] * r[i]; }
             }
             double gval = -(2.0 / ((double)pr->n_ess * pr->n_ess)) * (dR * pR + dT * pT); /* :155-159 */
+            if (g_cost_type) {                                                            /* :160-163 */
+                gval = 0.0;
+                for (int c = 0; c < nc; c++) {
+                    const double *p = hpd + (size_t)c * hcol + (size_t)(nt - 1) * slab, *r = R + (size_t)c * n2;
+                    const double *w = history + (size_t)c * hcol + (size_t)(nt - 1) * slab;
+                    for (int i = 0; i < n2; i++) gval += p[i] * (g_cost_type == 1 ? w[i] - r[i] : w[i]);
+                }
+            }
             double guard = 0.0;                                                          /* :168-184 */
             for (int n = 0; n < nt; n++) {
                 double val = 0.0;
@@ -1064,7 +1080,13 @@ static double objective_inf_plus_guard(const qo_prob *pr, const qo_control *cons
     double *fin = (double *)malloc(sizeof(double) * n2 * nc);
     for (int c = 0; c < nc; c++)
         memcpy(fin + (size_t)c * n2, hist + (size_t)c * hcol + (size_t)(nt - 1) * slab, sizeof(double) * n2);
-    double v = qo_infidelity_real(pr->N, nc, fin, R, pr->n_ess) + qo_guard_penalty_real(pr, m, hist);
+    double v = qo_guard_penalty_real(pr, m, hist);
+    if (g_cost_type == 0) v += qo_infidelity_real(pr->N, nc, fin, R, pr->n_ess);
+    else {                                                  /* eval_grad_finite_difference.jl:51-56 */
+        double s2 = 0.0;
+        for (size_t i = 0; i < (size_t)n2 * nc; i++) { const double d = (g_cost_type == 1) ? fin[i] - R[i] : fin[i]; s2 += d * d; }
+        v += 0.5 * s2;
+    }
     free(fin);
     return v;
 }

@@ -24,7 +24,7 @@ EXPORTS = [
     "qgd_dist_forward_begin", "qgd_dist_forward_end", "qgd_dist_adjoint_begin", "qgd_dist_adjoint_end",
     "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
     "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc", "qgd_cols_forward", "qgd_cols_adjoint",
-    "qgd_set_lambda_derivatives",
+    "qgd_set_lambda_derivatives", "qgd_set_cost_type",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
     L.qgd_register_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.qgd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_set_lambda_derivatives.argtypes = [C.c_void_p, C.c_int32]
+    L.qgd_set_cost_type.argtypes = [C.c_void_p, C.c_int32]
     _lib = L
     return L
 

@@ -907,6 +907,16 @@ int qgd_set_target(qgd_handle h, const double *target_real)
     return QGD_OK;
 }
 
+int qgd_set_cost_type(qgd_handle h, int32_t cost_type)
+{
+    if (h) drop_graph(h);
+    if (!h) return fail(h, QGD_ERR_ARGUMENT, "null handle");
+    if (cost_type < QGD_COST_INFIDELITY || cost_type > QGD_COST_NORM)
+        return fail(h, QGD_ERR_ARGUMENT, "Invalid cost type (0 :Infidelity, 1 :Tracking, 2 :Norm)");    // the reference throws "Invalid cost type"
+    h->k.cost_type = cost_type;     // (a stored forward sweep stays valid: history_precomputed re-forms the terminal condition)
+    return QGD_OK;
+}
+
 int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *const *Gp, const double *const *Gq)
 {
     if (h) drop_graph(h);
@@ -1173,15 +1183,19 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
     { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }
     { PhaseTimer t(h, "forced_sweeps"); K_TRY(h, qgdk_forced_chains(&k)); }
     if ((rc = check_status(h))) return rc;
-    std::vector<double> sN(hstepS), gacc(k.n_pcof), scal(4);
+    std::vector<double> sN(hstepS), gacc(k.n_pcof), scal(4), wN;
     HIP_TRY(h, hipMemcpy(sN.data(), k.fs_bnd + B * hstepS, hstepS * sizeof(double), hipMemcpyDeviceToHost));
+    if (k.cost_type) {     // :Tracking / :Norm need the final state itself (eval_grad_forced.jl:160-163)
+        wN.resize(hstep);
+        HIP_TRY(h, hipMemcpy(wN.data(), k.hist + (nt - 1) * hstep, hstep * sizeof(double), hipMemcpyDeviceToHost));
+    }
     HIP_TRY(h, hipMemcpy(gacc.data(), k.fs_gacc, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(scal.data(), k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
     // d(infidelity) = -(2/N_ess^2) (<w_N,R> <s_N,R> + <w_N,T> <s_N,T>), T = [R_im; -R_re] (infidelity.jl:13-17)
     const size_t N = k.N, PWs = 2 * cpS;
     const double a = scal[0], b = scal[1], f = -2.0 / ((double)k.n_ess * k.n_ess);
     for (int p = 0; p < k.n_pcof; p++) {
-        double sR = 0.0, sT = 0.0;
+        double sR = 0.0, sT = 0.0, sW = 0.0;
         for (int col = 0; col < k.c; col++)
             for (size_t i = 0; i < N; i++) {
                 const size_t o = panel_index((int)i, p * k.cp + col, (int)PWs);
@@ -1189,8 +1203,14 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
                 const double rre = h->target_host[i + 2 * N * col], rim = h->target_host[N + i + 2 * N * col];
                 sR += sre * rre + sim * rim;
                 sT += sre * rim - sim * rre;
+                if (k.cost_type) {      // d(0.5 |w_N - R|^2) = <s_N, w_N - R>,  d(0.5 |w_N|^2) = <s_N, w_N>
+                    const size_t ow = panel_index((int)i, col, 2 * k.cp);
+                    const double dre = wN[ow] - (k.cost_type == QGD_COST_TRACKING ? rre : 0.0);
+                    const double dim = wN[ow + 8] - (k.cost_type == QGD_COST_TRACKING ? rim : 0.0);
+                    sW += sre * dre + sim * dim;
+                }
             }
-        grad[p] = f * (a * sR + b * sT) + gacc[p];
+        grad[p] = (k.cost_type ? sW : f * (a * sR + b * sT)) + gacc[p];
     }
     return QGD_OK;
 }

@@ -10,6 +10,7 @@
 typedef struct qgdk_ctx {
     int N, Np, c, cp, n_ops, n_ess, m, nt, n_pcof, nc_max;
     int have_guard, have_target, inv_batch;
+    int cost_type;      // 0 :Infidelity, 1 :Tracking, 2 :Norm (eval_grad_discrete_adjoint.jl:26-35); the kernels get have_target * (1 + cost_type)
     double dt, tf;
     hipStream_t stream;
     // device buffers

@@ -823,8 +823,16 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
     const size_t hstep = (size_t)Np * PWc;
     const double *w = hist + (size_t)(nt - 1) * hstep;
+    // have_target: 0 none, 1 :Infidelity, 2 :Tracking, 3 :Norm (eval_grad_discrete_adjoint.jl:26-35).  The last two are
+    // local in the columns: scal[0] = 0.5 |w_N - R|^2 (0.5 |w_N|^2), scal[1] = 0, y_N = -(w_N - R) + f_N (-w_N + f_N).
+    const int cost = have_target > 1 ? have_target - 1 : 0;
     double a = 0.0, b = 0.0;
-    if (have_target && !given_ab) {
+    if (cost) {
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+            const double d = (cost == 1) ? w[e] - target[e] : w[e];
+            a += 0.5 * d * d;
+        }
+    } else if (have_target && !given_ab) {
         for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
             const int col = e % PWc;
             const int c16 = col & 15;
@@ -842,9 +850,18 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
     for (int q = 0; q < nw; q++) { a += red[q]; b += red[16 + q]; }
     // column shards: the overlaps are GLOBAL sums over all columns (infidelity.jl:13-17); after the ranks' all-reduce
     // they are in scal and the terminal condition is formed from them, not from this rank's columns
-    if (given_ab) { a = scal[0]; b = scal[1]; }
+    if (given_ab) { a = scal[0]; b = scal[1]; }       // (a column shard's Tracking / Norm cost was reduced like the overlaps)
     else if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
     if (!write_y) return;
+    if (cost) {
+        double *yc = yhist + (size_t)(nt - 1) * hstep;
+        const double *fc = forcing + (size_t)(nt - 1) * hstep;
+        for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
+            const double v = ((cost == 1) ? target[e] - w[e] : -w[e]) + fc[e];
+            yc[e] = v; y2[e] = v; y3[e] = v; y4[e] = v;
+        }
+        return;
+    }
     const double sc = 2.0 / ((double)n_ess * (double)n_ess);
     double *y = yhist + (size_t)(nt - 1) * hstep;
     const double *f = forcing + (size_t)(nt - 1) * hstep;
@@ -951,11 +968,12 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
 
 // the same in two launches of many workgroups, for panels of >= 32768 elements: partial overlaps by atomics, then y_N
 __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__ w, const double *__restrict__ target,
-                                                      double *__restrict__ scal, int hstep, int PWc)
+                                                      double *__restrict__ scal, int hstep, int PWc, int cost)
 {
     __shared__ double red[8];
     double a = 0.0, b = 0.0;
     for (int e = blockIdx.x * 2048 + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * 2048); e += 256) {
+        if (cost) { const double d = (cost == 1) ? w[e] - target[e] : w[e]; a += 0.5 * d * d; continue; }   // :Tracking / :Norm
         const int c16 = (e % PWc) & 15;
         const double tp = target[e ^ 8];
         a += w[e] * target[e];
@@ -973,10 +991,11 @@ __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__
 __global__ __launch_bounds__(256) void k_terminal_y(const double *__restrict__ target, const double *__restrict__ f,
                                                     const double *__restrict__ scal, double *__restrict__ y,
                                                     double *__restrict__ y2, double *__restrict__ y3, double *__restrict__ y4,
-                                                    int hstep, int PWc, int n_ess)
+                                                    int hstep, int PWc, int n_ess, int cost, const double *__restrict__ w)
 {
     const double a = scal[0], b = scal[1], sc = 2.0 / ((double)n_ess * (double)n_ess);
     for (int e = blockIdx.x * 2048 + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * 2048); e += 256) {
+        if (cost) { const double v = ((cost == 1) ? target[e] - w[e] : -w[e]) + f[e]; y[e] = v; y2[e] = v; y3[e] = v; y4[e] = v; continue; }
         const int c16 = (e % PWc) & 15;
         const double tv = target[e], tp = target[e ^ 8];
         const double Tv = (c16 < 8) ? tp : -tp;
@@ -1192,16 +1211,16 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
         const double *w = c->hist + (size_t)(c->nt - 1) * hstep;
         if (!given_ab) {
             HIPCHK(hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
-            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(nwg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp);
+            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(nwg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type);
         }
         if (write_y)
             hipLaunchKernelGGL(k_terminal_y, dim3(nwg), dim3(256), 0, c->stream, c->target, c->forcing + (size_t)(c->nt - 1) * hstep,
                                c->scal, c->yhist + (size_t)(c->nt - 1) * hstep, slot, c->bndY + (size_t)c->scan_blocks * hstep,
-                               c->bndY2 + (size_t)c->scan_blocks2 * hstep, (int)hstep, 2 * c->cp, c->n_ess);
+                               c->bndY2 + (size_t)c->scan_blocks2 * hstep, (int)hstep, 2 * c->cp, c->n_ess, c->cost_type, w);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
-                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target, write_y, slot,
+                       c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target * (1 + c->cost_type), write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab);
     return (int)hipGetLastError();
 }
@@ -1218,7 +1237,7 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
     if (c->fuse_terminal && chain_is_fast(c)) {          // y_N and the overlaps by an extra workgroup of this launch
         const size_t hstep = (size_t)c->Np * 2 * c->cp;
-        a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target;
+        a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target * (1 + c->cost_type);
         a.t_hist = c->hist; a.t_target = c->target; a.t_forcing = c->forcing; a.t_yhist = c->yhist; a.t_scal = c->scal;
         a.t_y2 = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
         a.t_y3 = c->bndY + (size_t)c->scan_blocks * hstep; a.t_y4 = c->bndY2 + (size_t)c->scan_blocks2 * hstep;

@@ -55,6 +55,9 @@ def real_to_complex(x):
     return x[:N] + 1j * x[N:]
 
 
+COST_TYPES = {"Infidelity": 0, ":Infidelity": 0, "Tracking": 1, ":Tracking": 1, "Norm": 2, ":Norm": 2}
+
+
 class DeviceProblem:
     """One qgd handle: a SchrodingerProb resident on one GPU for one Hermite order."""
 
@@ -218,6 +221,17 @@ class DeviceProblem:
         _lib.check(self.h, self.lib.qgd_eval_adjoint(self.h, _vp(pc), len(pc), _vp(term),
                                                      None if fo is None else _vp(fo), _vp(lam)))
         return lam
+
+    def set_cost_type(self, cost_type="Infidelity"):
+        """cost_type of discrete_adjoint / eval_grad_forced (eval_grad_discrete_adjoint.jl:26-35): ``Infidelity``,
+        ``Tracking`` (0.5 |w_N - target|^2) or ``Norm`` (0.5 |w_N|^2); a leading ':' as in Julia is accepted.
+        Anything else raises like the reference ("Invalid cost type")."""
+        code = COST_TYPES.get(str(cost_type))
+        if code is None:
+            raise ValueError(f"Invalid cost type: {cost_type}")
+        if code != getattr(self, "_cost_type", 0):
+            _lib.check(self.h, self.lib.qgd_set_cost_type(self.h, code))
+            self._cost_type = code
 
     def set_lambda_derivatives(self, on=True):
         """Fill ``lambda_history[:, 1:, :, :]`` as the reference leaves it (forward_evolution.jl:427-433, :471-480):
@@ -397,33 +411,38 @@ def eval_grad_forced(prob, controls, pcof, target, order=2, cost_type="Infidelit
     """eval_grad_forced(prob, controls, pcof, target; order, cost_type) (src/eval_grad_forced.jl:17-60):
     the gradient of infidelity + guard penalty by differentiating the forward sweep (one forced sweep
     per control parameter).  On the device all parameters run at once as extra columns of the scan."""
-    if cost_type not in ("Infidelity", ":Infidelity"):
-        raise NotImplementedError("cost_type other than :Infidelity")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
     dp.set_target(target)
-    return dp.eval_grad_forced(pcof)
+    dp.set_cost_type(cost_type)
+    try:
+        return dp.eval_grad_forced(pcof)
+    finally:
+        dp.set_cost_type("Infidelity")
 
 
 def eval_grad_finite_difference(prob, controls, pcof, target, dpcof=1e-5, order=2, cost_type="Infidelity"):
     """eval_grad_finite_difference (src/eval_grad_finite_difference.jl:1-72): centred differences of
     infidelity + guard penalty, two device forward evaluations per control parameter (the third leg of
     the reference's adjoint / forced / finite-difference contract, compare_gradients.jl:47-65)."""
-    if cost_type not in ("Infidelity", ":Infidelity"):
-        raise NotImplementedError("cost_type other than :Infidelity")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
     dp.set_target(target)
+    dp.set_cost_type(cost_type)
     pcof = np.asarray(pcof, dtype=np.float64)
+    plain = COST_TYPES[str(cost_type)] == 0
 
     def cost(p):
-        a, b, guard = dp.eval_forward(p)
-        return 1.0 - (a * a + b * b) / prob.N_ess_levels ** 2 + guard
+        a, b, guard = dp.eval_forward(p)       # (:Tracking / :Norm: a is the cost itself, b = 0)
+        return (1.0 - (a * a + b * b) / prob.N_ess_levels ** 2 if plain else a) + guard
 
     grad = np.zeros(len(pcof))
-    for i in range(len(pcof)):
-        e = np.zeros(len(pcof)); e[i] = dpcof
-        grad[i] = (cost(pcof + e) - cost(pcof - e)) / (2 * dpcof)
+    try:
+        for i in range(len(pcof)):
+            e = np.zeros(len(pcof)); e[i] = dpcof
+            grad[i] = (cost(pcof + e) - cost(pcof - e)) / (2 * dpcof)
+    finally:
+        dp.set_cost_type("Infidelity")
     return grad
 
 
@@ -480,16 +499,16 @@ def discrete_adjoint_(grad, history, lambda_history, adjoint_forcing, prob, cont
                       order=2, cost_type="Infidelity", history_precomputed=False, lambda_derivatives=False):
     """discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160).  ``lambda_derivatives=True``: columns 1..m of
     ``lambda_history`` as the reference leaves them (default: zeros; only column 0 is ever consumed)."""
-    if cost_type not in ("Infidelity", ":Infidelity"):
-        raise NotImplementedError("only cost_type=:Infidelity is implemented (the reference marks the others untested)")
     dp = device_problem(prob, order)
     dp.set_controls(controls)
     dp.set_target(target)
+    dp.set_cost_type(cost_type)
     if lambda_derivatives:
         dp.set_lambda_derivatives(True)
     try:
         g, _ = dp.discrete_adjoint(pcof, history_precomputed, history, lambda_history, adjoint_forcing)
     finally:
+        dp.set_cost_type("Infidelity")
         if lambda_derivatives:
             dp.set_lambda_derivatives(False)
     grad[:] = g

@@ -21,6 +21,8 @@ print("%%-40s %%.1f us  grad_norm %%.12f" %% (os.environ.get("TAG"), el * 1e6, n
 ''' % (ROOT, ROOT)
 settings = [dict(), dict(QGD_GRAPH="1"), dict(QGD_INV_STATIC="1"), dict(QGD_INV_STATIC="1", QGD_INV_PIVOTED="1"), dict(QGD_INV_MULTI="3"), dict(QGD_INV_MULTI="2"),
             dict(QGD_PIPE_CHUNKS="2"), dict(QGD_PIPE_CHUNKS="3"), dict(), dict(QGD_GRAPH="1")]
+if len(sys.argv) > 1:      # settings from the command line: "default" or "K=V,K=V" per argument
+    settings = [dict() if a == "default" else dict(kv.split("=", 1) for kv in a.split(",")) for a in sys.argv[1:]]
 for extra in settings:
     env = dict(os.environ, TAG=" ".join(f"{k}={v}" for k, v in extra.items()) or "default", **extra)
     subprocess.run([sys.executable, "-c", CODE], env=env)

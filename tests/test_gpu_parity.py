@@ -790,3 +790,72 @@ def test_cnot3_many_columns(qgd, c):
     assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
     a, b = ref["overlap"]          # the statement's overlap is sum conj(R) psi = <w,R> - i <w,T>  (T = [R_im; -R_re], infidelity.jl:13-17)
     assert abs(out3[0] - a) < 1e-11 and abs(out3[1] + b) < 1e-11 and abs(out3[2] - ref["guard"]) < 1e-11
+
+
+@pytest.mark.parametrize("cost_type", ["Tracking", "Norm"])
+def test_cost_types_vs_oracle(qgd, orc, cost_type):
+    """cost_type = :Tracking / :Norm (eval_grad_discrete_adjoint.jl:26-35, eval_grad_forced.jl:155-165,
+    eval_grad_finite_difference.jl:48-59): the terminal condition, lambda and the gradient against the oracle, the
+    reference's three-way contract (adjoint = forced = centred differences) on the device, the cost scalar, the stored
+    forward sweep, the fused and the stand-alone terminal kernel, the N > 64 path, and the error for anything else."""
+    orc.set_converged_terminal(True)
+    orc.set_cost_type(cost_type)
+    try:
+        todo = [(n, p, c, x, t, o) for (n, p, c, x, t) in cases.gradient_cases(qgd)[:4] for o in (2, 6)]
+        todo += [("guarded",) + cases.guarded_case(qgd, nsteps=20, tf=10.0) + (8,), ("cnot2",) + cases.cnot2_case(qgd) + (8,),
+                 ("cnot3",) + cases.cnot3_case(qgd, nsteps=12, tf=12.0) + (8,),
+                 ("synthetic72",) + cases.synthetic_case(qgd, N=72, c=4, n_ops=2, nsteps=6, tf=0.3, seed=72) + (4,)]
+        for name, prob, ctrl, pcof, target, order in todo:
+            prob.gmres_abstol = prob.gmres_reltol = 1e-15
+            g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+            lam = np.zeros(h_ref.shape, order="F")
+            grad = np.zeros_like(g_ref)
+            qgd.discrete_adjoint_(grad, None, lam, None, prob, ctrl, pcof, target, order=order, cost_type=":" + cost_type)
+            # (:Norm on a closed system differentiates the scheme's loss of unitarity: the gradient is 1e-5 of the O(1)
+            #  terms <lambda, dA w> it is summed from, so the bar is relative to those, not to the cancelled sum)
+            scale = max(np.abs(g_ref).max(), 1e-3 * np.abs(lam_ref[:, 0]).max())
+            assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, 0]).max()), name
+            assert np.abs(grad - g_ref).max() <= GRAD_RTOL * scale, name
+            # the cost scalar and the stored forward sweep
+            dp = qgd.device_problem(prob, order)
+            dp.set_controls(ctrl); dp.set_target(target); dp.set_cost_type(cost_type)
+            out3 = dp.eval_forward(pcof)
+            wN, tr = h_ref[:, 0, -1, :], orc.target_real(target)
+            cost = 0.5 * np.sum((wN - tr) ** 2) if cost_type == "Tracking" else 0.5 * np.sum(wN ** 2)
+            assert abs(out3[0] - cost) <= 1e-11 * max(1.0, cost) and out3[1] == 0.0, name
+            g_pre, _ = dp.discrete_adjoint(pcof, history_precomputed=True)
+            assert np.abs(g_pre - g_ref).max() <= GRAD_RTOL * scale, name
+            dp.set_cost_type("Infidelity")
+            if prob.N_tot_levels <= 64:
+                g_for = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order, cost_type=cost_type)
+                assert np.abs(g_for - grad).max() <= 1e-11 * scale, name
+                assert np.abs(g_for - orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)).max() <= 1e-10 * scale, name
+            if len(pcof) <= 50:
+                g_fd = qgd.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order, cost_type=cost_type)
+                assert np.abs(g_fd - grad).max() <= 1e-8 * max(1.0, scale), name
+            # the handle is back on :Infidelity afterwards
+            orc.set_cost_type("Infidelity")
+            g_inf = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+            orc.set_cost_type(cost_type)
+            assert np.abs(qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order) - g_inf).max() <= GRAD_RTOL * np.abs(g_inf).max(), name
+    finally:
+        orc.set_cost_type("Infidelity")
+        orc.set_converged_terminal(False)
+    with pytest.raises(ValueError, match="Invalid cost type"):
+        qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order, cost_type="Fidelity")
+    qgd.clear_cache()
+
+
+def test_cost_type_stand_alone_terminal_kernel(qgd, orc, monkeypatch):
+    """The same through k_terminal as its own launch (QGD_TERMINAL_KERNEL=1) instead of the extra workgroup of the first
+    adjoint launch."""
+    monkeypatch.setenv("QGD_TERMINAL_KERNEL", "1")
+    prob, ctrl, pcof, target = cases.guarded_case(qgd, nsteps=20, tf=10.0)
+    orc.set_converged_terminal(True); orc.set_cost_type("Tracking")
+    try:
+        g_ref = orc.discrete_adjoint(prob, ctrl, pcof, target, order=6)
+    finally:
+        orc.set_cost_type("Infidelity"); orc.set_converged_terminal(False)
+    grad = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=6, cost_type="Tracking")
+    assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max()
+    qgd.clear_cache()

@@ -112,6 +112,29 @@ def test_three_way_with_guard_and_two_controls(qgd, orc):
         assert np.abs(ga - gd).max() < 1e-8
 
 
+@pytest.mark.parametrize("cost_type", ["Tracking", "Norm"])
+def test_three_way_agreement_other_cost_types(qgd, orc, cost_type):
+    """The same contract for cost_type = :Tracking / :Norm (eval_grad_discrete_adjoint.jl:26-35, eval_grad_forced.jl:
+    160-163, eval_grad_finite_difference.jl:51-56), which the reference's own tests never exercise: the three gradients
+    of the oracle agree, so its terminal right-hand sides are the derivatives of the costs the other two legs use."""
+    orc.set_cost_type(cost_type)
+    try:
+        todo = [c + (o,) for c in cases.gradient_cases(qgd)[:4] for o in (2, 6)]
+        todo.append(("guarded",) + cases.guarded_case(qgd, nsteps=10, tf=5.0) + (4,))
+        for name, prob, ctrl, pcof, target, order in todo:
+            ga = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+            gf = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+            gd = orc.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order, dpcof=1e-5)
+            scale = max(1.0, np.abs(gf).max())
+            assert np.abs(ga - gf).max() <= 1e-13 * scale, (name, order)
+            assert np.abs(ga - gd).max() <= 2e-8 * scale, (name, order)
+    finally:
+        orc.set_cost_type("Infidelity")
+    # and the switch is really off again
+    name, prob, ctrl, pcof, target = cases.gradient_cases(qgd)[0]
+    assert np.abs(orc.discrete_adjoint(prob, ctrl, pcof, target, order=2) - orc.eval_grad_forced(prob, ctrl, pcof, target, order=2)).max() < 1e-14
+
+
 @pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
 def test_convergence_order(qgd, orc, order):
     """Step doubling: observed order within +-0.5 of nominal
