@@ -859,3 +859,14 @@ def test_cost_type_stand_alone_terminal_kernel(qgd, orc, monkeypatch):
     grad = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=6, cost_type="Tracking")
     assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max()
     qgd.clear_cache()
+
+
+def test_randomised_shape_sweep_small_n():
+    """scripts/fuzz_small_n.py: 40 random problems with N <= 64 (dispersive / sparse with guard levels and carrier
+    controls, random dense; 1..24 columns, orders 2..16, 1..200 steps) against the numpy statement, history and
+    gradient <= 1e-10 (its own process: every case creates and closes a handle)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_small_n.py"), "40", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "FAIL" not in r.stdout and "worst" in r.stdout
