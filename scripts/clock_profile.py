@@ -11,6 +11,8 @@ prob, ctrl, pcof, target = bench.workload(qgd, 550, 550.0)
 dp = qgd.DeviceProblem(prob, 8); dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(0)
 dp.discrete_adjoint(pcof); torch.cuda.synchronize()
 time.sleep(float(sys.argv[1]) if len(sys.argv) > 1 else 2.0)        # let the GPU go idle first
+if len(sys.argv) > 2 and sys.argv[2] == "nogc":
+    import gc; gc.collect(); gc.disable()
 out = []
 for chunk in range(40):
     t0 = time.perf_counter()

@@ -870,3 +870,28 @@ def test_randomised_shape_sweep_small_n():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_small_n.py"), "40", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAIL" not in r.stdout and "worst" in r.stdout
+
+
+@pytest.mark.parametrize("which", ["cnot2", "cnot3"])
+def test_baseline_configs_full_size_vs_oracle(qgd, orc, which):
+    """BASELINE.json configs 2 and 3 at their FULL grids -- cnot2 (N=4, 4 columns, 100 steps) and cnot3 (N=64, 8 columns,
+    550 steps at dt = 1), order 8 -- directly against the oracle: state history with all stage derivatives, guard forcing,
+    lambda and the gradient.  The oracle runs its SparseMatrixCSC operator mode (bit-identical to its dense mode,
+    test_oracle.py::test_csc_operators_equal_dense) on 8 threads over the columns, GMRES at 1e-15, terminal solve to
+    convergence: 5.5 s for cnot3.  The history bound is the oracle's own: 550 steps of 1e-15 residuals through L^-1."""
+    nsteps = 100 if which == "cnot2" else 550
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps))
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    orc.set_sparse_operators(True); orc.set_num_threads(8); orc.set_converged_terminal(True)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8, return_all=True)
+    finally:
+        orc.set_sparse_operators(False); orc.set_converged_terminal(False); orc.set_num_threads(0)
+    hist = np.zeros(h_ref.shape, order="F"); lam = np.zeros(h_ref.shape, order="F"); forcing = np.zeros(f_ref.shape, order="F")
+    grad = np.zeros_like(g_ref)
+    qgd.discrete_adjoint_(grad, hist, lam, forcing, prob, ctrl, pcof, target, order=8)
+    assert np.abs(hist - h_ref).max() <= 5e-11
+    assert np.abs(forcing - f_ref).max() <= 1e-12
+    assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-11 * np.abs(lam_ref[:, 0]).max()
+    assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max()
+    qgd.clear_cache()
