@@ -243,25 +243,6 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     // result is the step matrix itself / the forcing.  It is loaded straight into the buffer step 1 reads.
     constexpr bool SKIP0 = (MODE == 0 || MODE == 2);
     const int first = (SKIP0 && total > 0) ? 1 : 0;
-    for (int e = tid; e < NG * NP * 16; e += NTH) {
-        const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
-        double v;
-        if (SKIP0 && first) {
-            const int n0 = step_index(0);
-            if (MODE == 0) v = chain_matrix(a, n0)[(c >= 8 ? (size_t)NP * NP : 0) + row + (size_t)NP * ((grp0 + g) * 8 + (c & 7))];
-            else v = a.forcing[(size_t)(a.f_bpr ? n0 + n0 / a.f_bpr : n0) * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c];
-        }
-        else if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
-        else if (ZERO) v = 0.0;
-        else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
-        part[first][g][el] = v;
-        if (MODE == 1 && a.guard_diag && s0 == 0 && !(a.npre > 0 && a.pre_kind[0] == 0)) {   // the window's first point is nobody's product
-            const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
-            const double trap = (a.n_off == 0) ? 0.5 : 1.0;
-            a.guard_forcing[(size_t)row * PWc + (grp0 + g) * 16 + c] = -(2.0 * a.dt / a.tf) * trap * wv * v;
-            if (a.count_first) pen += trap * wv * v * v;
-        }
-    }
     double are[KST], aim[KST], fo[NG][4];
     double gw[4] = {0.0, 0.0, 0.0, 0.0};                 // guard weights of this lane's accumulator elements
     if (MODE == 1 && a.guard_diag) {
@@ -335,7 +316,44 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         }
     };
     const int st0 = (team < first) ? team + NT : team;   // this team's first step
-    if (st0 < total) issue(st0);
+    if (st0 < total) issue(st0);                          // (ahead of the start state: the two do not depend on each other)
+    // start state into part[first].  The loads of all iterations are issued before the first LDS write (the rolled loop
+    // waited for every global round trip in turn: two per workgroup on top of the operand loads above).
+    {
+        constexpr int NIT = (NG * NP * 16 + NTH - 1) / NTH;
+        double sv[NIT];
+        #pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int e = tid + it * NTH;
+            const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
+            double v = 0.0;
+            if (e < NG * NP * 16) {
+                if (SKIP0 && first) {
+                    const int n0 = step_index(0);
+                    if (MODE == 0) v = chain_matrix(a, n0)[(c >= 8 ? (size_t)NP * NP : 0) + row + (size_t)NP * ((grp0 + g) * 8 + (c & 7))];
+                    else v = a.forcing[(size_t)(a.f_bpr ? n0 + n0 / a.f_bpr : n0) * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c];
+                }
+                else if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
+                else if (ZERO) v = 0.0;
+                else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
+            }
+            sv[it] = v;
+        }
+        #pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int e = tid + it * NTH;
+            if (e >= NG * NP * 16) continue;
+            const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
+            const double v = sv[it];
+            part[first][g][el] = v;
+            if (MODE == 1 && a.guard_diag && s0 == 0 && !(a.npre > 0 && a.pre_kind[0] == 0)) {   // the window's first point is nobody's product
+                const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
+                const double trap = (a.n_off == 0) ? 0.5 : 1.0;
+                a.guard_forcing[(size_t)row * PWc + (grp0 + g) * 16 + c] = -(2.0 * a.dt / a.tf) * trap * wv * v;
+                if (a.count_first) pen += trap * wv * v * v;
+            }
+        }
+    }
     lds_barrier();
 
 #ifdef QGD_CHAIN_PROFILE   // scripts/ubench/chain_bench.hip: clock stamps of block 0 per step
