@@ -170,10 +170,6 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     constexpr bool ZERO = (MODE == 2 || MODE == 4);       // zero start, the final state is the block's affine part
     constexpr int NRB = NP / 16, NT = CHAIN_NT(MODE), KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
-    // the second B operand of a complex product, [-Bim | Bre] ([Bim | -Bre] for the adjoint), as its own panel: written
-    // once by the producer of a state instead of being formed by two vector instructions in front of every second MFMA
-    // of the consumer (beside a burst of f64 MFMAs each costs about a sixth of an MFMA slot: 77 -> 6x cycles per MFMA)
-    __shared__ __attribute__((aligned(16))) double part2[2][NG][NP * 16];
 
     if (MODE == 2 && a.t_on && blockIdx.x == gridDim.x - 1) {      // the extra workgroup: k_terminal's work
         terminal_block(a.t_hist, a.t_target, a.t_forcing, a.t_yhist, a.t_scal, NP, a.cp, a.t_nt, a.t_ness, a.t_have_target, 1,
@@ -248,6 +244,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     constexpr bool SKIP0 = (MODE == 0 || MODE == 2);
     const int first = (SKIP0 && total > 0) ? 1 : 0;
     double are[KST], aim[KST], fo[NG][4];
+    const double sgn2 = ((c16 < 8) != ADJ) ? -1.0 : 1.0;  // sign of the Aim [Bim|Bre] sum in this lane's output column
     double gw[4] = {0.0, 0.0, 0.0, 0.0};                 // guard weights of this lane's accumulator elements
     if (MODE == 1 && a.guard_diag) {
         #pragma unroll
@@ -350,7 +347,6 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             const int g = e / (NP * 16), el = e % (NP * 16), row = el >> 4, c = el & 15;
             const double v = sv[it];
             part[first][g][el] = v;
-            part2[first][g][el ^ 8] = (((c >= 8) != ADJ)) ? -v : v;
             if (MODE == 1 && a.guard_diag && s0 == 0 && !(a.npre > 0 && a.pre_kind[0] == 0)) {   // the window's first point is nobody's product
                 const double wv = (row < a.gN) ? a.guard_diag[row + ((c >= 8) ? a.gN : 0)] : 0.0;
                 const double trap = (a.n_off == 0) ? 0.5 : 1.0;
@@ -372,9 +368,12 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         CH_STAMP(0);
         const bool mainstep = st >= npfx;
         const int buf = st & 1, n = step_index(mainstep ? st - npfx : 0);
-        // B fragments of the whole step are read from LDS up front (NG * 2 * KST registers) and the products go to 2 * NA
-        // independent accumulators: with the reads issued one k-step ahead of their MFMAs and two dependent chains, an
-        // MFMA took 77-79 cycles instead of the pipe's 64 (scripts/ubench/chain_bench.hip -DQGD_CHAIN_PROFILE)
+        // C = Are [Bre|Bim] + Aim [-Bim|Bre]: the second right operand is the first with its halves swapped (the LDS address
+        // with c16 ^ 8) and a sign on one half.  The sign is the same for every k-step, so the two sums are kept apart and
+        // it is applied ONCE, to the finished sum: no vector instruction stands between the MFMAs of a step (a v_xor +
+        // v_cndmask in front of every second one cost about a sixth of an MFMA slot each beside the f64 MFMA stream:
+        // 77 cycles per MFMA instead of the pipe's 64, scripts/ubench/chain_bench.hip -DQGD_CHAIN_PROFILE).  The B fragments
+        // of the whole step are read from LDS up front.
         constexpr int NA = (NG == 1) ? 2 : 1;
         d4 acc[NG][2 * NA];
         #pragma unroll
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         for (int i = 0; i < KST; i++) {
             const int ko = (i * 4 + kk) * 16;
             #pragma unroll
-            for (int g = 0; g < NG; g++) { bv1[i][g] = part[buf][g][ko + c16]; bv2[i][g] = part2[buf][g][ko + c16]; }
+            for (int g = 0; g < NG; g++) { bv1[i][g] = part[buf][g][ko + c16]; bv2[i][g] = part[buf][g][ko + (c16 ^ 8)]; }
         }
         #pragma unroll
         for (int i = 0; i < KST; i++) {
@@ -403,12 +402,12 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
         for (int g = 0; g < NG; g++)
             #pragma unroll
             for (int r = 0; r < 4; r++) {
-                double v = acc[g][0][r] + acc[g][1][r];
-                if (NA == 2) v += acc[g][2][r] + acc[g][3][r];
+                double vre = acc[g][0][r], vim = acc[g][1][r];
+                if (NA == 2) { vre += acc[g][2][r]; vim += acc[g][3][r]; }
+                double v = __builtin_fma(sgn2, vim, vre);
                 if (FORC) v += fo[g][r];
                 res[g][r] = v;
                 part[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + c16] = v;
-                part2[buf ^ 1][g][(rb * 16 + kk + 4 * r) * 16 + (c16 ^ 8)] = ((c16 >= 8) != ADJ) ? -v : v;
             }
         CH_STAMP(2);
         lds_barrier(); done++;                            // the next team starts; the rest is off the critical path
