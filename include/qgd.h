@@ -104,10 +104,13 @@ int qgd_set_target(qgd_handle h, const double *target_real);
 int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff,
                           const double *const *Gp, const double *const *Gq);
 
-/* Controls, general path (any AbstractControl): the tables themselves for the
+/* Controls, general path (any AbstractControl, linear in pcof or not): the tables themselves for the
  * current pcof, Julia layout [(1+order/2), n_ops, nsteps+1] (the fill_p_mat!
- * output stacked over time points).  Pair with qgd_set_control_basis holding
- * the Jacobian at the current pcof when a gradient is wanted. */
+ * output stacked over time points).  For a gradient pair them with qgd_set_control_basis holding
+ * the Jacobian of the tables AT the current pcof (eval_grad_p_derivative! / eval_grad_q_derivative! over
+ * the grid), set the basis first, and call qgd_eval_forward / qgd_discrete_adjoint / qgd_eval_grad_forced /
+ * qgd_eval_adjoint with pcof = NULL: the device then steps with these tables and contracts its per-time-point
+ * gradient scalars with that Jacobian.  (With a non-NULL pcof the tables are basis * pcof: linear controls.) */
 int qgd_set_control_tables(qgd_handle h, const double *p_tables, const double *q_tables);
 
 /* eval_forward! (forward_evolution.jl:33-70).  pcof may be NULL when tables were

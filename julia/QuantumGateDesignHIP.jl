@@ -34,6 +34,8 @@ mutable struct DeviceProblem
     nsteps::Int
     basis_key::UInt
     pinned::Vector{Any}      # output arrays registered with the handle (kept alive until unregistered)
+    general::Bool            # controls that are not linear in pcof: tables + Jacobian per evaluation, NULL pcof
+    general_pcof::Vector{Float64}
 end
 
 function check(h, rc)
@@ -73,7 +75,7 @@ function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
         end
     end
     check(C_NULL, rc)
-    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0), Any[])
+    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0), Any[], false, Float64[])
     finalizer(x -> ccall((:qgd_destroy, libqgd), Cvoid, (Ptr{Cvoid},), x.handle), dp)
     return dp
 end
@@ -90,15 +92,21 @@ function pin!(dp::DeviceProblem, a::Array{Float64})
 end
 
 "Control basis G[n,d,l] = d/dpcof_l (p^(d)(t_n)/d!) from the package's own eval_grad_*_derivative!.
-The device path is exact only for controls that are LINEAR in pcof (every family the package ships is:
-B-splines with or without carriers, GRAPE, Hermite); AbstractControl is an open protocol
-(src/Controls/Control.jl:6-27), so linearity is probed -- the Jacobian must not depend on pcof -- and a
-non-linear control is refused instead of silently computing G(pcof)*pcof."
+Every family the package ships is LINEAR in pcof (B-splines with or without carriers, GRAPE, Hermite): the basis is
+uploaded once and an evaluation ships only pcof.  AbstractControl is an open protocol (src/Controls/Control.jl:6-27),
+so linearity is probed -- the Jacobian must not depend on pcof.  A control that fails the probe takes the GENERAL path
+of include/qgd.h: at every new pcof the tables (fill_p_mat!/fill_q_mat! over the grid, qgd_set_control_tables) and their
+Jacobian at that pcof (qgd_set_control_basis) are uploaded, and the evaluation is called with a NULL pcof.
+Returns the (pointer, length) to pass as pcof."
 function set_controls!(dp::DeviceProblem, prob, controls, pcof)
     key = hash((objectid(controls), prob.nsteps, prob.tf))
-    key == dp.basis_key && return
+    if key == dp.basis_key
+        dp.general || return (pointer(pcof), length(pcof))
+        dp.general_pcof == pcof && return (Ptr{Float64}(C_NULL), 0)
+    end
     m, nt, dt = div(dp.order, 2), prob.nsteps + 1, prob.tf / prob.nsteps
     Gp, Gq, ncoef = Vector{Array{Float64,3}}(), Vector{Array{Float64,3}}(), Int32[]
+    linear = true
     for k in 1:prob.N_operators
         c = controls[k]; nc = c.N_coeff; push!(ncoef, nc)
         gp, gq = zeros(nc, m + 1, nt), zeros(nc, m + 1, nt)
@@ -107,8 +115,7 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
         for n in (0, div(nt, 3), nt - 1), d in 0:m            # linearity probe at three time points
             for (f!) in (eval_grad_p_derivative!, eval_grad_q_derivative!)
                 f!(g1, c, n * dt, lp, d); f!(g2, c, n * dt, probe, d)
-                maximum(abs.(g1 .- g2)) <= 1e-12 * max(1.0, maximum(abs.(g1))) ||
-                    throw(ArgumentError("control $k is not linear in its coefficients: the device path needs a pcof-independent basis (use qgd_set_control_tables for the forward sweep only)"))
+                linear &= maximum(abs.(g1 .- g2)) <= 1e-12 * max(1.0, maximum(abs.(g1)))
             end
         end
         for n in 0:nt-1, d in 0:m
@@ -124,6 +131,17 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
               (Ptr{Cvoid}, Ptr{Int32}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), dp.handle, ncoef, pp, pq))
     end
     dp.basis_key = key
+    dp.general = !linear
+    linear && return (pointer(pcof), length(pcof))
+    # general path: the tables themselves, Julia layout [(1+m), N_operators, nsteps+1] (fill_p_mat! stacked over the grid)
+    pt, qt = zeros(m + 1, prob.N_operators, nt), zeros(m + 1, prob.N_operators, nt)
+    for n in 0:nt-1
+        QuantumGateDesign.fill_p_mat!(view(pt, :, :, 1 + n), controls, n * dt, pcof)
+        QuantumGateDesign.fill_q_mat!(view(qt, :, :, 1 + n), controls, n * dt, pcof)
+    end
+    check(dp.handle, ccall((:qgd_set_control_tables, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dp.handle, pt, qt))
+    dp.general_pcof = copy(pcof)
+    return (Ptr{Float64}(C_NULL), 0)
 end
 
 # Handle cache: at most MAX_HANDLES (a cnot3 handle holds ~300 MB of device memory), least recently used first out;
@@ -154,22 +172,22 @@ objective_terms(out3, N_ess) = (1 - (out3[1]^2 + out3[2]^2) / N_ess^2, out3[3])
 "Drop-in for eval_forward!(uv_history, prob, controls, pcof; order) -- src/forward_evolution.jl:33-70."
 function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, controls, pcof::Vector{Float64}; order::Int=2)
     dp = device_problem(prob, order)
-    set_controls!(dp, prob, controls, pcof)
+    pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     out3 = zeros(3)
-    check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
-          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pcof, length(pcof), uv_history, out3))
+    GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
+          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, uv_history, out3))
     return out3
 end
 
 "The objective without the history: what optimize_gate's eval_f needs (INTEGRATION.md section 2, variant B)."
 function hip_objective(prob::SchrodingerProb, controls, pcof::Vector{Float64}, target; order::Int=2)
     dp = device_problem(prob, order)
-    set_controls!(dp, prob, controls, pcof)
+    pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
     out3 = zeros(3)
-    check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
-          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pcof, length(pcof), C_NULL, out3))
+    GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
+          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, C_NULL, out3))
     return objective_terms(out3, prob.N_ess_levels)
 end
 
@@ -189,7 +207,7 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
         target::AbstractMatrix{<:Number}; order::Int=2, history_precomputed::Bool=false, cost_type=:Infidelity,
         lambda_derivatives::Bool=false)
     dp = device_problem(prob, order)
-    set_controls!(dp, prob, controls, pcof)
+    pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     set_cost_type!(dp, cost_type)
     shape = (prob.real_system_size, 1 + div(order, 2), 1 + prob.nsteps, prob.N_initial_conditions)
     for a in (history, lambda_history)
@@ -202,10 +220,10 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
     check(dp.handle, ccall((:qgd_set_lambda_derivatives, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, lambda_derivatives))
     out3 = zeros(3)
-    GC.@preserve history lambda_history adjoint_forcing begin
+    GC.@preserve pcof history lambda_history adjoint_forcing begin
         check(dp.handle, ccall((:qgd_discrete_adjoint, libqgd), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-              dp.handle, pcof, length(pcof), history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), out3))
+              dp.handle, pc_ptr, pc_len, history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), out3))
     end
     set_cost_type!(dp, :Infidelity)
     # (gradient; (infidelity, guard penalty) of this pcof -- with :Tracking / :Norm out3 is (cost, 0, guard penalty))
@@ -221,13 +239,13 @@ sensitivities, all control parameters in one device call.
 function hip_eval_grad_forced(prob::SchrodingerProb, controls, pcof::Vector{Float64},
         target::AbstractMatrix{<:Number}; order::Int=2, cost_type=:Infidelity)
     dp = device_problem(prob, order)
-    set_controls!(dp, prob, controls, pcof)
+    pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     set_cost_type!(dp, cost_type)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
     grad = zeros(length(pcof))
-    check(dp.handle, ccall((:qgd_eval_grad_forced, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}),
-          dp.handle, pcof, length(pcof), grad))
+    GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_grad_forced, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}),
+          dp.handle, pc_ptr, pc_len, grad))
     set_cost_type!(dp, :Infidelity)
     return grad
 end

@@ -462,6 +462,35 @@ def get_control_vector_slice(pcof, controls, control_index: int):
     return pcof[start:start + cl[control_index].N_coeff]
 
 
+def control_tables_general(controls, pcof, nsteps: int, tf: float, n_deriv: int):
+    """Any ``AbstractControl`` (Control.jl:6-27), linear in its coefficients or not, through its pointwise protocol:
+    the tables ``p[d, k, n] = p_k^(d)(t_n)/d!`` (what ``fill_p_mat!`` gives, Control.jl:125-149, stacked over the time
+    grid) and their Jacobians ``Gp[k][n, d, l] = d/dpcof_l`` of the same entries AT THIS pcof
+    (``eval_grad_p_derivative!``), which is what the discrete adjoint contracts its per-time-point scalars with.
+    Returns ``(p, q, Gp, Gq)``; ``p, q`` are ``[n_deriv+1, n_controls, nsteps+1]`` (Fortran order)."""
+    cl = as_control_list(controls)
+    pcof = np.asarray(pcof, float)
+    dt = tf / nsteps
+    nt = nsteps + 1
+    p = np.zeros((n_deriv + 1, len(cl), nt), order="F")
+    q = np.zeros_like(p, order="F")
+    Gp, Gq, off = [], [], 0
+    for k, c in enumerate(cl):
+        th = pcof[off:off + c.N_coeff]
+        gp = np.zeros((nt, n_deriv + 1, c.N_coeff)); gq = np.zeros_like(gp)
+        for n in range(nt):
+            t = n * dt
+            for d in range(n_deriv + 1):
+                f = 1.0 / math.factorial(d)
+                p[d, k, n] = f * c.eval_p_derivative(t, th, d)
+                q[d, k, n] = f * c.eval_q_derivative(t, th, d)
+                gp[n, d] = f * np.asarray(c.eval_grad_p_derivative(t, th, d), float)
+                gq[n, d] = f * np.asarray(c.eval_grad_q_derivative(t, th, d), float)
+        Gp.append(gp); Gq.append(gq)
+        off += c.N_coeff
+    return p, q, Gp, Gq
+
+
 def fill_p_mat(vals_mat, controls, t, pcof):
     """vals_mat[d, k] = p_k^(d)(t)/d!  (Control.jl:125-136)."""
     for k, c in enumerate(as_control_list(controls)):

@@ -1155,7 +1155,7 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
 int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad)
 {
     if (h) drop_graph(h);
-    if (!h || !pcof || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");     // (pcof may be NULL when the tables were set directly)
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");

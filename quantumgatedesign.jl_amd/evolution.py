@@ -134,7 +134,15 @@ class DeviceProblem:
         if key == self._basis_key:
             return
         if not all(getattr(c, "is_linear", False) for c in cl):
-            raise NotImplementedError("non-linear controls: use set_control_tables with explicit tables")
+            # general path (any AbstractControl): tables and their Jacobian at the current pcof are formed on the host
+            # from the pointwise protocol at every evaluation (_upload_general)
+            self._general = cl
+            self._general_pcof = None
+            self._basis_key = key
+            self._controls_keepalive = cl
+            self.n_pcof = int(sum(c.N_coeff for c in cl))
+            return
+        self._general = None
         Gp, Gq, _ = control_basis(cl, self.nsteps, self.tf, self.m)
         nco = np.array([c.N_coeff for c in cl], dtype=np.int32)
         gp_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gp])
@@ -143,6 +151,24 @@ class DeviceProblem:
         self._basis_key = key
         self._controls_keepalive = cl
         self.n_pcof = int(nco.sum())
+
+    def _upload_general(self, pcof):
+        """Non-linear controls: values and Jacobian of the control tables at this pcof (qgd.h: "Pair with
+        qgd_set_control_basis holding the Jacobian at the current pcof when a gradient is wanted")."""
+        pc = np.ascontiguousarray(pcof, dtype=np.float64)
+        if len(pc) != self.n_pcof:
+            raise ValueError("length of pcof does not match the controls")
+        if self._general_pcof is not None and np.array_equal(pc, self._general_pcof):
+            return
+        from .controls import control_tables_general
+        cl = self._general
+        p, q, Gp, Gq = control_tables_general(cl, pc, self.nsteps, self.tf, self.m)
+        nco = np.array([c.N_coeff for c in cl], dtype=np.int32)
+        gp_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gp])
+        gq_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gq])
+        _lib.check(self.h, self.lib.qgd_set_control_basis(self.h, _vp(nco), gp_ptrs, gq_ptrs))
+        _lib.check(self.h, self.lib.qgd_set_control_tables(self.h, _vp(p), _vp(q)))
+        self._general_pcof = pc.copy()
 
     def set_control_tables(self, p_tables, q_tables):
         p, q = _f(p_tables), _f(q_tables)
@@ -177,6 +203,9 @@ class DeviceProblem:
     def eval_forward(self, pcof=None, uv_history=None):
         _check_out(uv_history, self._hist_shape(), "uv_history")
         out3 = np.zeros(3)
+        if pcof is not None and getattr(self, "_general", None):
+            self._upload_general(pcof)
+            pcof = None                                   # (the tables are on the device)
         pc = None if pcof is None else np.ascontiguousarray(pcof, dtype=np.float64)
         _lib.check(self.h, self.lib.qgd_eval_forward(
             self.h, None if pc is None else _vp(pc), 0 if pc is None else len(pc),
@@ -185,6 +214,19 @@ class DeviceProblem:
 
     def discrete_adjoint(self, pcof, history_precomputed=False, uv_history=None, lambda_history=None,
                          adjoint_forcing=None):
+        if getattr(self, "_general", None):
+            self._upload_general(pcof)
+            _check_out(uv_history, self._hist_shape(), "history")
+            _check_out(lambda_history, self._hist_shape(), "lambda_history")
+            _check_out(adjoint_forcing, (2 * self.N, self.nsteps + 1, self.c), "adjoint_forcing")
+            grad = np.zeros(self.n_pcof)
+            out3 = np.zeros(3)
+            _lib.check(self.h, self.lib.qgd_discrete_adjoint(
+                self.h, None, 0, 1 if history_precomputed else 0, _vp(grad),
+                None if uv_history is None else _vp(uv_history),
+                None if lambda_history is None else _vp(lambda_history),
+                None if adjoint_forcing is None else _vp(adjoint_forcing), _vp(out3)))
+            return grad, out3
         if uv_history is None and lambda_history is None and adjoint_forcing is None and len(pcof) == self.n_pcof:
             # the optimiser's call: persistent host buffers with cached pointers (three ndarray.ctypes look-ups
             # cost 6 us, 1.5 % of a cnot3 evaluation)
@@ -212,13 +254,16 @@ class DeviceProblem:
         return grad, out3
 
     def eval_adjoint(self, pcof, terminal_condition, forcing=None):
+        if getattr(self, "_general", None):
+            self._upload_general(pcof)
+            pcof = np.zeros(0)                            # (NULL pcof: the tables are on the device)
         pc = np.ascontiguousarray(pcof, dtype=np.float64)
         term = _f(terminal_condition).reshape(2 * self.N, self.c, order="F")
         fo = None if forcing is None else _f(forcing)
         if fo is not None and fo.shape != (2 * self.N, self.nsteps + 1, self.c):
             raise ValueError(f"forcing must have shape {(2 * self.N, self.nsteps + 1, self.c)}")
         lam = np.zeros((2 * self.N, self.m + 1, self.nsteps + 1, self.c), order="F")
-        _lib.check(self.h, self.lib.qgd_eval_adjoint(self.h, _vp(pc), len(pc), _vp(term),
+        _lib.check(self.h, self.lib.qgd_eval_adjoint(self.h, _vp(pc) if len(pc) else None, len(pc), _vp(term),
                                                      None if fo is None else _vp(fo), _vp(lam)))
         return lam
 
@@ -268,6 +313,9 @@ class DeviceProblem:
     def eval_forward_forced(self, pcof, forcing, uv_history=None):
         """eval_forward with a forcing array ``[2N, order/2, 1+nsteps, n_cols]`` (Fortran order): the scaled
         Taylor coefficients of the forcing at every time point (forward_evolution.jl:118-129)."""
+        if getattr(self, "_general", None):
+            self._upload_general(pcof)
+            pcof = np.zeros(0)
         pcof = np.ascontiguousarray(pcof, dtype=np.float64)
         forcing = np.asfortranarray(forcing, dtype=np.float64)
         want = (2 * self.N, self.m, self.nsteps + 1, self.c)
@@ -275,12 +323,17 @@ class DeviceProblem:
             raise ValueError(f"forcing must have shape {want}")
         _check_out(uv_history, self._hist_shape(), "uv_history")
         out3 = np.zeros(3)
-        _lib.check(self.h, self.lib.qgd_eval_forward_forced(self.h, _vp(pcof), len(pcof), _vp(forcing),
+        _lib.check(self.h, self.lib.qgd_eval_forward_forced(self.h, _vp(pcof) if len(pcof) else None, len(pcof), _vp(forcing),
                                                              None if uv_history is None else _vp(uv_history), _vp(out3)))
         return out3
 
     def eval_grad_forced(self, pcof):
         """Gradient by forward sensitivities (eval_grad_forced.jl:17-194); needs controls and target."""
+        if getattr(self, "_general", None):               # tables and Jacobian at this pcof are uploaded; NULL pcof
+            self._upload_general(pcof)
+            grad = np.zeros(self.n_pcof)
+            _lib.check(self.h, self.lib.qgd_eval_grad_forced(self.h, None, 0, _vp(grad)))
+            return grad
         pcof = np.ascontiguousarray(pcof, dtype=np.float64)
         grad = np.zeros(len(pcof))
         _lib.check(self.h, self.lib.qgd_eval_grad_forced(self.h, _vp(pcof), len(pcof), _vp(grad)))

@@ -90,3 +90,47 @@ def synthetic_case(qgd, N=100, c=20, n_ops=4, nsteps=24, tf=0.5, seed=5):
     pcof = rng.random(qgd.get_number_of_control_parameters(ctrl))
     target = rng.random((N, c)) + 1j * rng.random((N, c))
     return prob, ctrl, pcof, target
+
+
+class SineControl:
+    """A control that is NOT linear in its coefficients theta = (A, omega, phi): p(t) = A sin(omega t + phi),
+    q(t) = A/2 cos(omega t + phi) -- the reference's AbstractControl protocol is open (Control.jl:6-27), its in-tree
+    families just happen to be linear.  Pointwise protocol only (unscaled time derivatives and their gradients)."""
+    is_linear = False
+    N_coeff = 3
+
+    def __init__(self, tf):
+        self.tf = float(tf)
+
+    def _arg(self, t, th, d):
+        return th[1] * t + th[2] + d * np.pi / 2
+
+    def eval_p_derivative(self, t, th, d):
+        return th[0] * th[1] ** d * np.sin(self._arg(t, th, d))
+
+    def eval_q_derivative(self, t, th, d):
+        return 0.5 * th[0] * th[1] ** d * np.cos(self._arg(t, th, d))
+
+    def eval_grad_p_derivative(self, t, th, d):
+        A, w, _ = th
+        s, c = np.sin(self._arg(t, th, d)), np.cos(self._arg(t, th, d))
+        return np.array([w ** d * s, A * (d * w ** (d - 1) if d else 0.0) * s + A * w ** d * t * c, A * w ** d * c])
+
+    def eval_grad_q_derivative(self, t, th, d):
+        A, w, _ = th
+        s, c = np.sin(self._arg(t, th, d)), np.cos(self._arg(t, th, d))
+        return 0.5 * np.array([w ** d * c, A * (d * w ** (d - 1) if d else 0.0) * c - A * w ** d * t * s, -A * w ** d * s])
+
+
+class PointwiseOnly:
+    """Any control seen through its pointwise protocol only (is_linear = False): sends a linear family down the
+    general path, where it must reproduce the basis path."""
+    is_linear = False
+
+    def __init__(self, inner):
+        self.inner, self.N_coeff, self.tf = inner, inner.N_coeff, inner.tf
+
+    def eval_p_derivative(self, t, th, d): return self.inner.eval_p_derivative(t, th, d)
+    def eval_q_derivative(self, t, th, d): return self.inner.eval_q_derivative(t, th, d)
+    def eval_grad_p_derivative(self, t, th, d): return self.inner.eval_grad_p_derivative(t, th, d)
+    def eval_grad_q_derivative(self, t, th, d): return self.inner.eval_grad_q_derivative(t, th, d)

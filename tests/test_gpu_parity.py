@@ -895,3 +895,36 @@ def test_baseline_configs_full_size_vs_oracle(qgd, orc, which):
     assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-11 * np.abs(lam_ref[:, 0]).max()
     assert np.abs(grad - g_ref).max() <= GRAD_RTOL * np.abs(g_ref).max()
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("order", [4, 8])
+def test_nonlinear_controls_general_path(qgd, order):
+    """Controls that are not linear in their coefficients (the AbstractControl protocol is open, Control.jl:6-27): the
+    tables and their Jacobian at the current pcof come from the pointwise protocol (qgd_set_control_tables +
+    qgd_set_control_basis, NULL pcof).  (1) A linear family seen through its pointwise protocol only reproduces the basis
+    path: history bitwise-close, gradient to 1e-13.  (2) A sine control with amplitude, frequency and phase as
+    coefficients: adjoint = forced on the device, both = centred differences, history_precomputed reuse."""
+    prob, ctrl, pcof, target = cases.guarded_case(qgd, nsteps=24, tf=8.0)
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    h_lin = np.zeros(shape, order="F"); h_gen = np.zeros(shape, order="F")
+    g_lin = np.zeros(len(pcof)); g_gen = np.zeros(len(pcof))
+    qgd.discrete_adjoint_(g_lin, h_lin, None, None, prob, ctrl, pcof, target, order=order)
+    wrapped = [cases.PointwiseOnly(c) for c in ctrl]
+    qgd.discrete_adjoint_(g_gen, h_gen, None, None, prob, wrapped, pcof, target, order=order)
+    assert np.abs(h_gen - h_lin).max() <= 1e-13 * max(1.0, np.abs(h_lin).max())
+    assert np.abs(g_gen - g_lin).max() <= 1e-13 * np.abs(g_lin).max()
+    # (2)
+    sines = [cases.SineControl(prob.tf), cases.SineControl(prob.tf)]
+    th = np.array([0.08, 1.3, 0.4, 0.05, 0.7, -1.1])
+    g_adj = qgd.discrete_adjoint(prob, sines, th, target, order=order)
+    g_for = qgd.eval_grad_forced(prob, sines, th, target, order=order)
+    g_fd = qgd.eval_grad_finite_difference(prob, sines, th, target, order=order, dpcof=1e-6)
+    scale = np.abs(g_adj).max()
+    assert np.abs(g_for - g_adj).max() <= 1e-11 * scale
+    assert np.abs(g_fd - g_adj).max() <= 1e-7 * max(1.0, scale)
+    dp = qgd.device_problem(prob, order)
+    dp.set_controls(sines); dp.set_target(target)
+    dp.eval_forward(th)
+    g_pre, _ = dp.discrete_adjoint(th, history_precomputed=True)
+    assert np.abs(g_pre - g_adj).max() <= 1e-13 * scale
+    qgd.clear_cache()
