@@ -1,5 +1,7 @@
+"""Per-phase device times (HIP events, every phase bracketed) of the cnot3 headline evaluation, mean of 10 evaluations;
+QGD_LIB_PATH selects another build of the library (knock-out / profiling builds)."""
 import os, sys, time
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from __graft_entry__ import import_package
