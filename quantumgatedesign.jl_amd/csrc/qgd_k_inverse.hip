@@ -364,7 +364,11 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
     bool used = lane >= NP;                             // panel wave: this lane's row has been a pivot row
     // which wave factors the panels (rotating it differently across workgroups that share a CU, e.g. with
     // blockIdx/256, changes nothing: 108-111 us for 550 matrices either way)
+#ifdef QGD_INV_PW_FIXED          // (experiment: the panel wave has the same index in every workgroup)
+    const int pw = QGD_INV_PW_FIXED;
+#else
     const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
+#endif
 
     for (int pn = 0; pn < NP / 4; pn++) {
         const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
@@ -450,12 +454,17 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             const int arow = 16 * w + c16;
             const double are = Gre[arow * 4 + kk] - ((arow == rho[p0 + kk]) ? 1.0 : 0.0);
             const double aim = Gim[arow * 4 + kk];
+#ifdef QGD_INV_KO_PW_MFMA         // (timing experiment, wrong results: the panel wave issues no MFMA)
+            if (w != pw)
+#endif
+            {
             #pragma unroll
             for (int g = 0; g < NG; g++) {
                 double b1, b2;
                 panel_b(Pr + kk * PW + 16 * g, c16, b1, b2);
                 M[g] = MFMA(are, b1, M[g]);
                 M[g] = MFMA(aim, b2, M[g]);
+            }
             }
             const int s = (c16 & 7) - q0;
             if (s >= 0 && s < 4) {
@@ -513,6 +522,9 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             }
         }
 #ifndef QGD_INV_KO_PRODUCT      // (knock-out experiments of scripts/ubench/inverse_bench.hip: timing only, wrong results)
+#ifdef QGD_INV_KO_PW_MFMA
+        if (w != pw)
+#endif
         #pragma unroll 4
         for (int ks = 0; ks < NP / 4; ks++) {
             const int k = 4 * ks + kk;
