@@ -928,3 +928,27 @@ def test_nonlinear_controls_general_path(qgd, order):
     g_pre, _ = dp.discrete_adjoint(th, history_precomputed=True)
     assert np.abs(g_pre - g_adj).max() <= 1e-13 * scale
     qgd.clear_cache()
+
+
+def test_long_grid_vs_statement(qgd):
+    """cnot3 on a grid eight times the headline's (4400 steps at dt = 1: scan blocks of 69 steps, the inverse at 17
+    matrices per CU) against the numpy statement of the algorithm: state history, infidelity, guard penalty, gradient."""
+    nsteps = 4400
+    prob, target = qgd.cnot3_problem(nsteps=nsteps, tf=float(nsteps))
+    ctrl = cases.cnot3_controls(qgd, prob)
+    npar = qgd.get_number_of_control_parameters(ctrl)
+    pcof = (np.random.default_rng(3).random(npar) - 0.5) * 2 * np.pi * 0.005
+    order = 8
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    dp = qgd.device_problem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    hist = np.zeros((128, 5, nsteps + 1, 8), order="F")
+    grad, out3 = dp.discrete_adjoint(pcof, False, hist)
+    href = pp.history_real(ref["ws"])
+    assert np.abs(hist[:, 0] - href[:, 0]).max() <= 1e-10
+    assert np.abs(hist - href).max() <= 1e-10 * max(1.0, np.abs(href).max())
+    assert np.abs(grad - ref["grad"]).max() <= GRAD_RTOL * np.abs(ref["grad"]).max()
+    infid = 1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2
+    assert abs(infid - ref["infidelity"]) <= 1e-11 and abs(out3[2] - ref["guard"]) <= 1e-11
+    qgd.clear_cache()
