@@ -71,6 +71,8 @@ struct qgd_handle_s {
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
     std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
     bool copies_pending = false;
+    bool forcing_zero = false;          // no guard projector: the adjoint forcing is all zeros and nothing has written it since
+                                        // (alloc_grid clears it, qgd_eval_adjoint uploads a caller's forcing into it)
     bool defer_terminal = false;        // a full gradient evaluation: the overlaps and y_N ride in the first adjoint launch
     double *lambda_out = nullptr;       // lambda_history of the evaluation in flight (copied out right after the lambda phase)
     // Time-chunk pipeline of the front of an evaluation (sparse path, N = 64).  build_LR, inverse+propagator and the
@@ -279,6 +281,7 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipMemsetAsync(k.yhist, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.forcing, 0, nt * hstep * sizeof(double), k.stream));
+    h->forcing_zero = true;
     if (k.blk_lo == 0)   // the first window starts at the (constant) initial state
         HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     // Hermite weights c_j dt^j and c_j (-dt)^j  (hermite.jl:398-399, :422-423)
@@ -542,7 +545,12 @@ int forward_end(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
-    if (!qgdk_guard_is_fused(&k)) { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k)); }   // else: done by the history pass
+    if (k.have_guard == 0 && h->forcing_zero) {
+        // nothing to do: without a guard projector the kernel only re-clears the forcing (6 us of the 100 us of a cnot2 evaluation)
+    } else if (!qgdk_guard_is_fused(&k)) {
+        PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k));      // else: done by the history pass
+        if (k.have_guard == 0) h->forcing_zero = true;
+    }
     if (k.part_rank == k.part_world - 1 && !h->defer_terminal) {   // the rank that owns the final time
         PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target));
     }
@@ -1244,6 +1252,7 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
             }
     }
     HIP_TRY(h, hipMemcpyAsync(k.forcing, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    h->forcing_zero = false;
     HIP_TRY(h, hipMemcpyAsync(k.lam + (nt - 1) * hstep, lamN.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     // y_N = L(t_N)^H lambda_N  (the terminal condition is lambda itself here, forward_evolution.jl:411-414)
     K_TRY(h, qgdk_apply_LH(&k));

@@ -1624,6 +1624,15 @@ extern "C" {
 int qgdk_inverse(const qgdk_ctx *c)
 {
     const int nmat = c->nt - 1;
+    // Np = 16, 32, 48: the same fused MFMA kernel as Np = 64 (one wave per 16 rows; inverse and propagator in one launch:
+    // cnot2 17.7 + 6.5 us for k_inverse_reg + k_propagator -> see DESIGN.md section 7); QGD_INVERSE_VALU=1 keeps the older pair
+    if (!getenv("QGD_INVERSE_VALU") && nmat > 0) switch (c->Np) {
+#define CALL_IMF(N) case N: hipLaunchKernelGGL((k_inverse_mfma<N>), dim3(nmat), dim3(N * 4), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status); \
+                            return (int)hipGetLastError()
+        CALL_IMF(16); CALL_IMF(32); CALL_IMF(48);
+#undef CALL_IMF
+        default: break;
+    }
     switch (c->Np) {
     case 16: SET_LDS_ONCE((k_inverse_reg<16, 16>), 2176); hipLaunchKernelGGL((k_inverse_reg<16, 16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
@@ -1696,7 +1705,7 @@ int qgdk_inverse(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
-int qgdk_propagator_is_fused(const qgdk_ctx *c) { return c->Np == 64 && !getenv("QGD_INVERSE_VALU"); }
+int qgdk_propagator_is_fused(const qgdk_ctx *c) { return (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64) && !getenv("QGD_INVERSE_VALU"); }
 
 int qgdk_propagator(const qgdk_ctx *c)
 {

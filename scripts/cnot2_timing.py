@@ -1,11 +1,12 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from __graft_entry__ import import_package
 import cases
 qgd = import_package()
-for order in (2, 4, 6, 8, 10):
-    prob, ctrl, pcof, target = cases.cnot2_case(qgd)
+for order in ((8,) if os.environ.get('QGD_CNOT2_ORDER8') else (2, 4, 6, 8, 10)):
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=100, tf=100.0)
     dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
     dp.set_timing(1)
     for _ in range(3): dp.discrete_adjoint(pcof)
