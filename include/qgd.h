@@ -243,7 +243,8 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
 /* eval_grad_forced (src/eval_grad_forced.jl:17-194): the same gradient by forward sensitivities --
  * one forced forward sweep per control parameter, all parameters batched as extra column groups of
  * the blocked scan.  The reference's cross-check of the discrete adjoint (agreement to rounding).
- * Needs qgd_set_control_basis and qgd_set_target; N <= 64; single GPU. */
+ * Needs qgd_set_control_basis and qgd_set_target; N <= 64; single GPU.  pcof may be NULL when the tables were set
+ * directly (general control path: the basis then holds the Jacobian at the current pcof).  Honours qgd_set_cost_type. */
 int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad);
 
 /* Operator path of the step-matrix and gradient kernels.  mode 0: automatic (sparse when every
