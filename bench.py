@@ -30,7 +30,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP64_MATRIX_TFLOPS = 78.6   # MI355X fp64 matrix = vector peak (spec); 256 CU * 4 SIMD * 2.4 GHz * 32 flop/clk
-RUN_IN_STEPS = 60                # untimed evaluations between the W warm-up steps and the K timed ones (clock ramp and boost, see main())
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -137,9 +136,9 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
     """Oracle ('port' of the reference CPU path; Julia is not in the image) on bounded samples of the same
     workload: cnot3 order 8 at dt=1, GMRES tolerance 1e-12 (examples/cnot3_optimize_gate.jl:12-19), columns in parallel
     as the reference's Threads.@threads (forward_evolution.jl:48,332), gradient accumulation serial
-    (eval_grad_discrete_adjoint.jl:148-157).  The headline object is the 8-thread dense-operator figure (regression.jl:30
-    builds dense operators); `variants` adds what BASELINE.md section 2 lists: one thread (the author's cluster runs,
-    cnot3_optimize_gate.sb:7), CSC operators (DispersiveProblem's default sparse_rep=true), and C2 (cnot2, order 8)."""
+    (eval_grad_discrete_adjoint.jl:148-157).  The headline object is the 8-thread CSC-operator figure (DispersiveProblem's
+    default sparse_rep=true; the faster CPU form); `variants` adds what BASELINE.md section 2 lists: dense operators
+    (regression.jl:30), one thread (the author's cluster runs, cnot3_optimize_gate.sb:7), and C2 (cnot2, order 8)."""
     import numpy as np
     import cases
     cores = os.cpu_count() or 1
@@ -155,9 +154,11 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
         prob.gmres_abstol = prob.gmres_reltol = 1e-12
         return prob, ctrl, pcof, target, 100
 
-    head = _oracle_rate(qgd, orc, cnot3, 8, threads, False, seconds_target)
+    # headline object: CSC operators -- what the reference's DispersiveProblem builds by default (sparse_rep=true,
+    # multi_qudit_systems.jl:118-162) and the faster of the two CPU forms; the dense form of regression.jl:30 beside it
+    head = _oracle_rate(qgd, orc, cnot3, 8, threads, True, seconds_target)
     variants = {}
-    for name, case, th, sp, budget in (("cnot3_dense_1thread", cnot3, 1, False, 4.0), ("cnot3_csc_%dthreads" % threads, cnot3, threads, True, 4.0),
+    for name, case, th, sp, budget in (("cnot3_dense_%dthreads" % threads, cnot3, threads, False, 6.0), ("cnot3_dense_1thread", cnot3, 1, False, 4.0),
                                        ("cnot3_csc_1thread", cnot3, 1, True, 4.0), ("cnot2_order8_csc_1thread", cnot2, 1, True, 2.0),
                                        ("cnot2_order8_csc_4threads", cnot2, min(4, cores), True, 2.0)):
         try:
@@ -166,7 +167,8 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
             variants[name] = {"error": repr(exc)}
     return {
         "value": head["value"], "unit": "timesteps/s", "cores": threads, "kind": "port",
-        "sample": f"cnot3 order 8, dt=1, {head['timesteps']} of 550 timesteps, all 8 columns, dense operators, GMRES tol 1e-12, "
+        "operators": "CSC",
+        "sample": f"cnot3 order 8, dt=1, {head['timesteps']} of 550 timesteps, all 8 columns, CSC (SparseMatrixCSC) operators, GMRES tol 1e-12, "
                   f"{threads} threads over columns (gradient accumulation serial as in the reference); "
                   f"mean GMRES iterations fwd {head['gmres_iters_fwd']} adj {head['gmres_iters_adj']}",
         "seconds": head["seconds"], "host_cores": cores, "variants": variants,
@@ -176,7 +178,24 @@ def cpu_baseline(qgd, orc, seconds_target=10.0):
 C5_GRAD_NORM_1GPU = 3454.7659605167805     # |grad| of the C5 workload on one GPU (profiles/r02_bench.json): what a partitioned run must reproduce
 
 
-def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3, shard="time"):
+def make_partitioned(qgd, args, prob, order, ctrl, target, rank, world, local_rank, uid):
+    """One rank's evaluator of a partitioned evaluation.  Default (--comm lib): RCCL inside the library, the call is
+    the plain qgd_discrete_adjoint.  --comm torch: the older route, phase hooks + torch.distributed collectives."""
+    import torch
+    if args.comm == "lib":
+        return qgd.RcclEvaluation(prob, order, ctrl, target, rank, world, uid(), shard=args.shard, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    if args.shard == "columns":
+        back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=stream)
+        dp = qgd.ColumnSharded(back, qgd.TorchComm())
+    else:
+        back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=stream)
+        dp = qgd.TimePartitioned(back, qgd.TorchComm())
+    dp.timings, dp.close, dp.set_timing = back.timings, back.close, back.set_timing
+    return dp
+
+
+def large_n_partitioned(qgd, np, args, rank, world, local_rank, uid, steps=3):
     """The same C5 evaluation spread over the ranks by time windows (strong scaling: the configuration where the
     windows can pay); every rank holds the reduced gradient, rank 0 reports."""
     import torch
@@ -186,13 +205,9 @@ def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3, shard="time")
     ctrl = [qgd.FortranBSplineControl(16, 20, prob.tf) for _ in range(n_ops)]
     pcof = np.random.default_rng(5).random(qgd.get_number_of_control_parameters(ctrl))
     target = prob.u0 + 1j * prob.v0
-    if shard == "columns":
-        back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        dp = qgd.ColumnSharded(back, qgd.TorchComm())
-    else:
-        back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        dp = qgd.TimePartitioned(back, qgd.TorchComm())
-    back.set_timing(0)
+    shard = args.shard
+    dp = make_partitioned(qgd, args, prob, order, ctrl, target, rank, world, local_rank, uid)
+    dp.set_timing(0)
     dp.discrete_adjoint(pcof)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -202,7 +217,7 @@ def large_n_partitioned(qgd, np, rank, world, local_rank, steps=3, shard="time")
     tm = torch.tensor([time.perf_counter() - t0], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     sec = float(tm.item()) / steps
-    back.close()
+    dp.close()
     gn = float(np.linalg.norm(grad))
     return {"workload": f"C5 synthetic: N={N}, 256 columns, {n_ops} control operators, order {order}, nsteps={nsteps}, "
                         f"{'time windows' if shard == 'time' else 'column blocks'} over {world} GPUs", "scaling": "strong", "timesteps_per_s": nsteps / sec,
@@ -255,23 +270,77 @@ def large_n_case(qgd, np, steps=3):
             "gradient_vs_central_difference_rel": fd_rel}
 
 
+def cnot2_case_gpu(qgd, np, steps=50):
+    """BASELINE.json configs[1] (C2: 2-qubit CNOT of examples/cnot2_optimization.jl:10-47, N=4, 4 columns, order 8,
+    tf=100, nsteps=100) on the GPU: north_star asks for the cnot2 rate beside the cnot3 one.  A 12-launch chain of
+    latency-bound kernels on 101 time points (bring-up configuration, not a throughput one)."""
+    import torch
+    import cases
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=100, tf=100.0, amp=1e-2)
+    dp = qgd.DeviceProblem(prob, 8, device=0)
+    dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(0)
+    for _ in range(5):
+        dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        grad, out3 = dp.discrete_adjoint(pcof)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    dp.close()
+    return {"workload": "cnot2 (examples/cnot2_optimization.jl): N=4, 4 columns, 2 controls x 22 coeffs, Hermite order 8, tf=100, nsteps=100",
+            "timesteps_per_s": 100 / sec, "ms_per_evaluation": sec * 1e3, "evaluations_timed": steps,
+            "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2), "grad_norm": float(np.linalg.norm(grad))}
+
+
+def executed_gflop(N, c, m, n_ops, nsteps, blocks, blen, sparse_ops):
+    """Real flops one cnot3-shaped evaluation EXECUTES on the N <= 64 path: Gauss-Jordan inverse +
+    L^-1 R (2 complex N^3 products per step), the matrix-matrix products of the two scan levels, the matrix-panel
+    products of the history passes with their prefixes, the affine parts, lambda, and the step-matrix build and
+    gradient kernels (fp64 vector ALU on the sparse path: counted from the ELL entry counts; MFMA GEMMs on the dense)."""
+    cg, ap = 8.0 * N ** 3, 8.0 * N * N * max(c, 8)
+    B = max(1, blocks)
+    B2 = max(1, int(round((2.0 * B) ** 0.5))) if B > 8 else 1
+    g = (B + B2 - 1) // B2
+    inv = nsteps * 2 * cg
+    scan_mm = (nsteps - B) * cg + (B - B2 if B2 > 1 else 0) * cg
+    hist_fwd = (nsteps + 3 * B * (B2 + 2)) * ap                   # own steps + prefixes of the 3-step sub-block workgroups
+    hist_adj = (nsteps + B * (B2 + g)) * ap
+    affine = (nsteps + B) * ap
+    lam = nsteps * ap
+    if sparse_ops:
+        build, grad = 0.76e9 * nsteps / 550.0, 0.35e9 * nsteps / 550.0
+    else:
+        build = (nsteps + 1) * (m * (m - 1) / 2) * cg
+        grad = (nsteps + 1) * (m * (m - 1) + n_ops * m) * ap
+    return (inv + scan_mm + hist_fwd + hist_adj + affine + lam + build + grad) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--run-in", type=int, default=0,
+                    help="extra untimed evaluations after the W warm-up steps (the card's clocks settle after ~20 ms of work, "
+                         "scripts/clock_profile.py); 0 = the contract's plain 'W warm-up, K timed'; recorded as run_in_steps")
     ap.add_argument("--nsteps", type=int, default=550, help="timesteps of the workload (tf = nsteps, dt = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-n", action="store_true", help="skip the secondary C5 (N=256) measurement")
+    ap.add_argument("--no-cnot2", action="store_true", help="skip the secondary C2 (cnot2) measurement")
     ap.add_argument("--no-with-history", action="store_true", help="skip the secondary measurement with the three output arrays "
                                                                    "(profiling runs: keeps the kernel statistics to the headline evaluation)")
     ap.add_argument("--force-dist", action="store_true", help="use the partitioned path even with one rank (plumbing check)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI, the product path) or gloo "
+    ap.add_argument("--comm", default="lib", choices=["lib", "torch"],
+                    help="N > 1: who issues the collectives -- lib (default): RCCL inside libqgd_hip.so (qgd_comm_init_rccl; the "
+                         "process group is gloo and carries only the 128-byte id, the barrier and the max over ranks of the "
+                         "elapsed time); torch: the phase hooks + torch.distributed collectives (--backend)")
+    ap.add_argument("--backend", default="nccl", help="--comm torch: torch.distributed backend, nccl (= RCCL) or gloo "
                                                       "(plumbing check of the multi-process protocol; collectives staged through the host)")
     ap.add_argument("--shard", default="time", choices=["time", "columns"],
                     help="N > 1: how ONE evaluation is split over the ranks -- time windows (default: 2 all-gathers + 1 all-reduce) or the "
                          "reference's thread axis, blocks of initial-condition columns (2 all-reduces; the step matrices are built on every rank)")
-    ap.add_argument("--oversubscribe", action="store_true", help="let several ranks share a GPU (test boxes with one GPU; with --backend gloo)")
+    ap.add_argument("--oversubscribe", action="store_true", help="let several ranks share a GPU (test boxes with one GPU; with --comm torch --backend gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -301,30 +370,43 @@ def main():
     use_dist = world > 1 or args.force_dist
     if args.oversubscribe:
         local_rank %= max(torch.cuda.device_count(), 1)
+    pg_backend = "gloo" if args.comm == "lib" else args.backend
     if use_dist:
         import datetime
         torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-            kw = dict(device_id=torch.device("cuda", local_rank)) if args.backend == "nccl" else {}
-            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
+            kw = dict(device_id=torch.device("cuda", local_rank)) if pg_backend == "nccl" else {}
+            dist.init_process_group(pg_backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
     n_gpus = max(world, 1)
 
     qgd = import_package()
+
+    def uid():
+        """a fresh RCCL id from rank 0 (one per communicator), carried to the other ranks by the process group"""
+        t = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(qgd.comm_unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            if pg_backend == "nccl":
+                t = t.cuda(); dist.broadcast(t, 0); t = t.cpu()
+            else:
+                dist.broadcast(t, 0)
+        return bytes(t.numpy().tobytes())
+
+    def max_over_ranks(sec):
+        if not use_dist:
+            return sec
+        t = torch.tensor([sec], device="cuda" if pg_backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     prob, ctrl, pcof, target = workload(qgd, args.nsteps, float(args.nsteps))
     order = 8
     if use_dist:
-        # time-partitioned: one problem spread over the ranks (strong scaling), DESIGN.md "Multi-GPU"
-        if args.shard == "columns":
-            back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank,
-                                     stream=torch.cuda.current_stream().cuda_stream)
-            dp = qgd.ColumnSharded(back, qgd.TorchComm())
-        else:
-            back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank,
-                                     stream=torch.cuda.current_stream().cuda_stream)
-            dp = qgd.TimePartitioned(back, qgd.TorchComm())
-        dp.timings, dp.close, dp.set_timing = back.timings, back.close, back.set_timing
+        # ONE problem spread over the ranks (strong scaling), DESIGN.md "Multi-GPU"
+        dp = make_partitioned(qgd, args, prob, order, ctrl, target, rank, world, local_rank, uid)
     else:
         dp = qgd.DeviceProblem(prob, order, device=0)
         dp.set_controls(ctrl)
@@ -349,18 +431,15 @@ def main():
             continue                      # first call pays one-time launch/JIT costs
         for k, v in dp.timings().items():
             breakdown[k] = breakdown.get(k, 0.0) + v / (nwarm - 1)
-    path = dp.operator_path() if hasattr(dp, "operator_path") else ("sparse", 0, 0)
+    inner = getattr(dp, "dp", dp)
+    path = inner.operator_path() if hasattr(inner, "operator_path") else ("sparse", 0, 0)
     model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1,
                         sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in breakdown))
     dom_raw = max((k for k in breakdown if k in model), key=breakdown.get)
-    dp.set_timing(2, dom_raw)
-    dp.discrete_adjoint(pcof)
-    # Clock state: after idle the card needs ~7 ms of work to leave its low clocks, then boosts for ~15 ms before it
-    # settles (scripts/clock_profile.py: 345 / 327 / 335 us per evaluation in chunks of 20).  The W warm-up steps of the
-    # contract (5 evaluations = 2 ms) end inside the ramp, so a fixed untimed run-in follows them and the K timed steps
-    # measure the settled rate an optimizer loop sees.  Reported as `run_in_steps`.
+    # (these warm-up evaluations ARE the contract's W: the breakdown is read from them, no further untimed work follows
+    # unless --run-in asks for it)
     dp.set_timing(0)
-    for _ in range(RUN_IN_STEPS):
+    for _ in range(args.run_in):
         dp.discrete_adjoint(pcof)
     phase_ms = {}
     barrier()
@@ -377,11 +456,20 @@ def main():
             for k, v in dp.timings().items():
                 phase_ms[k] = phase_ms.get(k, 0.0) + v
     barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    part_info = getattr(inner, "partition", None)
+    # the collectives of one evaluation, timed by HIP events on the library's stream (--comm lib)
+    comm_ms = None
+    if use_dist and args.comm == "lib":
+        dp.set_timing(1)
+        acc = {}
+        for _ in range(5):
+            dp.discrete_adjoint(pcof)
+            for k, v in dp.timings().items():
+                if k.startswith("comm_"):
+                    acc[k] = acc.get(k, 0.0) + v / 5
+        comm_ms = {k: round(v, 4) for k, v in acc.items()}
+        dp.set_timing(0)
     # N > 1, beside the strong-scaling `value`: the same evaluation on a time grid that grows with the rank count
     # (nsteps = 550 per GPU, dt unchanged), i.e. per-GPU work fixed -- where a 0.44 ms evaluation has no more
     # per-rank latency to give, this is what the time-window partition is for.  Reported as `weak_in_time`.
@@ -391,10 +479,8 @@ def main():
             dp.close()
             nsteps_w = args.nsteps * world
             prob_w, ctrl_w, pcof_w, target_w = workload(qgd, nsteps_w, float(nsteps_w))
-            back_w = qgd.DeviceBackend(prob_w, order, ctrl_w, target_w, rank, world, device=local_rank,
-                                       stream=torch.cuda.current_stream().cuda_stream)
-            dpw = qgd.TimePartitioned(back_w, qgd.TorchComm())
-            back_w.set_timing(0)
+            dpw = make_partitioned(qgd, args, prob_w, order, ctrl_w, target_w, rank, world, local_rank, uid)
+            dpw.set_timing(0)
             for _ in range(max(args.warmup, 2)):
                 dpw.discrete_adjoint(pcof_w)
             barrier()
@@ -402,11 +488,10 @@ def main():
             for _ in range(args.steps):
                 dpw.discrete_adjoint(pcof_w)
             barrier()
-            tw = torch.tensor([time.perf_counter() - t2], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            weak = {"nsteps": nsteps_w, "value": nsteps_w * args.steps / float(tw.item()), "unit": "timesteps/s",
-                    "ms_per_step": float(tw.item()) / args.steps * 1e3, "scaling": "weak"}
-            back_w.close()
+            tw = max_over_ranks(time.perf_counter() - t2)
+            weak = {"nsteps": nsteps_w, "value": nsteps_w * args.steps / tw, "unit": "timesteps/s",
+                    "ms_per_step": tw / args.steps * 1e3, "scaling": "weak"}
+            dpw.close()
         except Exception as exc:      # the secondary number must never cost the headline one
             weak = {"error": repr(exc)}
     # forward-only (eval_forward: tables .. history, guard, overlaps), reported beside the metric
@@ -454,7 +539,7 @@ def main():
     large_dist = None
     if use_dist and world > 1 and not args.no_large_n:
         try:
-            large_dist = large_n_partitioned(qgd, np, rank, world, local_rank, shard=args.shard)
+            large_dist = large_n_partitioned(qgd, np, args, rank, world, local_rank, uid)
         except Exception as exc:
             large_dist = {"error": repr(exc)}
 
@@ -474,26 +559,46 @@ def main():
         else:
             achieved = work / (timed[dom] * 1e-3) / 1e9
             peak, unit = PEAK_HBM_GBS, "GB/s"
-        # N > 1: ONE evaluation is spread over the ranks by time windows (strong scaling)
+        # N > 1: ONE evaluation is spread over the ranks (strong scaling)
         total_timesteps = args.nsteps * args.steps
+        sec_eval = elapsed / args.steps
         traffic, traffic_source = measured_traffic(dom)
+        N_, c_, m_ = prob.N_tot_levels, prob.N_initial_conditions, order // 2
+        # the only HBM-proportional term of the ALGORITHM is the history stream, written once and read
+        # once: B_step = 2*16*N*(1+m)*c + 2*16*N*c bytes per timestep
+        b_step = 2 * 16 * N_ * (1 + m_) * c_ + 2 * 16 * N_ * c_
+        hs = b_step * args.nsteps / sec_eval / 1e9
+        blocks = part_info["blocks"] if part_info else min(64, int(round(args.nsteps ** (2.0 / 3.0))))
+        blen = part_info["block_len"] if part_info else -(-args.nsteps // max(blocks, 1))
+        gflop = executed_gflop(N_, c_, m_, prob.N_operators, args.nsteps, -(-args.nsteps // blen), blen, path[0] == "sparse")
+        if args.comm == "lib":
+            how = "RCCL collectives issued inside libqgd_hip.so (qgd_comm_init_rccl)"
+        else:
+            how = f"phase hooks + torch.distributed ({args.backend}" + (")" if args.backend == "nccl" else ", host-staged: plumbing check, not a measurement)")
         out = {
             "metric": "forward+adjoint timesteps/sec, cnot3 order-8 fp64",
             "value": total_timesteps / elapsed, "unit": "timesteps/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "run_in_steps": RUN_IN_STEPS,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if n_gpus == 1 else "strong", "vs_baseline": None,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "run_in_steps": args.run_in,
+            "ms_per_step": sec_eval * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cnot3 dispersive CNOT (4,4,4)/(2,2,2), N=64, 8 columns, 3 controls x 60 coeffs, "
                                    f"Hermite order 8, tf={args.nsteps}, nsteps={args.nsteps}, one full discrete_adjoint! per step",
-                       "parallelism": "1 GPU" if n_gpus == 1 else (f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation" if args.shard == "time"
-                                                                   else f"column blocks over {n_gpus} GPUs, 2 all-reduces per evaluation")
-                                      + ("" if args.backend == "nccl" else f" ({args.backend} backend, host-staged: plumbing check, not a measurement)")},
+                       "parallelism": "1 GPU" if not use_dist else
+                                      ((f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation" if args.shard == "time"
+                                        else f"column blocks over {n_gpus} GPUs, 2 all-reduces per evaluation") + "; " + how)},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
-                         "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work},
+                         "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work,
+                         "history_stream": {"bound": "hbm", "bytes_per_timestep": b_step, "achieved": hs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                            "frac": hs / PEAK_HBM_GBS, "note": "SURVEY 8(d) B_step * nsteps / T_eval: the algorithm's history stream "
+                                                                               "(write once, read once) against HBM; the evaluation is latency-bound, not stream-bound"},
+                         "whole_evaluation": {"bound": "mfma", "executed_gflop": gflop, "achieved": gflop / sec_eval / 1e3, "peak": PEAK_FP64_MATRIX_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": gflop / sec_eval / 1e3 / PEAK_FP64_MATRIX_TFLOPS,
+                                              "note": "flops the kernels execute (bench.py executed_gflop), all phases, / wall time of one evaluation"}},
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
+            "collectives_ms": comm_ms,
             "weak_in_time": weak,
             "with_history_ms_per_step": None if not with_hist else with_hist.get("pinned_ms_per_step"),
             "with_history": with_hist,
@@ -501,16 +606,28 @@ def main():
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2),
             "grad_norm": float(np.linalg.norm(grad)),
         }
-        if not use_dist and not args.no_large_n:
+        if not use_dist:
             dp.close()
-            out["large_n"] = large_n_case(qgd, np)
+            if not args.no_cnot2:
+                try:
+                    out["cnot2"] = cnot2_case_gpu(qgd, np)
+                except Exception as exc:
+                    out["cnot2"] = {"error": repr(exc)}
+            if not args.no_large_n:
+                try:                      # a secondary measurement must never cost the headline line
+                    out["large_n"] = large_n_case(qgd, np)
+                except Exception as exc:
+                    out["large_n"] = {"error": repr(exc)}
         if large_dist is not None:
             out["large_n"] = large_dist
         if not args.no_cpu_baseline:
             orc = import_oracle()
             out["cpu_baseline"] = cpu_baseline(qgd, orc)
         print(json.dumps(out))
-    dp.close()
+    try:
+        dp.close()
+    except Exception:
+        pass
     if use_dist:
         dist.destroy_process_group()
 

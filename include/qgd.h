@@ -37,7 +37,9 @@ enum {
     QGD_ERR_NO_DEVICE = 2,   /* no usable GPU / HIP failure: the path never falls back to the CPU */
     QGD_ERR_STATE = 3,       /* call order (e.g. gradient before target/controls were set) */
     QGD_ERR_UNSUPPORTED = 4, /* size outside what the kernels cover */
-    QGD_ERR_NUMERIC = 5      /* singular step matrix */
+    QGD_ERR_NUMERIC = 5,     /* singular step matrix */
+    QGD_ERR_MEMORY = 6,      /* the problem does not fit in device memory (see qgd_set_memory_budget) */
+    QGD_ERR_COMM = 7         /* RCCL not loadable / a collective failed (qgd_comm_*) */
 };
 
 typedef struct qgd_handle_s *qgd_handle;
@@ -187,7 +189,9 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);
 
-/* ---- time-partitioned evaluation over several GPUs (one handle per rank) ----------------
+/* ---- time-partitioned evaluation over several GPUs (one handle per rank), phase by phase ----------------
+ * (The hooks the in-library protocol of qgd_comm_init_rccl is made of; a host that brings its own transport --
+ * MPI.jl, torch.distributed -- drives them itself.)
  * The reference's only parallel axis is the column loop (Threads.@threads,
  * src/forward_evolution.jl:48,332); this implementation's parallel axis is time, so ranks own
  * contiguous windows of the time grid.  The library never communicates: between the phases the
@@ -225,6 +229,34 @@ int qgd_dist_finish(qgd_handle h, double *grad, double *out3);
  * The step matrices are built on every rank; see DESIGN.md section 6 for when this split pays. */
 int qgd_cols_forward(qgd_handle h, const double *pcof, int32_t n_pcof);
 int qgd_cols_adjoint(qgd_handle h, int32_t keep_scalars);
+
+/* ---- several GPUs behind ONE call: RCCL over xGMI inside the library ------------------------------------------
+ * The reference spreads an evaluation over host threads (Threads.@threads over initial conditions,
+ * src/forward_evolution.jl:48,332) and combines the columns through the global overlaps of the terminal condition
+ * (src/infidelity.jl:13-17, src/eval_grad_discrete_adjoint.jl:26-28).  Here one process (or host thread) per GPU holds
+ * one handle; after qgd_comm_init_rccl the calls
+ *     qgd_discrete_adjoint   qgd_eval_forward
+ * are COLLECTIVE: every rank makes them with the same pcof, the library runs its share and issues the collectives
+ * itself (ncclAllGather / ncclAllReduce on the handle's stream between its phases, no host synchronisation in
+ * between), and every rank receives the full gradient and the global scalars.  The host only has to carry 128 bytes
+ * once: rank 0 calls qgd_comm_unique_id and hands the id to the other ranks by whatever it has (MPI.jl bcast, a
+ * socket, a shared file).
+ *   shard = QGD_SHARD_TIME     contiguous windows of the time grid per rank (default split: 2 all-gathers + 1
+ *                              all-reduce per evaluation).  Implies qgd_set_partition(rank, world):
+ *                              set the control basis AFTERWARDS, for the rank's own window (qgd_get_partition).
+ *   shard = QGD_SHARD_COLUMNS  the reference's axis: the handle was created from the rank's block of columns of
+ *                              u0, v0 (and gets its columns of the target), with the GLOBAL n_ess; 2 all-reduces.
+ * The optional outputs of qgd_discrete_adjoint / qgd_eval_forward then cover what the rank owns (its window of time
+ * points / its columns).  world = 1 is allowed (the collectives still run).  librccl.so.1 is bound at run time
+ * (dlopen; QGD_RCCL_LIB names another file): QGD_ERR_COMM when it cannot be loaded or a collective fails.
+ * qgd_comm_info: out3 = {rank (-1 without a communicator), world, shard}. */
+#define QGD_UNIQUE_ID_BYTES 128
+#define QGD_SHARD_TIME    0
+#define QGD_SHARD_COLUMNS 1
+int qgd_comm_unique_id(void *id128);
+int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_t world, int32_t shard);
+int qgd_comm_destroy(qgd_handle h);
+int qgd_comm_info(qgd_handle h, int32_t *out3);
 
 /* Per-phase device time of the last evaluation (HIP events), milliseconds.
  * names/ms hold up to cap entries; returns the number of phases through *n. */

@@ -151,6 +151,16 @@ class Controls:
             s.kind = 1
             s.degree = c.degree
             s.n_basis = c.N_basis_functions
+        elif name == "BSpline2Control":       # hard-coded quadratic B-spline (bspline_control.jl:21-249)
+            s.kind = 3
+            s.n_basis = c.D1
+        elif name == "BCarrier2Control":      # the reference's BSplineControl in its own bcarrier2 formulas (orders 0, 1)
+            s.kind = 4
+            fr = np.ascontiguousarray(c.omega, dtype=np.float64)
+            self.keep.append(fr)
+            s.n_basis = c.D1
+            s.n_freq = len(fr)
+            s.freqs = _dptr(fr)
         elif name == "CarrierControl":
             s.kind = 2
             fr = np.ascontiguousarray(c.carrier_frequencies, dtype=np.float64)
@@ -163,6 +173,17 @@ class Controls:
             raise TypeError(f"oracle has no restatement of control type {name}")
         self.keep.append(s)
         return s
+
+
+class BCarrier2Control:
+    """BSplineControl(tf, D1, omega) of the reference (bspline_control.jl:251-395) for the oracle: evaluated by the
+    restated bcarrier2 / bcarrier2_dt / gradbcarrier2 / gradbcarrier2_dt formulas (bspline_backend.jl:381-955), NOT through
+    the carrier-wave wrapper -- the independent statement the product's CarrierControl(BSpline2Control) is checked against.
+    Derivative orders 0 and 1 only, as in the reference (Hermite order 2)."""
+
+    def __init__(self, tf, D1, omega):
+        self.tf, self.D1, self.omega = float(tf), int(D1), [float(w) for w in omega]
+        self.N_coeff = 2 * self.D1 * len(self.omega)
 
 
 def set_num_threads(n: int):
@@ -215,6 +236,19 @@ def bspline_basis_derivs(degree, n_basis, x, nderiv):
     out = np.zeros((nderiv, k))
     first = lib().qo_bspline_basis_derivs(C.c_int(degree), C.c_int(n_basis), C.c_double(x), C.c_int(nderiv), _dptr(out))
     return first, out  # out[d, i]
+
+
+def recursive_magic(prob, controls, pcof, m, control_index, t, w_mat, lam, deriv_order, coeff):
+    """One recursive_magic! call: coeff * <d w_k/d theta_l, lambda> for the coefficients l of one control."""
+    P = Problem(prob)
+    cs = Controls(controls)
+    pc = np.ascontiguousarray(pcof, dtype=np.float64)
+    w = np.asfortranarray(np.array(w_mat, dtype=np.float64))
+    la = np.ascontiguousarray(lam, dtype=np.float64)
+    out = np.zeros(cs.structs[control_index].n_coeff)
+    lib().qo_recursive_magic(C.byref(P.c), cs.arr, _dptr(pc), C.c_int(m), C.c_int(control_index), C.c_double(t), _dptr(w),
+                             _dptr(la), C.c_int(deriv_order), C.c_double(coeff), _dptr(out))
+    return out
 
 
 def compute_derivatives(prob, pvals, qvals, uv, forcing=None, adjoint=False):

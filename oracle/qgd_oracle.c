@@ -155,9 +155,85 @@ static void carrier_factors(double w, double t, int kk, int is_q, double *c1, do
     }
 }
 
+/* The three non-zero pieces of the hard-coded quadratic B-spline at t and their first two derivatives
+ * (bspline2 / gradbspline2!, bspline_control.jl:139-249; the same formulas inside bcarrier2, bspline_backend.jl:796-826).
+ * idx[s] = 0-based coefficient index of piece s (nurbs k, k-1, k-2), w[s][d] = d-th derivative of its segment. */
+static void bspline2_pieces(int D1, double tf, double t, int idx[3], double w[3][3])
+{
+    const double dtknot = tf / (D1 - 2), width = 3.0 * dtknot;
+    int k = (int)ceil(t / dtknot + 2.0);          /* :149-150: t = 0 must give k = 3; protect against round-off at t = tf */
+    if (k < 3) k = 3;
+    if (k > D1) k = D1;
+    for (int s = 0; s < 3; s++) {
+        const int kk = k - s;                      /* 1-based nurb index */
+        const double tc = dtknot * ((double)kk - 1.5);   /* tcenter, :39 */
+        const double tau = (t - tc) / width;
+        idx[s] = kk - 1;
+        if (s == 0)      { w[s][0] = 9.0 / 8 + 4.5 * tau + 4.5 * tau * tau; w[s][1] = (4.5 + 9 * tau) / width;  w[s][2] = 9.0 / (width * width); }
+        else if (s == 1) { w[s][0] = 0.75 - 9 * tau * tau;                  w[s][1] = (-18 * tau) / width;      w[s][2] = -18.0 / (width * width); }
+        else             { w[s][0] = 9.0 / 8 - 4.5 * tau + 4.5 * tau * tau; w[s][1] = (-4.5 + 9 * tau) / width; w[s][2] = 9.0 / (width * width); }
+    }
+}
+
+/* bcarrier2 / bcarrier2_dt with an explicit pcof (bspline_backend.jl:783-848, :862-955), one control (osc = 0,
+ * baseIndex = 0): per frequency D1 coefficients of envelope 1 then D1 of envelope 2;
+ *   p = sum_f  b1 cos(w t) - b2 sin(w t),   q = sum_f  b1 sin(w t) + b2 cos(w t),  and their time derivatives. */
+static double bcarrier2_eval(const qo_control *c, double t, const double *pcof, int order, int is_q)
+{
+    const int D1 = c->n_basis;
+    int idx[3]; double w[3][3];
+    bspline2_pieces(D1, c->tf, t, idx, w);
+    double f = 0.0;
+    for (int fr = 0; fr < c->n_freq; fr++) {
+        const double *p1 = pcof + (size_t)fr * 2 * D1, *p2 = p1 + D1;
+        const double om = c->freqs[fr], cs = cos(om * t), sn = sin(om * t);
+        double b1 = 0, b2 = 0, b1p = 0, b2p = 0;
+        for (int s = 0; s < 3; s++) {
+            b1 += p1[idx[s]] * w[s][0]; b2 += p2[idx[s]] * w[s][0];
+            b1p += p1[idx[s]] * w[s][1]; b2p += p2[idx[s]] * w[s][1];
+        }
+        if (order == 0) f += is_q ? b1 * sn + b2 * cs : b1 * cs - b2 * sn;                      /* :840-844 */
+        else f += is_q ? b1p * sn + b1 * cs * om + b2p * cs - b2 * sn * om                      /* :935-946 */
+                       : b1p * cs - b1 * sn * om - b2p * sn - b2 * cs * om;
+    }
+    return f;
+}
+
+/* gradbcarrier2! / gradbcarrier2_dt! (bspline_backend.jl:381-440, :637-730) */
+static void bcarrier2_grad(const qo_control *c, double t, int order, int is_q, double *g)
+{
+    const int D1 = c->n_basis;
+    int idx[3]; double w[3][3];
+    bspline2_pieces(D1, c->tf, t, idx, w);
+    for (int fr = 0; fr < c->n_freq; fr++) {
+        double *g1 = g + (size_t)fr * 2 * D1, *g2 = g1 + D1;
+        const double om = c->freqs[fr], cs = cos(om * t), sn = sin(om * t);
+        for (int s = 0; s < 3; s++) {
+            const double bk = w[s][0], bkp = w[s][1];
+            if (order == 0) {
+                g1[idx[s]] = is_q ? bk * sn : bk * cs;
+                g2[idx[s]] = is_q ? bk * cs : -bk * sn;
+            } else {
+                g1[idx[s]] = is_q ? bkp * sn + bk * om * cs : bkp * cs - bk * om * sn;
+                g2[idx[s]] = is_q ? bkp * cs - bk * om * sn : -(bkp * sn + bk * om * cs);
+            }
+        }
+    }
+}
+
 static double eval_pq_derivative(const qo_control *c, double t, const double *pcof, int order, int is_q)
 {
     switch (c->kind) {
+    case QO_CTRL_BSPLINE2: { /* bspline_control.jl:67-86 (p: coefficients 1..D1, q: D1+1..2 D1), bspline2 :139-205 */
+        if (order > 2) return 0.0;               /* "If derivative order higher than 2, value is zero" (:202) */
+        int idx[3]; double w[3][3];
+        bspline2_pieces(c->n_basis, c->tf, t, idx, w);
+        const double *co = pcof + (is_q ? c->n_basis : 0);
+        return co[idx[0]] * w[0][order] + co[idx[1]] * w[1][order] + co[idx[2]] * w[2][order];
+    }
+    case QO_CTRL_BCARRIER2: /* bspline_control.jl:310-358: orders 0 and 1 only (the reference throws above that) */
+        if (order > 1) return NAN;
+        return bcarrier2_eval(c, t, pcof, order, is_q);
     case QO_CTRL_GRAPE: /* grape_control.jl:32-55 */
         if (order > 0) return 0.0;
         return pcof[grape_region(c, t) + (is_q ? c->n_amplitudes : 0)];
@@ -187,6 +263,18 @@ static void eval_grad_pq_derivative(const qo_control *c, double t, const double 
 {
     for (int i = 0; i < c->n_coeff; i++) grad[i] = 0.0;
     switch (c->kind) {
+    case QO_CTRL_BSPLINE2: { /* bspline_control.jl:106-131, gradbspline2! :208-270 */
+        if (order > 2) return;
+        int idx[3]; double w[3][3];
+        bspline2_pieces(c->n_basis, c->tf, t, idx, w);
+        double *g = grad + (is_q ? c->n_basis : 0);
+        for (int s = 0; s < 3; s++) g[idx[s]] = w[s][order];
+        return;
+    }
+    case QO_CTRL_BCARRIER2: /* bspline_control.jl:360-395 */
+        if (order > 1) { for (int i = 0; i < c->n_coeff; i++) grad[i] = NAN; return; }
+        bcarrier2_grad(c, t, order, is_q, grad);
+        return;
     case QO_CTRL_GRAPE: /* grape_control.jl:57-80 */
         if (order == 0) grad[grape_region(c, t) + (is_q ? c->n_amplitudes : 0)] = 1.0;
         return;
@@ -951,6 +1039,29 @@ static void accumulate_gradient_column(const qo_prob *pr, const qo_control *cons
         off += ctl->n_coeff;
     }
     free(mc.pvals); free(mc.qvals); free(mc.work_vec); free(work_mat);
+}
+
+/* Test hook: ONE call of recursive_magic! (eval_grad_discrete_adjoint.jl:656-726) -- "the contribution of
+ * <coeff * w_k, lambda>" to the gradient slice of control `control_index`, i.e. coeff * <d w_k / d theta_l, lambda>
+ * for every coefficient l of that control, through compute_inner_prod_S!/K! (:764-800).  w_mat: 2N x (1+m) Taylor
+ * coefficients at time t.  Pinned by the d/dtheta known-answer block of test/hardcoded_derivatives.jl:137-160. */
+void qo_recursive_magic(const qo_prob *pr, const qo_control *const *controls, const double *pcof, int m,
+                        int control_index, double t, const double *w_mat, const double *lambda, int deriv_order,
+                        double coeff, double *grad_contrib)
+{
+    const int n2 = 2 * pr->N;
+    magic_ctx mc;
+    mc.pr = pr; mc.controls = controls; mc.pcof = pcof; mc.m = m; mc.ctrl = control_index;
+    mc.pcof_off = 0;
+    for (int k = 0; k < control_index; k++) mc.pcof_off += controls[k]->n_coeff;
+    mc.pvals = (double *)malloc(sizeof(double) * (1 + m) * pr->n_ops);
+    mc.qvals = (double *)malloc(sizeof(double) * (1 + m) * pr->n_ops);
+    mc.work_vec = (double *)malloc(sizeof(double) * n2);
+    mc.work_pcof = (double *)malloc(sizeof(double) * controls[control_index]->n_coeff);
+    double *work_mat = (double *)malloc(sizeof(double) * n2 * (m > 0 ? m : 1));
+    fill_pq_mats(pr, controls, t, pcof, m, mc.pvals, mc.qvals);
+    recursive_magic(&mc, grad_contrib, w_mat, lambda, deriv_order, coeff, t, work_mat);
+    free(mc.pvals); free(mc.qvals); free(mc.work_vec); free(mc.work_pcof); free(work_mat);
 }
 
 int qo_discrete_adjoint(const qo_prob *pr, const qo_control *const *controls, const double *pcof,

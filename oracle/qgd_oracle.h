@@ -31,7 +31,10 @@ extern "C" {
 #endif
 
 /* ---- controls (src/Controls, all control files) ------------------------------------- */
-enum { QO_CTRL_GRAPE = 0, QO_CTRL_BSPLINE = 1, QO_CTRL_CARRIER = 2 };
+enum { QO_CTRL_GRAPE = 0, QO_CTRL_BSPLINE = 1, QO_CTRL_CARRIER = 2,
+       QO_CTRL_BSPLINE2 = 3,    /* hard-coded quadratic B-spline, bspline_control.jl:21-249: n_basis = D1, n_coeff = 2 D1 */
+       QO_CTRL_BCARRIER2 = 4 }; /* BSplineControl = Juqbox bcarrier2 layout, bspline_control.jl:251-395 + bspline_backend.jl:381-480,
+                                   :637-770, :783-955: n_basis = D1, n_freq/freqs = omega, n_coeff = 2 D1 n_freq; derivative orders 0, 1 */
 
 typedef struct qo_control {
     int32_t kind;
@@ -128,6 +131,10 @@ int  qo_compute_terminal_condition(const qo_prob *pr, const qo_control *const *c
                                    const double *pcof, int order, const double *target_real,
                                    const double *final_state, const double *forcing_end,
                                    double *terminal_out);                                           /* :1-67 */
+/* test hook: one recursive_magic! call (eval_grad_discrete_adjoint.jl:656-726), see qgd_oracle.c */
+void qo_recursive_magic(const qo_prob *pr, const qo_control *const *controls, const double *pcof, int m,
+                        int control_index, double t, const double *w_mat, const double *lambda, int deriv_order,
+                        double coeff, double *grad_contrib);
 /* grad[P]; history/lambda_history/adjoint_forcing are caller buffers     :107-160 */
 int  qo_discrete_adjoint(const qo_prob *pr, const qo_control *const *controls, const double *pcof,
                          int n_pcof, const double *target_real, int order, int history_precomputed,

@@ -17,7 +17,8 @@ from .problems import (DispersiveProblem, construct_rabi_prob, construct_rand_pr
 from .evolution import (DeviceProblem, device_problem, clear_cache, release, eval_forward, eval_forward_, eval_adjoint, eval_grad_forced, eval_grad_finite_difference, discrete_adjoint,
                         discrete_adjoint_, infidelity, infidelity_real, guard_penalty_real, complex_to_real,
                         real_to_complex)
-from .distributed import DeviceBackend, TimePartitioned, TorchComm, LocalGroup, ColumnBackend, ColumnSharded
+from .distributed import (DeviceBackend, TimePartitioned, TorchComm, LocalGroup, ColumnBackend, ColumnSharded,
+                          RcclEvaluation, comm_unique_id)
 from .optimize import optimize_gate, OptimizationHistory, read_optimization_history
 from .convergence import (get_histories, richardson_extrap_rel_err, richardson_extrap_sol, observed_orders,
                           save_histories, load_histories)

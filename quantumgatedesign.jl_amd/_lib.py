@@ -14,7 +14,9 @@ CSRC = os.path.join(_HERE, "csrc")
 # QGD_LIB_PATH: an alternative build of the same library (e.g. one compiled with the in-kernel cycle stamps on)
 LIB_PATH = os.environ.get("QGD_LIB_PATH") or os.path.join(CSRC, "libqgd_hip.so")
 
-QGD_OK, QGD_ERR_ARGUMENT, QGD_ERR_NO_DEVICE, QGD_ERR_STATE, QGD_ERR_UNSUPPORTED, QGD_ERR_NUMERIC = range(6)
+(QGD_OK, QGD_ERR_ARGUMENT, QGD_ERR_NO_DEVICE, QGD_ERR_STATE, QGD_ERR_UNSUPPORTED, QGD_ERR_NUMERIC, QGD_ERR_MEMORY,
+ QGD_ERR_COMM) = range(8)
+QGD_SHARD_TIME, QGD_SHARD_COLUMNS, QGD_UNIQUE_ID_BYTES = 0, 1, 128
 
 EXPORTS = [
     "qgd_abi_version", "qgd_create", "qgd_destroy", "qgd_last_error", "qgd_set_nsteps", "qgd_set_target",
@@ -25,6 +27,7 @@ EXPORTS = [
     "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
     "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc", "qgd_cols_forward", "qgd_cols_adjoint",
     "qgd_set_lambda_derivatives", "qgd_set_cost_type",
+    "qgd_comm_unique_id", "qgd_comm_init_rccl", "qgd_comm_destroy", "qgd_comm_info",
 ]
 
 
@@ -111,6 +114,10 @@ def lib():
     L.qgd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_set_lambda_derivatives.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_set_cost_type.argtypes = [C.c_void_p, C.c_int32]
+    L.qgd_comm_unique_id.argtypes = [C.c_void_p]
+    L.qgd_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.qgd_comm_destroy.argtypes = [C.c_void_p]
+    L.qgd_comm_info.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

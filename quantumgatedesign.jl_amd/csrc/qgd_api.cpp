@@ -4,6 +4,8 @@
 // discrete_adjoint! (src/eval_grad_discrete_adjoint.jl:107-160).
 // There is no CPU fallback: without a GPU every compute entry point fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is bound at run time (dlopen), see RcclApi
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -80,7 +82,8 @@ struct qgd_handle_s {
     // needs only time points n-1, n of the one before: the grid is cut into pipe_chunks groups of scan blocks; the
     // build kernels run back to back on the main stream, and chunk i's inverse + block products run on side stream i
     // as soon as its build is done -- beside the build of chunk i+1 and the inverses of the other chunks.
-    // QGD_PIPE_CHUNKS=1 turns it off.
+    // Off by default (1 chunk): measured slower on cnot3 ("time chunks over streams");
+    // QGD_PIPE_CHUNKS=2..8 turns it on.
     enum { MAX_CHUNKS = 8 };
     int pipe_chunks = getenv("QGD_PIPE_CHUNKS") ? atoi(getenv("QGD_PIPE_CHUNKS")) : 1;
     hipStream_t pipe_stream[MAX_CHUNKS] = {};
@@ -89,6 +92,13 @@ struct qgd_handle_s {
     hipGraphExec_t graph_exec = nullptr;
     int graph_calls = 0;
     bool graph_off = (getenv("QGD_GRAPH") == nullptr);
+    // multi-GPU INSIDE the library (qgd_comm_init_rccl): the ranks that share one evaluation talk over an RCCL
+    // communicator; qgd_discrete_adjoint / qgd_eval_forward then run the partitioned protocol themselves, the
+    // collectives issued on the handle's stream between the phases (no host synchronisation in between).
+    ncclComm_t comm = nullptr;
+    int comm_shard = QGD_SHARD_TIME, comm_rank = 0, comm_world = 1;
+    double *scal_local = nullptr;       // this rank's own {<w,R>, <w,T>, guard, flag} before a reduction made them global
+    bool scal_saved = false;
 };
 
 namespace {
@@ -111,7 +121,12 @@ int dev_alloc(qgd_handle h, std::vector<void *> &pool, T **p, size_t count)
 {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
-    if (e != hipSuccess) return fail(h, QGD_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        // an allocation that does not fit is the caller's problem size, not a missing device (qgd.h: QGD_ERR_MEMORY)
+        return fail(h, e == hipErrorOutOfMemory ? QGD_ERR_MEMORY : QGD_ERR_NO_DEVICE,
+                    std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+    }
     pool.push_back(q);
     *p = static_cast<T *>(q);
     return QGD_OK;
@@ -626,6 +641,167 @@ int fetch_results(qgd_handle h, double *grad, double *out3)
     return QGD_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time.  libqgd_hip.so has no link-time dependency on librccl: a single-GPU host never loads
+// it.  dlopen("librccl.so.1") returns the copy already in the process when there is one (torch ships its own under
+// the same SONAME), else the loader's search path, else /opt/rocm/lib.  QGD_RCCL_LIB names another file.
+// ---------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+
+RcclApi load_rccl()
+{
+    RcclApi a;
+    std::vector<std::string> names;
+    if (const char *e = getenv("QGD_RCCL_LIB")) names.push_back(e);
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+    for (const auto &n : names) {
+        a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (a.lib) break;
+        const char *de = dlerror();
+        a.err += n + ": " + (de ? de : "?") + "; ";
+    }
+    if (!a.lib) { a.err = "RCCL could not be loaded (" + a.err + ")"; return a; }
+    bool all = true;
+    auto sym = [&](const char *name) { void *p = dlsym(a.lib, name); if (!p) { all = false; a.err += std::string(name) + " missing; "; } return p; };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = all;
+    return a;
+}
+
+RcclApi &rccl() { static RcclApi a = load_rccl(); return a; }
+
+#define NCCL_TRY(h, expr)                                                                      \
+    do {                                                                                       \
+        ncclResult_t r__ = (expr);                                                             \
+        if (r__ != ncclSuccess)                                                                \
+            return fail((h), QGD_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r__)); \
+    } while (0)
+
+// which: the exchange buffers of qgd_exchange_buffer -- 0, 1 all-gather in place; 2 all-reduce(sum) of [grad | scalars];
+// 3 all-reduce(sum) of the scalars {<w,R>, <w,T>, guard, flag} alone.  Issued on the handle's stream.
+int comm_collective(qgd_handle h, int which)
+{
+    qgdk_ctx &k = h->k;
+    RcclApi &R = rccl();
+    const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp;
+    static const char *names[4] = {"comm_gather_fwd", "comm_gather_adj", "comm_reduce", "comm_reduce_scal"};
+    PhaseTimer t(h, names[which]);
+    if (which == 0) {
+        const size_t chunk = 4 * pl;
+        NCCL_TRY(h, R.AllGather(k.RX + (size_t)k.part_rank * chunk, k.RX, chunk, ncclDouble, h->comm, k.stream));
+    } else if (which == 1) {
+        const size_t chunk = 2 * hstep;
+        NCCL_TRY(h, R.AllGather(k.phiRX + (size_t)k.part_rank * chunk, k.phiRX, chunk, ncclDouble, h->comm, k.stream));
+    } else {
+        // the rank's own scalars are kept: a later history_precomputed call starts from them again, not from the sums
+        HIP_TRY(h, hipMemcpyAsync(h->scal_local, k.scal, 4 * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+        h->scal_saved = true;
+        if (which == 2) NCCL_TRY(h, R.AllReduce(k.redbuf, k.redbuf, (size_t)k.n_pcof + 4, ncclDouble, ncclSum, h->comm, k.stream));
+        else NCCL_TRY(h, R.AllReduce(k.scal, k.scal, 4, ncclDouble, ncclSum, h->comm, k.stream));
+    }
+    return QGD_OK;
+}
+
+bool same_pcof(qgd_handle h, const double *pcof, int n_pcof)
+{
+    return pcof ? ((size_t)n_pcof == h->fwd_pcof.size() && n_pcof > 0 && !memcmp(pcof, h->fwd_pcof.data(), sizeof(double) * n_pcof))
+                : h->fwd_pcof.empty();
+}
+
+// forward sweep of a handle with a communicator: the rank's share + the exchange that completes it.
+// Time windows: block products -> all-gather of the window products -> own history (+ overlaps on the last rank).
+// Column blocks: the whole sweep on the own columns; the overlaps become global with the first reduction.
+int comm_forward(qgd_handle h, const double *pcof, int n_pcof)
+{
+    int rc;
+    if (h->comm_shard == QGD_SHARD_TIME) {
+        if ((rc = forward_begin(h, pcof, n_pcof))) return rc;
+        if ((rc = comm_collective(h, 0))) return rc;
+        if ((rc = forward_end(h))) return rc;
+    } else {
+        if ((rc = forward_begin(h, pcof, n_pcof))) return rc;
+        if ((rc = forward_end(h))) return rc;
+    }
+    if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
+    h->scal_saved = false;
+    return QGD_OK;
+}
+
+// discrete_adjoint! of ONE SchrodingerProb spread over the ranks of the communicator (the reference's thread loop over
+// columns, src/forward_evolution.jl:48,332; the global overlaps of src/infidelity.jl:13-17 and
+// src/eval_grad_discrete_adjoint.jl:26-28 are what the collectives carry).  Every rank returns the full gradient and
+// the global scalars.  The optional outputs cover what the rank owns: its window of time points (time shards,
+// qgd_get_partition) or its columns (column shards).
+int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int history_precomputed, double *grad,
+                          double *uv_history, double *lambda_history, double *adjoint_forcing, double *out3)
+{
+    qgdk_ctx &k = h->k;
+    int rc;
+    struct CopyGuard { qgd_handle h; ~CopyGuard() { (void)finish_copies(h); h->defer_terminal = false; h->lambda_out = nullptr; } } guard{h};
+    if (history_precomputed && !h->forward_valid)
+        return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+    const bool reuse = history_precomputed && same_pcof(h, pcof, n_pcof);
+    const bool time = h->comm_shard == QGD_SHARD_TIME;
+    if (reuse) {
+        if (time) {
+            if (h->scal_saved) HIP_TRY(h, hipMemcpyAsync(k.scal, h->scal_local, 4 * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+            if (k.part_rank == k.part_world - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
+        }   // (column shards: the scalars on the device are the global ones of the call that made the history)
+    } else {
+        if ((rc = comm_forward(h, pcof, n_pcof))) return rc;
+        if (!time && (rc = comm_collective(h, 3))) return rc;      // <w_N,R>, <w_N,T>, guard: global before the terminal condition
+    }
+    if (!time) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal_given(&k)); }
+    if (adjoint_forcing && (rc = copy_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
+    if (uv_history) {
+        if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+        if ((rc = copy_history_out(h, uv_history))) return rc;
+    }
+    if ((rc = adjoint_begin(h))) return rc;
+    if (time && (rc = comm_collective(h, 1))) return rc;
+    h->lambda_out = lambda_history;
+    rc = adjoint_end(h);
+    h->lambda_out = nullptr;
+    if (rc) return rc;
+    // column shards: the scalars are global on every rank already -- all ranks but the first contribute zeros
+    if (!time && h->comm_rank != 0) HIP_TRY(h, hipMemsetAsync(k.scal, 0, 3 * sizeof(double), k.stream));
+    if ((rc = comm_collective(h, 2))) return rc;
+    if ((rc = fetch_results(h, grad, out3))) return rc;
+    return finish_copies(h);
+}
+
+int comm_eval_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history, double *out3)
+{
+    qgdk_ctx &k = h->k;
+    int rc = comm_forward(h, pcof, n_pcof);
+    if (rc) return rc;
+    if (uv_history) {
+        { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+        h->derivs_valid = true;
+        if ((rc = copy_history_out(h, uv_history))) return rc;
+    }
+    K_TRY(h, qgdk_flag_to_scal(&k));      // a singular step matrix on ANY rank fails the call on every rank
+    if ((rc = comm_collective(h, 3))) { (void)finish_copies(h); return rc; }
+    if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
+    return finish_copies(h);
+}
+
 }  // namespace
 
 extern "C" {
@@ -869,6 +1045,7 @@ void qgd_destroy(qgd_handle h)
     (void)hipSetDevice(h->device);
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
     drop_graph(h);
+    if (h->comm) (void)qgd_comm_destroy(h);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (int i = 0; i < qgd_handle_s::MAX_CHUNKS; i++) {
         if (h->pipe_stream[i]) { (void)hipStreamSynchronize(h->pipe_stream[i]); (void)hipStreamDestroy(h->pipe_stream[i]); }
@@ -917,10 +1094,11 @@ int qgd_set_target(qgd_handle h, const double *target_real)
 
 int qgd_set_cost_type(qgd_handle h, int32_t cost_type)
 {
-    if (h) drop_graph(h);
     if (!h) return fail(h, QGD_ERR_ARGUMENT, "null handle");
     if (cost_type < QGD_COST_INFIDELITY || cost_type > QGD_COST_NORM)
         return fail(h, QGD_ERR_ARGUMENT, "Invalid cost type (0 :Infidelity, 1 :Tracking, 2 :Norm)");    // the reference throws "Invalid cost type"
+    if (h->k.cost_type == cost_type) return QGD_OK;      // (a shim that sets it on every call must not cost a captured graph)
+    drop_graph(h);
     h->k.cost_type = cost_type;     // (a stored forward sweep stays valid: history_precomputed re-forms the terminal condition)
     return QGD_OK;
 }
@@ -1002,6 +1180,7 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
     if (!h) return QGD_ERR_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
+    if (h->comm) return comm_eval_forward(h, pcof, n_pcof, uv_history, out3);
     int rc = run_forward(h, pcof, n_pcof);
     if (rc) return rc;
     if (uv_history) {
@@ -1022,7 +1201,8 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     qgdk_ctx &k = h->k;
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_discrete_adjoint");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_discrete_adjoint");
-    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
+    if (h->comm) return comm_discrete_adjoint(h, pcof, n_pcof, history_precomputed, grad, uv_history, lambda_history, adjoint_forcing, out3);
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points, or give the handle a communicator (qgd_comm_init_rccl)");
     int rc;
     // full evaluation, nothing but [grad | scalars] coming back, no event bracketing: replay the captured launch sequence
     const bool graph_ok = !h->graph_off && !history_precomputed && !uv_history && !lambda_history && !adjoint_forcing &&
@@ -1043,7 +1223,10 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
                 if (ok) h->graph = g; else { if (g) (void)hipGraphDestroy(g); h->graph_exec = nullptr; }
             }
             (void)hipGetLastError();
-            if (!ok) h->graph_off = true;                    // e.g. the legacy default stream cannot be captured: plain launches from now on
+            if (!ok) {      // e.g. the legacy default stream cannot be captured: plain launches from now on
+                h->graph_off = true;
+                h->forcing_zero = false;      // (the capture only RECORDED the guard clear: the plain path must run it)
+            }
         }
         if (h->graph_exec) {
             memcpy(h->host_in, pcof, sizeof(double) * n_pcof);
@@ -1074,9 +1257,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     // reused only when it was computed from this very pcof, otherwise the sweep is simply redone.
     if (history_precomputed && !h->forward_valid)
         return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
-    const bool reuse = history_precomputed && (pcof ? ((size_t)n_pcof == h->fwd_pcof.size() && n_pcof > 0 &&
-                                                       !memcmp(pcof, h->fwd_pcof.data(), sizeof(double) * n_pcof))
-                                                    : h->fwd_pcof.empty());
+    const bool reuse = history_precomputed && same_pcof(h, pcof, n_pcof);
     if (reuse) {
         // the terminal right-hand side may not have been written if the target was set later
         { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
@@ -1457,6 +1638,69 @@ int qgd_dist_finish(qgd_handle h, double *grad, double *out3)
     return fetch_results(h, grad, out3);
 }
 
+// ---------------------------------------------------------------------------
+// Multi-GPU inside the library: RCCL over xGMI.  One process (or thread) per GPU, one handle per rank; rank 0 makes
+// the 128-byte id, the host moves it to the other ranks by any means it has (MPI.jl, a socket, a file), and every
+// rank gives its handle the communicator.  From then on qgd_discrete_adjoint / qgd_eval_forward are COLLECTIVE
+// calls: every rank makes them with the same pcof, and the library issues the all-gathers / all-reduces on the
+// handle's stream between its own phases.
+// ---------------------------------------------------------------------------
+int qgd_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(nullptr, QGD_ERR_ARGUMENT, "null argument");
+    RcclApi &R = rccl();
+    if (!R.ok) return fail(nullptr, QGD_ERR_COMM, R.err);
+    ncclUniqueId id;
+    ncclResult_t r = R.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, QGD_ERR_COMM, std::string("ncclGetUniqueId: ") + R.GetErrorString(r));
+    static_assert(sizeof(id) == QGD_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return QGD_OK;
+}
+
+int qgd_comm_destroy(qgd_handle h)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (!h->comm) return QGD_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->k.stream);
+    ncclResult_t r = rccl().CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+    if (r != ncclSuccess) return fail(h, QGD_ERR_COMM, std::string("ncclCommDestroy: ") + rccl().GetErrorString(r));
+    return QGD_OK;
+}
+
+int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_t world, int32_t shard)
+{
+    if (h) drop_graph(h);
+    if (!h || !unique_id) return fail(h, QGD_ERR_ARGUMENT, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, QGD_ERR_ARGUMENT, "rank/world out of range");
+    if (shard != QGD_SHARD_TIME && shard != QGD_SHARD_COLUMNS) return fail(h, QGD_ERR_ARGUMENT, "shard: 0 time windows, 1 column blocks");
+    RcclApi &R = rccl();
+    if (!R.ok) return fail(h, QGD_ERR_COMM, R.err);
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = qgd_comm_destroy(h);
+    if (rc) return rc;
+    if (!h->scal_local && (rc = dev_alloc(h, h->static_bufs, &h->scal_local, (size_t)8))) return rc;
+    // time windows: the rank's window of the grid (invalidates control basis and histories, like qgd_set_nsteps);
+    // column blocks: the handle was created from the rank's columns, the grid stays whole
+    if (shard == QGD_SHARD_TIME) { if ((rc = qgd_set_partition(h, rank, world))) return rc; }
+    else if (h->part_world != 1 && (rc = qgd_set_partition(h, 0, 1))) return rc;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(h, R.CommInitRank(&comm, world, id, rank));
+    h->comm = comm; h->comm_shard = shard; h->comm_rank = rank; h->comm_world = world; h->scal_saved = false;
+    return QGD_OK;
+}
+
+int qgd_comm_info(qgd_handle h, int32_t *out3)
+{
+    if (!h || !out3) return QGD_ERR_ARGUMENT;
+    out3[0] = h->comm ? h->comm_rank : -1; out3[1] = h->comm ? h->comm_world : 0; out3[2] = h->comm_shard;
+    return QGD_OK;
+}
+
 int qgd_register_host_buffer(qgd_handle h, void *ptr, size_t bytes)
 {
     if (!h || !ptr || !bytes) return fail(h, QGD_ERR_ARGUMENT, "null argument");
@@ -1538,6 +1782,7 @@ int qgd_get_operator_path(qgd_handle h, int32_t *out3)
 int qgd_set_lambda_derivatives(qgd_handle h, int32_t on)
 {
     if (!h) return QGD_ERR_ARGUMENT;
+    if (h->lambda_derivs == (on != 0)) return QGD_OK;      // unchanged: a registered lambda_history keeps its zero fill
     h->lambda_derivs = (on != 0);
     for (auto &r : h->regs) r.zeroed = false;      // columns 1..m of a registered lambda_history change meaning
     return QGD_OK;

@@ -129,6 +129,7 @@ int qgdk_dense_lambda(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 int qgdk_derivs_sparse(const qgdk_ctx *c);
 /* qgd_k_layout.hip: panels [n][j][Np][2cp] -> reference layout dst[col][n][j][2N] (to_panels = 0) or back */
+int qgdk_flag_to_scal(const qgdk_ctx *c);   /* scal[3] = 1.0 when the singularity flag is set (travels in the all-reduced range) */
 int qgdk_layout(const qgdk_ctx *c, const double *panels, long long src_n, long long src_j, double *ref,
                 long long dst_col, long long dst_n, long long dst_j, int n0, int n_cnt, int j_cnt,
                 int to_panels, hipStream_t stream, int max_workgroups);

@@ -88,3 +88,15 @@ extern "C" int qgdk_layout(const qgdk_ctx *c, const double *panels, long long sr
     hipLaunchKernelGGL(k_layout, dim3(grid), dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }
+
+// the singularity flag as a double inside the range a reduction sums (multi-GPU evaluations: every rank then fails together)
+__global__ void k_flag_to_scal(const int *__restrict__ status, double *__restrict__ scal)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) scal[3] = *status ? 1.0 : 0.0;
+}
+
+extern "C" int qgdk_flag_to_scal(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_flag_to_scal, dim3(1), dim3(64), 0, c->stream, c->status, c->scal);
+    return (int)hipGetLastError();
+}

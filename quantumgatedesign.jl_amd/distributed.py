@@ -22,6 +22,59 @@ from .controls import as_control_list, control_basis
 from .evolution import DeviceProblem, _vp
 
 
+def comm_unique_id() -> bytes:
+    """The 128-byte RCCL id rank 0 makes and every rank passes to ``comm_init`` (qgd_comm_unique_id)."""
+    buf = C.create_string_buffer(_lib.QGD_UNIQUE_ID_BYTES)
+    _lib.check(None, _lib.lib().qgd_comm_unique_id(buf))
+    return buf.raw
+
+
+class RcclEvaluation:
+    """discrete_adjoint! of ONE SchrodingerProb over the ranks of an RCCL communicator that lives INSIDE the library
+    (include/qgd.h, qgd_comm_init_rccl): this class only builds the rank's handle -- its window of the time grid, or its
+    block of initial-condition columns (the reference's thread axis, src/forward_evolution.jl:48,332) -- and then
+    calls the same two entry points a single-GPU host calls.  No collective is issued from Python."""
+
+    def __init__(self, prob, order, controls, target, rank, world, unique_id, shard="time", device=0):
+        self.rank, self.world, self.shard = rank, world, shard
+        target = np.asarray(target)
+        if shard == "columns":
+            c = prob.N_initial_conditions
+            if world > c:
+                raise ValueError(f"{world} ranks for {c} initial conditions: a rank would own no column")
+            lo, hi = rank * c // world, (rank + 1) * c // world
+            sub = prob.copy()
+            sub.u0 = np.asfortranarray(prob.u0[:, lo:hi]); sub.v0 = np.asfortranarray(prob.v0[:, lo:hi])
+            sub.N_initial_conditions = hi - lo            # N_ess_levels stays the global one
+            self.columns = (lo, hi)
+            self.dp = DeviceProblem(sub, order, device)
+            self.dp.comm_init(unique_id, rank, world, "columns")
+            self.dp.set_controls(controls)
+            self.dp.set_target(target[:, lo:hi])
+        else:
+            self.dp = DeviceProblem(prob, order, device)
+            self.dp.comm_init(unique_id, rank, world, "time")
+            self.partition = self.dp.partition
+            self.dp.set_controls(controls)
+            self.dp.set_target(target)
+        self.n_pcof = self.dp.n_pcof
+
+    def discrete_adjoint(self, pcof, history_precomputed=False, uv_history=None, lambda_history=None, adjoint_forcing=None):
+        return self.dp.discrete_adjoint(pcof, history_precomputed, uv_history, lambda_history, adjoint_forcing)
+
+    def eval_forward(self, pcof, uv_history=None):
+        return self.dp.eval_forward(pcof, uv_history)
+
+    def timings(self):
+        return self.dp.timings()
+
+    def set_timing(self, mode, phase=None):
+        self.dp.set_timing(mode, phase)
+
+    def close(self):
+        self.dp.close()
+
+
 class _DevArray:
     """Expose raw device memory to torch through the CUDA array interface."""
 

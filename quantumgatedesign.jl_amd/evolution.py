@@ -144,6 +144,10 @@ class DeviceProblem:
             return
         self._general = None
         Gp, Gq, _ = control_basis(cl, self.nsteps, self.tf, self.m)
+        win = getattr(self, "window", None)
+        if win is not None:                               # time-partitioned handle: the basis of the rank's own time points
+            Gp = [np.ascontiguousarray(g[win[0]:win[1] + 1]) for g in Gp]
+            Gq = [np.ascontiguousarray(g[win[0]:win[1] + 1]) for g in Gq]
         nco = np.array([c.N_coeff for c in cl], dtype=np.int32)
         gp_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gp])
         gq_ptrs = (C.c_void_p * max(self.n_ops, 1))(*[_vp(g) for g in Gq])
@@ -177,9 +181,38 @@ class DeviceProblem:
             raise ValueError(f"control tables must have shape {shape}")
         _lib.check(self.h, self.lib.qgd_set_control_tables(self.h, _vp(p), _vp(q)))
 
+    # -- several GPUs behind one call (qgd_comm_init_rccl) -------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int, shard: str = "time"):
+        """Give the handle its RCCL communicator: discrete_adjoint / eval_forward become collective calls whose
+        exchanges the library issues itself.  ``shard="time"``: this rank's window of the time grid (set the controls
+        afterwards); ``"columns"``: the handle must have been created from this rank's columns."""
+        if len(unique_id) != _lib.QGD_UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        code = {"time": _lib.QGD_SHARD_TIME, "columns": _lib.QGD_SHARD_COLUMNS}[shard]
+        buf = C.create_string_buffer(bytes(unique_id), _lib.QGD_UNIQUE_ID_BYTES)
+        _lib.check(self.h, self.lib.qgd_comm_init_rccl(self.h, buf, int(rank), int(world), code))
+        self._basis_key = None
+        self.window = None
+        if shard == "time":
+            part = np.zeros(8, dtype=np.int32)
+            _lib.check(self.h, self.lib.qgd_get_partition(self.h, _vp(part)))
+            self.window = (int(part[0]), int(part[1]))
+            self.partition = dict(n_lo=int(part[0]), n_hi=int(part[1]), blocks=int(part[2]), blocks_per_rank=int(part[3]),
+                                  block_len=int(part[4]), rank=int(part[5]), world=int(part[6]), nt=int(part[7]))
+
+    def comm_destroy(self):
+        _lib.check(self.h, self.lib.qgd_comm_destroy(self.h))
+
+    def comm_info(self):
+        out = (C.c_int32 * 3)()
+        _lib.check(self.h, self.lib.qgd_comm_info(self.h, out))
+        return dict(rank=out[0], world=out[1], shard="columns" if out[2] == _lib.QGD_SHARD_COLUMNS else "time")
+
     # -- evaluation --------------------------------------------------------
     def _hist_shape(self):
-        return (2 * self.N, self.m + 1, self.nsteps + 1, self.c)
+        win = getattr(self, "window", None)               # (a time-partitioned handle returns its own window)
+        nt = self.nsteps + 1 if win is None else win[1] - win[0] + 1
+        return (2 * self.N, self.m + 1, nt, self.c)
 
     def pin(self, array):
         """Register (pin) an output array that will be handed to discrete_adjoint / eval_forward repeatedly
@@ -242,7 +275,7 @@ class DeviceProblem:
             return io[1].copy(), io[2].copy()
         _check_out(uv_history, self._hist_shape(), "history")
         _check_out(lambda_history, self._hist_shape(), "lambda_history")
-        _check_out(adjoint_forcing, (2 * self.N, self.nsteps + 1, self.c), "adjoint_forcing")
+        _check_out(adjoint_forcing, (2 * self.N, self._hist_shape()[2], self.c), "adjoint_forcing")
         pc = np.ascontiguousarray(pcof, dtype=np.float64)
         grad = np.zeros(len(pc))
         out3 = np.zeros(3)

@@ -152,8 +152,9 @@ def test_handle_cache_follows_the_problem(qgd):
 @pytest.mark.parametrize("shard", ["time", "columns"])
 def test_bench_two_processes_share_the_gpu(shard):
     """`python bench.py --gpus 2` as the driver starts it (bare: it launches two ranks itself), here with two PROCESSES
-    on the one GPU of the test box and the gloo backend (collectives staged through the host: RCCL refuses two ranks on
-    one device).  Every step of the multi-process protocol is real -- rendezvous, one handle per process, the two
+    on the one GPU of the test box, through the phase hooks (--comm torch) with the gloo backend (collectives staged through
+    the host: RCCL refuses two ranks on one device; the in-library RCCL route is covered with one rank below and in
+    tests/test_gpu_rccl.py).  Every step of the multi-process protocol is real -- rendezvous, one handle per process, the two
     all-gathers and the all-reduce on the library's exchange buffers -- only the transport differs from the product
     path.  The partitioned gradient must equal the single-process one, for cnot3 and for C5."""
     import json
@@ -162,7 +163,7 @@ def test_bench_two_processes_share_the_gpu(shard):
     env = dict(os.environ, MASTER_PORT="29631")
     one = subprocess.run([sys.executable, bench, "--gpus", "1", "--no-large-n"] + common, capture_output=True, text=True, timeout=600, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--shard", shard] + common,
+    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--comm", "torch", "--backend", "gloo", "--oversubscribe", "--shard", shard] + common,
                          capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
@@ -173,6 +174,27 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert "error" not in j2["large_n"], j2["large_n"]
     assert j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10
     assert j2["weak_in_time"] is None or "error" not in j2["weak_in_time"], j2["weak_in_time"]
+
+
+@pytest.mark.parametrize("shard", ["time", "columns"])
+def test_bench_in_library_rccl_one_rank(shard):
+    """`bench.py --force-dist`: the partitioned evaluation with the collectives issued INSIDE the library over an RCCL
+    communicator (one rank on the one GPU of the test box); same gradient as the plain single-GPU run, and the JSON
+    line carries the event-timed collectives."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-large-n", "--no-cnot2", "--no-with-history", "--nsteps", "120"]
+    env = dict(os.environ, MASTER_PORT="29633")
+    one = subprocess.run([sys.executable, bench] + common, capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    lib = subprocess.run([sys.executable, bench, "--force-dist", "--shard", shard] + common, capture_output=True, text=True, timeout=600, env=env)
+    assert lib.returncode == 0, lib.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in lib.stdout.splitlines() if l.startswith("{")][-1])
+    assert "inside libqgd_hip.so" in j2["config"]["parallelism"]
+    assert abs(j2["grad_norm"] - j1["grad_norm"]) <= 1e-11 * j1["grad_norm"]
+    assert abs(j2["infidelity"] - j1["infidelity"]) <= 1e-12
+    assert j2["collectives_ms"] and all(v >= 0 for v in j2["collectives_ms"].values()), j2["collectives_ms"]
 
 
 @pytest.mark.parametrize("which,order,world", [("cnot2", 4, 2), ("cnot2", 8, 4), ("guarded", 6, 2), ("cnot3", 8, 2), ("cnot3", 8, 8),

@@ -200,3 +200,129 @@ def test_csc_operators_equal_dense(qgd, orc):
         finally:
             orc.set_sparse_operators(False)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_hardcoded_partial_derivatives(qgd, orc):
+    """The d/dtheta known-answer block of test/hardcoded_derivatives.jl:137-160 (compute_partial_derivative!, hermite.jl:
+    321-386) against BOTH gradient routes of the oracle, to 1e-15: (a) the forced route -- the Taylor recursion on the
+    partial-derivative matrix with the (dA/dtheta) w_i terms as its forcing (eval_grad_forced.jl:95-131); (b) the adjoint
+    route -- recursive_magic! with compute_inner_prod_S!/K! (eval_grad_discrete_adjoint.jl:656-800), which must return
+    coeff * <d w_k/d theta, lambda> for any lambda.  p(t) = theta cos(t) is CarrierControl(GRAPE(1), [1.0]) with
+    pcof = [theta, 0] (its q = theta sin(t) multiplies the zero antisymmetric operator of the test)."""
+    rng = np.random.default_rng(11)
+    w = rng.random(4); t = rng.random(); th = rng.random()
+    Ks = np.array([[1.0, 0], [0, 0]]); Kc = np.array([[0.0, 1], [1, 0]]); Z = np.zeros((2, 2))
+    blk = lambda K: np.block([[Z, K], [-K, Z]])
+    c, s = math.cos(t), math.sin(t)
+    A = blk(Ks + th * c * Kc); A1 = blk(-th * s * Kc); A2 = blk(-th * c * Kc)
+    dA = blk(c * Kc); dA1 = blk(-s * Kc); dA2 = blk(-c * Kc)
+    hard = np.stack([np.zeros(4), dA @ w, (dA1 + dA @ A + A @ dA) @ w / 2,
+                     (dA2 + 2 * dA1 @ A + 2 * A1 @ dA + dA @ A1 + A @ dA1 + dA @ A @ A + A @ dA @ A + A @ A @ dA) @ w / 6], axis=1)
+    prob = qgd.SchrodingerProb(Ks, Z, [Kc], [Z], np.zeros(2), np.zeros(2), None, 1.0, 1, 2)
+    ctrl = qgd.CarrierControl(qgd.GRAPEControl(1, 1.0), [1.0])
+    pcof = np.array([th, 0.0])
+    m = 3
+    pv = np.array([orc.fill_p_vec(ctrl, t, pcof, m + 1)]).T          # [(1+m), 1]: p^(d)/d!
+    qv = np.array([orc.fill_p_vec(ctrl, t, pcof, m + 1, q=True)]).T
+    assert np.abs(pv[:, 0] - th * np.array([c, -s, -c / 2, s / 6])).max() < 1e-16
+    uv = np.zeros((4, m + 1), order="F"); uv[:, 0] = w
+    wm = orc.compute_derivatives(prob, pv, qv, uv)                   # w_0 .. w_3
+    # (a) forcing of the partial-derivative recursion: F_j = sum_{i<=j} (dA_{j-i}/dtheta) w_i, dA_d/dtheta = (d^d/dt^d cos t / d!) [0 Kc; -Kc 0]
+    gp = [orc.eval_grad_derivative(ctrl, t, pcof, d)[0] / math.factorial(d) for d in range(m)]
+    assert np.abs(np.array(gp) - np.array([c, -s, -c / 2])).max() < 1e-16
+    F = np.zeros((4, m), order="F")
+    for j in range(m):
+        for i in range(j + 1):
+            F[:, j] += gp[j - i] * (blk(Kc) @ wm[:, i])
+    part = orc.compute_derivatives(prob, pv, qv, np.zeros((4, m + 1), order="F"), forcing=F)
+    assert np.abs(part - hard).max() < 1e-15
+    # (b) recursive_magic! for k = 0..3
+    lam = rng.standard_normal(4)
+    for k in range(m + 1):
+        coeff = 0.37 * (k + 1)
+        got = orc.recursive_magic(prob, ctrl, pcof, m, 0, t, wm, lam, k, coeff)
+        assert abs(got[0] - coeff * (hard[:, k] @ lam)) < 2e-15, (k, got, coeff * (hard[:, k] @ lam))
+
+
+@pytest.mark.parametrize("which,order", [("cnot3", 8), ("cnot3", 12), ("synthetic72", 12), ("synthetic80", 4)])
+def test_propagator_form_equals_reference_form_large(qgd, orc, which, order):
+    """The same tie as above where half of the GPU suite leans on the numpy statement: Hermite order 12 and N >= 64
+    (cnot3: N = 64 with guard levels; dense random N = 72 / 80 at order 12 / 4).  State history with every stage
+    derivative, adjoint forcing, lambda and gradient of the statement against the reference-structured oracle (its
+    terminal solve run to convergence, see test_reference_terminal_solve_stalls)."""
+    if which == "cnot3":
+        # (order 12 at dt = 0.25: at dt = 1 the oracle's own GMRES residuals accumulate to 1e-10 in the m = 6 stage derivatives)
+        nsteps = 20 if order == 8 else 8
+        prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps) * (1.0 if order == 8 else 0.25))
+    else:
+        N = int(which[len("synthetic"):])
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=3, nsteps=5, tf=0.1)
+        prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    m = order // 2
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, m)
+    r = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    orc.set_converged_terminal(True)
+    orc.set_num_threads(8)
+    try:
+        g, hist, lam, forcing, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    finally:
+        orc.set_converged_terminal(False)
+    hs = max(1.0, np.abs(hist).max())
+    assert np.abs(pp.history_real(r["ws"]) - hist).max() < 1e-11 * hs
+    assert np.abs(g - r["grad"]).max() <= 1e-10 * np.abs(g).max()
+    assert abs(r["guard"] - orc.guard_penalty_real(prob, hist)) < 1e-12
+
+
+def test_legacy_controls_oracle_vs_host(qgd, orc):
+    """the hard-coded quadratic B-spline (BSpline2Control, bspline_control.jl:21-249) and the Juqbox
+    bcarrier2 layout (BSplineControl, bspline_control.jl:251-395 + bspline_backend.jl:381-955) restated in the oracle,
+    against the product's host classes: values p^(d), q^(d) and the d/dtheta rows at knots, end points and random
+    times.  BSplineControl is checked through the oracle's direct bcarrier2 restatement (orders 0, 1 -- all the
+    reference implements), which is independent of the carrier-wave wrapper the product builds it from."""
+    rng = np.random.default_rng(21)
+    tf, D1 = 7.0, 9
+    omega = [0.0, 1.3, -2.1]
+    b2 = qgd.BSpline2Control(D1, tf)
+    bc_host = qgd.BSplineControl(tf, D1, omega)
+    from oracle.oracle import BCarrier2Control
+    bc_orc = BCarrier2Control(tf, D1, omega)
+    assert bc_host.N_coeff == bc_orc.N_coeff == 2 * D1 * len(omega)
+    dtk = tf / (D1 - 2)
+    times = np.concatenate([[0.0, tf, dtk, 3 * dtk, tf - 1e-13], rng.random(12) * tf])
+    for host, oc, dmax in ((b2, b2, 3), (bc_host, bc_orc, 1)):
+        pcof = rng.standard_normal(host.N_coeff)
+        for t in times:
+            for d in range(dmax + 1):
+                for is_q in (False, True):
+                    want = (host.eval_q_derivative if is_q else host.eval_p_derivative)(t, pcof, d)
+                    got = orc.fill_p_vec(oc, t, pcof, d + 1, q=is_q)[d] * math.factorial(d)
+                    assert abs(got - want) <= 1e-13 * max(1.0, abs(want)), (type(oc).__name__, t, d, is_q)
+                    gw = (host.eval_grad_q_derivative if is_q else host.eval_grad_p_derivative)(t, pcof, d)
+                    gg = orc.eval_grad_derivative(oc, t, pcof, d, q=is_q)
+                    assert np.abs(gg - gw).max() <= 1e-13 * max(1.0, np.abs(gw).max()), (type(oc).__name__, t, d, is_q)
+    # the spline is a partition of unity inside [0, tf] and its derivative rows sum to zero (bspline2's three pieces)
+    ones = np.concatenate([np.ones(D1), np.zeros(D1)])
+    for t in times:
+        v = orc.fill_p_vec(b2, t, ones, 3)
+        assert abs(v[0] - 1.0) < 1e-13 and abs(v[1]) < 1e-12 and abs(v[2]) < 1e-12
+
+
+def test_legacy_controls_three_way_contract(qgd, orc):
+    """The reference's parity contract (test/GradientTests/compare_gradients.jl:47-65: adjoint == forced <= 1e-14,
+    == central differences <= 3e-9) met by the oracle with the legacy control families: BSpline2Control under carrier
+    waves (my_bspline_controls, bspline_control.jl:52-64) at orders 2-6, and BSplineControl in its bcarrier2 form at
+    order 2 (it implements derivative orders 0 and 1 only)."""
+    from oracle.oracle import BCarrier2Control
+    prob = qgd.construct_rand_prob(4, 1, tf=1.0, nsteps=10, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    target = cases.rand_target(prob)
+    rng = np.random.default_rng(5)
+    for ctrl, orders in ((qgd.CarrierControl(qgd.BSpline2Control(6, prob.tf), [-3.0, 0.0, 2.0]), (2, 4, 6)),
+                         (BCarrier2Control(prob.tf, 6, [-3.0, 0.0, 2.0]), (2,))):
+        pcof = rng.random(ctrl.N_coeff)
+        for order in orders:
+            ga = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+            gf = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+            gd = orc.eval_grad_finite_difference(prob, ctrl, pcof, target, order=order)
+            scale = np.abs(ga).max()
+            assert np.abs(ga - gf).max() <= 1e-13 * scale, (type(ctrl).__name__, order)
+            assert np.abs(ga - gd).max() <= 3e-8 * scale, (type(ctrl).__name__, order)
