@@ -91,6 +91,20 @@ int qgd_abi_version(void);
  * re-parameterisation; invalidates control tables and histories. */
 int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
 
+/* Long time grids in bounded memory.  The step matrices of a grid (~330 KB per time step at cnot3, 18 MB at N = 256)
+ * stay resident when they fit; when they do not -- the reference's low-order runs have 10^4 .. 10^6 steps
+ * (examples/cnot3_optimize_gate.sb:27-40) and keep no matrices at all -- the grid is processed in windows that share one
+ * set of buffers: a forward pass over the windows (only the state at each window boundary is kept) and an adjoint pass
+ * back over them that forms a window's matrices and forward history again before differentiating it.  Results equal the
+ * resident evaluation to rounding; the price is build + inverse + forward history once more.
+ * bytes = 0 (default): 70 % of the device memory that is free when the grid is allocated; a grid whose single time step
+ * does not fit returns QGD_ERR_MEMORY.  Re-allocates the grid (set the control basis afterwards, for the WHOLE grid).
+ * With more than one window the reference-layout history outputs, the forced sweeps, qgd_eval_adjoint,
+ * qgd_set_control_tables and qgd_get_intermediate return QGD_ERR_UNSUPPORTED (they need the grid resident).
+ * qgd_get_memory_plan: out4 = { windows, time steps per window, bytes of the per-window buffers, budget (0 = automatic) }. */
+int qgd_set_memory_budget(qgd_handle h, size_t bytes);
+int qgd_get_memory_plan(qgd_handle h, int64_t *out4);
+
 /* Target gate in the stacked real form [Re; Im], 2N x n_cols -- what both call
  * sites build with vcat(real, imag) (eval_grad_discrete_adjoint.jl:126,
  * ipopt_optimal_control.jl:218). */
@@ -122,6 +136,13 @@ int qgd_set_control_tables(qgd_handle h, const double *p_tables, const double *q
  * 1 - (out3[0]^2 + out3[1]^2)/n_ess^2  (infidelity.jl:7-18). */
 int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof,
                      double *uv_history, double *out3);
+
+/* eval_forward's keyword saveEveryNsteps (src/forward_evolution.jl:15-19, :104, :178, :239-241): after
+ * qgd_set_save_every(h, s) the uv_history of qgd_eval_forward / qgd_eval_forward_forced is
+ * [2N, 1+order/2, 1 + nsteps / s, n_cols] and slot k holds time point k * s (the device keeps every time point; the
+ * re-layout kernel reads them with a stride).  The histories of qgd_discrete_adjoint are not affected -- the reference's
+ * discrete_adjoint! has no such keyword.  Default 1. */
+int qgd_set_save_every(qgd_handle h, int32_t save_every_nsteps);
 
 /* discrete_adjoint! (eval_grad_discrete_adjoint.jl:107-160): gradient of
  * infidelity + guard penalty (no ridge term, as the reference).  With

@@ -33,9 +33,12 @@ mutable struct DeviceProblem
     order::Int
     nsteps::Int
     basis_key::UInt
-    pinned::Vector{Any}      # output arrays registered with the handle (kept alive until unregistered)
+    pinned::Vector{Any}      # output arrays registered with the handle (at most MAX_PINNED, oldest unregistered first)
     general::Bool            # controls that are not linear in pcof: tables + Jacobian per evaluation, NULL pcof
     general_pcof::Vector{Float64}
+    cost_type::Symbol        # what the handle is set to (ccall only on change)
+    lambda_derivatives::Bool
+    last_out3::Vector{Float64}   # the three scalars of the last evaluation (objective_terms / last_objective)
 end
 
 function check(h, rc)
@@ -75,7 +78,7 @@ function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
         end
     end
     check(C_NULL, rc)
-    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0), Any[], false, Float64[])
+    dp = DeviceProblem(h[], order, prob.nsteps, UInt(0), Any[], false, Float64[], :Infidelity, false, zeros(3))
     finalizer(x -> ccall((:qgd_destroy, libqgd), Cvoid, (Ptr{Cvoid},), x.handle), dp)
     return dp
 end
@@ -83,8 +86,14 @@ end
 "Pin an output array that is handed to hip_discrete_adjoint! on every iteration (optimize_gate allocates
 state_history, lambda_history and adjoint_forcing once, src/ipopt_optimal_control.jl:207-214): its download then
 runs at PCIe speed beside the adjoint sweep.  The array is kept alive by the handle."
+const MAX_PINNED = 6        # two sets of (history, lambda_history, adjoint_forcing): a caller that passes fresh arrays
+                            # on every call must not grow pinned memory without bound
 function pin!(dp::DeviceProblem, a::Array{Float64})
     any(x -> x === a, dp.pinned) && return a
+    while length(dp.pinned) >= MAX_PINNED
+        old = popfirst!(dp.pinned)
+        ccall((:qgd_unregister_host_buffer, libqgd), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dp.handle, old)
+    end
     check(dp.handle, ccall((:qgd_register_host_buffer, libqgd), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
           dp.handle, a, sizeof(a)))
     push!(dp.pinned, a)
@@ -104,7 +113,8 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
         dp.general || return (pointer(pcof), length(pcof))
         dp.general_pcof == pcof && return (Ptr{Float64}(C_NULL), 0)
     end
-    m, nt, dt = div(dp.order, 2), prob.nsteps + 1, prob.tf / prob.nsteps
+    n_lo, n_hi = time_window(dp)           # the whole grid unless comm_init!(...; shard=:time) gave this rank a window
+    m, nt, dt = div(dp.order, 2), n_hi - n_lo + 1, prob.tf / prob.nsteps
     Gp, Gq, ncoef = Vector{Array{Float64,3}}(), Vector{Array{Float64,3}}(), Int32[]
     linear = true
     for k in 1:prob.N_operators
@@ -114,13 +124,13 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
         probe, g1, g2 = lp .+ 0.37 .* (1 .+ abs.(lp)), zeros(nc), zeros(nc)
         for n in (0, div(nt, 3), nt - 1), d in 0:m            # linearity probe at three time points
             for (f!) in (eval_grad_p_derivative!, eval_grad_q_derivative!)
-                f!(g1, c, n * dt, lp, d); f!(g2, c, n * dt, probe, d)
+                f!(g1, c, (n_lo + n) * dt, lp, d); f!(g2, c, (n_lo + n) * dt, probe, d)
                 linear &= maximum(abs.(g1 .- g2)) <= 1e-12 * max(1.0, maximum(abs.(g1)))
             end
         end
         for n in 0:nt-1, d in 0:m
-            eval_grad_p_derivative!(view(gp, :, 1 + d, 1 + n), c, n * dt, lp, d)
-            eval_grad_q_derivative!(view(gq, :, 1 + d, 1 + n), c, n * dt, lp, d)
+            eval_grad_p_derivative!(view(gp, :, 1 + d, 1 + n), c, (n_lo + n) * dt, lp, d)
+            eval_grad_q_derivative!(view(gq, :, 1 + d, 1 + n), c, (n_lo + n) * dt, lp, d)
             gp[:, 1 + d, 1 + n] ./= factorial(d); gq[:, 1 + d, 1 + n] ./= factorial(d)
         end
         push!(Gp, gp); push!(Gq, gq)
@@ -136,8 +146,8 @@ function set_controls!(dp::DeviceProblem, prob, controls, pcof)
     # general path: the tables themselves, Julia layout [(1+m), N_operators, nsteps+1] (fill_p_mat! stacked over the grid)
     pt, qt = zeros(m + 1, prob.N_operators, nt), zeros(m + 1, prob.N_operators, nt)
     for n in 0:nt-1
-        QuantumGateDesign.fill_p_mat!(view(pt, :, :, 1 + n), controls, n * dt, pcof)
-        QuantumGateDesign.fill_q_mat!(view(qt, :, :, 1 + n), controls, n * dt, pcof)
+        QuantumGateDesign.fill_p_mat!(view(pt, :, :, 1 + n), controls, (n_lo + n) * dt, pcof)
+        QuantumGateDesign.fill_q_mat!(view(qt, :, :, 1 + n), controls, (n_lo + n) * dt, pcof)
     end
     check(dp.handle, ccall((:qgd_set_control_tables, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), dp.handle, pt, qt))
     dp.general_pcof = copy(pcof)
@@ -169,32 +179,49 @@ release!(prob) = foreach(e -> finalize(e[3]), splice!(_cache, findall(e -> e[1] 
 (infidelity_real, guard_penalty_real: src/infidelity.jl:7-18, :56-96) -- no state history needed on the host."
 objective_terms(out3, N_ess) = (1 - (out3[1]^2 + out3[2]^2) / N_ess^2, out3[3])
 
-"Drop-in for eval_forward!(uv_history, prob, controls, pcof; order) -- src/forward_evolution.jl:33-70."
-function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, controls, pcof::Vector{Float64}; order::Int=2)
+"Drop-in for eval_forward!(uv_history, prob, controls, pcof; order, saveEveryNsteps) -- src/forward_evolution.jl:33-70.
+With saveEveryNsteps = s the array is [2N, 1+order/2, 1+div(nsteps,s), N_initial_conditions] and the library's re-layout
+kernel fills it with every s-th time point (qgd_set_save_every; :104, :239-241)."
+function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, controls, pcof::Vector{Float64};
+                           order::Int=2, saveEveryNsteps::Int=1)
     dp = device_problem(prob, order)
+    set_cost_type!(dp, :Infidelity)
     pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
-    out3 = zeros(3)
-    GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
-          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, uv_history, out3))
-    return out3
+    size(uv_history, 3) == 1 + div(prob.nsteps, saveEveryNsteps) || throw(DimensionMismatch("uv_history: $(size(uv_history, 3)) time slots for saveEveryNsteps=$saveEveryNsteps"))
+    check(dp.handle, ccall((:qgd_set_save_every, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, saveEveryNsteps))
+    try
+        GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
+              (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, uv_history, dp.last_out3))
+    finally
+        ccall((:qgd_set_save_every, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, 1)
+    end
+    return nothing      # (as the reference; the three scalars: last_objective(prob, order))
+end
+
+"(infidelity, guard penalty) of the last evaluation of (prob, order) -- with :Tracking / :Norm: (cost, guard penalty)."
+function last_objective(prob::SchrodingerProb, order::Integer)
+    dp = device_problem(prob, order)
+    return dp.cost_type == :Infidelity ? objective_terms(dp.last_out3, prob.N_ess_levels) : (dp.last_out3[1], dp.last_out3[3])
 end
 
 "The objective without the history: what optimize_gate's eval_f needs (INTEGRATION.md section 2, variant B)."
 function hip_objective(prob::SchrodingerProb, controls, pcof::Vector{Float64}, target; order::Int=2)
     dp = device_problem(prob, order)
+    set_cost_type!(dp, :Infidelity)         # (every entry point states the cost type it computes with)
     pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
-    out3 = zeros(3)
     GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
-          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, C_NULL, out3))
-    return objective_terms(out3, prob.N_ess_levels)
+          (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}), dp.handle, pc_ptr, pc_len, C_NULL, dp.last_out3))
+    return objective_terms(dp.last_out3, prob.N_ess_levels)
 end
 
 "cost_type as in src/eval_grad_discrete_adjoint.jl:26-35; anything else throws like the reference."
 function set_cost_type!(dp, cost_type)
     code = cost_type == :Infidelity ? 0 : cost_type == :Tracking ? 1 : cost_type == :Norm ? 2 : throw("Invalid cost type: $cost_type")
+    dp.cost_type == cost_type && return
     check(dp.handle, ccall((:qgd_set_cost_type, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, code))
+    dp.cost_type = cost_type
 end
 
 "Drop-in for discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, prob, controls, pcof, target;
@@ -209,7 +236,8 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
     dp = device_problem(prob, order)
     pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
     set_cost_type!(dp, cost_type)
-    shape = (prob.real_system_size, 1 + div(order, 2), 1 + prob.nsteps, prob.N_initial_conditions)
+    n_lo, n_hi = time_window(dp)          # (a time-partitioned handle returns its own window of time points)
+    shape = (prob.real_system_size, 1 + div(order, 2), n_hi - n_lo + 1, prob.N_initial_conditions)
     for a in (history, lambda_history)
         a === nothing || size(a) == shape || throw(DimensionMismatch("history arrays must be $shape, got $(size(a))"))
     end
@@ -218,16 +246,18 @@ function hip_discrete_adjoint!(grad::Vector{Float64}, history::Union{Array{Float
     ptr(a) = a === nothing ? Ptr{Float64}(C_NULL) : pointer(a)
     tr = Matrix{Float64}(vcat(real(target), imag(target)))       # as eval_grad_discrete_adjoint.jl:126
     check(dp.handle, ccall((:qgd_set_target, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}), dp.handle, tr))
-    check(dp.handle, ccall((:qgd_set_lambda_derivatives, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, lambda_derivatives))
-    out3 = zeros(3)
+    if dp.lambda_derivatives != lambda_derivatives      # (only on change: the setter makes the library re-zero a registered lambda_history)
+        check(dp.handle, ccall((:qgd_set_lambda_derivatives, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, lambda_derivatives))
+        dp.lambda_derivatives = lambda_derivatives
+    end
     GC.@preserve pcof history lambda_history adjoint_forcing begin
         check(dp.handle, ccall((:qgd_discrete_adjoint, libqgd), Cint,
               (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-              dp.handle, pc_ptr, pc_len, history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), out3))
+              dp.handle, pc_ptr, pc_len, history_precomputed, grad, ptr(history), ptr(lambda_history), ptr(adjoint_forcing), dp.last_out3))
     end
-    set_cost_type!(dp, :Infidelity)
-    # (gradient; (infidelity, guard penalty) of this pcof -- with :Tracking / :Norm out3 is (cost, 0, guard penalty))
-    return grad, (cost_type == :Infidelity ? objective_terms(out3, prob.N_ess_levels) : (out3[1], out3[3]))
+    # returns the gradient, as the reference (src/eval_grad_discrete_adjoint.jl:158); the scalars of this pcof --
+    # (infidelity, guard penalty), or (cost, guard penalty) with :Tracking / :Norm -- are last_objective(prob, order)
+    return grad
 end
 
 """
@@ -246,8 +276,41 @@ function hip_eval_grad_forced(prob::SchrodingerProb, controls, pcof::Vector{Floa
     grad = zeros(length(pcof))
     GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_grad_forced, libqgd), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}),
           dp.handle, pc_ptr, pc_len, grad))
-    set_cost_type!(dp, :Infidelity)
     return grad
+end
+
+# ---- several GPUs: RCCL inside the library (include/qgd.h, "several GPUs behind ONE call") ------------------------------
+# One Julia process (or task pinned to a thread) per GPU.  Rank 0 makes the id; the host carries its 128 bytes to the
+# other ranks once (e.g. MPI.jl: `id = MPI.bcast(rank == 0 ? comm_unique_id() : nothing, 0, MPI.COMM_WORLD)`); after
+# comm_init! the very same hip_discrete_adjoint! / hip_objective calls are collective -- every rank makes them with the
+# same pcof, the library issues the all-gathers / all-reduce on its stream -- and every rank gets the full gradient.
+# This replaces the reference's Threads.@threads loop over initial conditions (src/forward_evolution.jl:48,332).
+
+"128-byte RCCL id (rank 0)."
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(C_NULL, ccall((:qgd_comm_unique_id, libqgd), Cint, (Ptr{UInt8},), id))
+    return id
+end
+
+"Give the handle of (prob, order) on this process's GPU its communicator.  shard = :time (windows of the time grid per
+rank; the controls' basis is then built for the rank's own window by the next set_controls!) or :columns (prob must hold
+this rank's columns of u0, v0 -- and the caller passes its columns of the target -- with the global N_ess_levels)."
+function comm_init!(prob::SchrodingerProb, order::Integer, id::Vector{UInt8}, rank::Integer, world::Integer; shard::Symbol=:time, device::Integer=rank)
+    i = findfirst(e -> e[1] === prob && e[2] == order, _cache)
+    i === nothing && push!(_cache, (prob, order, DeviceProblem(prob, order; device=device)))
+    dp = device_problem(prob, order)
+    check(dp.handle, ccall((:qgd_comm_init_rccl, libqgd), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Int32),
+          dp.handle, id, rank, world, shard == :columns ? 1 : 0))
+    dp.basis_key = UInt(0)          # (a time window re-allocates the grid: the basis is set again, for the window)
+    return dp
+end
+
+"First and last global time point of this rank's window (qgd_get_partition); (0, nsteps) without a time partition."
+function time_window(dp::DeviceProblem)
+    out = zeros(Int32, 8)
+    check(dp.handle, ccall((:qgd_get_partition, libqgd), Cint, (Ptr{Cvoid}, Ptr{Int32}), dp.handle, out))
+    return Int(out[1]), Int(out[2])
 end
 
 end # module

@@ -27,7 +27,8 @@ EXPORTS = [
     "qgd_dist_finish", "qgd_set_timing", "qgd_eval_adjoint", "qgd_set_operator_path", "qgd_get_operator_path", "qgd_eval_grad_forced", "qgd_eval_forward_forced",
     "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc", "qgd_cols_forward", "qgd_cols_adjoint",
     "qgd_set_lambda_derivatives", "qgd_set_cost_type",
-    "qgd_comm_unique_id", "qgd_comm_init_rccl", "qgd_comm_destroy", "qgd_comm_info",
+    "qgd_comm_unique_id", "qgd_comm_init_rccl", "qgd_comm_destroy", "qgd_comm_info", "qgd_set_save_every",
+    "qgd_set_memory_budget", "qgd_get_memory_plan",
 ]
 
 
@@ -114,6 +115,9 @@ def lib():
     L.qgd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_set_lambda_derivatives.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_set_cost_type.argtypes = [C.c_void_p, C.c_int32]
+    L.qgd_set_save_every.argtypes = [C.c_void_p, C.c_int32]
+    L.qgd_set_memory_budget.argtypes = [C.c_void_p, C.c_size_t]
+    L.qgd_get_memory_plan.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_comm_unique_id.argtypes = [C.c_void_p]
     L.qgd_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.qgd_comm_destroy.argtypes = [C.c_void_p]

@@ -97,8 +97,19 @@ struct qgd_handle_s {
     // collectives issued on the handle's stream between the phases (no host synchronisation in between).
     ncclComm_t comm = nullptr;
     int comm_shard = QGD_SHARD_TIME, comm_rank = 0, comm_world = 1;
-    double *scal_local = nullptr;       // this rank's own {<w,R>, <w,T>, guard, flag} before a reduction made them global
-    bool scal_saved = false;
+    // bounded-memory time grid (qgd_set_memory_budget): chunks_eff windows of the grid share the per-time-point buffers
+    size_t mem_budget = 0;              // bytes; 0 = 70 % of the free device memory when the grid is allocated
+    int chunks_eff = 1;                 // windows the grid is processed in (1: everything resident)
+    int chunks_req = 1;                 // the count plan_windows derived that layout from
+    size_t window_bytes = 0;            // device bytes of the per-window buffers
+    int resident_window = 0;            // whose step matrices are in the buffers right now
+    double *chunk_state = nullptr;      // [chunks_eff + 1][Np][2cp]: the state at the start of every window (+ the final state)
+    double *carry_y = nullptr;          // y at the end of the window the adjoint pass does next
+    double *scal_scratch = nullptr;     // where a re-run of a window's forward sweep puts its guard sum (already counted)
+    int save_every = 1;                 // qgd_set_save_every: uv_history of qgd_eval_forward holds every save_every-th time point
+    double *redglob = nullptr;          // [n_pcof + 8] time shards: the reductions are out of place (send = the rank's own
+                                        // [grad | scalars], receive = this), so a later history_precomputed call still finds
+                                        // the rank's OWN guard sum and overlaps on the device, not the sums over the ranks
 };
 
 namespace {
@@ -171,6 +182,139 @@ struct PhaseTimer {
     ~PhaseTimer() { if (on) (void)hipEventRecord(h->phases[idx].e1, stream); }
 };
 
+// The scan layout of one window of `S_w` steps: B blocks of blen steps (+ the second level for B > 8).
+static void plan_scan(const qgdk_ctx &k, int S_w, int &B0)
+{
+    // two scan levels: chain length 2*S/B + 2*B/B2 + B2, near its minimum for B ~ S^(2/3), B2 ~ sqrt(2B)
+    B0 = (int)std::lround(std::pow((double)S_w, 2.0 / 3.0));
+    if (S_w < 24) B0 = 1;
+    if (B0 > 64) B0 = 64;
+    if (getenv("QGD_SCAN_B0")) B0 = atoi(getenv("QGD_SCAN_B0"));      // (tuning experiments)
+    if (B0 < 1) B0 = 1;
+    if (k.Np > 64 && k.Np <= 288) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile
+        const int ngt = std::max(k.Np / 32, k.cp / 32);
+        B0 = std::min(B0, std::max(8, 256 / std::max(ngt, 1)));
+    }
+}
+
+// Window layout of the time grid for (part_rank, part_world) -- ranks of a multi-GPU partition -- or, on one GPU, for
+// `chunks` windows processed one after the other in the same buffers (bounded memory): sets bpr, blocks_glob, scan_blen,
+// scan_blocks(2), scan_g and the window [n_off, n_off + nt) of window `win`.
+static int plan_windows(qgd_handle h, int chunks, int win)
+{
+    qgdk_ctx &k = h->k;
+    const int S = h->nsteps;
+    int W = h->part_world, r = h->part_rank;
+    if (chunks > 1) {
+        // every chunk gets the scan layout of a stand-alone grid of ceil(S / chunks) steps
+        const int Sc = (S + chunks - 1) / chunks;
+        int B0; plan_scan(k, Sc, B0);
+        k.scan_blen = (Sc + B0 - 1) / B0;
+        k.bpr = (Sc + k.scan_blen - 1) / k.scan_blen;
+        const int wsteps = k.bpr * k.scan_blen;
+        W = (S + wsteps - 1) / wsteps;                 // (>= 1 step in the last window by construction)
+        r = win;
+        k.blocks_glob = k.bpr * W;
+        h->chunks_eff = W;
+    } else {
+        int B0; plan_scan(k, S, B0);
+        k.bpr = (B0 + W - 1) / W;
+        for (;;) {   // every rank must own at least one non-empty block
+            k.blocks_glob = k.bpr * W;
+            k.scan_blen = (S + k.blocks_glob - 1) / k.blocks_glob;
+            const int nonempty = (S + k.scan_blen - 1) / k.scan_blen;
+            if ((W - 1) * k.bpr < nonempty || k.bpr == 1) break;
+            k.bpr--;
+        }
+        h->chunks_eff = 1;
+    }
+    k.scan_blocks = k.bpr;     // the scan inside a window runs over its own blocks
+    k.blk_lo = r * k.bpr; k.blk_hi = k.blk_lo + k.bpr;
+    const int s_lo = k.blk_lo * k.scan_blen;
+    const int s_hi = std::min(S, k.blk_hi * k.scan_blen);
+    if (s_lo >= S) return fail(h, QGD_ERR_UNSUPPORTED, "too few timesteps for this many ranks (a rank would own no step)");
+    k.n_off = s_lo; k.nt = s_hi - s_lo + 1; k.nt_glob = S + 1;
+    k.dt = k.tf / S;
+    if (chunks > 1) {          // a chunk is a stand-alone grid to the scan kernels; only the time index is global
+        k.part_rank = 0; k.part_world = 1;
+        k.g_n0 = k.n_off;      // (g_nt is set with the control basis, which covers the whole grid)
+    } else {
+        k.part_rank = h->part_rank; k.part_world = W;
+        k.g_n0 = 0; k.g_nt = 0;
+    }
+    if (k.scan_blocks > 8) {
+        int B2 = (int)std::lround(std::sqrt(2.0 * k.scan_blocks));
+        if (getenv("QGD_SCAN_B2")) B2 = std::max(1, atoi(getenv("QGD_SCAN_B2")));
+        k.scan_g = (k.scan_blocks + B2 - 1) / B2;
+        k.scan_blocks2 = (k.scan_blocks + k.scan_g - 1) / k.scan_g;
+    } else { k.scan_blocks2 = 1; k.scan_g = k.scan_blocks; }
+    return QGD_OK;
+}
+
+// Allocate (dry = false) or only add up (dry = true, into *bytes) every device buffer whose size follows the window.
+static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
+{
+    qgdk_ctx &k = h->k;
+    size_t total = 0;
+    int rc = QGD_OK;
+    auto A = [&](double **p, size_t count) -> bool {
+        total += count * sizeof(double) + 64;
+        if (dry) return true;
+        rc = dev_alloc(h, h->grid_bufs, p, count);
+        return rc == QGD_OK;
+    };
+    const size_t Np = k.Np, PW = 2 * Np, PWc = 2 * k.cp, nt = k.nt, m = k.m;
+    const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
+    const size_t nb = (size_t)k.scan_blocks, W = (size_t)k.part_world, nb2 = (size_t)k.scan_blocks2;
+    k.sigma_planes = k.cp / 8;
+    bool ok = A(&k.tab, nt * (m + 1) * (size_t)std::max(k.n_ops, 1) * 2) && A(&k.D, nt * m * panel) && A(&k.L, nt * panel) &&
+              A(&k.R, nt * panel) && A(&k.LinvA, nt * 2 * pl) && A(&k.LinvT, nt * 2 * pl) && A(&k.Pr, nt * panel) &&
+              A(&k.Pc, nt * 2 * pl) && A(&k.hist, nt * hstep) && A(&k.dpsi, nt * m * hstep) && A(&k.forcing, nt * hstep) &&
+              A(&k.yhist, nt * hstep) && A(&k.lam, nt * hstep) &&
+              A(&k.sigma, (size_t)k.sigma_planes * nt * (size_t)std::max(k.n_ops, 1) * m * 2) &&
+              // blocked scan of the sweeps: chain length 2*blen + B; exchange buffers hold every rank's chunk
+              A(&k.PiX, 2 * nb * 2 * pl) && A(&k.phiX, (nb + 1) * hstep) && A(&k.RX, W * 4 * pl) && A(&k.phiRX, W * 2 * hstep) &&
+              A(&k.wbnd, (W + 1) * hstep) && A(&k.wbndY, (W + 1) * hstep) && A(&k.bnd, (nb + 1) * hstep) &&
+              A(&k.bndY, (nb + 1) * hstep) && A(&k.psi0, hstep) && A(&k.zero_panel, hstep) && A(&k.PiC2, nb2 * 2 * pl) &&
+              A(&k.PiR2, nb2 * 2 * pl) && A(&k.phi2, nb2 * hstep) && A(&k.bnd2, (nb2 + 1) * hstep) && A(&k.bndY2, (nb2 + 1) * hstep);
+    if (!ok) return rc;
+    // sub-block history pass (qgd_k_chain.hip): only with compiled-size chains, blocks of at least 6 steps
+    k.sub_hist = 0; k.sub_n = 0; if (!dry) k.Hmid = k.Qmid = nullptr;
+    if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blen >= 6 && !getenv("QGD_HIST_WHOLE_BLOCKS")) {
+        k.sub_hist = 1; k.sub_n = (k.scan_blen + 2) / 3 - 1;      // stored products after 3, 6, ... steps
+        if (!A(&k.Hmid, nb * (size_t)k.sub_n * 2 * pl) || !A(&k.Qmid, (nb2 + 1) * (size_t)std::max(k.scan_g, 2) * 2 * pl)) return rc;
+    }
+    // derivative / gradient kernels.  N <= 64: panels in LDS.  N > 64: the GEMM-style kernels of qgd_k_dense.hip
+    // (faster than the LDS-panel kernels at every size measured, scripts/mid_n_timing.py), which keep the m seed
+    // panels g_j of a time point in HBM.  QGD_DENSE_OLD=1 keeps the older kernels (LDS panels, or HBM slabs when
+    // they do not fit) for comparison.
+    if (!dry) { k.panel_scratch = nullptr; k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr; }
+    const bool lds_too_small = qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS");
+    if (Np > 64 && !getenv("QGD_DENSE_OLD")) {
+        if (!A(&k.panel_scratch, nt * m * hstep) || !A(&k.Afrag, nt * m * 2 * pl) || !A(&k.Dfrag, nt * m * 2 * pl) ||
+            !A(&k.OpFrag, (size_t)std::max(k.n_ops, 1) * 2 * pl)) return rc;
+        if (!dry) {
+            if (qgdk_dense_operator_frag(&k)) return fail(h, QGD_ERR_NO_DEVICE, "operator fragment kernel failed to launch");
+            k.dense_gemm = 1;
+        }
+    } else if (lds_too_small) {
+        const size_t slabs = nt * (size_t)(k.cp / 8);
+        if (!A(&k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16)) return rc;
+    }
+    // inverse work slabs when the matrix does not fit in LDS
+    const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
+    if (need > 150 * 1024 || Np > 64) {      // (the blocked kernel for Np > 64 always works in a slab)
+        k.inv_batch = 512;
+        // (work slab + the 64 pivot rows of a super-step of k_inverse_blocked2, per workgroup)
+        if (!A(&k.inv_scratch, (size_t)k.inv_batch * (2 * pl + 64 * 2 * Np))) return rc;
+    } else {
+        k.inv_batch = 0; if (!dry) k.inv_scratch = nullptr;
+    }
+    if (h->chunks_eff > 1 && (!A(&h->chunk_state, ((size_t)h->chunks_eff + 1) * hstep) || !A(&h->carry_y, hstep) || !A(&h->scal_scratch, 8))) return rc;
+    if (bytes) *bytes = total;
+    return QGD_OK;
+}
+
 int alloc_grid(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
@@ -180,118 +324,41 @@ int alloc_grid(qgd_handle h)
     free_pool(h->forcing_bufs); h->forcing_key = 0;
     free_pool(h->stage_bufs); h->stage_hist = h->stage_lam = h->stage_f = nullptr;
     h->dlam = h->dlam_scratch = h->stage_lam_full = nullptr;
-    // ---- time partition: S global steps in B = bpr*world blocks of blen steps; rank r owns blocks
-    //      [r*bpr, (r+1)*bpr) and the time points [n_off, n_off + nt) (window ends shared with neighbours)
-    {
-        const int S = h->nsteps, W = h->part_world;
-        // two scan levels: chain length 2*S/B + 2*B/B2 + B2, near its minimum for B ~ S^(2/3), B2 ~ sqrt(2B)
-        int B0 = (int)std::lround(std::pow((double)S, 2.0 / 3.0));
-        if (S < 24) B0 = 1;
-        if (B0 > 64) B0 = 64;
-        if (getenv("QGD_SCAN_B0")) B0 = atoi(getenv("QGD_SCAN_B0"));      // (tuning experiments)
-        if (B0 < 1) B0 = 1;
-        if (k.Np > 64 && k.Np <= 288) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile
-            const int ngt = std::max(k.Np / 32, k.cp / 32);
-            B0 = std::min(B0, std::max(8, 256 / std::max(ngt, 1)));
-        }
-        k.bpr = (B0 + W - 1) / W;
-        for (;;) {   // every rank must own at least one non-empty block
-            k.blocks_glob = k.bpr * W;
-            k.scan_blen = (S + k.blocks_glob - 1) / k.blocks_glob;
-            const int nonempty = (S + k.scan_blen - 1) / k.scan_blen;
-            if ((W - 1) * k.bpr < nonempty || k.bpr == 1) break;
-            k.bpr--;
-        }
-        k.scan_blocks = k.bpr;     // the scan inside a rank's window runs over its own blocks
-        k.part_rank = h->part_rank; k.part_world = W;
-        k.blk_lo = h->part_rank * k.bpr; k.blk_hi = k.blk_lo + k.bpr;
-        const int s_lo = k.blk_lo * k.scan_blen;
-        const int s_hi = std::min(S, k.blk_hi * k.scan_blen);
-        if (s_lo >= S) return fail(h, QGD_ERR_UNSUPPORTED, "too few timesteps for this many ranks (a rank would own no step)");
-        k.n_off = s_lo; k.nt = s_hi - s_lo + 1; k.nt_glob = S + 1;
-        k.dt = k.tf / S;
-        if (k.scan_blocks > 8) {
-            int B2 = (int)std::lround(std::sqrt(2.0 * k.scan_blocks));
-            if (getenv("QGD_SCAN_B2")) B2 = std::max(1, atoi(getenv("QGD_SCAN_B2")));
-            k.scan_g = (k.scan_blocks + B2 - 1) / B2;
-            k.scan_blocks2 = (k.scan_blocks + k.scan_g - 1) / k.scan_g;
-        } else { k.scan_blocks2 = 1; k.scan_g = k.scan_blocks; }
-    }
-    const size_t Np = k.Np, PW = 2 * Np, PWc = 2 * k.cp, nt = k.nt, m = k.m;
-    const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
+    h->chunk_state = h->carry_y = h->scal_scratch = nullptr; h->resident_window = 0;
+    // ---- how much of the time grid is resident.  Everything (one window) when it fits the budget; else the grid is
+    //      processed in `chunks` windows, one after the other in the same buffers (chunked_forward / chunked_adjoint).
+    //      Budget: qgd_set_memory_budget, or 70 % of what is free now (the control basis and the reference-layout
+    //      staging buffers come on top).
+    int chunks = 1;
     int rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.tab, nt * (m + 1) * (size_t)std::max(k.n_ops, 1) * 2))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.D, nt * m * panel))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.L, nt * panel))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.R, nt * panel))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.LinvA, nt * 2 * pl))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.LinvT, nt * 2 * pl))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.Pr, nt * panel))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.Pc, nt * 2 * pl))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.hist, nt * hstep))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.dpsi, nt * m * hstep))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.forcing, nt * hstep))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.yhist, nt * hstep))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.lam, nt * hstep))) return rc;
-    if ((rc = dev_alloc(h, h->grid_bufs, &k.sigma, nt * (size_t)std::max(k.n_ops, 1) * m * 2))) return rc;
-    // blocked scan of the sweeps: chain length 2*blen + B; exchange buffers hold every rank's chunk
-    {
-        const size_t nb = (size_t)k.scan_blocks, W = (size_t)k.part_world;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiX, 2 * nb * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiX, (nb + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.RX, W * 4 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.phiRX, W * 2 * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.wbnd, (W + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.wbndY, (W + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd, (nb + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY, (nb + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.psi0, hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.zero_panel, hstep))) return rc;
-        HIP_TRY(h, hipMemsetAsync(k.zero_panel, 0, hstep * sizeof(double), k.stream));
-        const size_t nb2 = (size_t)k.scan_blocks2;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiC2, nb2 * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.PiR2, nb2 * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.phi2, nb2 * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.bnd2, (nb2 + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.bndY2, (nb2 + 1) * hstep))) return rc;
-        // sub-block history pass (qgd_k_chain.hip): only with compiled-size chains, one rank, blocks of at least 6 steps
-        k.sub_hist = 0; k.sub_n = 0; k.Hmid = k.Qmid = nullptr;
-        if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blen >= 6 && !getenv("QGD_HIST_WHOLE_BLOCKS")) {
-            k.sub_hist = 1; k.sub_n = (k.scan_blen + 2) / 3 - 1;      // stored products after 3, 6, ... steps
-            if ((rc = dev_alloc(h, h->grid_bufs, &k.Hmid, nb * (size_t)k.sub_n * 2 * pl))) return rc;
-            if ((rc = dev_alloc(h, h->grid_bufs, &k.Qmid, (nb2 + 1) * (size_t)std::max(k.scan_g, 2) * 2 * pl))) return rc;
+    if ((rc = plan_windows(h, 1, 0))) return rc;
+    if (h->part_world == 1 && !h->comm) {
+        size_t budget = h->mem_budget, fr = 0, tot = 0;
+        if (!budget && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = (size_t)(0.7 * (double)fr);
+        size_t need = 0;
+        (void)alloc_window(h, true, &need);
+        const int S = h->nsteps;
+        while (budget && need > budget) {
+            if (chunks >= S) return fail(h, QGD_ERR_MEMORY, "one time step of this problem does not fit the memory budget (" +
+                                                             std::to_string(need) + " bytes needed, " + std::to_string(budget) + " allowed)");
+            // the need is close to linear in the window length: jump, then verify
+            chunks = std::min<long long>(S, std::max<long long>(chunks + 1, (long long)std::ceil((double)chunks * (double)need / (double)budget)));
+            if ((rc = plan_windows(h, chunks, 0))) return rc;
+            (void)alloc_window(h, true, &need);
         }
-        HIP_TRY(h, hipMemcpyAsync(k.bnd2, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
-        HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
-        HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    } else if (h->mem_budget) {
+        size_t need = 0;
+        (void)alloc_window(h, true, &need);
+        if (need > h->mem_budget) return fail(h, QGD_ERR_MEMORY, "a partitioned handle keeps its whole window resident: " + std::to_string(need) +
+                                                                 " bytes needed, budget " + std::to_string(h->mem_budget));
     }
-    // derivative / gradient kernels.  N <= 64: panels in LDS.  N > 64: the GEMM-style kernels of qgd_k_dense.hip
-    // (faster than the LDS-panel kernels at every size measured, scripts/mid_n_timing.py), which keep the m seed
-    // panels g_j of a time point in HBM.  QGD_DENSE_OLD=1 keeps the older kernels (LDS panels, or HBM slabs when
-    // they do not fit) for comparison.
-    k.panel_scratch = nullptr;
-    k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr;
-    const bool lds_too_small = qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS");
-    if (Np > 64 && !getenv("QGD_DENSE_OLD")) {
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, nt * m * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.Afrag, nt * m * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.Dfrag, nt * m * 2 * pl))) return rc;
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.OpFrag, (size_t)std::max(k.n_ops, 1) * 2 * pl))) return rc;
-        if (qgdk_dense_operator_frag(&k)) return fail(h, QGD_ERR_NO_DEVICE, "operator fragment kernel failed to launch");
-        k.dense_gemm = 1;
-    } else if (lds_too_small) {
-        const size_t slabs = nt * (size_t)(k.cp / 8);
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.panel_scratch, slabs * (size_t)(2 * m + 1) * Np * 16))) return rc;
-    }
-    // inverse work slabs when the matrix does not fit in LDS
-    const size_t need = (3 * Np + 16 + 2 * pl) * sizeof(double);
-    if (need > 150 * 1024 || Np > 64) {      // (the blocked kernel for Np > 64 always works in a slab)
-        k.inv_batch = 512;
-        // (work slab + the 64 pivot rows of a super-step of k_inverse_blocked2, per workgroup)
-        if ((rc = dev_alloc(h, h->grid_bufs, &k.inv_scratch, (size_t)k.inv_batch * (2 * pl + 64 * 2 * Np)))) return rc;
-    } else {
-        k.inv_batch = 0; k.inv_scratch = nullptr;
-    }
+    h->chunks_req = chunks;
+    if ((rc = alloc_window(h, false, &h->window_bytes))) return rc;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt;
+    HIP_TRY(h, hipMemsetAsync(k.zero_panel, 0, hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemcpyAsync(k.bnd2, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     HIP_TRY(h, hipMemsetAsync(k.hist, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.yhist, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
@@ -299,6 +366,7 @@ int alloc_grid(qgd_handle h)
     h->forcing_zero = true;
     if (k.blk_lo == 0)   // the first window starts at the (constant) initial state
         HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    if (h->chunk_state) HIP_TRY(h, hipMemcpyAsync(h->chunk_state, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     // Hermite weights c_j dt^j and c_j (-dt)^j  (hermite.jl:398-399, :422-423)
     for (int j = 0; j <= k.m; j++) {
         double cj = hermite_coefficient(j, k.m, k.m);
@@ -379,10 +447,12 @@ int zerocopy_wgs()
     return e ? atoi(e) : 0;
 }
 
-int copy_history_out(qgd_handle h, double *uv_history)
+int copy_history_out(qgd_handle h, double *uv_history, int save = 1)
 {
     qgdk_ctx &k = h->k;
-    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N;
+    // save > 1 (eval_forward's saveEveryNsteps, forward_evolution.jl:104,178,239-241): slot s of the output holds time
+    // point s * save -- the re-layout kernel reads the panels with a stride of `save` time points
+    const size_t hstep = (size_t)k.Np * 2 * k.cp * (size_t)save, nt = 1 + ((size_t)k.nt - 1) / (size_t)save, m = k.m, n2 = 2 * (size_t)k.N;
     const size_t total = n2 * (m + 1) * nt * k.c;
     int rc = copy_side(h);
     if (rc) return rc;
@@ -392,12 +462,13 @@ int copy_history_out(qgd_handle h, double *uv_history)
         double *dst = reinterpret_cast<double *>(static_cast<char *>(reg->dev) + (reinterpret_cast<char *>(uv_history) - static_cast<char *>(reg->host)));
         if ((rc = hand_over(h))) return rc;
         K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, dst, dcol, dn, dj, 0, (int)nt, 1, 0, h->copy_stream, zerocopy_wgs()));
-        K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, dst + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, h->copy_stream, zerocopy_wgs()));
+        K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)(hstep / save), dst + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, h->copy_stream, zerocopy_wgs()));
         return QGD_OK;
     }
-    if (!h->stage_hist && (rc = dev_alloc(h, h->stage_bufs, &h->stage_hist, total))) return rc;
+    // (the staging buffer is sized for the full grid: a strided call uses its front)
+    if (!h->stage_hist && (rc = dev_alloc(h, h->stage_bufs, &h->stage_hist, n2 * (m + 1) * (size_t)k.nt * k.c))) return rc;
     K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, h->stage_hist, dcol, dn, dj, 0, (int)nt, 1, 0, k.stream, 0));
-    K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream, 0));
+    K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)(hstep / save), h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream, 0));
     if ((rc = hand_over(h))) return rc;
     return download(h, uv_history, h->stage_hist, n2 * (m + 1) * sizeof(double), nt * k.c);
 }
@@ -598,8 +669,92 @@ int adjoint_end(qgd_handle h)
     return QGD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Bounded-memory time grid.  The per-time-point matrices (D, L, R, L^-1, P: ~330 KB per step at cnot3, 18 MB at N = 256)
+// of a long grid do not have to be resident together: the grid is cut into chunks_eff windows that use the SAME
+// buffers one after the other.  Forward pass, windows in order: build -> inverse -> block products -> history of the
+// window from the state the previous window ended in; only that state (one panel per window) is kept.  Adjoint pass,
+// windows in reverse: the window's matrices and forward history are formed again from its stored start state (unless
+// they are the ones still in the buffers), then the adjoint scan of the window from the y the next window ended in,
+// lambda, and the window's share of the gradient, which k_contract ADDS to grad.  Cost: build + inverse + forward
+// history once more for all windows but one.  The reference keeps O(nsteps) state history but no matrices at all
+// (matrix-free GMRES); its low-order runs with 10^4 .. 10^6 steps (examples/cnot3_optimize_gate.sb:27-40) are what
+// this mode is for.
+// ---------------------------------------------------------------------------
+int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool rerun)
+{
+    qgdk_ctx &k = h->k;
+    int rc = plan_windows(h, h->chunks_req, r);
+    if (rc) return rc;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp;
+    const double *start = h->chunk_state + (size_t)r * hstep;
+    for (double *dst : {k.psi0, k.hist, k.bnd, k.bnd2})
+        HIP_TRY(h, hipMemcpyAsync(dst, start, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+    k.keep_scal = (r > 0 || rerun) ? 1 : 0;
+    double *scal_real = k.scal;
+    if (rerun) k.scal = h->scal_scratch;          // (the guard sum of this window was counted by the forward pass)
+    rc = forward_begin(h, pcof, n_pcof);
+    if (!rc) { PhaseTimer t(h, "sweep_forward2"); int e = qgdk_forward_finish(&k); if (e) rc = fail(h, QGD_ERR_NO_DEVICE, "forward history pass failed to launch"); }
+    if (!rc && !qgdk_guard_is_fused(&k) && (k.have_guard || !h->forcing_zero)) {
+        PhaseTimer t(h, "guard");
+        if (qgdk_guard(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "guard kernel failed to launch");
+        if (k.have_guard == 0) h->forcing_zero = true;
+    }
+    k.scal = scal_real; k.keep_scal = 0;
+    if (rc) return rc;
+    if (!rerun)
+        HIP_TRY(h, hipMemcpyAsync(h->chunk_state + (size_t)(r + 1) * hstep, k.hist + (size_t)(k.nt - 1) * hstep, hstep * sizeof(double),
+                                  hipMemcpyDeviceToDevice, k.stream));
+    h->resident_window = r;
+    return QGD_OK;
+}
+
+int chunked_forward(qgd_handle h, const double *pcof, int n_pcof)
+{
+    qgdk_ctx &k = h->k;
+    if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
+    int rc;
+    for (int r = 0; r < h->chunks_eff; r++)
+        if ((rc = chunk_forward(h, pcof, n_pcof, r, false))) return rc;
+    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }      // overlaps (and y_N) from the final state
+    h->forward_valid = true; h->derivs_valid = false;
+    h->fwd_pcof.assign(pcof, pcof + n_pcof);
+    return QGD_OK;
+}
+
+int chunked_adjoint(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp;
+    const int W = h->chunks_eff;
+    int rc;
+    for (int r = W - 1; r >= 0; r--) {
+        if (h->resident_window != r) {
+            if ((rc = chunk_forward(h, h->fwd_pcof.data(), (int)h->fwd_pcof.size(), r, true))) return rc;
+        } else if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
+        if (r == W - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
+        else            // y at the end of this window = y at the start of the next one
+            for (double *dst : {k.yhist + (size_t)(k.nt - 1) * hstep, k.bndY + (size_t)k.scan_blocks * hstep, k.bndY2 + (size_t)k.scan_blocks2 * hstep})
+                HIP_TRY(h, hipMemcpyAsync(dst, h->carry_y, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+        k.grad_accumulate = (r != W - 1) ? 1 : 0;
+        h->derivs_valid = false;
+        rc = adjoint_begin(h);
+        if (!rc) rc = adjoint_end(h);
+        k.grad_accumulate = 0;
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->carry_y, k.yhist, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+    }
+    h->forward_valid = true;          // (the window-boundary states of this pcof are still there for history_precomputed)
+    return QGD_OK;
+}
+
+#define NEEDS_RESIDENT_GRID(h, what)                                                                                   \
+    do { if ((h)->chunks_eff > 1) return fail((h), QGD_ERR_UNSUPPORTED, std::string(what) + " needs the whole time grid resident: this handle " \
+                                               "processes it in " + std::to_string((h)->chunks_eff) + " windows (raise qgd_set_memory_budget)"); } while (0)
+
 int run_forward(qgd_handle h, const double *pcof, int n_pcof)
 {
+    if (h->chunks_eff > 1) return chunked_forward(h, pcof, n_pcof);
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
     int rc = forward_begin(h, pcof, n_pcof);
     if (rc) return rc;
@@ -619,9 +774,10 @@ int check_status(qgd_handle h)
 
 // status + results of an evaluation in one device-to-host copy (the three separate copies cost
 // ~25 us of the 0.5 ms evaluation on cnot3)
-int fetch_results(qgd_handle h, double *grad, double *out3)
+int fetch_results(qgd_handle h, double *grad, double *out3, const double *src = nullptr)
 {
     qgdk_ctx &k = h->k;
+    if (!src) src = k.redbuf;
     if (!k.redbuf || !h->host_out) {
         int rc = check_status(h);
         if (rc) return rc;
@@ -630,10 +786,10 @@ int fetch_results(qgd_handle h, double *grad, double *out3)
         return QGD_OK;
     }
     const size_t np = (size_t)k.n_pcof;
-    HIP_TRY(h, hipMemcpyAsync(h->host_out, k.redbuf, (np + 5) * sizeof(double), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(h, hipMemcpyAsync(h->host_out, src, (np + 5) * sizeof(double), hipMemcpyDeviceToHost, k.stream));
     HIP_TRY(h, hipStreamSynchronize(k.stream));      // (spinning on hipStreamQuery instead: no difference, 359 us either way)
-    int st;
-    memcpy(&st, h->host_out + np + 4, sizeof(int));
+    int st = 0;
+    if (src == k.redbuf) memcpy(&st, h->host_out + np + 4, sizeof(int));      // (a reduced buffer carries the flag as the double in front of it)
     // (host_out[np + 3]: the same flag as a double, summed over the ranks of a time-partitioned evaluation)
     if (st || h->host_out[np + 3] != 0.0) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
     if (grad) memcpy(grad, h->host_out, np * sizeof(double));
@@ -708,15 +864,18 @@ int comm_collective(qgd_handle h, int which)
     } else if (which == 1) {
         const size_t chunk = 2 * hstep;
         NCCL_TRY(h, R.AllGather(k.phiRX + (size_t)k.part_rank * chunk, k.phiRX, chunk, ncclDouble, h->comm, k.stream));
-    } else {
-        // the rank's own scalars are kept: a later history_precomputed call starts from them again, not from the sums
-        HIP_TRY(h, hipMemcpyAsync(h->scal_local, k.scal, 4 * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
-        h->scal_saved = true;
+    } else if (h->comm_shard == QGD_SHARD_TIME) {      // out of place: the rank's own sums stay where the kernels left them
+        const size_t np = (size_t)k.n_pcof;
+        if (which == 2) NCCL_TRY(h, R.AllReduce(k.redbuf, h->redglob, np + 4, ncclDouble, ncclSum, h->comm, k.stream));
+        else NCCL_TRY(h, R.AllReduce(k.scal, h->redglob + np, 4, ncclDouble, ncclSum, h->comm, k.stream));
+    } else {                                            // column blocks: the terminal condition reads the global overlaps in place
         if (which == 2) NCCL_TRY(h, R.AllReduce(k.redbuf, k.redbuf, (size_t)k.n_pcof + 4, ncclDouble, ncclSum, h->comm, k.stream));
         else NCCL_TRY(h, R.AllReduce(k.scal, k.scal, 4, ncclDouble, ncclSum, h->comm, k.stream));
     }
     return QGD_OK;
 }
+
+const double *comm_result(qgd_handle h) { return h->comm_shard == QGD_SHARD_TIME ? h->redglob : h->k.redbuf; }
 
 bool same_pcof(qgd_handle h, const double *pcof, int n_pcof)
 {
@@ -739,7 +898,6 @@ int comm_forward(qgd_handle h, const double *pcof, int n_pcof)
         if ((rc = forward_end(h))) return rc;
     }
     if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
-    h->scal_saved = false;
     return QGD_OK;
 }
 
@@ -759,10 +917,9 @@ int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int hist
     const bool reuse = history_precomputed && same_pcof(h, pcof, n_pcof);
     const bool time = h->comm_shard == QGD_SHARD_TIME;
     if (reuse) {
-        if (time) {
-            if (h->scal_saved) HIP_TRY(h, hipMemcpyAsync(k.scal, h->scal_local, 4 * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
-            if (k.part_rank == k.part_world - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
-        }   // (column shards: the scalars on the device are the global ones of the call that made the history)
+        // time shards: the rank's own guard sum is still in scal (the reductions are out of place); column shards: the
+        // scalars on the device are the global ones of the call that made the history
+        if (time && k.part_rank == k.part_world - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
     } else {
         if ((rc = comm_forward(h, pcof, n_pcof))) return rc;
         if (!time && (rc = comm_collective(h, 3))) return rc;      // <w_N,R>, <w_N,T>, guard: global before the terminal condition
@@ -782,7 +939,7 @@ int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int hist
     // column shards: the scalars are global on every rank already -- all ranks but the first contribute zeros
     if (!time && h->comm_rank != 0) HIP_TRY(h, hipMemsetAsync(k.scal, 0, 3 * sizeof(double), k.stream));
     if ((rc = comm_collective(h, 2))) return rc;
-    if ((rc = fetch_results(h, grad, out3))) return rc;
+    if ((rc = fetch_results(h, grad, out3, comm_result(h)))) return rc;
     return finish_copies(h);
 }
 
@@ -794,11 +951,11 @@ int comm_eval_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_h
     if (uv_history) {
         { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
         h->derivs_valid = true;
-        if ((rc = copy_history_out(h, uv_history))) return rc;
+        if ((rc = copy_history_out(h, uv_history, h->save_every))) return rc;
     }
     K_TRY(h, qgdk_flag_to_scal(&k));      // a singular step matrix on ANY rank fails the call on every rank
     if ((rc = comm_collective(h, 3))) { (void)finish_copies(h); return rc; }
-    if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
+    if ((rc = fetch_results(h, nullptr, out3, comm_result(h)))) { (void)finish_copies(h); return rc; }
     return finish_copies(h);
 }
 
@@ -1115,7 +1272,10 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr; if (h->status_static) k.status = h->status_static;
     h->ncoef.assign(k.n_ops, 0); h->poff.assign(k.n_ops, 0); h->goff.assign(k.n_ops, 0);
     size_t total = 0; int np = 0, ncmax = 0;
-    const size_t per = (size_t)k.nt * (k.m + 1);
+    // (a chunked time grid: the basis covers the WHOLE grid, the kernels of a window index it from the window's offset)
+    k.g_nt = 0;
+    if (h->chunks_eff > 1) { int rcw = plan_windows(h, h->chunks_req, 0); if (rcw) return rcw; k.g_nt = k.nt_glob; }
+    const size_t per = (size_t)(h->chunks_eff > 1 ? k.nt_glob : k.nt) * (k.m + 1);
     for (int o = 0; o < k.n_ops; o++) {
         if (n_coeff[o] < 0) return fail(h, QGD_ERR_ARGUMENT, "negative coefficient count");
         h->ncoef[o] = n_coeff[o]; h->poff[o] = np; h->goff[o] = (int64_t)total;
@@ -1130,6 +1290,12 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     if ((rc = dev_alloc(h, h->basis_bufs, &k.poff, (size_t)k.n_ops + 1))) return rc;
     if ((rc = dev_alloc(h, h->basis_bufs, &h->pcof_dev, (size_t)np + 1))) return rc;
     if ((rc = dev_alloc(h, h->basis_bufs, &k.redbuf, (size_t)np + 8))) return rc;
+    if ((rc = dev_alloc(h, h->basis_bufs, &h->redglob, (size_t)np + 8))) return rc;
+    {   // k_contract: per-time-chunk partial sums, added in chunk order by k_contract_sum
+        // (rows: the time chunks of k_contract, or -- sparse path -- one per (column group, time point) from k_gradpoint_ell)
+        const size_t chunks = std::max(((size_t)k.nt + 7) / 8, (size_t)(k.cp / 8) * (size_t)k.nt);
+        if ((rc = dev_alloc(h, h->basis_bufs, &k.cpart, chunks * (size_t)std::max(np, 1)))) return rc;
+    }
     k.grad = k.redbuf; k.scal = k.redbuf + np;     // [grad | scal]: one all-reduce in the multi-GPU path
     k.status = reinterpret_cast<int *>(k.redbuf + np + 4);   // ... and [grad | scal | status]: one copy to the host
     HIP_TRY(h, hipMemset(k.redbuf, 0, ((size_t)np + 8) * sizeof(double)));
@@ -1162,6 +1328,7 @@ int qgd_set_control_tables(qgd_handle h, const double *pt, const double *qt)
     if (!h || !pt || !qt) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
+    NEEDS_RESIDENT_GRID(h, "qgd_set_control_tables");
     const size_t cnt = (size_t)k.nt * (k.m + 1) * k.n_ops;
     double *tmp = nullptr;
     HIP_TRY(h, hipMalloc((void **)&tmp, 2 * cnt * sizeof(double) + 64));
@@ -1181,13 +1348,14 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     if (h->comm) return comm_eval_forward(h, pcof, n_pcof, uv_history, out3);
+    if (uv_history) NEEDS_RESIDENT_GRID(h, "the uv_history output");
     int rc = run_forward(h, pcof, n_pcof);
     if (rc) return rc;
     if (uv_history) {
         { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
         h->derivs_valid = true;
     }
-    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
+    if (uv_history && (rc = copy_history_out(h, uv_history, h->save_every))) return rc;
     if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
     return finish_copies(h);
 }
@@ -1204,6 +1372,13 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     if (h->comm) return comm_discrete_adjoint(h, pcof, n_pcof, history_precomputed, grad, uv_history, lambda_history, adjoint_forcing, out3);
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points, or give the handle a communicator (qgd_comm_init_rccl)");
     int rc;
+    if (h->chunks_eff > 1) {      // bounded-memory time grid: forward pass over the windows, adjoint pass back over them
+        if (uv_history || lambda_history || adjoint_forcing) NEEDS_RESIDENT_GRID(h, "the history outputs of discrete_adjoint!");
+        if (history_precomputed && !h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+        if (!(history_precomputed && same_pcof(h, pcof, n_pcof)) && (rc = chunked_forward(h, pcof, n_pcof))) return rc;
+        if ((rc = chunked_adjoint(h))) return rc;
+        return fetch_results(h, grad, out3);
+    }
     // full evaluation, nothing but [grad | scalars] coming back, no event bracketing: replay the captured launch sequence
     const bool graph_ok = !h->graph_off && !history_precomputed && !uv_history && !lambda_history && !adjoint_forcing &&
                           !h->timing && k.redbuf && h->host_out && h->host_in && h->host_out_len >= (size_t)n_pcof && pcof;
@@ -1298,6 +1473,7 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced forward sweep is single-GPU");
+    NEEDS_RESIDENT_GRID(h, "eval_forward with a forcing");
     if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || (size_t)(k.m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024)
         return fail(h, QGD_ERR_UNSUPPORTED, "eval_forward with forcing on the device needs N <= 64");
     int rc = forward_begin(h, pcof, n_pcof);
@@ -1336,7 +1512,7 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
         K_TRY(h, qgdk_forcing_add_derivs(&k));     // w_j = D_j w_0 + E_j
         h->derivs_valid = false;
     }
-    if (uv_history && (rc = copy_history_out(h, uv_history))) return rc;
+    if (uv_history && (rc = copy_history_out(h, uv_history, h->save_every))) return rc;
     if ((rc = fetch_results(h, nullptr, out3))) { (void)finish_copies(h); return rc; }
     return finish_copies(h);
 }
@@ -1350,6 +1526,7 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced gradient is single-GPU");
+    NEEDS_RESIDENT_GRID(h, "eval_grad_forced");
     if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || qgdk_forced_lds(k.Np, k.m) > 150 * 1024)
         return fail(h, QGD_ERR_UNSUPPORTED, "forced gradient on the device needs N <= 64 (and order <= 16 at N = 64)");
     int rc;
@@ -1412,6 +1589,7 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: eval_adjoint is single-GPU");
+    NEEDS_RESIDENT_GRID(h, "eval_adjoint");
     int rc = forward_begin(h, pcof, n_pcof);          // tables, L/R, inverses, propagators, block propagators
     if (rc) return rc;
     // the second scan level (super-block propagators) is produced by the forward boundary phase
@@ -1470,6 +1648,7 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
     if (!h || !in || !out) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
+    NEEDS_RESIDENT_GRID(h, "qgd_apply_hamiltonian");
     if (time_index < 0 || time_index >= k.nt || deriv_order < 0 || deriv_order > k.m)
         return fail(h, QGD_ERR_ARGUMENT, "time index or derivative order out of range");
     const size_t PWc = 2 * k.cp, cnt = (size_t)k.Np * PWc;
@@ -1509,6 +1688,7 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
     if (needed) *needed = need;
     if (!out) return QGD_OK;
+    NEEDS_RESIDENT_GRID(h, "qgd_get_intermediate");
     if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     if (s == "repivoted") {     // workgroups of the last inverse launch whose static-pivot attempt was redone with partial pivoting
@@ -1517,7 +1697,16 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         out[0] = (double)v[1];
         return QGD_OK;
     }
-    if (s == "sigma") { HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
+    if (s == "sigma") {      // (the column groups' planes of the N <= 64 gradient kernels are summed here)
+        const bool planes = k.use_sparse || (k.Np == 64 && k.m <= 5 && k.n_ops >= 1);
+        HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> pl_(need);
+        for (int g = 1; planes && g < k.sigma_planes; g++) {
+            HIP_TRY(h, hipMemcpy(pl_.data(), k.sigma + (size_t)g * need, need * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t e = 0; e < need; e++) out[e] += pl_[e];
+        }
+        return QGD_OK;
+    }
     if (s == "tables") { HIP_TRY(h, hipMemcpy(out, k.tab, need * sizeof(double), hipMemcpyDeviceToHost)); return QGD_OK; }
     memset(out, 0, need * sizeof(double));
     if (s == "Linv") {
@@ -1681,7 +1870,6 @@ int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = qgd_comm_destroy(h);
     if (rc) return rc;
-    if (!h->scal_local && (rc = dev_alloc(h, h->static_bufs, &h->scal_local, (size_t)8))) return rc;
     // time windows: the rank's window of the grid (invalidates control basis and histories, like qgd_set_nsteps);
     // column blocks: the handle was created from the rank's columns, the grid stays whole
     if (shard == QGD_SHARD_TIME) { if ((rc = qgd_set_partition(h, rank, world))) return rc; }
@@ -1690,7 +1878,7 @@ int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t comm = nullptr;
     NCCL_TRY(h, R.CommInitRank(&comm, world, id, rank));
-    h->comm = comm; h->comm_shard = shard; h->comm_rank = rank; h->comm_world = world; h->scal_saved = false;
+    h->comm = comm; h->comm_shard = shard; h->comm_rank = rank; h->comm_world = world;
     return QGD_OK;
 }
 
@@ -1785,6 +1973,32 @@ int qgd_set_lambda_derivatives(qgd_handle h, int32_t on)
     if (h->lambda_derivs == (on != 0)) return QGD_OK;      // unchanged: a registered lambda_history keeps its zero fill
     h->lambda_derivs = (on != 0);
     for (auto &r : h->regs) r.zeroed = false;      // columns 1..m of a registered lambda_history change meaning
+    return QGD_OK;
+}
+
+int qgd_set_memory_budget(qgd_handle h, size_t bytes)
+{
+    if (h) drop_graph(h);
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (h->comm || h->part_world != 1) return fail(h, QGD_ERR_STATE, "a partitioned handle keeps its window resident: set the budget before the partition");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->mem_budget = bytes;
+    return alloc_grid(h);          // (invalidates control basis and histories, like qgd_set_nsteps)
+}
+
+int qgd_get_memory_plan(qgd_handle h, int64_t *out4)
+{
+    if (!h || !out4) return QGD_ERR_ARGUMENT;
+    const qgdk_ctx &k = h->k;
+    out4[0] = h->chunks_eff; out4[1] = (int64_t)k.bpr * k.scan_blen; out4[2] = (int64_t)h->window_bytes; out4[3] = (int64_t)h->mem_budget;
+    return QGD_OK;
+}
+
+int qgd_set_save_every(qgd_handle h, int32_t save_every_nsteps)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (save_every_nsteps < 1) return fail(h, QGD_ERR_ARGUMENT, "saveEveryNsteps must be a positive integer");
+    h->save_every = save_every_nsteps;
     return QGD_OK;
 }
 

@@ -42,7 +42,11 @@ typedef struct qgdk_ctx {
     double *forcing;    // [nt][Np][2cp]
     double *yhist;      // [nt][Np][2cp]
     double *lam;        // [nt][Np][2cp]
-    double *sigma;      // [nt][n_ops][m][2]
+    double *sigma;      // [sigma_planes][nt][n_ops][m][2]: one plane per column group for the kernels whose grid is
+                        // (column group, time point) -- each workgroup STORES its plane, k_contract adds the planes in
+                        // order (no atomics: the gradient is bitwise reproducible); the other kernels add into plane 0
+    int sigma_planes;   // planes allocated (cp / 8)
+    double *cpart;      // [time chunks of k_contract][n_pcof] partial sums, added in chunk order by k_contract_sum
     double *grad;       // [n_pcof]
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
@@ -71,6 +75,11 @@ typedef struct qgdk_ctx {
     int sub_hist, sub_n;
     double *Hmid, *Qmid;
     int part_rank, part_world, n_off, nt_glob;
+    // chunked time grid (bounded memory, qgd_set_memory_budget): the handle's per-time-point buffers hold ONE window of
+    // the grid at a time.  The control basis G stays whole: g_nt time points, the current window starts at g_n0
+    // (g_nt = 0: the basis covers exactly the nt points of the buffers).  keep_scal: k_tables must not clear the
+    // scalars (a later window of the same evaluation); grad_accumulate: k_contract adds to grad instead of storing it.
+    int g_nt, g_n0, keep_scal, grad_accumulate;
     // forced (forward-sensitivity) gradient, qgd_k_forced.hip: basis responses and sensitivity scan buffers
     double *fs_BR, *fs_BL;   // [nt][n_ops*2*m][Np][2cp]
     double *fs_phi, *fs_bnd; // [B][Np][2cpS], [B+1][Np][2cpS], cpS = n_pcof * cp

@@ -10,13 +10,17 @@
 __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
                          const double *__restrict__ pcof, double *__restrict__ tab, int nt, int m,
-                         int n_ops, double *__restrict__ scal, int *__restrict__ status)
+                         int n_ops, double *__restrict__ scal, int *__restrict__ status, int g_nt, int g_n0, int keep)
 {
-    // 16 lanes per table entry: contiguous 128-byte reads of the basis row, DPP sum over the 16 lanes
+    // 16 lanes per table entry: contiguous 128-byte reads of the basis row, DPP sum over the 16 lanes.
+    // The basis holds g_nt time points and this launch covers nt of them from g_n0 on (a window of a chunked grid;
+    // g_nt = nt, g_n0 = 0 otherwise).  keep: a later chunk of the same evaluation -- the scalars go on accumulating.
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < 4) scal[gid] = 0.0;            // objective scalars and the singularity flag start at zero
-    if (gid == 4) *status = 0;
-    if (gid == 5) status[1] = 0;          // workgroups of the inverse that fell back to partial pivoting
+    if (!keep) {
+        if (gid < 4) scal[gid] = 0.0;        // objective scalars and the singularity flag start at zero
+        if (gid == 4) *status = 0;
+        if (gid == 5) status[1] = 0;      // workgroups of the inverse that fell back to partial pivoting
+    }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
     double s = 0.0;
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
         const int n = ((idx >> 1) / n_ops) / (m + 1);
         const int nc = ncoef[k];
         // G for control k: [pq][nt][m+1][nc]
-        const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
+        const double *g = G + goff[k] + (((size_t)pq * g_nt + n + g_n0) * (m + 1) + d) * nc;
         const double *pc = pcof + poff[k];
         for (int l = sub; l < nc; l += 16) s = __builtin_fma(g[l], pc[l], s);
     }
@@ -43,12 +47,14 @@ template <int NMAX>
 __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
                          const PcofArg<NMAX> pcof, double *__restrict__ tab, int nt, int m,
-                         int n_ops, double *__restrict__ scal, int *__restrict__ status)
+                         int n_ops, double *__restrict__ scal, int *__restrict__ status, int g_nt, int g_n0, int keep)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < 4) scal[gid] = 0.0;
-    if (gid == 4) *status = 0;
-    if (gid == 5) status[1] = 0;          // workgroups of the inverse that fell back to partial pivoting
+    if (!keep) {
+        if (gid < 4) scal[gid] = 0.0;
+        if (gid == 4) *status = 0;
+        if (gid == 5) status[1] = 0;      // workgroups of the inverse that fell back to partial pivoting
+    }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
     double s = 0.0;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G
         const int d = ((idx >> 1) / n_ops) % (m + 1);
         const int n = ((idx >> 1) / n_ops) / (m + 1);
         const int nc = ncoef[k];
-        const double *g = G + goff[k] + (((size_t)pq * nt + n) * (m + 1) + d) * nc;
+        const double *g = G + goff[k] + (((size_t)pq * g_nt + n + g_n0) * (m + 1) + d) * nc;
         const double *pc = pcof.v + poff[k];
         for (int l = sub; l < nc; l += 16) s = __builtin_fma(g[l], pc[l], s);
     }
@@ -351,7 +357,7 @@ static int launch_tables_arg(const qgdk_ctx *c, const double *pcof_host, int n_p
     memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
     int total = c->nt * (c->m + 1) * c->n_ops * 2;
     hipLaunchKernelGGL((k_tables_arg<NMAX>), dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
-                       c->poff, arg, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
+                       c->poff, arg, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status, c->g_nt ? c->g_nt : c->nt, c->g_n0, c->keep_scal);
     return (int)hipGetLastError();
 }
 
@@ -361,7 +367,7 @@ int qgdk_tables(const qgdk_ctx *c, const double *pcof)
 {
     int total = c->nt * (c->m + 1) * c->n_ops * 2;
     hipLaunchKernelGGL(k_tables, dim3((total * 16 + 255) / 256 + 1), dim3(256), 0, c->stream, c->G, c->goff, c->ncoef,
-                       c->poff, pcof, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status);
+                       c->poff, pcof, c->tab, c->nt, c->m, c->n_ops, c->scal, c->status, c->g_nt ? c->g_nt : c->nt, c->g_n0, c->keep_scal);
     return (int)hipGetLastError();
 }
 

@@ -1434,7 +1434,7 @@ int qgdk_lambda(const qgdk_ctx *c)
 {
     if (c->dense_gemm && !c->use_sparse && c->nt > 1) return qgdk_dense_lambda(c);
 #define CALL_LC(N) hipLaunchKernelGGL((k_lambda_c<N>), dim3(c->cp / 8, c->nt - 1), dim3(256), 0, c->stream, c->LinvT, c->yhist, c->lam, \
-                                      c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof)
+                                      c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->grad_accumulate ? 0 : c->n_pcof)
     if (c->nt > 1) switch (c->Np) {
         case 16: CALL_LC(16); return (int)hipGetLastError();
         case 32: CALL_LC(32); return (int)hipGetLastError();
@@ -1445,7 +1445,7 @@ int qgdk_lambda(const qgdk_ctx *c)
 #undef CALL_LC
     size_t shm = (size_t)c->Np * 16 * sizeof(double);
     hipLaunchKernelGGL(k_lambda, dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->LinvT, c->yhist, c->lam,
-                       c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof);
+                       c->Np, c->cp, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->grad_accumulate ? 0 : c->n_pcof);
     return (int)hipGetLastError();
 }
 

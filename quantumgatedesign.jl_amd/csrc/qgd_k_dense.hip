@@ -497,7 +497,7 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
     const int ng = c->cp / 8;
 #define CALL_LF(RB, NG) hipLaunchKernelGGL((k_lambda_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, 1, c->nt - 1)), dim3(256), 0, \
                                            c->stream, c->LinvT, c->yhist, c->lam, c->Np, c->cp, c->nt, c->sigma,                       \
-                                           c->nt * c->n_ops * c->m * 2, c->grad, c->n_pcof)
+                                           c->nt * c->n_ops * c->m * 2, c->grad, c->grad_accumulate ? 0 : c->n_pcof)
     DISPATCH_SHAPE(ng, CALL_LF);
 #undef CALL_LF
     return (int)hipGetLastError();

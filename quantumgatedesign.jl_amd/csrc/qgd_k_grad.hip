@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gradpoint64(const double *__restrict__ 
     extern __shared__ double smem[];
     double *psi = smem;                         // [M][PS]
     double *gsrc = smem + (size_t)M * PS;       // [PS]
-    double *sig = gsrc + PS;                    // [n_ops*M*2]
+    double *sig = gsrc + PS;                    // [n_ops*M*2][4 waves]
     const int n = blockIdx.y, grp = blockIdx.x;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)NP * PWc, pl = (size_t)NP * NP;
@@ -204,8 +204,6 @@ __global__ __launch_bounds__(256) void k_gradpoint64(const double *__restrict__ 
 
     for (int e = tid; e < PS; e += 256)
         psi[e] = hist[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
-    for (int e = tid; e < n_ops * M * 2; e += 256) sig[e] = 0.0;
-
     // seeds in accumulator layout
     d4 g[M];
     {
@@ -360,18 +358,18 @@ __global__ __launch_bounds__(256) void k_gradpoint64(const double *__restrict__ 
         for (int d = 0; d < M; d++) {
             #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { sp[d] += __shfl_down(sp[d], off); sq[d] += __shfl_down(sq[d], off); }
-            if (lane == 0) { atomicAdd(&sig[(o * M + d) * 2], sp[d]); atomicAdd(&sig[(o * M + d) * 2 + 1], sq[d]); }
+            if (lane == 0) { sig[((o * M + d) * 2) * 4 + rb] = sp[d]; sig[((o * M + d) * 2 + 1) * 4 + rb] = sq[d]; }   // one slot per wave
         }
     }
     __syncthreads();
-    for (int e = tid; e < n_ops * M * 2; e += 256)
-        atomicAdd(&sigma[(size_t)n * n_ops * M * 2 + e], sig[e]);
+    for (int e = tid; e < n_ops * M * 2; e += 256)      // the four waves in order, into this column group's plane (no atomics)
+        sigma[((size_t)grp * nt + n) * n_ops * M * 2 + e] = ((sig[e * 4] + sig[e * 4 + 1]) + sig[e * 4 + 2]) + sig[e * 4 + 3];
 }
 
 template <int M, int NOPS>
 static int launch_gradpoint64(const qgdk_ctx *c)
 {
-    const size_t shm = ((size_t)(M + 1) * 64 * 16 + (size_t)c->n_ops * M * 2) * sizeof(double);
+    const size_t shm = ((size_t)(M + 1) * 64 * 16 + (size_t)c->n_ops * M * 2 * 4) * sizeof(double);
     SET_LDS_ONCE((k_gradpoint64<M, NOPS>), shm);
     hipLaunchKernelGGL((k_gradpoint64<M, NOPS>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab,
                        c->hist, c->lam, c->sigma, c->cw, c->cp, c->nt, c->n_ops);
@@ -397,10 +395,15 @@ __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, 
                                                   const int32_t *__restrict__ ncoef,
                                                   const int32_t *__restrict__ poff,
                                                   const double *__restrict__ sigma,
-                                                  double *__restrict__ grad, int nt, int m, int n_ops,
-                                                  const int *__restrict__ status, double *__restrict__ scal)
+                                                  int nt, int m, int n_ops,
+                                                  const int *__restrict__ status, double *__restrict__ scal,
+                                                  int planes, double *__restrict__ cpart, int n_pcof, int g_nt, int g_n0)
 {
-    // grid (time chunks, n_ops, coefficient tiles of 64); thread = (coefficient, time sub-slot)
+    // grid (time chunks, n_ops, coefficient tiles of 64); thread = (coefficient, time sub-slot).
+    // No atomics: every time chunk STORES its partial sums, and k_contract_sum adds the chunks in chunk order -- the
+    // gradient is bitwise reproducible from run to run (the reference accumulates serially,
+    // eval_grad_discrete_adjoint.jl:603-643).  (One kernel with a "last workgroup adds" ticket was measured: the
+    // device-scope release/acquire around the ticket cost 10 us against 4 us for this second launch.)
     __shared__ double red[4][64];
     // the singularity flag also travels as a double in the spare scalar slot, INSIDE the range the ranks all-reduce:
     // every rank of a time-partitioned evaluation then fails together (qgd_dist_finish)
@@ -409,21 +412,56 @@ __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, 
     const int nc = ncoef[k];
     const int l = blockIdx.z * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     const double *gp = G + goff[k];
-    const double *gq = gp + (size_t)nt * (m + 1) * nc;
+    const double *gq = gp + (size_t)g_nt * (m + 1) * nc;      // (the basis holds g_nt time points; this window starts at g_n0)
+    const size_t plane = (size_t)nt * n_ops * m * 2;
     double s = 0.0;
     if (l < nc) {
         const int n1 = min(nt, (int)(blockIdx.x + 1) * CT_CHUNK);
         for (int n = blockIdx.x * CT_CHUNK + sub; n < n1; n += 4)
             for (int d = 0; d < m; d++) {
-                const double sp = sigma[(((size_t)n * n_ops + k) * m + d) * 2];
-                const double sq = sigma[(((size_t)n * n_ops + k) * m + d) * 2 + 1];
-                s += gp[((size_t)n * (m + 1) + d) * nc + l] * sp + gq[((size_t)n * (m + 1) + d) * nc + l] * sq;
+                const size_t e = (((size_t)n * n_ops + k) * m + d) * 2;
+                double sp = sigma[e], sq = sigma[e + 1];
+                for (int g = 1; g < planes; g++) { sp += sigma[g * plane + e]; sq += sigma[g * plane + e + 1]; }   // column groups, in order
+                s += gp[((size_t)(n + g_n0) * (m + 1) + d) * nc + l] * sp + gq[((size_t)(n + g_n0) * (m + 1) + d) * nc + l] * sq;
             }
     }
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
     if (sub == 0 && l < nc)
-        atomicAdd(&grad[poff[k] + l], -(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+        cpart[(size_t)blockIdx.x * n_pcof + poff[k] + l] = -(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// grad[p] (=, or += for a later window of a chunked time grid) the time chunks of k_contract in chunk order:
+// thread = (coefficient, quarter of the chunks), the four quarters added in order
+// grad[p] (=, or += for a later window of a chunked time grid) the rows of cpart in a FIXED order: workgroup = 16
+// coefficients x 64 row slots; a slot adds its rows (slot, slot + 64, ...) in order with the loads issued four at a time
+// (a rolled loop waited one memory round trip per row: 11 us for the 551 rows of the benchmark grid), then a fixed binary
+// tree over the 64 slots.  Same shape on every run => same bits.
+__global__ __launch_bounds__(1024) void k_contract_sum(const double *__restrict__ cpart, double *__restrict__ grad, int n_pcof, int rows,
+                                                       int accumulate, const int *__restrict__ status, double *__restrict__ scal)
+{
+    __shared__ double red[64][17];
+    // the singularity flag also travels as a double in the spare scalar slot, INSIDE the range the ranks all-reduce
+    if (status && blockIdx.x == 0 && threadIdx.x == 0 && *status) scal[3] = 1.0;
+    const int pl = threadIdx.x & 15, slot = threadIdx.x >> 4, p = blockIdx.x * 16 + pl;
+    double tot = 0.0;
+    if (p < n_pcof) {
+        int c = slot;
+        for (; c + 192 < rows; c += 256) {
+            const double v0 = cpart[(size_t)c * n_pcof + p], v1 = cpart[(size_t)(c + 64) * n_pcof + p];
+            const double v2 = cpart[(size_t)(c + 128) * n_pcof + p], v3 = cpart[(size_t)(c + 192) * n_pcof + p];
+            tot = (((tot + v0) + v1) + v2) + v3;
+        }
+        for (; c < rows; c += 64) tot += cpart[(size_t)c * n_pcof + p];
+    }
+    red[slot][pl] = tot;
+    __syncthreads();
+    #pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        if (slot < w) red[slot][pl] += red[slot + w][pl];
+        __syncthreads();
+    }
+    if (slot == 0 && p < n_pcof) grad[p] = accumulate ? grad[p] + red[0][pl] : red[0][pl];
 }
 
 // ---------------------------------------------------------------------------
@@ -548,9 +586,12 @@ int qgdk_derivs(const qgdk_ctx *c)
 int qgdk_gradient(const qgdk_ctx *c)
 {
     if (c->n_ops == 0) return 0;                       // no control parameters: nothing to differentiate
-    if (c->use_sparse) {
+    if (c->use_sparse) {      // k_gradpoint_ell contracts with the basis itself: one row of cpart per (column group, time point)
         const int rc = qgdk_gradient_sparse(c);
-        return rc ? rc : qgdk_contract(c);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof,
+                           (c->cp / 8) * c->nt, c->grad_accumulate, c->status, c->scal);
+        return (int)hipGetLastError();
     }
     if (c->dense_gemm) {
         const int rc = qgdk_dense_gradient(c);
@@ -581,8 +622,13 @@ int qgdk_gradient(const qgdk_ctx *c)
 
 int qgdk_contract(const qgdk_ctx *c)
 {
-    hipLaunchKernelGGL(k_contract, dim3((c->nt + CT_CHUNK - 1) / CT_CHUNK, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
-                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->grad, c->nt, c->m, c->n_ops, c->status, c->scal);
+    const int chunks = (c->nt + CT_CHUNK - 1) / CT_CHUNK;
+    hipLaunchKernelGGL(k_contract, dim3(chunks, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
+                       c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->nt, c->m, c->n_ops, c->status, c->scal,
+                       (c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)) ? c->sigma_planes : 1, c->cpart, c->n_pcof,
+                       c->g_nt ? c->g_nt : c->nt, c->g_n0);
+    hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof, chunks,
+                       c->grad_accumulate, (const int *)nullptr, (double *)nullptr);
     return (int)hipGetLastError();
 }
 

@@ -217,7 +217,10 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
                                                        const double *__restrict__ lam,
                                                        double *__restrict__ sigma,
                                                        const double *__restrict__ cw, int Np, int cp,
-                                                       int nt, int n_ops, int Z, int Zo)
+                                                       int nt, int n_ops, int Z, int Zo,
+                                                       const double *__restrict__ G, const int64_t *__restrict__ goff,
+                                                       const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
+                                                       double *__restrict__ cpart, int n_pcof, int g_nt, int g_n0)
 {
     constexpr int PS = 9, ND = (M > 1) ? M - 1 : 1, NO = NOPS_LIM(NOPS);
     extern __shared__ __attribute__((aligned(16))) double smem_raw[];
@@ -368,11 +371,35 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
         }
     }
     __syncthreads();
-    for (int e = tid; e < n_ops * M * 2; e += 256) {
+    double sv[(NO * M * 2 + 255) / 256];
+    #pragma unroll
+    for (int it = 0; it < (NO * M * 2 + 255) / 256; it++) {
+        const int e = tid + it * 256;
         double v = 0.0;
+        if (e < n_ops * M * 2) {
+            #pragma unroll
+            for (int q = 0; q < 16; q++) v += red[e * 16 + q];
+            sigma[((size_t)grp * nt + n) * n_ops * M * 2 + e] = v;      // this column group's plane: stored, not accumulated
+        }
+        sv[it] = v;
+    }
+    // Contraction with the control basis for THIS time point (the "grad_slice .-= contrib" of
+    // eval_grad_discrete_adjoint.jl:642-643): row (column group, n) of cpart, which k_contract_sum adds over the rows in
+    // row order -- no atomics between here and grad, so the gradient is bitwise reproducible.  14 KB of G per workgroup.
+    __syncthreads();                                    // every partial sum has been read: red is free
+    #pragma unroll
+    for (int it = 0; it < (NO * M * 2 + 255) / 256; it++) { const int e = tid + it * 256; if (e < n_ops * M * 2) red[e] = sv[it]; }
+    __syncthreads();
+    for (int p = tid; p < n_pcof; p += 256) {
+        int kq = 0;
+        while (kq + 1 < n_ops && p >= poff[kq + 1]) kq++;
+        const int l = p - poff[kq], nc = ncoef[kq];
+        const double *gp = G + goff[kq] + ((size_t)(n + g_n0) * (M + 1)) * nc + l;
+        const double *gq = gp + (size_t)g_nt * (M + 1) * nc;
+        double acc = 0.0;
         #pragma unroll
-        for (int q = 0; q < 16; q++) v += red[e * 16 + q];
-        atomicAdd(&sigma[(size_t)n * n_ops * M * 2 + e], v);
+        for (int d = 0; d < M; d++) acc += gp[(size_t)d * nc] * red[(kq * M + d) * 2] + gq[(size_t)d * nc] * red[(kq * M + d) * 2 + 1];
+        cpart[((size_t)grp * nt + n) * n_pcof + p] = -acc;
     }
     SP_PROF(22);
 }
@@ -477,7 +504,7 @@ static int launch_grad_ell_n(const qgdk_ctx *c)
     SET_LDS_ONCE((k_gradpoint_ell<M, NOPS>), shm);
     hipLaunchKernelGGL((k_gradpoint_ell<M, NOPS>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ell_col, c->ell_val,
                        c->op_col, c->op_val, c->tab, c->hist, c->lam, c->sigma, c->cw, c->Np, c->cp, c->nt, c->n_ops,
-                       c->ell_z, c->op_z);
+                       c->ell_z, c->op_z, c->G, c->goff, c->ncoef, c->poff, c->cpart, c->n_pcof, c->g_nt ? c->g_nt : c->nt, c->g_n0);
     return (int)hipGetLastError();
 }
 

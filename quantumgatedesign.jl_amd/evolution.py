@@ -181,6 +181,18 @@ class DeviceProblem:
             raise ValueError(f"control tables must have shape {shape}")
         _lib.check(self.h, self.lib.qgd_set_control_tables(self.h, _vp(p), _vp(q)))
 
+    # -- long time grids in bounded memory -----------------------------------
+    def set_memory_budget(self, nbytes=0):
+        """qgd_set_memory_budget: device bytes the per-time-point buffers may take (0 = automatic).  A grid that does not
+        fit is processed in windows (same results to rounding, build + inverse done twice).  Re-allocates the grid."""
+        _lib.check(self.h, self.lib.qgd_set_memory_budget(self.h, int(nbytes)))
+        self._basis_key = None
+
+    def memory_plan(self):
+        out = np.zeros(4, dtype=np.int64)
+        _lib.check(self.h, self.lib.qgd_get_memory_plan(self.h, _vp(out)))
+        return dict(windows=int(out[0]), steps_per_window=int(out[1]), window_bytes=int(out[2]), budget=int(out[3]))
+
     # -- several GPUs behind one call (qgd_comm_init_rccl) -------------------
     def comm_init(self, unique_id: bytes, rank: int, world: int, shard: str = "time"):
         """Give the handle its RCCL communicator: discrete_adjoint / eval_forward become collective calls whose
@@ -209,10 +221,18 @@ class DeviceProblem:
         return dict(rank=out[0], world=out[1], shard="columns" if out[2] == _lib.QGD_SHARD_COLUMNS else "time")
 
     # -- evaluation --------------------------------------------------------
-    def _hist_shape(self):
+    def _hist_shape(self, save=1):
         win = getattr(self, "window", None)               # (a time-partitioned handle returns its own window)
         nt = self.nsteps + 1 if win is None else win[1] - win[0] + 1
-        return (2 * self.N, self.m + 1, nt, self.c)
+        return (2 * self.N, self.m + 1, 1 + (nt - 1) // save, self.c)
+
+    def set_save_every(self, save_every_nsteps=1):
+        """eval_forward's saveEveryNsteps (forward_evolution.jl:104,239-241): uv_history of eval_forward then holds
+        the time points 0, s, 2s, ... (qgd_set_save_every)."""
+        save = int(save_every_nsteps)
+        if save != getattr(self, "_save_every", 1):
+            _lib.check(self.h, self.lib.qgd_set_save_every(self.h, save))
+            self._save_every = save
 
     def pin(self, array):
         """Register (pin) an output array that will be handed to discrete_adjoint / eval_forward repeatedly
@@ -234,7 +254,7 @@ class DeviceProblem:
         return array
 
     def eval_forward(self, pcof=None, uv_history=None):
-        _check_out(uv_history, self._hist_shape(), "uv_history")
+        _check_out(uv_history, self._hist_shape(getattr(self, "_save_every", 1)), "uv_history")
         out3 = np.zeros(3)
         if pcof is not None and getattr(self, "_general", None):
             self._upload_general(pcof)
@@ -354,7 +374,7 @@ class DeviceProblem:
         want = (2 * self.N, self.m, self.nsteps + 1, self.c)
         if forcing.shape != want:
             raise ValueError(f"forcing must have shape {want}")
-        _check_out(uv_history, self._hist_shape(), "uv_history")
+        _check_out(uv_history, self._hist_shape(getattr(self, "_save_every", 1)), "uv_history")
         out3 = np.zeros(3)
         _lib.check(self.h, self.lib.qgd_eval_forward_forced(self.h, _vp(pcof) if len(pcof) else None, len(pcof), _vp(forcing),
                                                              None if uv_history is None else _vp(uv_history), _vp(out3)))
@@ -475,14 +495,14 @@ def eval_forward_(uv_history, prob, controls, pcof, order=2, saveEveryNsteps=1, 
     dp = device_problem(prob, order)
     dp.set_controls(controls)
     run = dp.eval_forward if forcing is None else (lambda p, hist: dp.eval_forward_forced(p, forcing, hist))
-    if save == 1:
-        run(pcof, uv_history)
-        return None
     # the device keeps every time point; the stored ones are n = 0, save, 2 save, ... <= nsteps
-    # (forward_evolution.jl:104,178,239-241: slot 1 + div(n, saveEveryNsteps) when n % saveEveryNsteps == 0)
-    full = np.zeros(_history_shape(prob, order), order="F")
-    run(pcof, full)
-    uv_history[...] = full[:, :, ::save, :][:, :, :shape[2], :]
+    # (forward_evolution.jl:104,178,239-241: slot 1 + div(n, saveEveryNsteps) when n % saveEveryNsteps == 0): the
+    # library's re-layout kernel reads them with that stride (qgd_set_save_every)
+    dp.set_save_every(save)
+    try:
+        run(pcof, uv_history)
+    finally:
+        dp.set_save_every(1)
     return None
 
 

@@ -42,8 +42,36 @@ def test_csc_constructor_matches_dense(qgd, which, order):
         out.append(dp.discrete_adjoint(pcof))
         assert dp.operator_path()[0] == "sparse"
         dp.close()
-    # (to rounding, not bitwise: the contraction kernel adds its time chunks with atomics, in whatever order they finish)
-    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-14 * np.abs(out[0][0]).max() and np.allclose(out[0][1], out[1][1], rtol=1e-14, atol=1e-15)
+    # bitwise: the same kernels ran on the same operands, and the gradient reductions have a fixed order (k_contract adds
+    # its time chunks in chunk order, the column groups' sigma planes in group order -- no atomics on the way to grad)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-14, atol=1e-15)      # (the guard-penalty scalar is still an atomic sum)
+
+
+@pytest.mark.parametrize("which,order,cols", [("cnot3", 8, 8), ("cnot3", 8, 24), ("cnot2", 8, 4), ("guarded", 6, 4)])
+def test_gradient_is_bitwise_reproducible(qgd, which, order, cols):
+    """The reference accumulates the gradient serially (eval_grad_discrete_adjoint.jl:603-643, :148-157): the same
+    inputs give the same bits.  So does the device path for N <= 64: five evaluations of one handle and one of a
+    fresh handle, with 1 and with 3 column groups (cnot3 with 24 initial conditions)."""
+    if which == "cnot3":
+        prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=130, tf=130.0)
+        if cols != prob.N_initial_conditions:
+            rng = np.random.default_rng(9)
+            z = rng.standard_normal((prob.N_tot_levels, cols)) + 1j * rng.standard_normal((prob.N_tot_levels, cols))
+            z /= np.linalg.norm(z, axis=0)
+            prob.u0, prob.v0 = np.asfortranarray(z.real), np.asfortranarray(z.imag)
+            prob.N_initial_conditions = cols
+            target = rng.standard_normal((prob.N_tot_levels, cols)) + 1j * rng.standard_normal((prob.N_tot_levels, cols))
+    else:
+        prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    grads = []
+    for fresh in range(2):
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        for _ in range(5 if not fresh else 1):
+            grads.append(dp.discrete_adjoint(pcof)[0])
+        dp.close()
+    for g in grads[1:]:
+        assert np.array_equal(g, grads[0])
 
 
 @pytest.mark.parametrize("zerocopy", [None, "16"])
@@ -222,3 +250,23 @@ def test_column_sharded_matches_single_gpu(qgd, which, order, world):
             assert np.abs(o - o_ref).max() <= 1e-12 * max(1.0, np.abs(o_ref).max())
     for b in backs:
         b.close()
+
+
+@pytest.mark.parametrize("which,order", [("cnot3", 8), ("guarded", 6)])
+def test_save_every_nsteps_in_the_c_abi(qgd, which, order):
+    """qgd_set_save_every: the strided history of eval_forward(...; saveEveryNsteps) (forward_evolution.jl:104,178,
+    239-241) comes out of the library's re-layout kernel directly -- every Taylor column of every stored time point
+    equals the full history's, for strides that divide the grid, that do not, and that exceed it."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=50, tf=25.0)
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    full = np.zeros(shape, order="F")
+    qgd.eval_forward_(full, prob, ctrl, pcof, order=order)
+    for save in (1, 5, 7, 50, 64):
+        nslots = 1 + prob.nsteps // save
+        sub = np.full((shape[0], shape[1], nslots, shape[3]), np.nan, order="F")
+        qgd.eval_forward_(sub, prob, ctrl, pcof, order=order, saveEveryNsteps=save)
+        assert np.array_equal(sub, full[:, :, ::save, :][:, :, :nslots, :]), save
+    again = np.zeros(shape, order="F")          # the stride does not stick to the handle
+    qgd.eval_forward_(again, prob, ctrl, pcof, order=order)
+    assert np.array_equal(again, full)
+    qgd.clear_cache()

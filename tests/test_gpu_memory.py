@@ -1,0 +1,95 @@
+"""GPU tests of the bounded-memory time grid (qgd_set_memory_budget): a grid whose step matrices
+do not fit the budget is processed in windows that share one set of buffers -- forward pass over the windows, adjoint
+pass back over them with the window's matrices formed again.  Same discrete quantities in the same order inside a
+window, so the results must equal the resident evaluation to rounding."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(qgd, prob, ctrl, pcof, target, order, budget):
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    assert dp.memory_plan()["windows"] == 1
+    g_ref, o_ref = dp.discrete_adjoint(pcof)
+    f_ref = dp.eval_forward(pcof)
+    dp.close()
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_memory_budget(budget)
+    dp.set_controls(ctrl); dp.set_target(target)
+    return dp, g_ref, np.asarray(o_ref), np.asarray(f_ref)
+
+
+@pytest.mark.parametrize("which,order,nsteps,windows", [("cnot3", 8, 550, 4), ("cnot3", 8, 137, 3), ("cnot2", 8, 100, 3), ("guarded", 6, 90, 2),
+                                                        ("dense_guard", 6, 48, 3), ("synthetic", 12, 240, 3), ("synthetic", 4, 301, 4)])
+def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
+    if which == "synthetic":
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=80, c=16, nsteps=nsteps, tf=0.002 * nsteps)
+    else:
+        prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / (1 if which.startswith("cnot") else 2))
+    probe = qgd.DeviceProblem(prob, order)
+    full = probe.memory_plan()["window_bytes"]
+    probe.close()
+    dp, g_ref, o_ref, f_ref = _pair(qgd, prob, ctrl, pcof, target, order, int(full / windows * 1.15))
+    plan = dp.memory_plan()
+    # (N > 64 has ~95 MB of buffers that do not shrink with the window -- inverse work slabs -- hence the loose upper bound)
+    assert 2 <= plan["windows"] <= 4 * windows and plan["window_bytes"] <= plan["budget"], plan
+    scale = max(1.0, np.abs(o_ref).max())
+    for rep in range(2):
+        g, o = dp.discrete_adjoint(pcof)
+        assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max(), (which, plan, rep)
+        assert np.abs(np.asarray(o) - o_ref).max() <= 1e-12 * scale
+    f = dp.eval_forward(pcof)
+    assert np.abs(np.asarray(f) - f_ref).max() <= 1e-12 * scale
+    g, _ = dp.discrete_adjoint(pcof, history_precomputed=True)          # reuses the stored window-boundary states
+    assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    g2, _ = dp.discrete_adjoint(0.5 * pcof, history_precomputed=True)    # a different pcof: the sweep is redone
+    chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl); chk.set_target(target)
+    g2_ref, _ = chk.discrete_adjoint(0.5 * pcof)
+    chk.close()
+    assert np.abs(g2 - g2_ref).max() <= 1e-11 * np.abs(g2_ref).max()
+    # what needs the grid resident says so
+    hist = np.zeros((prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions), order="F")
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.eval_forward(pcof, hist)
+    assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
+    dp.close()
+
+
+def test_budget_too_small_is_a_memory_error(qgd):
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
+    dp = qgd.DeviceProblem(prob, 8)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.set_memory_budget(100_000)           # less than one time step's matrices
+    assert e.value.code == qgd._lib.QGD_ERR_MEMORY
+    dp.close()
+
+
+def test_reference_low_order_long_grid(qgd):
+    """examples/cnot3_optimize_gate.sb:27-40 runs cnot3 at order 2 with dt = 1e-2: 55 000 time steps over tf = 550.
+    Resident that is 25 GB of step matrices; under a 2 GB budget the grid takes ~13 windows.  Same gradient."""
+    import time
+    nsteps = 55_000
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=550.0)
+    order = 2
+    out = {}
+    for label, budget in (("resident", 0), ("2GB", 2 << 30)):
+        dp = qgd.DeviceProblem(prob, order)
+        if budget:
+            dp.set_memory_budget(budget)
+        dp.set_controls(ctrl); dp.set_target(target)
+        plan = dp.memory_plan()
+        dp.discrete_adjoint(pcof)
+        t0 = time.perf_counter()
+        g, o = dp.discrete_adjoint(pcof)
+        out[label] = (g, np.asarray(o), plan, time.perf_counter() - t0)
+        dp.close()
+    assert out["resident"][2]["windows"] == 1 and out["2GB"][2]["windows"] >= 8, (out["resident"][2], out["2GB"][2])
+    assert out["2GB"][2]["window_bytes"] <= 2 << 30
+    g_ref = out["resident"][0]
+    assert np.abs(out["2GB"][0] - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    assert np.abs(out["2GB"][1] - out["resident"][1]).max() <= 1e-11
+    print(f"\n55000-step cnot3, order 2: resident {out['resident'][3] * 1e3:.1f} ms ({out['resident'][2]['window_bytes'] / 2**30:.1f} GiB), "
+          f"2 GB budget {out['2GB'][3] * 1e3:.1f} ms in {out['2GB'][2]['windows']} windows")
