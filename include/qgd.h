@@ -289,14 +289,15 @@ int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 
 /* eval_forward(prob, controls, pcof; forcing) (src/forward_evolution.jl:15-70, forcing path :118-129,
  * :167-206): w' = A w + F with the scaled Taylor coefficients of F given at every time point,
- * forcing[2N, order/2, 1+nsteps, n_cols] (column-major).  N <= 64; single GPU. */
+ * forcing[2N, order/2, 1+nsteps, n_cols] (column-major).  Any N (N <= 64: the pipelined scan kernels; larger: a plain
+ * affine chain kernel, correct but not tuned -- this is a cross-check path); single GPU, resident time grid. */
 int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, const double *forcing,
                             double *uv_history, double *out3);
 
 /* eval_grad_forced (src/eval_grad_forced.jl:17-194): the same gradient by forward sensitivities --
  * one forced forward sweep per control parameter, all parameters batched as extra column groups of
  * the blocked scan.  The reference's cross-check of the discrete adjoint (agreement to rounding).
- * Needs qgd_set_control_basis and qgd_set_target; N <= 64; single GPU.  pcof may be NULL when the tables were set
+ * Needs qgd_set_control_basis and qgd_set_target; any N (see above); single GPU.  pcof may be NULL when the tables were set
  * directly (general control path: the basis then holds the Jacobian at the current pcof).  Honours qgd_set_cost_type. */
 int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad);
 

@@ -38,6 +38,7 @@ struct qgd_handle_s {
     std::vector<void *> static_bufs, grid_bufs, basis_bufs, forced_bufs;
     std::vector<double> target_host;   // stacked real target [2N x c] (forced gradient: the overlaps are host arithmetic)
     size_t forced_key = 0;             // (nt, n_pcof) the forced-gradient buffers were sized for
+    double *fsc_forced = nullptr, *fsc_forcing = nullptr;   // HBM work-panel slabs of the forced kernels when they exceed the LDS (N > 64)
     std::vector<void *> forcing_bufs;  // eval_forward with a user forcing
     size_t forcing_key = 0;
     bool have_basis = false, have_tables = false, forward_valid = false, derivs_valid = false;
@@ -1474,8 +1475,6 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced forward sweep is single-GPU");
     NEEDS_RESIDENT_GRID(h, "eval_forward with a forcing");
-    if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || (size_t)(k.m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024)
-        return fail(h, QGD_ERR_UNSUPPORTED, "eval_forward with forcing on the device needs N <= 64");
     int rc = forward_begin(h, pcof, n_pcof);
     if (rc) return rc;
     const size_t nt = k.nt, m = k.m, N = k.N, n2 = 2 * N, PWc = 2 * k.cp, hstep = (size_t)k.Np * PWc, B = k.scan_blocks;
@@ -1488,8 +1487,12 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
         if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_Q, nt * hstep))) return rc;
         if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_phi, (B + 1) * hstep))) return rc;
         if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_bnd, (B + 2) * hstep))) return rc;
+        h->fsc_forcing = nullptr;     // (N > 64 at high order: the m+2 work panels of k_forcing_terms do not fit in LDS)
+        if ((size_t)(m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024 &&
+            (rc = dev_alloc(h, h->forcing_bufs, &h->fsc_forcing, nt * (size_t)(k.cp / 8) * (m + 2) * k.Np * 16))) return rc;
         h->forcing_key = nt;
     }
+    k.fs_scratch = h->fsc_forcing;
     {   // forcing [2N, m, nt, c] (Julia layout, forward_evolution.jl:42-44) -> panels [nt][m][Np][2cp]
         std::vector<double> f(nt * m * hstep, 0.0);
         for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) for (size_t j = 0; j < m; j++) {
@@ -1527,8 +1530,6 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced gradient is single-GPU");
     NEEDS_RESIDENT_GRID(h, "eval_grad_forced");
-    if (!(k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) || qgdk_forced_lds(k.Np, k.m) > 150 * 1024)
-        return fail(h, QGD_ERR_UNSUPPORTED, "forced gradient on the device needs N <= 64 (and order <= 16 at N = 64)");
     int rc;
     if ((rc = run_forward(h, pcof, n_pcof))) return rc;
     if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
@@ -1542,8 +1543,12 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
         if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_phi, B * hstepS))) return rc;
         if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_bnd, (B + 1) * hstepS))) return rc;
         if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_gacc, (size_t)k.n_pcof + 1))) return rc;
+        h->fsc_forced = nullptr;      // (the 2m+2 work panels of k_forced_basis: LDS up to 150 KB, else an HBM slab per workgroup)
+        if (qgdk_forced_lds(k.Np, k.m) > 150 * 1024 &&
+            (rc = dev_alloc(h, h->forced_bufs, &h->fsc_forced, nt * (size_t)(k.cp / 8) * (size_t)(2 * k.m + 2) * k.Np * 16))) return rc;
         h->forced_key = key;
     }
+    k.fs_scratch = h->fsc_forced;
     HIP_TRY(h, hipMemsetAsync(k.fs_bnd, 0, hstepS * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.fs_gacc, 0, ((size_t)k.n_pcof + 1) * sizeof(double), k.stream));
     { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }

@@ -84,6 +84,7 @@ typedef struct qgdk_ctx {
     double *fs_BR, *fs_BL;   // [nt][n_ops*2*m][Np][2cp]
     double *fs_phi, *fs_bnd; // [B][Np][2cpS], [B+1][Np][2cpS], cpS = n_pcof * cp
     double *fs_gacc;         // [n_pcof]
+    double *fs_scratch;      // per-workgroup panel slabs of k_forced_basis / k_forcing_terms when they exceed the LDS (N > 64), else null
     // eval_forward with a user forcing: F, E [nt][m][Np][2cp]; XR, XL, Q [nt][Np][2cp]; scan buffers
     double *ff_F, *ff_E, *ff_XR, *ff_XL, *ff_Q, *ff_phi, *ff_bnd;
     int *status;

@@ -578,6 +578,103 @@ __global__ __launch_bounds__(256) void k_chain_generic(const ChainArgs a)
     }
 }
 
+// MODE 4/5 for any Np (forward sensitivities of eval_grad_forced and eval_forward with a forcing, N > 64 -- the
+// reference's cross-check of the adjoint, src/eval_grad_forced.jl:17-194, src/forward_evolution.jl:118-129,167-206, has
+// no size limit): the same affine forward chain as k_chain_fast MODE 4/5, one workgroup = (block, column group), the
+// state in two LDS panels, no prefetch.  ZERO (MODE 4): start from zero, the block's affine part goes to phi.  MODE 5:
+// start from a.start, optional history out[n+1], optional final state to phi, optional guard sums -<f_n, s_n>.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_chain_forced_generic(const ChainArgs a)
+{
+    constexpr bool ZERO = (MODE == 4);
+    extern __shared__ double smem[];
+    __shared__ double pred[16];
+    const int Np = a.Np;
+    double *cur = smem, *nxt = smem + (size_t)Np * 16;
+    const int b = blockIdx.x / a.ngroups, grp = blockIdx.x % a.ngroups;
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = 2 * a.cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int c16 = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < Np * 16; e += blockDim.x)
+        cur[e] = ZERO ? 0.0 : a.start[(size_t)b * a.start_stride + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+    __syncthreads();
+    // the parameter this column group belongs to (fs_mode 1: its forcing is assembled from the basis responses)
+    int ctl = 0, lco = 0, ncf = 0;
+    const int par = a.fs_gpc ? grp / a.fs_gpc : 0, cg = a.fs_gpc ? grp % a.fs_gpc : 0;
+    if (a.fs_mode == 1) {
+        while (ctl + 1 < a.fs_nops && par >= a.fs_poff[ctl + 1]) ctl++;
+        lco = par - a.fs_poff[ctl]; ncf = a.fs_ncoef[ctl];
+    }
+    double pen = 0.0;
+    for (int st = 0; st < e0 - s0; st++) {
+        const int n = s0 + st, nout = n + 1;
+        const double *Pn = chain_matrix(a, n);
+        for (int rb = wave; rb * 16 < Np; rb += nw) {
+            d4 acc = (d4){0, 0, 0, 0};
+            const int arow = rb * 16 + c16;
+            for (int k0 = 0; k0 < Np; k0 += 4) {
+                double are, aim, b1, b2;
+                chain_a<false>(Pn, Np, arow, k0 + kk, are, aim);
+                panel_b(cur + (size_t)(k0 + kk) * 16, c16, b1, b2);
+                acc = MFMA(are, b1, acc);
+                acc = MFMA(aim, b2, acc);
+            }
+            double fo[4] = {0.0, 0.0, 0.0, 0.0};
+            if (a.fs_mode == 1) {       // q_n = sum_{tau,d} G^tau_l(n,d) BR[n][b] - G^tau_l(n+1,d) BL[n+1][b]
+                const int NB = a.fs_nops * 2 * a.fs_m, PWb = 16 * a.fs_gpc;
+                const size_t pstep = (size_t)Np * PWb;
+                const double *gk = a.fs_G + a.fs_goff[ctl];
+                for (int tau = 0; tau < 2; tau++)
+                    for (int d = 0; d < a.fs_m; d++) {
+                        const double g0 = gk[(((size_t)tau * a.fs_nt + n) * (a.fs_m + 1) + d) * ncf + lco];
+                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + 1) * (a.fs_m + 1) + d) * ncf + lco];
+                        const int bidx = (ctl * 2 + tau) * a.fs_m + d;
+                        const double *br = a.fs_BR + ((size_t)n * NB + bidx) * pstep + cg * 16 + c16;
+                        const double *bl = a.fs_BL + ((size_t)(n + 1) * NB + bidx) * pstep + cg * 16 + c16;
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const size_t ro = (size_t)(rb * 16 + kk + 4 * r) * PWb;
+                            fo[r] += g0 * br[ro] - g1 * bl[ro];
+                        }
+                    }
+            } else if (a.forcing) {
+                #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    fo[r] = a.forcing[(size_t)(a.f_bpr ? n + n / a.f_bpr : n) * hstep + (size_t)(rb * 16 + kk + 4 * r) * PWc + grp * 16 + c16];
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 + kk + 4 * r;
+                const double v = acc[r] + fo[r];
+                nxt[(size_t)row * 16 + c16] = v;
+                if (MODE == 5 && a.out) a.out[(size_t)nout * hstep + (size_t)row * PWc + grp * 16 + c16] = v;
+                if (MODE == 5 && a.fs_gf) {
+                    const int PWb = 16 * a.fs_gpc;
+                    pen -= a.fs_gf[(size_t)nout * Np * PWb + (size_t)row * PWb + cg * 16 + c16] * v;
+                }
+            }
+        }
+        __syncthreads();
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (MODE == 5 && a.fs_gf) {
+        pen = row16_sum(pen);
+        if ((lane & 15) == 15) pred[tid >> 4] = pen;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int q = 0; q < (int)(blockDim.x >> 4); q++) tot += pred[q];
+            atomicAdd(&a.fs_gacc[par], tot);
+        }
+    }
+    if (ZERO || (MODE == 5 && a.phi))
+        for (int e = tid; e < Np * 16; e += blockDim.x)
+            a.phi[(size_t)b * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = cur[e];
+}
+
 // Large N: one workgroup = one (block, tile of 4 column groups = 32 complex columns), all Np rows.
 // The step matrix is streamed once per 32 columns instead of once per 8 (the generic kernel is bound by
 // exactly that L2 traffic), the state tile lives in ONE LDS buffer [Np][64] (128 KB at Np = 256) and the
@@ -741,7 +838,12 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
     case 48: hipLaunchKernelGGL((k_chain_fast<48, MODE, NG>), dim3(nwg), dim3(48 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
     case 64:         hipLaunchKernelGGL((k_chain_fast<64, MODE, NG>), dim3(nwg), dim3(64 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
     default: {
-        if (MODE >= 4) return (int)hipErrorNotSupported;
+        if (MODE >= 4) {
+            const size_t shm4 = (size_t)2 * a.Np * 16 * sizeof(double);
+            if (shm4 > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_chain_forced_generic<(MODE >= 4 ? MODE : 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm4));
+            hipLaunchKernelGGL((k_chain_forced_generic<(MODE >= 4 ? MODE : 4)>), dim3(a.nblocks * a.ngroups), dim3(256), shm4, stream, a);
+            return (int)hipGetLastError();
+        }
         if (chain_is_dense(a)) return launch_chain_dense<(MODE >= 4 ? 1 : MODE)>(a, stream);
         size_t shm = (size_t)2 * a.Np * 16 * sizeof(double);
         hipLaunchKernelGGL((k_chain_generic<(MODE >= 4 ? 1 : MODE)>), dim3(nwg), dim3(256), shm, stream, a);
@@ -1383,7 +1485,6 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
 // blocks accumulating -<f_n, s_n>.
 int qgdk_forced_chains(const qgdk_ctx *c)
 {
-    if (!(c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64)) return (int)hipErrorNotSupported;
     const int cpS = c->n_pcof * c->cp, B = c->scan_blocks;
     const size_t hstepS = (size_t)c->Np * 2 * cpS;
     ChainArgs f{};
@@ -1411,7 +1512,6 @@ int qgdk_forced_chains(const qgdk_ctx *c)
 // chain over the block propagators, history pass
 int qgdk_forcing_sweep(const qgdk_ctx *c)
 {
-    if (!chain_is_fast(c)) return (int)hipErrorNotSupported;
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     const int B = c->scan_blocks;
     int rc;

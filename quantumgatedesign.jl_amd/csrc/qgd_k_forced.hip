@@ -39,10 +39,12 @@ __global__ __launch_bounds__(256) void k_forced_basis(const double *__restrict__
                                                       const double *__restrict__ dpsi,
                                                       double *__restrict__ BR, double *__restrict__ BL,
                                                       const double *__restrict__ cw, int Np, int cp,
-                                                      int n_ops, int m)
+                                                      int n_ops, int m, double *__restrict__ gscratch)
 {
-    extern __shared__ double smem[];
+    extern __shared__ double lds_fb[];
     const int ps = Np * 16;
+    // the 2m+2 work panels: LDS, or (N > 64 at high order: more than 150 KB) this workgroup's slab of an HBM scratch
+    double *smem = gscratch ? gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(2 * m + 2) * ps : lds_fb;
     double *V = smem, *U = smem + (size_t)m * ps, *rR = U + (size_t)m * ps, *rL = rR + ps;
     const int grp = blockIdx.x, n = blockIdx.y;
     const int PWc = 2 * cp;
@@ -67,10 +69,10 @@ __global__ __launch_bounds__(256) void k_forced_basis(const double *__restrict__
                     #pragma unroll
                     for (int r = 0; r < 4; r++) V[(size_t)i * ps + (rb * 16 + kk + 4 * r) * 16 + c16] = acc[r];
                 }
-            __syncthreads();
+            __threadfence_block(); __syncthreads();
             for (int d = 0; d < m; d++) {
                 for (int e = threadIdx.x; e < ps; e += 256) { rR[e] = 0.0; rL[e] = 0.0; }
-                __syncthreads();
+                __threadfence_block(); __syncthreads();
                 for (int j = d; j < m; j++) {       // U_{j+1} = (V_{j-d} + sum_{i=d+1..j} A_{j-i} U_i)/(j+1), slot j
                     for (int rb = wave; rb * 16 < Np; rb += 4) {
                         d4 acc;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_forced_basis(const double *__restrict__
                             rR[o] += cR * u; rL[o] += cL * u;
                         }
                     }
-                    __syncthreads();
+                    __threadfence_block(); __syncthreads();
                 }
                 const int b = (k * 2 + tau) * m + d;
                 double *oR = BR + ((size_t)n * NB + b) * hstep + grp * 16, *oL = BL + ((size_t)n * NB + b) * hstep + grp * 16;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_forced_basis(const double *__restrict__
                     oR[(size_t)(e >> 4) * PWc + (e & 15)] = rR[e];
                     oL[(size_t)(e >> 4) * PWc + (e & 15)] = rL[e];
                 }
-                __syncthreads();
+                __threadfence_block(); __syncthreads();
             }
         }
 }
@@ -149,10 +151,11 @@ __global__ __launch_bounds__(256) void k_forcing_terms(const double *__restrict_
                                                        const double *__restrict__ F, double *__restrict__ E,
                                                        double *__restrict__ XR, double *__restrict__ XL,
                                                        const double *__restrict__ cw, int Np, int cp,
-                                                       int n_ops, int m)
+                                                       int n_ops, int m, double *__restrict__ gscratch)
 {
-    extern __shared__ double smem[];
+    extern __shared__ double lds_ft[];
     const int ps = Np * 16;
+    double *smem = gscratch ? gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(m + 2) * ps : lds_ft;
     double *U = smem, *rR = U + (size_t)m * ps, *rL = rR + ps;
     const int grp = blockIdx.x, n = blockIdx.y;
     const int PWc = 2 * cp;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void k_forcing_terms(const double *__restrict_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c16 = lane & 15, kk = lane >> 4;
     for (int e = threadIdx.x; e < ps; e += 256) { rR[e] = 0.0; rL[e] = 0.0; }
-    __syncthreads();
+    __threadfence_block(); __syncthreads();
     for (int j = 0; j < m; j++) {
         const double *Fj = F + ((size_t)n * m + j) * hstep + grp * 16;
         for (int rb = wave; rb * 16 < Np; rb += 4) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void k_forcing_terms(const double *__restrict_
                 rR[o] += cR * u; rL[o] += cL * u;
             }
         }
-        __syncthreads();
+        __threadfence_block(); __syncthreads();
     }
     for (int e = threadIdx.x; e < ps; e += 256) {
         XR[(size_t)n * hstep + (size_t)(e >> 4) * PWc + grp * 16 + (e & 15)] = rR[e];
@@ -214,14 +217,17 @@ extern "C" {
 // forcing terms of eval_forward(...; forcing): E, then Q[n] = L_{n+1}^-1 (rhoR_n - rhoL_{n+1})
 int qgdk_forcing_terms(const qgdk_ctx *c)
 {
-    const size_t shm = (size_t)(c->m + 2) * c->Np * 16 * sizeof(double);
+    size_t shm = (size_t)(c->m + 2) * c->Np * 16 * sizeof(double);
+    if (c->fs_scratch) shm = 0;           // (panels in this workgroup's HBM slab)
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
-#define CALL_FT(N) do { HIPCHK(hipFuncSetAttribute((const void *)k_forcing_terms<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+#define CALL_FT(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_forcing_terms<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((k_forcing_terms<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->ff_F, c->ff_E, \
-                           c->ff_XR, c->ff_XL, c->cw, c->Np, c->cp, c->n_ops, c->m); } while (0)
+                           c->ff_XR, c->ff_XL, c->cw, c->Np, c->cp, c->n_ops, c->m, c->fs_scratch); } while (0)
     DISPATCH_NOPS(c->n_ops, CALL_FT)
 #undef CALL_FT
     HIPCHK(hipGetLastError());
+    if ((size_t)c->Np * 16 * sizeof(double) > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_forced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)c->Np * 16 * sizeof(double))));
     hipLaunchKernelGGL(k_forced_solve, dim3(c->cp / 8, c->nt, 2), dim3(256), (size_t)c->Np * 16 * sizeof(double), c->stream,
                        c->LinvT, c->ff_XR, c->ff_XL, c->Np, c->cp, 1, c->nt);
     const size_t cnt = (size_t)(c->nt - 1) * hstep;
@@ -243,14 +249,17 @@ size_t qgdk_forced_lds(int Np, int m) { return (size_t)(2 * m + 2) * Np * 16 * s
 
 int qgdk_forced_basis(const qgdk_ctx *c)
 {
-    const size_t shm = qgdk_forced_lds(c->Np, c->m);
-#define CALL_FB(N) do { HIPCHK(hipFuncSetAttribute((const void *)k_forced_basis<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    size_t shm = qgdk_forced_lds(c->Np, c->m);
+    if (c->fs_scratch) shm = 0;
+#define CALL_FB(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_forced_basis<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((k_forced_basis<N>), dim3(c->cp / 8, c->nt), dim3(256), shm, c->stream, c->ops, c->tab, c->hist, c->dpsi, \
-                           c->fs_BR, c->fs_BL, c->cw, c->Np, c->cp, c->n_ops, c->m); } while (0)
+                           c->fs_BR, c->fs_BL, c->cw, c->Np, c->cp, c->n_ops, c->m, c->fs_scratch); } while (0)
     DISPATCH_NOPS(c->n_ops, CALL_FB)
 #undef CALL_FB
     HIPCHK(hipGetLastError());
     const int NB = c->n_ops * 2 * c->m;
+    if ((size_t)c->Np * 16 * sizeof(double) > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)k_forced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)c->Np * 16 * sizeof(double))));
     hipLaunchKernelGGL(k_forced_solve, dim3(NB * (c->cp / 8), c->nt, 2), dim3(256), (size_t)c->Np * 16 * sizeof(double), c->stream,
                        c->LinvT, c->fs_BR, c->fs_BL, c->Np, c->cp, NB, c->nt);
     return (int)hipGetLastError();

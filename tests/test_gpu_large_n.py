@@ -136,3 +136,50 @@ def test_config5_full_size_properties(qgd):
         assert np.allclose(o, out3, rtol=1e-12, atol=0)
     for b in backs:
         b.close()
+
+
+@pytest.mark.parametrize("N,c,n_ops,nsteps,order", [(72, 4, 1, 8, 4), (80, 3, 2, 7, 12), (100, 9, 2, 6, 8)])
+def test_large_n_forced_gradient_vs_oracle(qgd, orc, N, c, n_ops, nsteps, order):
+    """eval_grad_forced for N > 64 (src/eval_grad_forced.jl:17-194 has no size limit): the reference's own parity
+    contract -- adjoint == forced (compare_gradients.jl:47-65) -- on the device, and the device's forced gradient
+    against the ORACLE's eval_grad_forced.  (80, order 12) and (100, order 8) keep the work panels of k_forced_basis
+    in HBM (more than 150 KB); the sensitivity scan runs in k_chain_forced_generic."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=nsteps, tf=0.05 * nsteps, seed=N)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    prob.guard_subspace_projector = np.asfortranarray(np.diag(np.random.default_rng(N).random(2 * N)))      # exercise the guard part too
+    g_orc = orc.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+    g_forced = qgd.eval_grad_forced(prob, ctrl, pcof, target, order=order)
+    g_adj = qgd.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+    scale = np.abs(g_orc).max()
+    assert np.abs(g_forced - g_orc).max() <= 1e-10 * scale
+    assert np.abs(g_forced - g_adj).max() <= 1e-12 * scale
+    qgd.clear_cache()
+
+
+def test_config5_shape_adjoint_equals_forced(qgd):
+    """C5's shape (N = 256, 256 columns, 4 control operators x 40 coefficients, order 12) at 24 steps: the discrete
+    adjoint and the forward-sensitivity gradient agree to 1e-12 -- the reference's 1e-14-class cross-check
+    (compare_gradients.jl:47-65) on a C5-shaped problem, where the oracle would need hours."""
+    prob, ctrl, pcof, target = c5_problem(qgd, 24, 0.24)
+    order = 12
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g_adj, _ = dp.discrete_adjoint(pcof)
+    g_forced = dp.eval_grad_forced(pcof)
+    dp.close()
+    assert np.abs(g_forced - g_adj).max() <= 1e-12 * np.abs(g_adj).max()
+
+
+@pytest.mark.parametrize("N,c,nsteps,order", [(72, 4, 8, 4), (100, 9, 6, 12)])
+def test_large_n_forward_with_forcing_vs_oracle(qgd, orc, N, c, nsteps, order):
+    """eval_forward(...; forcing) for N > 64 (forward_evolution.jl:118-129,167-206) against the oracle's forced sweep."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=nsteps, tf=0.05 * nsteps, seed=N)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    m = order // 2
+    forcing = np.asfortranarray(0.3 * np.random.default_rng(3).standard_normal((2 * N, m, nsteps + 1, c)))
+    h_ref = orc.eval_forward(prob, ctrl, pcof, order=order, forcing=forcing)
+    hist = np.zeros(h_ref.shape, order="F")
+    qgd.eval_forward_(hist, prob, ctrl, pcof, order=order, forcing=forcing)
+    for j in range(m + 1):
+        assert np.abs(hist[:, j] - h_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(h_ref[:, j]).max()), j
+    qgd.clear_cache()
