@@ -58,8 +58,18 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
     const int T = rtiles * ctiles * nsub;
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
     t.n = (s / T) * 8 + xcd;
-    if (t.n >= nt) return false;
     int r = s % T;
+    // The last group holds only nt % 8 time points: with "time point = XCD" its tiles would all land on the first nt % 8
+    // XCDs while the others idle (config 5: 201 time points = 25 groups + 1 point -- XCD 0 did 26 units of work, the
+    // other seven 25: 3.4 % of every per-time-point kernel).  The tiles of the tail are dealt over all eight XCDs instead.
+    const int full = nt & ~7, rem = nt - full;
+    if (rem && t.n >= full) {
+        const int q = r * 8 + xcd;                     // flat slot of the tail group, 8 T of them
+        if (q >= rem * T) { t.n = nt; return false; }
+        t.n = full + q / T;
+        r = q % T;
+    }
+    if (t.n >= nt) return false;
     t.sub = r / (rtiles * ctiles);
     r %= rtiles * ctiles;
     const int rt = r / ctiles, ct = r % ctiles;
