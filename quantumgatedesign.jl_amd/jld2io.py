@@ -21,8 +21,15 @@ hold:
 What is NOT reproduced: the committed datatypes with ``julia_type`` attributes that JLD2 adds for Julia structs
 (``Setup/schrodinger_prob``, ``Setup/controls``) and for ``Dict`` values.  Plain datasets need none of it: JLD2 maps
 the HDF5 types above back to the Julia types named on the left, which is what ``read_optimization_history`` consumes.
-Nothing here could be checked against a Julia session (none in the image); the files are checked with the HDF5
-tools (``h5dump``) and by reading them back (tests/test_host.py).
+STATUS: HDF5-valid and self-round-tripping; a JLD2 round trip is UNVERIFIED -- nothing here could be checked against a
+Julia session (none in the image), and the reference holds no ``.jld2`` file to read.  Known points where JLD2 may
+differ from this reading of its format: a bare ``{re, im}`` compound without JLD2's committed datatype loads as a
+NamedTuple / reconstructed type rather than ``ComplexF64`` (only ``Setup/target`` is complex; the nine
+``OptimizationHistory`` keys are real); an untyped reference dataset loads as ``Vector{Any}`` (which the
+``OptimizationHistory`` constructor converts); groups with more than 8 links use dense (fractal-heap) link storage under
+the 1.8 format bounds, which needs a JLD2 recent enough to read it (the nine keys sit in the root group: 9-10 links).
+INTEGRATION.md section 3a lists the HDF5 objects of the nine keys.  The files are checked by reading them back
+(tests/test_host.py) and, where the HDF5 tools are installed, with ``h5dump``.
 
 The library is looked up as ``$QGD_HDF5_LIB``, then ``libhdf5.so`` on the loader path, then ``/opt/conda/lib``;
 without it every entry point raises ``RuntimeError`` -- there is no silent fallback to another format.
@@ -49,6 +56,11 @@ _H5_INDEX_NAME, _H5_ITER_INC = 0, 0
 hid_t = C.c_int64
 
 _lib = None
+
+
+class _GInfo(C.Structure):
+    """H5G_info_t"""
+    _fields_ = [("storage_type", C.c_int), ("nlinks", C.c_uint64), ("max_corder", C.c_int64), ("mounted", C.c_int)]
 
 
 def _load():
@@ -87,7 +99,7 @@ def _load():
         "H5Tset_cset": (C.c_int, [hid_t, C.c_int]), "H5Tget_class": (C.c_int, [hid_t]), "H5Tget_size": (C.c_size_t, [hid_t]),
         "H5Tis_variable_str": (C.c_int, [hid_t]), "H5Tget_nmembers": (C.c_int, [hid_t]),
         "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]), "H5Gclose": (C.c_int, [hid_t]),
-        "H5Gget_num_objs": (C.c_int, [hid_t, C.c_void_p]),
+        "H5Gget_info": (C.c_int, [hid_t, C.c_void_p]),
         "H5Lexists": (C.c_int, [hid_t, C.c_char_p, hid_t]),
         "H5Lget_name_by_idx": (C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, hid_t]),
         "H5Oopen": (hid_t, [hid_t, C.c_char_p, hid_t]), "H5Oclose": (C.c_int, [hid_t]), "H5Iget_type": (C.c_int, [hid_t]),
@@ -284,10 +296,10 @@ class _Reader:
         if kind == _H5I_DATASET:
             return self._read_dataset(o)
         if kind == _H5I_GROUP:
-            n = C.c_uint64()
-            L.H5Gget_num_objs(o, C.byref(n))
+            info = _GInfo()                       # (H5Gget_info: the 1.8 API; H5Gget_num_objs is absent from builds without the 1.6 API)
+            L.H5Gget_info(o, C.byref(info))
             out = {}
-            for i in range(n.value):
+            for i in range(info.nlinks):
                 ln = L.H5Lget_name_by_idx(o, b".", _H5_INDEX_NAME, _H5_ITER_INC, i, None, 0, 0)
                 buf = C.create_string_buffer(ln + 1)
                 L.H5Lget_name_by_idx(o, b".", _H5_INDEX_NAME, _H5_ITER_INC, i, buf, ln + 1, 0)
