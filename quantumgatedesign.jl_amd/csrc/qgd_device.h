@@ -55,6 +55,7 @@ typedef struct qgdk_ctx {
     // large N, GEMM-style kernels (qgd_k_dense.hip): A_d(t_n), D_j(t_n) and {S_o, K_o} in MFMA fragment order
     int dense_gemm;
     double *Afrag, *Dfrag, *OpFrag;
+    double *Xouter;     // [nt][m][Np][2Np]: X_j = (1/j) g_j psi_0^H of the gradient scalars' outer-product form (k_gouter), or null
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.
     double *PiX;        // own blocks: [B x PiC | B x PiR], 2*Np*Np doubles each (B = scan_blocks = blocks of this rank)
@@ -135,6 +136,7 @@ int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
 int qgdk_dense_derivs(const qgdk_ctx *c);
 int qgdk_dense_gradient(const qgdk_ctx *c);
+int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_dense_lambda(const qgdk_ctx *c);
 int qgdk_gradient_sparse(const qgdk_ctx *c);
 int qgdk_derivs_sparse(const qgdk_ctx *c);

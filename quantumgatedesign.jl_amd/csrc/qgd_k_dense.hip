@@ -463,6 +463,231 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if ((e >> 1) % m < dmax) atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + e], sig[e]);
 }
 
+// The same scalars from OUTER products over the columns instead of operator applications:
+//   sigma^P[o][d] = sum_i (1/j) Re<-i S_o psi_i, g_j>,  sigma^Q[o][d] = sum_i (1/j) Re<K_o psi_i, g_j>,  j = i + 1 + d
+// with S_o, K_o real:  Re<K psi, g> = <K, Re M>_F and Re<-i S psi, g> = -<S, Im M>_F for the N x N matrix
+//   M(i, j)[r1, r2] = sum_col g_j[r1, col] conj(psi_i[r2, col]),
+// so per time point  M_d = sum_i (1/j) M(i, i+1+d), d = 0..m-1, costs m(m+1)/2 products N x N x c -- independent of the
+// number of control operators -- against n_ops * m for k_ginner_f, and sigma[.][d] is 2 n_ops Frobenius products with
+// M_d in the epilogue.  Used when (m+1)/2 < n_ops (config 5: 21 instead of 24 GEMM units, the largest kernel of the
+// evaluation).  Tile: a wave owns DN_RB x DN_NG blocks of 16 x 16 of M_d (rows r1 from g, columns r2 from psi), the
+// contraction runs over the columns of the state panels: both operands are read as [row][8 re | 8 im] groups, a lane
+// takes two adjacent columns in one 16-byte load and feeds them to two MFMAs (the contraction order is free as long
+// as both operands use the same one).  Three accumulators per block: Re M, sum g_im psi_re, sum g_re psi_im.  The
+// weights 1/j differ from pair to pair: the running sum is rescaled by j/(j+1)... (w_prev/w_next) between pairs.
+// (aR, aA, aB) += { Re, sum A_im B_re, sum A_re B_im } of  A B^H  for the wave's blocks: A, B row-major [row][groups of 8 re | 8 im]
+// with row stride ld doubles, contraction over ngc groups of 8 columns.  A lane takes two adjacent columns per 16-byte
+// load and feeds them to two MFMAs (the contraction order is free as long as both operands use the same one); the
+// operands of group q+1 are in flight while the 32 MFMAs of group q issue.  Im(A B^H) = aA - aB.
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void outer_tile(d4 (&aR)[DN_RB][DN_NG], d4 (&aA)[DN_RB][DN_NG], d4 (&aB)[DN_RB][DN_NG],
+                                           const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ A, const double *__restrict__ B,
+                                           size_t ld, int ngc)
+{
+    size_t ao[DN_RB], bo[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) ao[r] = (size_t)((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16) * ld + 2 * t.kk;
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bo[g] = (size_t)((t.g[g] >= 0 ? t.g[g] : t.g[0]) * 16 + t.c16) * ld + 2 * t.kk;
+    d2 are[DN_RB], aim[DN_RB], bre[DN_NG], bim[DN_NG], aren[DN_RB], aimn[DN_RB], bren[DN_NG], bimn[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) { are[r] = *reinterpret_cast<const d2 *>(A + ao[r]); aim[r] = *reinterpret_cast<const d2 *>(A + ao[r] + 8); }
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) { bre[g] = *reinterpret_cast<const d2 *>(B + bo[g]); bim[g] = *reinterpret_cast<const d2 *>(B + bo[g] + 8); }
+    for (int q = 0; q < ngc; q++) {
+        const size_t qn = (size_t)((q + 1 < ngc) ? q + 1 : q) * 16;
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) { aren[r] = *reinterpret_cast<const d2 *>(A + ao[r] + qn); aimn[r] = *reinterpret_cast<const d2 *>(A + ao[r] + qn + 8); }
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) { bren[g] = *reinterpret_cast<const d2 *>(B + bo[g] + qn); bimn[g] = *reinterpret_cast<const d2 *>(B + bo[g] + qn + 8); }
+        #pragma unroll
+        for (int s_ = 0; s_ < 2; s_++) {
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++)
+                #pragma unroll
+                for (int g = 0; g < DN_NG; g++) aR[r][g] = MFMA(are[r][s_], bre[g][s_], aR[r][g]);
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++)
+                #pragma unroll
+                for (int g = 0; g < DN_NG; g++) aA[r][g] = MFMA(aim[r][s_], bre[g][s_], aA[r][g]);
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++)
+                #pragma unroll
+                for (int g = 0; g < DN_NG; g++) aR[r][g] = MFMA(aim[r][s_], bim[g][s_], aR[r][g]);
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++)
+                #pragma unroll
+                for (int g = 0; g < DN_NG; g++) aB[r][g] = MFMA(are[r][s_], bim[g][s_], aB[r][g]);
+        }
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) { are[r] = aren[r]; aim[r] = aimn[r]; }
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) { bre[g] = bren[g]; bim[g] = bimn[g]; }
+    }
+}
+
+// sigma[n][o][d][2] += { -<S_o, Im M>, <K_o, Re M> } * w for the wave's blocks of M (Re = aR, Im = aA - aB).  Element e of block
+// (r, g): r1 = rb*16 + kk + 4e, r2 = g*16 + c16.  S_o is symmetric and K_o antisymmetric (SchrodingerProb.jl:73-95): they are
+// read TRANSPOSED, [r2 + Np r1] of the column-major planes, so that the 16 lanes of a row read 16 consecutive doubles.
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], const d4 (&aA)[DN_RB][DN_NG], const d4 (&aB)[DN_RB][DN_NG],
+                                                const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ ops, int Np, int n_ops,
+                                                double w, double *sig)
+{
+    const size_t pl = (size_t)Np * Np;
+    for (int o = 0; o < n_ops; o++) {
+        const double *Ko = ops + (size_t)(2 + 2 * o) * pl, *So = ops + (size_t)(3 + 2 * o) * pl;
+        double sp = 0.0, sq = 0.0;
+        #pragma unroll
+        for (int r = 0; r < DN_RB; r++) {
+            if (t.rb[r] < 0) continue;
+            #pragma unroll
+            for (int g = 0; g < DN_NG; g++) {
+                if (t.g[g] < 0) continue;
+                #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const size_t at = (size_t)(t.g[g] * 16 + t.c16) + (size_t)Np * (t.rb[r] * 16 + t.kk + 4 * e);
+                    sq -= Ko[at] * aR[r][g][e];                       // K[r1,r2] = -K[r2,r1]
+                    sp += So[at] * (aB[r][g][e] - aA[r][g][e]);      // -<S, Im M>
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
+        if (t.lane == 0) { atomicAdd(&sig[o * 2], sp * w); atomicAdd(&sig[o * 2 + 1], sq * w); }
+    }
+}
+
+// The same scalars from OUTER products over the columns instead of operator applications:
+//   sigma^P[o][d] = sum_i (1/j) Re<-i S_o psi_i, g_j>,  sigma^Q[o][d] = sum_i (1/j) Re<K_o psi_i, g_j>,  j = i + 1 + d
+// with S_o, K_o real:  Re<K psi, g> = <K, Re M>_F and Re<-i S psi, g> = -<S, Im M>_F for the N x N matrix
+//   M(i, j)[r1, r2] = sum_col g_j[r1, col] conj(psi_i[r2, col]),
+// so per time point  M_d = sum_i (1/j) M(i, i+1+d), d = 0..m-1, costs m(m+1)/2 products N x N x c -- independent of the
+// number of control operators -- against n_ops * m for k_ginner_f, and sigma[.][d] is 2 n_ops Frobenius products with
+// M_d in the epilogue.  Used when (m+1)/2 < n_ops.  Tile: a wave owns DN_RB x DN_NG blocks of 16 x 16 of M_d (rows r1
+// from g, columns r2 from psi).  The weights 1/j differ from pair to pair: the running sum is kept in units of the
+// current weight (times w_prev / w_next between pairs).
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_m(const double *__restrict__ ops, const double *__restrict__ hist,
+                                                  const double *__restrict__ dpsi, const double *__restrict__ Gp,
+                                                  double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
+{
+    extern __shared__ double sig[];          // [n_ops][2] of this workgroup's d
+    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x) sig[e] = 0.0;
+    __syncthreads();
+    DenseTile<DN_RB, DN_NG> t;
+    const bool active = dense_tile(t, Np >> 4, Np >> 4, m, nt);      // "groups" = 16-row blocks r2 of psi
+    const int d = t.sub;
+    if (active) {
+        const int PWc = 2 * cp;
+        const size_t hstep = (size_t)Np * PWc;
+        d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
+        ZERO_ACC(aR); ZERO_ACC(aA); ZERO_ACC(aB);
+        for (int i = 0; i + d < m; i++) {
+            const int j = i + 1 + d;
+            if (i > 0) {                     // running sum in units of the current weight 1/j: times (1/(j-1)) / (1/j)
+                const double sc = (double)j / (double)(j - 1);
+                #pragma unroll
+                for (int r = 0; r < DN_RB; r++)
+                    #pragma unroll
+                    for (int g = 0; g < DN_NG; g++) { aR[r][g] *= sc; aA[r][g] *= sc; aB[r][g] *= sc; }
+            }
+            outer_tile(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep,
+                       (i == 0) ? hist + (size_t)t.n * hstep : dpsi + ((size_t)t.n * m + (i - 1)) * hstep, (size_t)PWc, cp >> 3);
+        }
+        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, 1.0 / (double)m, sig);      // (the last pair of every d has j = m)
+    }
+    __syncthreads();
+    if (!active && t.n >= nt) return;
+    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x)
+        atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)], sig[e]);
+}
+
+// ... and without the stage derivatives psi_i = D_i psi_0 at all:  M(i, j) = g_j psi_0^H D_i^H, so
+//   stage 1 (k_gouter):   X_j = (1/j) g_j psi_0^H, j = 1..m            m products N x N x c, stored as panels [Np][2Np]
+//   stage 2 (k_ginner_d): M_d = X_{d+1} + sum_{i>=1} X_{i+1+d} D_i^H     m(m-1)/2 products N x N x N with the D_i of the
+//                                                                      step-matrix build (k_level_f) as they lie in HBM
+// against m (k_derivs_f) + m(m+1)/2 (k_ginner_m) products N x N x c: fewer when (m-1) N < (m+1) c -- config 5 (c = N):
+// 21 units instead of 27, and the 2.6 ms k_derivs_f launch disappears from the gradient evaluation.
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gouter(const double *__restrict__ hist, const double *__restrict__ Gp,
+                                                double *__restrict__ X, int Np, int cp, int m, int nt)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, Np >> 4, m, nt)) return;
+    const int j = t.sub + 1, PWc = 2 * cp, PW = 2 * Np;
+    const size_t hstep = (size_t)Np * PWc, panel = (size_t)Np * PW;
+    d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
+    ZERO_ACC(aR); ZERO_ACC(aA); ZERO_ACC(aB);
+    outer_tile(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    double *out = X + ((size_t)t.n * m + (j - 1)) * panel;
+    const double w = 1.0 / (double)j;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {      // element (r1, r2 = g*16 + c16): column group r2 / 8, slot r2 % 8 (re), + 8 (im)
+                double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PW + (t.g[g] * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
+                o[0] = w * aR[r][g][e];
+                o[8] = w * (aA[r][g][e] - aB[r][g][e]);
+            }
+        }
+    }
+}
+
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_d(const double *__restrict__ ops, const double *__restrict__ X,
+                                                  const double *__restrict__ D, double *__restrict__ sigma, int Np, int n_ops, int m, int nt)
+{
+    extern __shared__ double sig[];          // [n_ops][2] of this workgroup's d
+    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x) sig[e] = 0.0;
+    __syncthreads();
+    DenseTile<DN_RB, DN_NG> t;
+    const bool active = dense_tile(t, Np >> 4, Np >> 4, m, nt);
+    const int d = t.sub;
+    if (active) {
+        const int PW = 2 * Np;
+        const size_t panel = (size_t)Np * PW;
+        const double *Xn = X + (size_t)t.n * m * panel, *Dn = D + (size_t)t.n * m * panel;     // X_j at slot j-1, D_i at slot i-1
+        d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
+        ZERO_ACC(aB);
+        {   // i = 0: D_0 = I, the term is X_{d+1} itself
+            const double *x0 = Xn + (size_t)d * panel;
+            #pragma unroll
+            for (int r = 0; r < DN_RB; r++)
+                #pragma unroll
+                for (int g = 0; g < DN_NG; g++)
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int rb = t.rb[r] >= 0 ? t.rb[r] : t.rb[0], gb = t.g[g] >= 0 ? t.g[g] : t.g[0];
+                        const double *o = x0 + (size_t)(rb * 16 + t.kk + 4 * e) * PW + (gb * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
+                        aR[r][g][e] = o[0]; aA[r][g][e] = o[8];
+                    }
+        }
+        for (int i = 1; i + d < m; i++)
+            outer_tile(aR, aA, aB, t, Xn + (size_t)(i + d) * panel, Dn + (size_t)(i - 1) * panel, (size_t)PW, Np >> 3);
+        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, 1.0, sig);
+    }
+    __syncthreads();
+    if (!active && t.n >= nt) return;
+    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x)
+        atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)], sig[e]);
+}
+
+// which form the gradient scalars take on the N > 64 path: 0 operator applications (k_ginner_f), 1 outer products with the
+// stage derivatives (k_ginner_m), 2 outer products through the stored D_i (k_gouter + k_ginner_d: no k_derivs_f).
+// QGD_GINNER=0|1|2 forces one (tests, A/B timing).
+static int dense_sigma_form(const qgdk_ctx *c)
+{
+    if (const char *e = getenv("QGD_GINNER")) { const int f = atoi(e); return (f == 2 && !c->Xouter) ? 1 : f; }
+    if (c->Np < 128 || c->cp < 64) return 0;
+    const int m = c->m;
+    if (c->Xouter && (long long)(m - 1) * c->Np < (long long)(m + 1) * c->cp && m * (m + 1) / 2 <= c->n_ops * m + m) return 2;
+    return ((m + 1) / 2 < c->n_ops) ? 1 : 0;
+}
+
 extern "C" {
 
 int qgdk_dense_operator_frag(const qgdk_ctx *c)
@@ -513,6 +738,8 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
+int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c) { return dense_sigma_form(c) != 2; }
+
 int qgdk_dense_gradient(const qgdk_ctx *c)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
@@ -531,6 +758,21 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
                                            (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream,                             \
                                            reinterpret_cast<const d2 *>(c->OpFrag), c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,  \
                                            c->n_ops, c->m, c->nt)
+    // outer-product forms when they are fewer GEMM units and the contraction is long enough (dense_sigma_form)
+    const int form = dense_sigma_form(c);
+    const int ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
+    if (form == 2) {
+        hipLaunchKernelGGL((k_gouter<2, 2>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt);
+        hipLaunchKernelGGL((k_ginner_d<2, 2>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->Xouter,
+                           c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt);
+        return (int)hipGetLastError();
+    }
+    if (form == 1) {
+        hipLaunchKernelGGL((k_ginner_m<2, 2>), dim3(ogrid), dim3(256),
+                           (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,
+                           c->n_ops, c->m, c->nt);
+        return (int)hipGetLastError();
+    }
     DISPATCH_SHAPE(ng, CALL_GI);      // (a 2 x 2 tile at 4 waves per SIMD was slower: 13.2 vs 11.4 ms at config 5)
 #undef CALL_GI
     return (int)hipGetLastError();

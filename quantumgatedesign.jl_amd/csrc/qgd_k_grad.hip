@@ -657,7 +657,11 @@ int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch)
     return (int)hipGetLastError();
 }
 
-int qgdk_gradient_needs_derivs(const qgdk_ctx *c) { return !(c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)); }
+int qgdk_gradient_needs_derivs(const qgdk_ctx *c)
+{
+    if (c->dense_gemm && !c->use_sparse) return qgdk_dense_gradient_needs_derivs(c);      // (the outer-product form through D_i needs none)
+    return !(c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1));
+}
 
 
 } // extern "C"

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r02
+#   bash scripts/collect_profiles.sh r03
 # -> gpurun_out/prof_<tag>/{kernel_stats_cnot3.csv, kernel_stats_c5.csv, bench_under_rocprof.json, pmc_*.json};
 # copy what is to be judged into profiles/.  Counters are collected in their own passes (--pmc with --kernel-trace only;
 # FETCH_SIZE and WRITE_SIZE cannot share a pass), exactly as MI355X_MICROARCH.md 'HBM' / 'rocprofv3 PMC slots' prescribe.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-large-n --no-with-history"
-BENCH_S="python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-large-n --no-with-history"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-large-n --no-with-history --no-cnot2"
+BENCH_S="python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-large-n --no-with-history --no-cnot2"
 C5="python3 $REPO/scripts/c5_synthetic.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cnot3 -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats_cnot3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- $C5 > $OUT/c5_under_rocprof.txt 2> $OUT/stats_c5.err
