@@ -229,8 +229,8 @@ def large_n_case(qgd, np, steps=3):
     order 12, tf=2, nsteps=200) -- the configuration where the MFMA roofline is the binding one.
     Reported beside the headline line, never as `value`.  Flops are the ones the kernels EXECUTE (complex
     N x N x N contractions of 8 N^3 flop): recursion on the identity m(m-1)/2, four chain passes, inverse, propagator,
-    lambda, reverse sweep m(m-1)/2, gradient scalars m + m(m-1)/2 (outer products through the stored D_i; round 2: stage
-    derivatives m + inner products N_op*m) -- per time point.  `frac` counts what is executed NOW; the same time priced
+    lambda, and for the gradient 2 outer products + the reverse sweep on N x N matrices m(m-1)/2 + the contraction with the
+    stored D_i m(m-1)/2 (round 2: sweep on the panels m(m-1)/2, stage derivatives m, inner products N_op*m) -- per time point.  `frac` counts what is executed NOW; the same time priced
     at round 2's flop count is reported beside it (removing work lowers the time, not the executed-flop fraction)."""
     import torch
     N, c, n_ops, nsteps, order = 256, 256, 4, 200, 12
@@ -263,11 +263,12 @@ def large_n_case(qgd, np, steps=3):
     fd_rel = abs(fd - grad @ d) / abs(fd)
     assert np.isfinite(grad).all() and fd_rel < 1e-6, f"C5 gradient check failed: adjoint {grad @ d}, centred difference {fd}"
     dp.close()
-    # gradient scalars: round 2 applied every control operator to every stage derivative (n_ops*m units + m for the stage
-    # derivatives themselves); round 3 forms them from outer products through the stored D_i (m + m(m-1)/2 units, no stage
-    # derivatives) when that is fewer -- it is here (21 against 30)
-    sigma_units = min(n_ops * m + m, m + m * (m - 1) // 2)
-    gemms = m * (m - 1) // 2 + 4.0 * nsteps / (nsteps + 1) + 3 + m * (m - 1) // 2 + sigma_units
+    # gradient: round 2 swept the seeds on the state panels (m(m-1)/2 units), formed the stage derivatives (m) and applied
+    # every control operator to every one of them (n_ops*m); round 3 works on N x N matrices instead -- two outer products
+    # lambda psi_0^H per time point, the same reverse sweep on the matrices Y_j = g_j psi_0^H (m(m-1)/2), and the scalars as
+    # Frobenius products of sum_i (1/j) Y_j D_i^H (m(m-1)/2) with the control operators
+    grad_units = min(m * (m - 1) // 2 + m + n_ops * m, 2 + m * (m - 1) // 2 + m * (m - 1) // 2)
+    gemms = m * (m - 1) // 2 + 4.0 * nsteps / (nsteps + 1) + 3 + grad_units
     gemms_r02 = m * (m - 1) // 2 + m + 4.0 * nsteps / (nsteps + 1) + 3 + m * (m - 1) // 2 + n_ops * m
     tflop = 8.0 * N ** 3 * gemms * (nsteps + 1) / 1e12
     return {"workload": f"C5 synthetic: N={N}, {c} columns, {n_ops} control operators, order {order}, nsteps={nsteps}",

@@ -55,6 +55,7 @@ typedef struct qgdk_ctx {
     // large N, GEMM-style kernels (qgd_k_dense.hip): A_d(t_n), D_j(t_n) and {S_o, K_o} in MFMA fragment order
     int dense_gemm;
     double *Afrag, *Dfrag, *OpFrag;
+    double *Tlam;       // [nt][2][Np][2Np]: Lambda+ = lambda_{n+1} psi_0^H, Lambda- = lambda_n psi_0^H (third form of the gradient scalars), or null
     double *Xouter;     // [nt][m][Np][2Np]: X_j = (1/j) g_j psi_0^H of the gradient scalars' outer-product form (k_gouter), or null
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.

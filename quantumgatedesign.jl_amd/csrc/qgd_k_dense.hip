@@ -637,7 +637,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int DN_RB, int DN_NG>
+// WEIGHTED = false: X_j carries its weight 1/j (k_gouter).  WEIGHTED = true: the panels are the swept Y_j = g_j psi_0^H of the
+// third form (below) and the weights 1/j are applied here, the running sum kept in units of the current pair's weight.
+template <int DN_RB, int DN_NG, bool WEIGHTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_d(const double *__restrict__ ops, const double *__restrict__ X,
                                                   const double *__restrict__ D, double *__restrict__ sigma, int Np, int n_ops, int m, int nt)
 {
@@ -666,9 +668,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         aR[r][g][e] = o[0]; aA[r][g][e] = o[8];
                     }
         }
-        for (int i = 1; i + d < m; i++)
+        for (int i = 1; i + d < m; i++) {
+            if (WEIGHTED) {                  // (1/(j-1)) / (1/j), j = i + 1 + d
+                const double sc = (double)(i + 1 + d) / (double)(i + d);
+                #pragma unroll
+                for (int r = 0; r < DN_RB; r++)
+                    #pragma unroll
+                    for (int g = 0; g < DN_NG; g++) { aR[r][g] *= sc; aA[r][g] *= sc; aB[r][g] *= sc; }
+            }
             outer_tile(aR, aA, aB, t, Xn + (size_t)(i + d) * panel, Dn + (size_t)(i - 1) * panel, (size_t)PW, Np >> 3);
-        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, 1.0, sig);
+        }
+        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, WEIGHTED ? 1.0 / (double)m : 1.0, sig);
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
@@ -676,14 +686,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)], sig[e]);
 }
 
+// Third form: the reverse sweep itself on N x N matrices.  g_j enters the scalars only through Y_j = g_j psi_0^H, the sweep
+// g_i -= (1/j) A_{j-1-i} g_j is a multiplication from the LEFT, and every seed is a combination of two vectors,
+// g_j = c_j dt^j lambda_{n+1} - c_j (-dt)^j lambda_n.  So: two outer products per time point (k_youter: Lambda+ =
+// lambda_{n+1} psi_0^H, Lambda- = lambda_n psi_0^H), the m seeds Y_j = c_j dt^j Lambda+ - c_j (-dt)^j Lambda- (k_yinit,
+// elementwise), the SAME sweep kernel on the Y panels (width N instead of c), then k_ginner_d with the weights 1/j.
+// 2 + m(m-1)/2 + m(m-1)/2 units against m(m-1)/2 + m + m(m-1)/2 of the second form when c = N (config 5: 32 against 36).
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_youter(const double *__restrict__ hist, const double *__restrict__ lam,
+                                                double *__restrict__ T, int Np, int cp, int nt)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, Np >> 4, 2, nt)) return;
+    const int PWc = 2 * cp, PW = 2 * Np;
+    const size_t hstep = (size_t)Np * PWc, panel = (size_t)Np * PW;
+    const int nl = t.sub == 0 ? t.n + 1 : t.n;          // Lambda+ pairs lambda_{n+1}, Lambda- pairs lambda_n, both with psi_0(t_n)
+    if (nl < 1 || nl > nt - 1) return;                  // (k_yinit treats the missing one as zero)
+    d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
+    ZERO_ACC(aR); ZERO_ACC(aA); ZERO_ACC(aB);
+    outer_tile(aR, aA, aB, t, lam + (size_t)nl * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    double *out = T + ((size_t)t.n * 2 + t.sub) * panel;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (t.g[g] < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PW + (t.g[g] * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
+                o[0] = aR[r][g][e];
+                o[8] = aA[r][g][e] - aB[r][g][e];
+            }
+        }
+    }
+}
+
+// Y[n][j-1] = c_j dt^j Lambda+[n] [n <= nt-2] - c_j (-dt)^j Lambda-[n] [n >= 1].  grid (ceil(panel/256), nt)
+__global__ __launch_bounds__(256) void k_yinit(const double *__restrict__ T, const double *__restrict__ cw, double *__restrict__ Y,
+                                               size_t panel, int m, int nt)
+{
+    const int n = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= panel) return;
+    const double lx = (n <= nt - 2) ? T[((size_t)n * 2) * panel + e] : 0.0;
+    const double ln = (n >= 1) ? T[((size_t)n * 2 + 1) * panel + e] : 0.0;
+    for (int j = 1; j <= m; j++) Y[((size_t)n * m + (j - 1)) * panel + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+}
+
 // which form the gradient scalars take on the N > 64 path: 0 operator applications (k_ginner_f), 1 outer products with the
 // stage derivatives (k_ginner_m), 2 outer products through the stored D_i (k_gouter + k_ginner_d: no k_derivs_f).
-// QGD_GINNER=0|1|2 forces one (tests, A/B timing).
+// 3 the whole reverse sweep on the N x N matrices Y_j (k_youter + k_yinit + k_gsweep_f on Y + k_ginner_d: neither stage
+// derivatives nor a sweep on the state panels).  QGD_GINNER=0|1|2|3 forces one (tests, A/B timing).
 static int dense_sigma_form(const qgdk_ctx *c)
 {
-    if (const char *e = getenv("QGD_GINNER")) { const int f = atoi(e); return (f == 2 && !c->Xouter) ? 1 : f; }
+    if (const char *e = getenv("QGD_GINNER")) { const int f = atoi(e); return (f >= 2 && !c->Xouter) ? 1 : f; }
     if (c->Np < 128 || c->cp < 64) return 0;
     const int m = c->m;
+    if (c->Xouter && c->Tlam && (long long)(m * (m - 1) / 2) * c->Np < (long long)(m * (m + 1) / 2 - 2) * c->cp) return 3;
     if (c->Xouter && (long long)(m - 1) * c->Np < (long long)(m + 1) * c->cp && m * (m + 1) / 2 <= c->n_ops * m + m) return 2;
     return ((m + 1) / 2 < c->n_ops) ? 1 : 0;
 }
@@ -738,7 +798,7 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
-int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c) { return dense_sigma_form(c) != 2; }
+int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c) { return dense_sigma_form(c) < 2; }
 
 int qgdk_dense_gradient(const qgdk_ctx *c)
 {
@@ -746,6 +806,23 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     const d2 *Af = reinterpret_cast<const d2 *>(c->Afrag);
     double *Gp = c->panel_scratch;
     const int ng = c->cp / 8;
+    if (dense_sigma_form(c) == 3) {      // the sweep on the matrices Y_j = g_j psi_0^H (see k_youter)
+        const size_t panel = (size_t)c->Np * 2 * c->Np;
+        const int ogrid2 = dense_grid(2, 2, c->Np / 16, c->Np / 16, 2, c->nt), ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
+        hipLaunchKernelGGL((k_youter<2, 2>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
+        hipLaunchKernelGGL(k_yinit, dim3((unsigned)((panel + 255) / 256), c->nt), dim3(256), 0, c->stream, c->Tlam, c->cw, c->Xouter, panel,
+                           c->m, c->nt);
+        const int ngy = c->Np / 8;
+        for (int j = c->m; j >= 2; j--) {
+#define CALL_GY(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, \
+                                           c->stream, Af, c->Xouter, c->Np, c->Np, c->m, c->nt, j)
+            DISPATCH_SHAPE(ngy, CALL_GY);
+#undef CALL_GY
+        }
+        hipLaunchKernelGGL((k_ginner_d<2, 2, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                           c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((hstep + 255) / 256), c->nt), dim3(256), 0, c->stream, c->lam, c->cw, Gp, hstep,
                        c->m, c->nt);
     for (int j = c->m; j >= 2; j--) {
@@ -763,7 +840,7 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     const int ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
     if (form == 2) {
         hipLaunchKernelGGL((k_gouter<2, 2>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt);
-        hipLaunchKernelGGL((k_ginner_d<2, 2>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->Xouter,
+        hipLaunchKernelGGL((k_ginner_d<2, 2, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->Xouter,
                            c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt);
         return (int)hipGetLastError();
     }

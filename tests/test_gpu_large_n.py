@@ -187,20 +187,21 @@ def test_large_n_forward_with_forcing_vs_oracle(qgd, orc, N, c, nsteps, order):
 
 @pytest.mark.parametrize("N,c,n_ops,order", [(80, 16, 2, 12), (100, 40, 4, 8), (144, 144, 3, 4), (160, 150, 2, 12), (256, 64, 4, 12)])
 def test_sigma_forms_agree(qgd, N, c, n_ops, order, monkeypatch):
-    """The gradient scalars of the N > 64 path in their three forms -- operator applications (k_ginner_f: n_ops m GEMM
-    units per time point), outer products over the columns with the stage derivatives (k_ginner_m: m(m+1)/2 units), and
-    outer products through the stored D_i (k_gouter + k_ginner_d: no stage derivatives at all; only where its panels are
-    allocated, (m-1) N < (m+1) c and N >= 128, else the request falls back to the second form) -- forced each way, on
-    shapes with partial row blocks too (N = 80, 100: 5 and 7 blocks of 16), against the numpy statement."""
+    """The gradient scalars of the N > 64 path in their four forms -- operator applications (k_ginner_f: n_ops m GEMM
+    units per time point), outer products over the columns with the stage derivatives (k_ginner_m: m(m+1)/2 units),
+    outer products through the stored D_i (k_gouter + k_ginner_d: no stage derivatives), and the reverse sweep itself on
+    the matrices Y_j = g_j psi_0^H (k_youter + k_yinit + k_gsweep_f + k_ginner_d) -- the last two only where their panels
+    are allocated ((m-1) N < (m+1) c and N >= 128; else the request falls back to the second form) -- forced each way,
+    on shapes with partial row blocks too (N = 80, 100: 5 and 7 blocks of 16), against the numpy statement."""
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=5, tf=0.05, seed=N)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
     grads = {}
-    for f in ("0", "1", "2"):
+    for f in ("0", "1", "2", "3"):
         monkeypatch.setenv("QGD_GINNER", f)
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         grads[f], _ = dp.discrete_adjoint(pcof)
         dp.close()
         assert np.abs(grads[f] - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max(), f
-    for f in ("1", "2"):
+    for f in ("1", "2", "3"):
         assert np.abs(grads["0"] - grads[f]).max() <= 1e-12 * np.abs(ref["grad"]).max(), f
