@@ -261,7 +261,8 @@ int qgd_cols_adjoint(qgd_handle h, int32_t keep_scalars);
  * itself (ncclAllGather / ncclAllReduce on the handle's stream between its phases, no host synchronisation in
  * between), and every rank receives the full gradient and the global scalars.  The host only has to carry 128 bytes
  * once: rank 0 calls qgd_comm_unique_id and hands the id to the other ranks by whatever it has (MPI.jl bcast, a
- * socket, a shared file).
+ * socket, a shared file).  An id serves ONE communicator (every handle that gets one needs a fresh id, as with
+ * ncclGetUniqueId).
  *   shard = QGD_SHARD_TIME     contiguous windows of the time grid per rank (default split: 2 all-gathers + 1
  *                              all-reduce per evaluation).  Implies qgd_set_partition(rank, world):
  *                              set the control basis AFTERWARDS, for the rank's own window (qgd_get_partition).

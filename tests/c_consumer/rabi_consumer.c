@@ -8,7 +8,9 @@
  *   3. qgd_discrete_adjoint with a two-coefficient control basis (p = theta_0, q = theta_1) against centred
  *      differences of the infidelity from qgd_eval_forward (the reference's adjoint-vs-FD contract,
  *      test/GradientTests/compare_gradients.jl:47-65), to 1e-7 relative;
- *   4. the same problem through qgd_create_csc gives the same gradient.
+ *   4. the same problem through qgd_create_csc gives the same gradient;
+ *   5. qgd_comm_unique_id / qgd_comm_init_rccl (one rank, both shard kinds): the collective qgd_discrete_adjoint gives it too;
+ *   6. qgd_set_memory_budget: the grid in windows gives it too, and an impossible budget is QGD_ERR_MEMORY.
  * Exit code 0 and "C_CONSUMER_OK" on success; 3 when there is no GPU (the library has no CPU path).
  */
 #include <math.h>
@@ -113,6 +115,41 @@ int main(void)
         fprintf(stderr, "CSC handle differs: %.15g %.15g vs %.15g %.15g\n", gc[0], gc[1], grad[0], grad[1]);
         return 1;
     }
+    /* 5. several GPUs behind one call, from plain C: rank 0 of a communicator of one (the box has one GPU).  The id is what
+     *    a host would carry to the other ranks; after qgd_comm_init_rccl the SAME qgd_discrete_adjoint is a collective call
+     *    whose all-gathers / all-reduce the library issues itself.  (QGD_ERR_COMM when librccl cannot be loaded.) */
+    unsigned char id[QGD_UNIQUE_ID_BYTES];
+    int32_t info[3];
+    for (int shard = QGD_SHARD_TIME; shard <= QGD_SHARD_COLUMNS; shard++) {
+        if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);      /* one id per communicator */
+        if ((rc = qgd_comm_init_rccl(hc, id, 0, 1, shard))) return die("qgd_comm_init_rccl", hc, rc);
+        if ((rc = qgd_comm_info(hc, info)) || info[0] != 0 || info[1] != 1 || info[2] != shard) { fprintf(stderr, "qgd_comm_info\n"); return 1; }
+        if (shard == QGD_SHARD_TIME) {      /* a time window re-allocates the grid: basis and target again */
+            if ((rc = qgd_set_control_basis(hc, ncoef, gp, gq))) return die("qgd_set_control_basis(comm)", hc, rc);
+            if ((rc = qgd_set_target(hc, target))) return die("qgd_set_target(comm)", hc, rc);
+        }
+        double gm[2], om3[3];
+        if ((rc = qgd_discrete_adjoint(hc, theta, 2, 0, gm, NULL, NULL, NULL, om3))) return die("qgd_discrete_adjoint(comm)", hc, rc);
+        if (fabs(gm[0] - grad[0]) > 1e-13 || fabs(gm[1] - grad[1]) > 1e-13 || fabs(infidelity_of(om3) - infid0) > 1e-13) {
+            fprintf(stderr, "communicator handle (shard %d) differs: %.15g %.15g vs %.15g %.15g\n", shard, gm[0], gm[1], grad[0], grad[1]);
+            return 1;
+        }
+        if ((rc = qgd_comm_destroy(hc))) return die("qgd_comm_destroy", hc, rc);
+    }
+    /* 6. a memory budget too small for the grid: windows; the gradient stays; the plan says how many */
+    int64_t plan[4];
+    if ((rc = qgd_get_memory_plan(h, plan)) || plan[0] != 1) { fprintf(stderr, "memory plan: %d windows\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_memory_budget(h, (size_t)plan[2] / 2))) return die("qgd_set_memory_budget", h, rc);
+    if ((rc = qgd_get_memory_plan(h, plan)) || plan[0] < 2) { fprintf(stderr, "memory plan after the budget: %d windows\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_control_basis(h, ncoef, gp, gq))) return die("qgd_set_control_basis(budget)", h, rc);
+    if ((rc = qgd_set_target(h, target))) return die("qgd_set_target(budget)", h, rc);
+    double gw[2];
+    if ((rc = qgd_discrete_adjoint(h, theta, 2, 0, gw, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(budget)", h, rc);
+    if (fabs(gw[0] - grad[0]) > 1e-12 || fabs(gw[1] - grad[1]) > 1e-12) {
+        fprintf(stderr, "windowed grid differs: %.15g %.15g vs %.15g %.15g\n", gw[0], gw[1], grad[0], grad[1]);
+        return 1;
+    }
+    if (qgd_set_memory_budget(h, 64) != QGD_ERR_MEMORY) { fprintf(stderr, "a 64-byte budget must be QGD_ERR_MEMORY\n"); return 1; }
     qgd_destroy(hc);
     qgd_destroy(h);
     printf("infidelity(0.4, 0.1) = %.12f  grad = [%.12f, %.12f]  fd = [%.12f, %.12f]\nC_CONSUMER_OK\n", infid0, grad[0], grad[1], fd[0], fd[1]);
