@@ -182,15 +182,35 @@ def make_partitioned(qgd, args, prob, order, ctrl, target, rank, world, local_ra
     """One rank's evaluator of a partitioned evaluation.  Default (--comm lib): RCCL inside the library, the call is
     the plain qgd_discrete_adjoint.  --comm torch: the older route, phase hooks + torch.distributed collectives."""
     import torch
+    import torch.distributed as dist
     if args.comm == "lib":
-        return qgd.RcclEvaluation(prob, order, ctrl, target, rank, world, uid(), shard=args.shard, device=local_rank)
+        # every rank must agree on the route: a rank that cannot get its communicator (QGD_ERR_COMM: librccl not loadable,
+        # ...) makes ALL ranks fall back to the phase hooks with torch.distributed's own nccl group
+        ev, ok = None, 1
+        try:
+            ev = qgd.RcclEvaluation(prob, order, ctrl, target, rank, world, uid(), shard=args.shard, device=local_rank)
+        except Exception as exc:
+            ok = 0
+            print(f"[bench rank {rank}] in-library RCCL unavailable ({exc!r}); falling back to --comm torch", file=sys.stderr)
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            return ev
+        if ev is not None:
+            ev.close()
+        args.comm = "torch"
+        if getattr(args, "_torch_group", None) is None:
+            args._torch_group = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None
+    group = getattr(args, "_torch_group", None)
     stream = torch.cuda.current_stream().cuda_stream
     if args.shard == "columns":
         back = qgd.ColumnBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=stream)
-        dp = qgd.ColumnSharded(back, qgd.TorchComm())
+        dp = qgd.ColumnSharded(back, qgd.TorchComm(group))
     else:
         back = qgd.DeviceBackend(prob, order, ctrl, target, rank, world, device=local_rank, stream=stream)
-        dp = qgd.TimePartitioned(back, qgd.TorchComm())
+        dp = qgd.TimePartitioned(back, qgd.TorchComm(group))
     dp.timings, dp.close, dp.set_timing = back.timings, back.close, back.set_timing
     return dp
 

@@ -280,7 +280,9 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
               A(&k.PiR2, nb2 * 2 * pl) && A(&k.phi2, nb2 * hstep) && A(&k.bnd2, (nb2 + 1) * hstep) && A(&k.bndY2, (nb2 + 1) * hstep);
     if (!ok) return rc;
     // sub-block history pass (qgd_k_chain.hip): only with compiled-size chains, blocks of at least 6 steps
-    k.sub_hist = 0; k.sub_n = 0; if (!dry) k.Hmid = k.Qmid = nullptr;
+    k.sub_hist = 0; k.sub_n = 0; if (!dry) k.Hmid = k.Qmid = k.SufP = k.SufPhi = nullptr;
+    if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blocks2 > 1 && k.scan_g > 2 &&
+        (!A(&k.SufP, (nb2 + 1) * (size_t)(k.scan_g - 2) * 2 * pl) || !A(&k.SufPhi, (nb2 + 1) * (size_t)(k.scan_g - 2) * hstep))) return rc;
     if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blen >= 6 && !getenv("QGD_HIST_WHOLE_BLOCKS")) {
         k.sub_hist = 1; k.sub_n = (k.scan_blen + 2) / 3 - 1;      // stored products after 3, 6, ... steps
         if (!A(&k.Hmid, nb * (size_t)k.sub_n * 2 * pl) || !A(&k.Qmid, (nb2 + 1) * (size_t)std::max(k.scan_g, 2) * 2 * pl)) return rc;
@@ -1873,6 +1875,9 @@ int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_
     if (!h || !unique_id) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(h, QGD_ERR_ARGUMENT, "rank/world out of range");
     if (shard != QGD_SHARD_TIME && shard != QGD_SHARD_COLUMNS) return fail(h, QGD_ERR_ARGUMENT, "shard: 0 time windows, 1 column blocks");
+    if (shard == QGD_SHARD_COLUMNS && h->chunks_eff > 1)
+        return fail(h, QGD_ERR_UNSUPPORTED, "a time grid processed in windows (memory budget) cannot also be sharded by columns: raise the budget, "
+                                            "or shard by time -- every rank then holds only its own window");
     RcclApi &R = rccl();
     if (!R.ok) return fail(h, QGD_ERR_COMM, R.err);
     HIP_TRY(h, hipSetDevice(h->device));

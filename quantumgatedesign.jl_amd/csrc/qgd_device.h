@@ -76,6 +76,9 @@ typedef struct qgdk_ctx {
     // [B][sub_n] after 3, 6, ... steps) and of the level-2 chains (Qmid: [B2][g-2] after 2 .. g-1 blocks)
     int sub_hist, sub_n;
     double *Hmid, *Qmid;
+    // adjoint history pass: suffix products of the blocks of every super-block (panel layout, [B2][g-2]) and their affine
+    // parts ([B2][g-2] panels) -- the block-level prefix of the pass is then one step (qgd_k_chain.hip, ChainArgs::suf_P)
+    double *SufP, *SufPhi;
     int part_rank, part_world, n_off, nt_glob;
     // chunked time grid (bounded memory, qgd_set_memory_budget): the handle's per-time-point buffers hold ONE window of
     // the grid at a time.  The control basis G stays whole: g_nt time points, the current window starts at g_n0

@@ -69,6 +69,12 @@ struct ChainArgs {
     double *mid_out; int mid_every, mid_n, mid_first;
     int sub_T, sub_len, sub_n, pre_Qn;
     const double *sub_H, *pre_Q;
+    // Adjoint history pass (MODE 3) with the block-level prefix in ONE step: the level-2 launches also store
+    //   suf_P[j * suf_n + cnt - 2]   = Pi_{e-1} ... Pi_{e-cnt} in panel layout (MODE 6 chains beside the level-2 products),
+    //   suf_phi[j * suf_n + cnt - 2] = the affine part of those cnt blocks (running values of the MODE 2 level-2 chain),
+    // cnt = 2 .. g-1, e = end of super-block j: y at the end of block bb is then suf_P^H y_e + suf_phi instead of cnt
+    // steps (cnt = 1 is the block propagator / affine part itself).  MODE 2: mid_out/mid_n describe the affine stores.
+    const double *suf_P, *suf_phi; int suf_n;
     // MODE 2, t_on: ONE extra workgroup (the last of the grid) does the work of k_terminal -- overlaps <w_N,R>, <w_N,T>
     // and y_N -- beside the affine parts of the blocks, which do not need it: the adjoint sweep starts one launch earlier
     int t_on, t_nt, t_ness, t_have_target;
@@ -90,17 +96,18 @@ __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
 }
 
 template <int MODE>
-__device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &grp)
+__device__ __forceinline__ void chain_block_of(const ChainArgs &a, int &b, int &grp, int bid = -1)
 {
-    if (MODE == 0) {
+    if (bid < 0) bid = blockIdx.x;
+    if (MODE == 0 || MODE == 6) {
         // XCD-aware: the ngroups workgroups of one block share blockIdx%8, hence one XCD's L2,
         // because they all stream the same P_n (speed only; MI355X_MICROARCH.md "Workgroup dispatch").
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bid & 7, slot = bid >> 3;
         b = xcd + 8 * (slot / a.ngroups);
         grp = slot % a.ngroups;
     } else {
-        b = blockIdx.x / a.ngroups;
-        grp = blockIdx.x % a.ngroups;
+        b = bid / a.ngroups;
+        grp = bid % a.ngroups;
     }
 }
 
@@ -162,16 +169,20 @@ __device__ __forceinline__ void chain_a_raw(const double *__restrict__ Pn, int N
 #ifdef QGD_CHAIN_PROFILE
 __device__ long long g_chain_prof[64 * 8];
 #endif
+// MODE 6 (round 3): the adjoint matrix chain X <- Pi_b^H X from the identity over the blocks of a super-block, last block
+// first, with P^H read from the PANEL copies of the block propagators; its running values are the conjugate transposes of
+// the suffix products Pi_{e-1} ... Pi_{e-cnt}, stored in panel layout for the adjoint history pass (ChainArgs::suf_P).
 template <int NP, int MODE, int NG>
-__global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const ChainArgs a)
+__device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bid, const int nbid)
 {
-    constexpr bool ADJ = (MODE == 2 || MODE == 3);      // backward in time with P^H
-    constexpr bool FORC = (MODE >= 2);                    // affine: a forcing term is added every step
+    constexpr bool ADJ = (MODE == 2 || MODE == 3 || MODE == 6);      // backward in time with P^H
+    constexpr bool FORC = (MODE >= 2 && MODE != 6);       // affine: a forcing term is added every step
     constexpr bool ZERO = (MODE == 2 || MODE == 4);       // zero start, the final state is the block's affine part
+    constexpr bool MAT = (MODE == 0 || MODE == 6);        // the state is a whole matrix (NP columns), not a panel of the problem's columns
     constexpr int NRB = NP / 16, NT = CHAIN_NT(MODE), KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
-    if (MODE == 2 && a.t_on && blockIdx.x == gridDim.x - 1) {      // the extra workgroup: k_terminal's work
+    if (MODE == 2 && a.t_on && bid == nbid - 1) {      // the extra workgroup: k_terminal's work
         terminal_block(a.t_hist, a.t_target, a.t_forcing, a.t_yhist, a.t_scal, NP, a.cp, a.t_nt, a.t_ness, a.t_have_target, 1,
                        a.t_y2, a.t_y3, a.t_y4, 0);
         return;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     int b, grp0;
     {
         ChainArgs a2 = a; a2.ngroups = a.ngroups / NG;
-        chain_block_of<MODE>(a2, b, grp0);
+        chain_block_of<MODE>(a2, b, grp0, bid);
         grp0 *= NG;
     }
     if (b >= a.nblocks) return;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     const int s0 = bb * a.blen + (subs ? tsub * a.sub_len : 0);
     const int e0 = subs ? ((s0 + a.sub_len < blk_end) ? s0 + a.sub_len : blk_end) : blk_end;
     if (subs && s0 >= blk_end) return;                   // (a short last block has fewer sub-blocks)
-    const int PWc = (MODE == 0) ? 2 * NP : 2 * a.cp;
+    const int PWc = MAT ? 2 * NP : 2 * a.cp;
     const size_t hstep = (size_t)NP * PWc;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kk = lane >> 4;
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     // prefix segments (MODE 1/3): counts and first indices for this block
     int pcnt[4] = {0, 0, 0, 0}, pfirst[4] = {0, 0, 0, 0}, npfx = 0;
     const double *pfix[4] = {nullptr, nullptr, nullptr, nullptr};   // a segment of ONE step with this stored product
+    const double *pffix[4] = {nullptr, nullptr, nullptr, nullptr};  // ... and (adjoint) this stored affine part
     const size_t pl2_ = (size_t)2 * NP * NP;
     if ((MODE == 1 || MODE == 3) && a.npre > 0) {
         bool have1 = false;
@@ -225,6 +237,12 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             } else {    // descending: first = highest index
                 pfirst[q] = (kind == 0) ? a.pre_rank_count - 1 : (kind == 1) ? a.pre_B2 - 1 : ej - 1;
                 pcnt[q] = (kind == 0) ? a.pre_rank_count : (kind == 1) ? a.pre_B2 - 1 - j : ej - 1 - bb;
+                if (MODE == 3 && kind == 2 && a.suf_P && have1 && pcnt[q] >= 2) {   // the stored suffix product and affine part of those blocks
+                    const int cnt = pcnt[q];
+                    pfix[q] = a.suf_P + ((size_t)j * a.suf_n + (cnt - 2)) * pl2_;
+                    pffix[q] = a.suf_phi + ((size_t)j * a.suf_n + (cnt - 2)) * hstep;
+                    pcnt[q] = 1;
+                }
             }
             if (pcnt[q] < 0) pcnt[q] = 0;
             npfx += pcnt[q];
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
     auto step_index = [&](int st) { return ADJ ? e0 - 1 - st : s0 + st; };
     // The first step of a chain that starts from the identity (MODE 0) or from zero (MODE 2) needs no product: its
     // result is the step matrix itself / the forcing.  It is loaded straight into the buffer step 1 reads.
-    constexpr bool SKIP0 = (MODE == 0 || MODE == 2);
+    constexpr bool SKIP0 = (MODE == 0 || MODE == 2 || MODE == 6);
     const int first = (SKIP0 && total > 0) ? 1 : 0;
     double are[KST], aim[KST], fo[NG][4];
     const double sgn2 = ((c16 < 8) != ADJ) ? -1.0 : 1.0;  // sign of the Aim [Bim|Bre] sum in this lane's output column
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             else Pn = a.pre_pm_bpr[q] ? a.pre_P[q] + (size_t)(n / a.pre_pm_bpr[q]) * a.pre_pm_chunk[q] + (size_t)(n % a.pre_pm_bpr[q]) * pl2
                                       : a.pre_P[q] + (size_t)n * pl2;
             if (q < a.npre) { fsrc = a.pre_f[q]; fbpr = a.pre_f_bpr[q]; }
+            if (pffix[q]) { fsrc = pffix[q]; fbpr = 0; n = 0; }
         }
         // Addresses = buffer descriptor on the step's matrix (SGPRs) + a per-lane byte offset computed once + constants:
         // no vector ALU per load.  While the other team runs its burst of f64 MFMAs, a wave on the same SIMD gets about
@@ -332,9 +351,13 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
                 if (SKIP0 && first) {
                     const int n0 = step_index(0);
                     if (MODE == 0) v = chain_matrix(a, n0)[(c >= 8 ? (size_t)NP * NP : 0) + row + (size_t)NP * ((grp0 + g) * 8 + (c & 7))];
+                    else if (MODE == 6) {   // (Pi^H)[row][col] = conj(Pi[col][row]) from the panel copy of Pi
+                        const double pv = chain_matrix(a, n0)[(size_t)((grp0 + g) * 8 + (c & 7)) * 2 * NP + (row >> 3) * 16 + (row & 7) + (c >= 8 ? 8 : 0)];
+                        v = (c >= 8) ? -pv : pv;
+                    }
                     else v = a.forcing[(size_t)(a.f_bpr ? n0 + n0 / a.f_bpr : n0) * hstep + (size_t)row * PWc + (grp0 + g) * 16 + c];
                 }
-                else if (MODE == 0) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
+                else if (MAT) v = (c < 8 && row == (grp0 + g) * 8 + c) ? 1.0 : 0.0;
                 else if (ZERO) v = 0.0;
                 else v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + (grp0 + g) * 16 + c];
             }
@@ -424,6 +447,30 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
                         pc[(size_t)(rb * 16 + kk + 4 * r) + (size_t)NP * ((grp0 + g) * 8 + (c16 & 7))] = res[g][r];
             }
         }
+        if (MODE == 6 && a.mid_out) {                   // (Pi_{e-1} ... Pi_{e-kdone}) = X^H, panel layout, kdone = 2 .. blocks-1
+            const int kdone = st + 1;
+            if (kdone >= 2 && kdone < total && kdone - 2 < a.mid_n) {
+                double *pm = a.mid_out + ((size_t)b * a.mid_n + (kdone - 2)) * 2 * NP * NP;
+                #pragma unroll
+                for (int g = 0; g < NG; g++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int xrow = rb * 16 + kk + 4 * r, xcol = (grp0 + g) * 8 + (c16 & 7);      // element X[xrow][xcol] (re: c16 < 8, im: else)
+                        pm[(size_t)xcol * 2 * NP + (xrow >> 3) * 16 + (xrow & 7) + (c16 >= 8 ? 8 : 0)] = (c16 >= 8) ? -res[g][r] : res[g][r];
+                    }
+            }
+        }
+        if (MODE == 2 && a.mid_out) {                   // the affine part of the last kdone blocks of the super-block, kdone = 2 .. blocks-1
+            const int kdone = st + 1;
+            if (kdone >= 2 && kdone < total && kdone - 2 < a.mid_n) {
+                const __amdgpu_buffer_rsrc_t rM = buffer_of(a.mid_out + ((size_t)b * a.mid_n + (kdone - 2)) * hstep + (size_t)grp0 * 16);
+                #pragma unroll
+                for (int g = 0; g < NG; g++)
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        buffer_store_f64(res[g][r], rM, o_lane, (4 * r * PWc + g * 16) * 8);
+            }
+        }
         if (((MODE == 1 || MODE == 3) && mainstep) || (MODE == 5 && a.out)) {
             const __amdgpu_buffer_rsrc_t rO = buffer_of(a.out + (size_t)nout * hstep + (size_t)grp0 * 16);
             #pragma unroll
@@ -508,6 +555,22 @@ __global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const Ch
             }
         }
     }
+}
+
+template <int NP, int MODE, int NG>
+__global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE)) void k_chain_fast(const ChainArgs a)
+{
+    chain_fast_body<NP, MODE, NG>(a, blockIdx.x, gridDim.x);
+}
+
+// Two independent chains in ONE grid (they need the same inputs and nothing from each other): the first nA workgroups
+// run MODE_A on `a`, the others MODE_B on `b`.  Used for the level-2 launch of the forward sweep, where the 44 workgroups
+// of the super-block products leave most of the chip idle: the suffix products of the adjoint history pass ride along.
+template <int NP, int MODE_A, int MODE_B, int NG>
+__global__ __launch_bounds__(NP * 4 * CHAIN_NT(MODE_A)) void k_chain_fast2(const ChainArgs a, const ChainArgs b, const int nA)
+{
+    if ((int)blockIdx.x < nA) chain_fast_body<NP, MODE_A, NG>(a, blockIdx.x, nA);
+    else chain_fast_body<NP, MODE_B, NG>(b, (int)blockIdx.x - nA, (int)gridDim.x - nA);
 }
 
 // any Np: runtime sizes, each wave loops over its row blocks, no K split, no prefetch
@@ -862,6 +925,22 @@ static int launch_chain(const ChainArgs &a, hipStream_t stream)
     return launch_chain_ng<MODE, 1>(a, stream);
 }
 
+// level-2 products of the forward sweep (MODE 0 over the block propagators) with the suffix products of the adjoint
+// history pass (MODE 6) in the same grid; falls back to the plain MODE 0 launch where MODE 6 does not apply
+static int launch_chain_level2(const ChainArgs &a0, const ChainArgs &a6, bool with_suffix, hipStream_t stream)
+{
+    const bool fast = (a0.Np == 16 || a0.Np == 32 || a0.Np == 48 || a0.Np == 64);
+    if (!with_suffix || !fast || (long long)a0.nblocks * a0.ngroups > 256) return launch_chain<0>(a0, stream);
+    const int nA = 8 * a0.ngroups * ((a0.nblocks + 7) / 8), nB = 8 * a6.ngroups * ((a6.nblocks + 7) / 8);
+    switch (a0.Np) {
+    case 16: hipLaunchKernelGGL((k_chain_fast2<16, 0, 6, 1>), dim3(nA + nB), dim3(16 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
+    case 32: hipLaunchKernelGGL((k_chain_fast2<32, 0, 6, 1>), dim3(nA + nB), dim3(32 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
+    case 48: hipLaunchKernelGGL((k_chain_fast2<48, 0, 6, 1>), dim3(nA + nB), dim3(48 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
+    default: hipLaunchKernelGGL((k_chain_fast2<64, 0, 6, 1>), dim3(nA + nB), dim3(64 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
+    }
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // K5: guard penalty and adjoint forcing (infidelity.jl:56-96,
 // eval_grad_discrete_adjoint.jl:732-752).  One workgroup per time point.
@@ -1174,6 +1253,13 @@ static inline bool guard_is_fused(const qgdk_ctx *c)
 //   RX   : exchange buffer 0, per rank [R planes | R panel]
 //   phiRX: exchange buffer 1, per rank [phi^rank | y_N (last rank only)]
 // ---------------------------------------------------------------------------
+// the adjoint history pass takes the blocks after its own inside the super-block in ONE step (stored suffix products and
+// affine parts, ChainArgs::suf_P): compiled-size chains with a second scan level of more than two blocks per super-block
+static inline bool suffix_on(const qgdk_ctx *c)
+{
+    return c->SufP && c->SufPhi && chain_is_fast(c) && c->scan_blocks2 > 1 && c->scan_g > 2 && !getenv("QGD_NO_SUFFIX");
+}
+
 static inline size_t rx_chunk(const qgdk_ctx *c) { return (size_t)4 * c->Np * c->Np; }
 static inline size_t phirx_chunk(const qgdk_ctx *c) { return (size_t)2 * c->Np * 2 * c->cp; }
 
@@ -1194,7 +1280,14 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
         if (c->sub_hist && g > 2) { a2.mid_out = c->Qmid; a2.mid_every = 1; a2.mid_first = 2; a2.mid_n = g - 2; }
-        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+        // beside them (same grid, idle CUs): the suffix products of the blocks of every super-block for the adjoint history pass
+        ChainArgs a6{};
+        const bool suf = suffix_on(c);
+        if (suf) {
+            a6.Np = c->Np; a6.cp = c->cp; a6.S = B; a6.Pmat = c->PiX + (size_t)B * pl2; a6.nblocks = B2; a6.blen = g; a6.ngroups = c->Np / 8;
+            a6.mid_out = c->SufP; a6.mid_n = g - 2;
+        }
+        if ((rc = launch_chain_level2(a2, a6, suf, c->stream))) return rc;
     }
     if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
         ChainArgs r{};
@@ -1232,7 +1325,14 @@ int qgdk_forward_blocks_upper(const qgdk_ctx *c)
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
         if (c->sub_hist && g > 2) { a2.mid_out = c->Qmid; a2.mid_every = 1; a2.mid_first = 2; a2.mid_n = g - 2; }
-        if ((rc = launch_chain<0>(a2, c->stream))) return rc;
+        // beside them (same grid, idle CUs): the suffix products of the blocks of every super-block for the adjoint history pass
+        ChainArgs a6{};
+        const bool suf = suffix_on(c);
+        if (suf) {
+            a6.Np = c->Np; a6.cp = c->cp; a6.S = B; a6.Pmat = c->PiX + (size_t)B * pl2; a6.nblocks = B2; a6.blen = g; a6.ngroups = c->Np / 8;
+            a6.mid_out = c->SufP; a6.mid_n = g - 2;
+        }
+        if ((rc = launch_chain_level2(a2, a6, suf, c->stream))) return rc;
     }
     if (c->part_world > 1) {   // the product of the whole window, into this rank's chunk of RX
         ChainArgs r{};
@@ -1384,6 +1484,7 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
         ChainArgs a2{};
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = PiRx; a2.forcing = c->phiX; a2.phi = c->phi2;
         a2.nblocks = B2; a2.blen = g; a2.ngroups = c->cp / 8;
+        if (suffix_on(c)) { a2.mid_out = c->SufPhi; a2.mid_n = g - 2; }      // running affine parts: the suffix sums of the history pass
         if ((rc = launch_chain<2>(a2, c->stream))) return rc;
     }
     if (c->part_world > 1) {   // affine part of the whole window, into this rank's chunk of phiRX
@@ -1440,6 +1541,7 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
         if (B2 > 1) { s3.pre_kind[q] = 1; s3.pre_P[q] = c->PiR2; s3.pre_f[q] = c->phi2; q++; }
         if (B > 1) { s3.pre_kind[q] = 2; s3.pre_P[q] = PiRx; s3.pre_f[q] = c->phiX; q++; }
         s3.npre = q; s3.pre_g = g; s3.pre_B2 = B2;
+        if (suffix_on(c)) { s3.suf_P = c->SufP; s3.suf_phi = c->SufPhi; s3.suf_n = g - 2; }
         return launch_chain<3>(s3, c->stream);
     }
     if (r < W - 1) {   // y at the window end: y <- R_q^H y + phi^rank_q for q = W-1 .. r+1, from y_N

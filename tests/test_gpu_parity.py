@@ -952,3 +952,32 @@ def test_long_grid_vs_statement(qgd):
     infid = 1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2
     assert abs(infid - ref["infidelity"]) <= 1e-11 and abs(out3[2] - ref["guard"]) <= 1e-11
     qgd.clear_cache()
+
+
+@pytest.mark.parametrize("which,nsteps,order", [("cnot3", 550, 8), ("cnot3", 200, 4), ("guarded", 420, 6), ("cnot2", 300, 8), ("cnot3", 1100, 8)])
+def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeypatch):
+    """The adjoint history pass reaches the end of its block through the stored suffix product and affine part of the
+    blocks behind it in the super-block (k_chain_fast MODE 6 beside the level-2 products, running values of the MODE 2
+    level-2 chain) instead of stepping over them: same lambda and gradient as with QGD_NO_SUFFIX=1 (the stepping pass),
+    on grids whose last super-block is full and not, and under a time partition."""
+    import torch
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / 2)
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    out = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("QGD_NO_SUFFIX", "1")
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        lam = np.zeros(shape, order="F")
+        g, o = dp.discrete_adjoint(pcof, False, None, lam, None)
+        out[off] = (g, np.asarray(o), lam)
+        dp.close()
+    assert np.abs(out[False][2] - out[True][2]).max() <= 1e-13 * max(1.0, np.abs(out[True][2]).max())
+    assert np.abs(out[False][0] - out[True][0]).max() <= 1e-13 * np.abs(out[True][0]).max()
+    monkeypatch.delenv("QGD_NO_SUFFIX")
+    stream = torch.cuda.current_stream().cuda_stream
+    backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, 2, device=0, stream=stream) for r in range(2)]
+    for g, o in qgd.LocalGroup(backs).discrete_adjoint(pcof):
+        assert np.abs(g - out[True][0]).max() <= 1e-12 * np.abs(out[True][0]).max()
+    for b in backs:
+        b.close()
