@@ -927,6 +927,9 @@ int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int hist
         // scalars on the device are the global ones of the call that made the history
         if (time && k.part_rank == k.part_world - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
     } else {
+        // (time shards: on the rank that owns the final time the overlaps and y_N ride in the first adjoint launch, as in
+        //  the single-GPU evaluation, instead of a k_terminal launch of their own)
+        h->defer_terminal = time && k.have_target && k.part_rank == k.part_world - 1 && qgdk_terminal_can_fuse(&k) != 0;
         if ((rc = comm_forward(h, pcof, n_pcof))) return rc;
         if (!time && (rc = comm_collective(h, 3))) return rc;      // <w_N,R>, <w_N,T>, guard: global before the terminal condition
     }
