@@ -388,6 +388,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (RCCL between processes needs dmabuf IPC on this driver; before any HIP call)
     import numpy as np
     import torch   # first: so that one HIP runtime (torch's) serves both torch and libqgd_hip
     import torch.distributed as dist
