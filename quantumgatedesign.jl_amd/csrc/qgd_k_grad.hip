@@ -388,7 +388,7 @@ static int launch_gradpoint64_m(const qgdk_ctx *c)
 // ---------------------------------------------------------------------------
 // K11: gradient contraction  grad[off_k + l] = - sum_{n,d} Gp[k][n][d][l] sigP[n][k][d] + Gq.. sigQ..
 // (the "grad_slice .-= contrib" of eval_grad_discrete_adjoint.jl:642-643)
-// grid: (ceil(nc_max/64), n_ops, NSPLIT); atomicAdd over the time splits.
+// grid: (time chunks of 8 points, n_ops, coefficient tiles of 64); every chunk stores its row of cpart, k_contract_sum adds the rows.
 // ---------------------------------------------------------------------------
 #define CT_CHUNK 8
 __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, const int64_t *__restrict__ goff,
