@@ -99,8 +99,10 @@ int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
  * resident evaluation to rounding; the price is build + inverse + forward history once more.
  * bytes = 0 (default): 70 % of the device memory that is free when the grid is allocated; a grid whose single time step
  * does not fit returns QGD_ERR_MEMORY.  Re-allocates the grid (set the control basis afterwards, for the WHOLE grid).
- * With more than one window the reference-layout history outputs, the forced sweeps, qgd_eval_adjoint,
- * qgd_set_control_tables and qgd_get_intermediate return QGD_ERR_UNSUPPORTED (they need the grid resident).
+ * With more than one window the reference-layout outputs (uv_history, lambda_history, adjoint_forcing) are filled window
+ * by window into the caller's full arrays; the forced sweeps, qgd_eval_adjoint, qgd_set_control_tables,
+ * qgd_get_intermediate, qgd_set_save_every != 1 and the derivative columns of lambda_history return QGD_ERR_UNSUPPORTED
+ * (they need the grid resident).
  * qgd_get_memory_plan: out4 = { windows, time steps per window, bytes of the per-window buffers, budget (0 = automatic) }. */
 int qgd_set_memory_budget(qgd_handle h, size_t bytes);
 int qgd_get_memory_plan(qgd_handle h, int64_t *out4);

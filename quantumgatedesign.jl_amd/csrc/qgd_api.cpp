@@ -687,6 +687,52 @@ int adjoint_end(qgd_handle h)
 // (matrix-free GMRES); its low-order runs with 10^4 .. 10^6 steps (examples/cnot3_optimize_gate.sb:27-40) are what
 // this mode is for.
 // ---------------------------------------------------------------------------
+// The reference-layout outputs of a chunked grid, one window at a time: the window's panels are re-laid out into a compact
+// staging buffer on the device and copied into the caller's FULL array at the window's time offset (a pitched copy per
+// column); the copy is awaited before the next window overwrites the panels.  Windows share their end points (same values).
+int window_history_out(qgd_handle h, double *uv_history)       // [2N, 1+m, nt_glob, c]
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N, ntg = k.nt_glob;
+    const size_t nt0 = std::min<size_t>((size_t)k.bpr * k.scan_blen + 1, ntg);      // the longest window
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (!h->stage_hist && (rc = dev_alloc(h, h->stage_bufs, &h->stage_hist, n2 * (m + 1) * nt0 * k.c))) return rc;
+    const long long dcol = (long long)(nt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
+    K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, h->stage_hist, dcol, dn, dj, 0, (int)nt, 1, 0, k.stream, 0));
+    K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream, 0));
+    if ((rc = hand_over(h))) return rc;
+    const size_t row = nt * (m + 1) * n2 * sizeof(double);
+    HIP_TRY(h, hipMemcpy2DAsync(uv_history + (size_t)k.n_off * (m + 1) * n2, ntg * (m + 1) * n2 * sizeof(double), h->stage_hist, row, row,
+                                (size_t)k.c, hipMemcpyDeviceToHost, h->copy_stream));
+    return finish_copies(h);
+}
+
+int window_panels_out(qgd_handle h, const double *panels, double **stage, double *out, size_t J, int n_first)     // [2N, J, nt_glob, c], j = 0
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, n2 = 2 * (size_t)k.N, ntg = k.nt_glob;
+    const size_t nt0 = std::min<size_t>((size_t)k.bpr * k.scan_blen + 1, ntg);
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (!*stage && (rc = dev_alloc(h, h->stage_bufs, stage, n2 * nt0 * k.c))) return rc;
+    K_TRY(h, qgdk_layout(&k, panels, (long long)hstep, 0, *stage, (long long)(nt * n2), (long long)n2, 0, n_first, (int)nt - n_first, 1, 0, k.stream, 0));
+    if ((rc = hand_over(h))) return rc;
+    const size_t cnt = nt - (size_t)n_first;
+    if (cnt) {
+        if (J == 1) {
+            HIP_TRY(h, hipMemcpy2DAsync(out + ((size_t)k.n_off + n_first) * n2, ntg * n2 * sizeof(double), *stage + (size_t)n_first * n2,
+                                        nt * n2 * sizeof(double), cnt * n2 * sizeof(double), (size_t)k.c, hipMemcpyDeviceToHost, h->copy_stream));
+        } else {
+            for (size_t col = 0; col < (size_t)k.c; col++)      // rows of 2N doubles, J * 2N apart in the caller's array
+                HIP_TRY(h, hipMemcpy2DAsync(out + ((col * ntg + k.n_off + n_first) * J) * n2, J * n2 * sizeof(double),
+                                            *stage + (col * nt + n_first) * n2, n2 * sizeof(double), n2 * sizeof(double), cnt,
+                                            hipMemcpyDeviceToHost, h->copy_stream));
+        }
+    }
+    return finish_copies(h);
+}
+
 int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool rerun)
 {
     qgdk_ctx &k = h->k;
@@ -715,29 +761,37 @@ int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool reru
     return QGD_OK;
 }
 
-int chunked_forward(qgd_handle h, const double *pcof, int n_pcof)
+int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history = nullptr)
 {
     qgdk_ctx &k = h->k;
     if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
     int rc;
-    for (int r = 0; r < h->chunks_eff; r++)
+    for (int r = 0; r < h->chunks_eff; r++) {
         if ((rc = chunk_forward(h, pcof, n_pcof, r, false))) return rc;
+        if (uv_history) {      // the window's share of the state history with its stage derivatives
+            { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+            if ((rc = window_history_out(h, uv_history))) return rc;
+        }
+    }
     { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }      // overlaps (and y_N) from the final state
     h->forward_valid = true; h->derivs_valid = false;
     h->fwd_pcof.assign(pcof, pcof + n_pcof);
     return QGD_OK;
 }
 
-int chunked_adjoint(qgd_handle h)
+int chunked_adjoint(qgd_handle h, double *lambda_history = nullptr, double *adjoint_forcing = nullptr)
 {
     qgdk_ctx &k = h->k;
     const size_t hstep = (size_t)k.Np * 2 * k.cp;
     const int W = h->chunks_eff;
     int rc;
+    if (lambda_history)      // (the library writes the j = 0 columns; the others, and time index 0, are zero as in the resident call)
+        memset(lambda_history, 0, sizeof(double) * 2 * (size_t)k.N * (k.m + 1) * (size_t)k.nt_glob * k.c);
     for (int r = W - 1; r >= 0; r--) {
         if (h->resident_window != r) {
             if ((rc = chunk_forward(h, h->fwd_pcof.data(), (int)h->fwd_pcof.size(), r, true))) return rc;
         } else if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
+        if (adjoint_forcing && (rc = window_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
         if (r == W - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
         else            // y at the end of this window = y at the start of the next one
             for (double *dst : {k.yhist + (size_t)(k.nt - 1) * hstep, k.bndY + (size_t)k.scan_blocks * hstep, k.bndY2 + (size_t)k.scan_blocks2 * hstep})
@@ -748,6 +802,7 @@ int chunked_adjoint(qgd_handle h)
         if (!rc) rc = adjoint_end(h);
         k.grad_accumulate = 0;
         if (rc) return rc;
+        if (lambda_history && (rc = window_panels_out(h, k.lam, &h->stage_lam, lambda_history, (size_t)k.m + 1, 1))) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->carry_y, k.yhist, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
     }
     h->forward_valid = true;          // (the window-boundary states of this pcof are still there for history_precomputed)
@@ -1357,7 +1412,11 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
     HIP_TRY(h, hipSetDevice(h->device));
     qgdk_ctx &k = h->k;
     if (h->comm) return comm_eval_forward(h, pcof, n_pcof, uv_history, out3);
-    if (uv_history) NEEDS_RESIDENT_GRID(h, "the uv_history output");
+    if (h->chunks_eff > 1 && uv_history) {      // the history of a chunked grid comes out window by window
+        if (h->save_every != 1) return fail(h, QGD_ERR_UNSUPPORTED, "saveEveryNsteps with a time grid processed in windows: raise qgd_set_memory_budget");
+        int rcw = chunked_forward(h, pcof, n_pcof, uv_history);
+        return rcw ? rcw : fetch_results(h, nullptr, out3);
+    }
     int rc = run_forward(h, pcof, n_pcof);
     if (rc) return rc;
     if (uv_history) {
@@ -1382,10 +1441,11 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points, or give the handle a communicator (qgd_comm_init_rccl)");
     int rc;
     if (h->chunks_eff > 1) {      // bounded-memory time grid: forward pass over the windows, adjoint pass back over them
-        if (uv_history || lambda_history || adjoint_forcing) NEEDS_RESIDENT_GRID(h, "the history outputs of discrete_adjoint!");
+        if (lambda_history && h->lambda_derivs) NEEDS_RESIDENT_GRID(h, "the derivative columns of lambda_history");
         if (history_precomputed && !h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
-        if (!(history_precomputed && same_pcof(h, pcof, n_pcof)) && (rc = chunked_forward(h, pcof, n_pcof))) return rc;
-        if ((rc = chunked_adjoint(h))) return rc;
+        // (uv_history is an output: a reused forward pass would have nothing to copy it from, so the pass is redone)
+        if ((uv_history || !(history_precomputed && same_pcof(h, pcof, n_pcof))) && (rc = chunked_forward(h, pcof, n_pcof, uv_history))) return rc;
+        if ((rc = chunked_adjoint(h, lambda_history, adjoint_forcing))) return rc;
         return fetch_results(h, grad, out3);
     }
     // full evaluation, nothing but [grad | scalars] coming back, no event bracketing: replay the captured launch sequence

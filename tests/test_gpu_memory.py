@@ -50,10 +50,26 @@ def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
     g2_ref, _ = chk.discrete_adjoint(0.5 * pcof)
     chk.close()
     assert np.abs(g2 - g2_ref).max() <= 1e-11 * np.abs(g2_ref).max()
+    # the reference-shaped call: the three arrays are filled window by window and equal the resident call's
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl); chk.set_target(target)
+    ref = [np.zeros(shape, order="F"), np.zeros(shape, order="F"), np.zeros((shape[0], shape[2], shape[3]), order="F")]
+    chk.discrete_adjoint(pcof, False, *ref)
+    chk.close()
+    got = [np.full(shape, np.nan, order="F"), np.full(shape, np.nan, order="F"), np.full((shape[0], shape[2], shape[3]), np.nan, order="F")]
+    g, _ = dp.discrete_adjoint(pcof, False, *got)
+    assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    for name, a, b in zip(("uv_history", "lambda_history", "adjoint_forcing"), got, ref):
+        for j in range(a.shape[1] if a.ndim == 4 else 1):      # per Taylor index: the high coefficients of a random problem are large
+            x, y = (a[:, j], b[:, j]) if a.ndim == 4 else (a, b)
+            assert np.isfinite(x).all() and np.abs(x - y).max() <= 1e-11 * max(1.0, np.abs(y).max()), (name, j)
+    hist = np.full(shape, np.nan, order="F")
+    dp.eval_forward(pcof, hist)
+    assert np.abs(hist[:, 0] - ref[0][:, 0]).max() <= 1e-11
     # what needs the grid resident says so
-    hist = np.zeros((prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions), order="F")
+    dp.set_lambda_derivatives(True)
     with pytest.raises(qgd._lib.QGDError) as e:
-        dp.eval_forward(pcof, hist)
+        dp.discrete_adjoint(pcof, False, None, got[1], None)
     assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
     dp.close()
 
