@@ -56,6 +56,7 @@ typedef struct qgdk_ctx {
     int dense_gemm;
     double *Afrag, *Dfrag, *OpFrag;
     double *Tlam;       // [nt][2][Np][2Np]: Lambda+ = lambda_{n+1} psi_0^H, Lambda- = lambda_n psi_0^H (third form of the gradient scalars), or null
+    double *Xfrag;      // [nt][m] the same matrices as Xouter in fragment order {Re, Im} (left operand of k_ginner_d's 3M tiles), or null
     double *Xouter;     // [nt][m][Np][2Np]: X_j = (1/j) g_j psi_0^H of the gradient scalars' outer-product form (k_gouter), or null
     // blocked scan + time partition (DESIGN.md "Multi-GPU").  The handle covers the time points
     // [n_off, n_off + nt) of a global grid of nt_glob points; blocks [blk_lo, blk_hi) of scan_blocks.

@@ -216,6 +216,87 @@ __device__ __forceinline__ void rgemm2_tile(d4 (&U)[DN_RB][DN_NG], d4 (&V)[DN_RB
 #define ZERO_ACC(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
 
 // ---------------------------------------------------------------------------
+// The same complex product with THREE real products per complex multiply instead of four ("3M"):
+//     P1 = Are Bre,  P2 = Aim Bim,  P3 = (Are + Aim)(Bre + Bim);   Re C = P1 - P2,  Im C = P3 - P1 - P2.
+// An MFMA wants 16 real columns of ONE kind, so two column groups are taken together: lanes c16 < 8 work on the 8
+// complex columns of group g[2p], lanes c16 >= 8 on those of group g[2p+1] -- the lane's address picks the real half
+// (+0) or the imaginary half (+8) of ITS group, no cross-lane movement at all.  Per k-step of a <2, 4> tile: 12 MFMAs
+// instead of 16, 6 loads, 4 f64 adds (the two operand sums); three accumulators per 16 x 16 block instead of two (96
+// instead of 64 registers).  The result of lane (c16, kk), element e, is the complex entry (row kk + 4e of the block,
+// column 8 g + c16 % 8) with both parts in the same lane.  Rounding: the imaginary part is exact to eps * |A||B|
+// (norm-wise) instead of component-wise -- 1e-16-level on this path's matrices (tests/test_gpu_large_n.py).
+// ---------------------------------------------------------------------------
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ int lane_group(const DenseTile<DN_RB, DN_NG> &t, int p)     // -1: the lane's columns are outside
+{
+    return (t.c16 < 8) ? t.g[2 * p] : t.g[2 * p + 1];
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d2 buffer_load_d2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return (d2){__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
+}
+
+// The k-loop carries no vector-ALU instruction but the four operand sums: buffer-addressed loads (per-lane offset fixed,
+// the k-step offset in an SGPR) and two register sets that swap roles by unrolling -- beside twelve f64 MFMAs per k-step
+// every other vector instruction costs about a sixth of an MFMA slot, and the pointer updates and
+// register copies of the plain loop were 12 of them (MFMA pipe busy 0.73 -> see DESIGN.md section 4b).
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void cgemm3_tile(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)[DN_RB][DN_NG / 2], d4 (&p3)[DN_RB][DN_NG / 2],
+                                            const DenseTile<DN_RB, DN_NG> &t, const d2 *__restrict__ A,
+                                            const double *__restrict__ B, size_t ldb, int Np)
+{
+    constexpr int NP = DN_NG / 2;
+    const __amdgpu_buffer_rsrc_t ra = buffer_of(reinterpret_cast<const double *>(A)), rb_ = buffer_of(B);
+    int av[DN_RB], bv[NP];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) av[r] = ((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * (Np >> 2) * 64 + t.lane) * 16;
+    #pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int g = lane_group(t, p);
+        if (g < 0) g = t.g[0];
+        bv[p] = (t.kk * (int)ldb + g * 16 + (t.c16 & 7)) * 8;
+    }
+    const int nk4 = Np >> 2, bstep = 4 * (int)ldb * 8;      // (Np is a multiple of 16: nk4 is even)
+    d2 a0[DN_RB], a1[DN_RB];
+    double br0[NP], bi0[NP], br1[NP], bi1[NP];
+#define C3_LOAD(a, br, bi, k) do {                                                                            \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) a[r] = buffer_load_d2(ra, av[r], (k) * 1024);          \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) { br[p] = buffer_load_f64(rb_, bv[p], (k) * bstep);       \
+                                                         bi[p] = buffer_load_f64(rb_, bv[p] + 64, (k) * bstep); } } while (0)
+#define C3_MFMA(a, br, bi) do {                                                                               \
+        double as[DN_RB], bs[NP];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) as[r] = a[r].x + a[r].y;                              \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) bs[p] = br[p] + bi[p];                                   \
+        _Pragma("unroll") for (int p = 0; p < NP; p++)                                                         \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++) {                                                \
+                p1[r][p] = MFMA(a[r].x, br[p], p1[r][p]);                                                      \
+                p2[r][p] = MFMA(a[r].y, bi[p], p2[r][p]);                                                      \
+                p3[r][p] = MFMA(as[r], bs[p], p3[r][p]);                                                       \
+            } } while (0)
+    C3_LOAD(a0, br0, bi0, 0);
+    for (int k4 = 0; k4 < nk4; k4 += 2) {
+        C3_LOAD(a1, br1, bi1, k4 + 1);
+        C3_MFMA(a0, br0, bi0);
+        const int kn = (k4 + 2 < nk4) ? k4 + 2 : k4;
+        C3_LOAD(a0, br0, bi0, kn);
+        C3_MFMA(a1, br1, bi1);
+    }
+#undef C3_LOAD
+#undef C3_MFMA
+}
+
+#define ZERO_ACC3(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG / 2; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
+// 3M switch of the N > 64 kernels (QGD_DENSE_4M=1 keeps the four-product tiles: A/B timing and tests)
+static bool dense_3m()
+{
+    static const bool on = getenv("QGD_DENSE_4M") == nullptr;
+    return on;
+}
+
+// ---------------------------------------------------------------------------
 // A_d(t_n), d = 0..m-1, in fragment order.  grid (Np^2/256, m, nt)
 // ---------------------------------------------------------------------------
 template <int NOPS>
@@ -295,6 +376,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                     Ln[o] = lv;
                     Rn[o] = rv;
+                }
+            }
+        }
+    }
+}
+
+// the same level with the three-product tiles (cgemm3_tile)
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_level_f3(const d2 *__restrict__ Afrag, double *D,
+                                                 double *__restrict__ Dfrag, double *__restrict__ L,
+                                                 double *__restrict__ R, const double *__restrict__ cw, int Np, int m, int nt, int j,
+                                                 double cL, double cR)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, Np >> 3, 1, nt)) return;
+    const int PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, fr = (size_t)Np * Np;
+    double *Dn = D + (size_t)t.n * m * panel;
+    const d2 *An = Afrag + (size_t)t.n * m * fr;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    for (int i = 1; i <= j; i++) cgemm3_tile(p1, p2, p3, t, An + (size_t)(j - i) * fr, Dn + (size_t)(i - 1) * panel, PW, Np);
+    const double inv = 1.0 / (double)(j + 1);
+    const d2 *Aj = An + (size_t)j * fr;
+    double *Dout = Dn + (size_t)j * panel;
+    d2 *Fout = reinterpret_cast<d2 *>(Dfrag) + ((size_t)t.n * m + j) * fr;
+    double *Ln = L + (size_t)t.n * panel, *Rn = R + (size_t)t.n * panel;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            const int ccol = g * 8 + (t.c16 & 7);
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t.rb[r] * 16 + t.kk + 4 * e;
+                const size_t fi = frag_index(Np, row, ccol);
+                const d2 aj = Aj[fi];
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                const double vre = (p1[r][p][e] - p2[r][p][e] + aj.x) * inv, vim = (p3[r][p][e] - s12 + aj.y) * inv;
+                const size_t o = (size_t)row * PW + g * 16 + (t.c16 & 7);
+                Dout[o] = vre; Dout[o + 8] = vim;
+                Fout[fi] = (d2){vre, vim};
+                if (j == m - 1) {
+                    const double id = (row == ccol) ? 1.0 : 0.0;
+                    double lre = id + cL * vre, rre = id + cR * vre, lim = cL * vim, rim = cR * vim;
+                    for (int q = 0; q < j; q++) {
+                        const double dre = Dn[(size_t)q * panel + o], dim = Dn[(size_t)q * panel + o + 8];
+                        const double wl = cw[2 * (q + 1) + 1], wr = cw[2 * (q + 1)];
+                        lre += wl * dre; lim += wl * dim;
+                        rre += wr * dre; rim += wr * dim;
+                    }
+                    Ln[o] = lre; Ln[o + 8] = lim;
+                    Rn[o] = rre; Rn[o + 8] = rim;
                 }
             }
         }
@@ -403,6 +540,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             #pragma unroll
             for (int e = 0; e < 4; e++)
                 out[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16] += sc * acc[r][g][e];
+        }
+    }
+}
+
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gsweep_f3(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
+                                                  int m, int nt, int j, d2 *__restrict__ Gfrag)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
+    const int i = t.sub + 1;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    cgemm3_tile(p1, p2, p3, t, Afrag + ((size_t)t.n * m + (j - 1 - i)) * fr, Gp + ((size_t)t.n * m + (j - 1)) * hstep, PWc, Np);
+    double *out = Gp + ((size_t)t.n * m + (i - 1)) * hstep;
+    const double sc = -1.0 / (double)j;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t.rb[r] * 16 + t.kk + 4 * e;
+                double *o = out + (size_t)row * PWc + g * 16 + (t.c16 & 7);
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                const double vre = o[0] + sc * (p1[r][p][e] - p2[r][p][e]), vim = o[8] + sc * (p3[r][p][e] - s12);
+                o[0] = vre; o[8] = vim;
+                // level j is the last one that touches g_{j-1}: its final value also in fragment order (square panels only:
+                // the matrices Y_j of the third gradient form, left operands of k_ginner_d)
+                if (Gfrag && i == j - 1) Gfrag[((size_t)t.n * m + (i - 1)) * fr + frag_index(Np, row, g * 8 + (t.c16 & 7))] = (d2){vre, vim};
+            }
         }
     }
 }
@@ -526,11 +699,120 @@ __device__ __forceinline__ void outer_tile(d4 (&aR)[DN_RB][DN_NG], d4 (&aA)[DN_R
     }
 }
 
-// sigma[n][o][d][2] += { -<S_o, Im M>, <K_o, Re M> } * w for the wave's blocks of M (Re = aR, Im = aA - aB).  Element e of block
+// The same product with three real products per complex multiply (see cgemm3_tile):  A B^H = (Ar Br + Ai Bi) + i (Ai Br - Ar Bi),
+//     P1 = Ar Br,  P2 = Ai Bi,  P3 = (Ar + Ai)(Br - Bi);   Re = P1 + P2,  Im = P3 - P1 + P2.
+// Both operands already have their real and imaginary parts in different registers, so nothing but the two operand
+// sums is added: 24 MFMAs instead of 32 per group of 8 contraction columns of a <2, 2> tile.  Buffer-addressed loads and
+// two register sets as in cgemm3_tile.
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void outer_tile3(d4 (&p1)[DN_RB][DN_NG], d4 (&p2)[DN_RB][DN_NG], d4 (&p3)[DN_RB][DN_NG],
+                                            const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ A, const double *__restrict__ B,
+                                            size_t ld, int ngc)
+{
+    const __amdgpu_buffer_rsrc_t ra = buffer_of(A), rb_ = buffer_of(B);
+    int av[DN_RB], bv[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) av[r] = (((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16) * (int)ld + 2 * t.kk) * 8;
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bv[g] = (((t.g[g] >= 0 ? t.g[g] : t.g[0]) * 16 + t.c16) * (int)ld + 2 * t.kk) * 8;
+    // (the loop body must stay free of branches: with a conditional step inside, the compiler's wait-count pass falls back to
+    //  s_waitcnt vmcnt(0) in front of every group and the prefetch is gone -- seen in the ISA, 0.61 MFMA busy)
+    d2 ar0[DN_RB], ai0[DN_RB], br0[DN_NG], bi0[DN_NG], ar1[DN_RB], ai1[DN_RB], br1[DN_NG], bi1[DN_NG];
+#define O3_LOAD(ar, ai, br, bi, q) do {                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) { ar[r] = buffer_load_d2(ra, av[r], (q) * 128); ai[r] = buffer_load_d2(ra, av[r] + 64, (q) * 128); }  \
+        _Pragma("unroll") for (int g = 0; g < DN_NG; g++) { br[g] = buffer_load_d2(rb_, bv[g], (q) * 128); bi[g] = buffer_load_d2(rb_, bv[g] + 64, (q) * 128); } } while (0)
+#define O3_MFMA(ar, ai, br, bi) do {                                                                                             \
+        d2 as[DN_RB], bd[DN_NG];                                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) as[r] = ar[r] + ai[r];                                                   \
+        _Pragma("unroll") for (int g = 0; g < DN_NG; g++) bd[g] = br[g] - bi[g];                                                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++) {                                                                        \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++)                                                                     \
+                _Pragma("unroll") for (int g = 0; g < DN_NG; g++) p1[r][g] = MFMA(ar[r][s_], br[g][s_], p1[r][g]);                 \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++)                                                                     \
+                _Pragma("unroll") for (int g = 0; g < DN_NG; g++) p2[r][g] = MFMA(ai[r][s_], bi[g][s_], p2[r][g]);                 \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++)                                                                     \
+                _Pragma("unroll") for (int g = 0; g < DN_NG; g++) p3[r][g] = MFMA(as[r][s_], bd[g][s_], p3[r][g]);                 \
+        } } while (0)
+    O3_LOAD(ar0, ai0, br0, bi0, 0);
+    const int npair = ngc >> 1;
+    for (int q = 0; q < 2 * npair; q += 2) {
+        O3_LOAD(ar1, ai1, br1, bi1, q + 1);
+        O3_MFMA(ar0, ai0, br0, bi0);
+        const int q2 = (q + 2 < ngc) ? q + 2 : q;
+        O3_LOAD(ar0, ai0, br0, bi0, q2);
+        O3_MFMA(ar1, ai1, br1, bi1);
+    }
+    if (ngc & 1) O3_MFMA(ar0, ai0, br0, bi0);        // (an odd group count: the last group was loaded by the final q2)
+#undef O3_LOAD
+#undef O3_MFMA
+}
+
+// ... and with BOTH operands in fragment order (frag[(rb * K/4 + k4) * 64 + lane] = {Re, Im} of element (16 rb + lane % 16,
+// 4 k4 + lane / 16), the layout k_level_f writes the D_i in): every load is one contiguous KB per wave.  With the row-major
+// panels of outer_tile3 the 16 lanes of an MFMA row are 16 rows 4 KB apart -- 64 cache-line lookups per load instruction,
+// and k_ginner_d sat on the L1's tag rate (MFMA pipe busy 0.64 after the 3M change).
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void outer_frag3(d4 (&p1)[DN_RB][DN_NG], d4 (&p2)[DN_RB][DN_NG], d4 (&p3)[DN_RB][DN_NG],
+                                            const DenseTile<DN_RB, DN_NG> &t, const d2 *__restrict__ A, const d2 *__restrict__ B, int K)
+{
+    const __amdgpu_buffer_rsrc_t ra = buffer_of(reinterpret_cast<const double *>(A)), rb_ = buffer_of(reinterpret_cast<const double *>(B));
+    int av[DN_RB], bv[DN_NG];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) av[r] = ((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * (K >> 2) * 64 + t.lane) * 16;
+    #pragma unroll
+    for (int g = 0; g < DN_NG; g++) bv[g] = ((t.g[g] >= 0 ? t.g[g] : t.g[0]) * (K >> 2) * 64 + t.lane) * 16;
+    const int nk4 = K >> 2;              // (K is a multiple of 16: nk4 is even)
+    d2 a0[DN_RB], b0[DN_NG], a1[DN_RB], b1[DN_NG];
+#define F3_LOAD(a, b, k) do {                                                                            \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) a[r] = buffer_load_d2(ra, av[r], (k) * 1024);    \
+        _Pragma("unroll") for (int g = 0; g < DN_NG; g++) b[g] = buffer_load_d2(rb_, bv[g], (k) * 1024); } while (0)
+#define F3_MFMA(a, b) do {                                                                               \
+        double as[DN_RB], bd[DN_NG];                                                                     \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) as[r] = a[r].x + a[r].y;                         \
+        _Pragma("unroll") for (int g = 0; g < DN_NG; g++) bd[g] = b[g].x - b[g].y;                         \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++)                                                 \
+            _Pragma("unroll") for (int g = 0; g < DN_NG; g++) {                                           \
+                p1[r][g] = MFMA(a[r].x, b[g].x, p1[r][g]);                                                \
+                p2[r][g] = MFMA(a[r].y, b[g].y, p2[r][g]);                                                \
+                p3[r][g] = MFMA(as[r], bd[g], p3[r][g]);                                                  \
+            } } while (0)
+    F3_LOAD(a0, b0, 0);
+    for (int k4 = 0; k4 < nk4; k4 += 2) {
+        F3_LOAD(a1, b1, k4 + 1);
+        F3_MFMA(a0, b0);
+        const int kn = (k4 + 2 < nk4) ? k4 + 2 : k4;
+        F3_LOAD(a0, b0, kn);
+        F3_MFMA(a1, b1);
+    }
+#undef F3_LOAD
+#undef F3_MFMA
+}
+
+// accumulators of either tile routine -> (Re, Im) of A B^H in (x, y);  M3: (P1, P2, P3), else (Re, sum A_im B_re, sum A_re B_im)
+template <bool M3, int DN_RB, int DN_NG>
+__device__ __forceinline__ void outer_finish(d4 (&x)[DN_RB][DN_NG], d4 (&y)[DN_RB][DN_NG], const d4 (&z)[DN_RB][DN_NG])
+{
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++)
+        #pragma unroll
+        for (int g = 0; g < DN_NG; g++) {
+            if (M3) { const d4 re = x[r][g] + y[r][g], im = z[r][g] - x[r][g] + y[r][g]; x[r][g] = re; y[r][g] = im; }
+            else y[r][g] = y[r][g] - z[r][g];
+        }
+}
+template <bool M3, int DN_RB, int DN_NG>
+__device__ __forceinline__ void outer_any(d4 (&x)[DN_RB][DN_NG], d4 (&y)[DN_RB][DN_NG], d4 (&z)[DN_RB][DN_NG],
+                                          const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ A, const double *__restrict__ B,
+                                          size_t ld, int ngc)
+{
+    if (M3) outer_tile3(x, y, z, t, A, B, ld, ngc); else outer_tile(x, y, z, t, A, B, ld, ngc);
+}
+
+// sigma[n][o][d][2] += { -<S_o, Im M>, <K_o, Re M> } * w for the wave's blocks of M (Re = aR, Im = aI).  Element e of block
 // (r, g): r1 = rb*16 + kk + 4e, r2 = g*16 + c16.  S_o is symmetric and K_o antisymmetric (SchrodingerProb.jl:73-95): they are
 // read TRANSPOSED, [r2 + Np r1] of the column-major planes, so that the 16 lanes of a row read 16 consecutive doubles.
 template <int DN_RB, int DN_NG>
-__device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], const d4 (&aA)[DN_RB][DN_NG], const d4 (&aB)[DN_RB][DN_NG],
+__device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], const d4 (&aI)[DN_RB][DN_NG],
                                                 const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ ops, int Np, int n_ops,
                                                 double w, double *sig)
 {
@@ -548,7 +830,7 @@ __device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], co
                 for (int e = 0; e < 4; e++) {
                     const size_t at = (size_t)(t.g[g] * 16 + t.c16) + (size_t)Np * (t.rb[r] * 16 + t.kk + 4 * e);
                     sq -= Ko[at] * aR[r][g][e];                       // K[r1,r2] = -K[r2,r1]
-                    sp += So[at] * (aB[r][g][e] - aA[r][g][e]);      // -<S, Im M>
+                    sp -= So[at] * aI[r][g][e];                       // -<S, Im M>
                 }
             }
         }
@@ -566,7 +848,7 @@ __device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], co
 // M_d in the epilogue.  Used when (m+1)/2 < n_ops.  Tile: a wave owns DN_RB x DN_NG blocks of 16 x 16 of M_d (rows r1
 // from g, columns r2 from psi).  The weights 1/j differ from pair to pair: the running sum is kept in units of the
 // current weight (times w_prev / w_next between pairs).
-template <int DN_RB, int DN_NG>
+template <int DN_RB, int DN_NG, bool M3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_m(const double *__restrict__ ops, const double *__restrict__ hist,
                                                   const double *__restrict__ dpsi, const double *__restrict__ Gp,
                                                   double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
@@ -591,10 +873,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     #pragma unroll
                     for (int g = 0; g < DN_NG; g++) { aR[r][g] *= sc; aA[r][g] *= sc; aB[r][g] *= sc; }
             }
-            outer_tile(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep,
-                       (i == 0) ? hist + (size_t)t.n * hstep : dpsi + ((size_t)t.n * m + (i - 1)) * hstep, (size_t)PWc, cp >> 3);
+            outer_any<M3>(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep,
+                          (i == 0) ? hist + (size_t)t.n * hstep : dpsi + ((size_t)t.n * m + (i - 1)) * hstep, (size_t)PWc, cp >> 3);
         }
-        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, 1.0 / (double)m, sig);      // (the last pair of every d has j = m)
+        outer_finish<M3>(aR, aA, aB);
+        frobenius_sigma(aR, aA, t, ops, Np, n_ops, 1.0 / (double)m, sig);      // (the last pair of every d has j = m)
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
@@ -608,9 +891,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //                                                                      step-matrix build (k_level_f) as they lie in HBM
 // against m (k_derivs_f) + m(m+1)/2 (k_ginner_m) products N x N x c: fewer when (m-1) N < (m+1) c -- config 5 (c = N):
 // 21 units instead of 27, and the 2.6 ms k_derivs_f launch disappears from the gradient evaluation.
-template <int DN_RB, int DN_NG>
+template <int DN_RB, int DN_NG, bool M3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gouter(const double *__restrict__ hist, const double *__restrict__ Gp,
-                                                double *__restrict__ X, int Np, int cp, int m, int nt)
+                                                double *__restrict__ X, int Np, int cp, int m, int nt, d2 *__restrict__ Xfrag)
 {
     DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, Np >> 4, m, nt)) return;
@@ -618,7 +901,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t hstep = (size_t)Np * PWc, panel = (size_t)Np * PW;
     d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
     ZERO_ACC(aR); ZERO_ACC(aA); ZERO_ACC(aB);
-    outer_tile(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    outer_any<M3>(aR, aA, aB, t, Gp + ((size_t)t.n * m + (j - 1)) * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    outer_finish<M3>(aR, aA, aB);
     double *out = X + ((size_t)t.n * m + (j - 1)) * panel;
     const double w = 1.0 / (double)j;
     #pragma unroll
@@ -631,7 +915,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; e++) {      // element (r1, r2 = g*16 + c16): column group r2 / 8, slot r2 % 8 (re), + 8 (im)
                 double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PW + (t.g[g] * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
                 o[0] = w * aR[r][g][e];
-                o[8] = w * (aA[r][g][e] - aB[r][g][e]);
+                o[8] = w * aA[r][g][e];
+                if (Xfrag) Xfrag[((size_t)t.n * m + (j - 1)) * (size_t)Np * Np + frag_index(Np, t.rb[r] * 16 + t.kk + 4 * e, t.g[g] * 16 + t.c16)] =
+                               (d2){w * aR[r][g][e], w * aA[r][g][e]};
             }
         }
     }
@@ -639,9 +925,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // WEIGHTED = false: X_j carries its weight 1/j (k_gouter).  WEIGHTED = true: the panels are the swept Y_j = g_j psi_0^H of the
 // third form (below) and the weights 1/j are applied here, the running sum kept in units of the current pair's weight.
-template <int DN_RB, int DN_NG, bool WEIGHTED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_d(const double *__restrict__ ops, const double *__restrict__ X,
-                                                  const double *__restrict__ D, double *__restrict__ sigma, int Np, int n_ops, int m, int nt)
+template <int DN_RB, int DN_NG, bool WEIGHTED, bool M3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_ginner_d(const double *__restrict__ ops, const double *__restrict__ X,
+                                                  const double *__restrict__ D, double *__restrict__ sigma, int Np, int n_ops, int m, int nt,
+                                                  const d2 *__restrict__ Xfrag, const d2 *__restrict__ Dfrag)
 {
     extern __shared__ double sig[];          // [n_ops][2] of this workgroup's d
     for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x) sig[e] = 0.0;
@@ -654,8 +941,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const size_t panel = (size_t)Np * PW;
         const double *Xn = X + (size_t)t.n * m * panel, *Dn = D + (size_t)t.n * m * panel;     // X_j at slot j-1, D_i at slot i-1
         d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
-        ZERO_ACC(aB);
-        {   // i = 0: D_0 = I, the term is X_{d+1} itself
+        {   // i = 0: D_0 = I, the term is X_{d+1} itself  (M3: Re = P1 + P2, Im = P3 - P1 + P2 with P2 = 0)
             const double *x0 = Xn + (size_t)d * panel;
             #pragma unroll
             for (int r = 0; r < DN_RB; r++)
@@ -665,7 +951,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int e = 0; e < 4; e++) {
                         const int rb = t.rb[r] >= 0 ? t.rb[r] : t.rb[0], gb = t.g[g] >= 0 ? t.g[g] : t.g[0];
                         const double *o = x0 + (size_t)(rb * 16 + t.kk + 4 * e) * PW + (gb * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
-                        aR[r][g][e] = o[0]; aA[r][g][e] = o[8];
+                        if (M3) { aR[r][g][e] = o[0]; aA[r][g][e] = 0.0; aB[r][g][e] = o[8] + o[0]; }
+                        else { aR[r][g][e] = o[0]; aA[r][g][e] = o[8]; aB[r][g][e] = 0.0; }
                     }
         }
         for (int i = 1; i + d < m; i++) {
@@ -676,9 +963,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     #pragma unroll
                     for (int g = 0; g < DN_NG; g++) { aR[r][g] *= sc; aA[r][g] *= sc; aB[r][g] *= sc; }
             }
-            outer_tile(aR, aA, aB, t, Xn + (size_t)(i + d) * panel, Dn + (size_t)(i - 1) * panel, (size_t)PW, Np >> 3);
+            if (M3) outer_frag3(aR, aA, aB, t, Xfrag + ((size_t)t.n * m + (i + d)) * Np * Np, Dfrag + ((size_t)t.n * m + (i - 1)) * Np * Np, Np);
+            else outer_tile(aR, aA, aB, t, Xn + (size_t)(i + d) * panel, Dn + (size_t)(i - 1) * panel, (size_t)PW, Np >> 3);
         }
-        frobenius_sigma(aR, aA, aB, t, ops, Np, n_ops, WEIGHTED ? 1.0 / (double)m : 1.0, sig);
+        outer_finish<M3>(aR, aA, aB);
+        frobenius_sigma(aR, aA, t, ops, Np, n_ops, WEIGHTED ? 1.0 / (double)m : 1.0, sig);
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
@@ -692,7 +981,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // lambda_{n+1} psi_0^H, Lambda- = lambda_n psi_0^H), the m seeds Y_j = c_j dt^j Lambda+ - c_j (-dt)^j Lambda- (k_yinit,
 // elementwise), the SAME sweep kernel on the Y panels (width N instead of c), then k_ginner_d with the weights 1/j.
 // 2 + m(m-1)/2 + m(m-1)/2 units against m(m-1)/2 + m + m(m-1)/2 of the second form when c = N (config 5: 32 against 36).
-template <int DN_RB, int DN_NG>
+template <int DN_RB, int DN_NG, bool M3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_youter(const double *__restrict__ hist, const double *__restrict__ lam,
                                                 double *__restrict__ T, int Np, int cp, int nt)
 {
@@ -704,7 +993,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (nl < 1 || nl > nt - 1) return;                  // (k_yinit treats the missing one as zero)
     d4 aR[DN_RB][DN_NG], aA[DN_RB][DN_NG], aB[DN_RB][DN_NG];
     ZERO_ACC(aR); ZERO_ACC(aA); ZERO_ACC(aB);
-    outer_tile(aR, aA, aB, t, lam + (size_t)nl * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    outer_any<M3>(aR, aA, aB, t, lam + (size_t)nl * hstep, hist + (size_t)t.n * hstep, (size_t)PWc, cp >> 3);
+    outer_finish<M3>(aR, aA, aB);
     double *out = T + ((size_t)t.n * 2 + t.sub) * panel;
     #pragma unroll
     for (int r = 0; r < DN_RB; r++) {
@@ -716,7 +1006,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; e++) {
                 double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PW + (t.g[g] * 2 + (t.c16 >> 3)) * 16 + (t.c16 & 7);
                 o[0] = aR[r][g][e];
-                o[8] = aA[r][g][e] - aB[r][g][e];
+                o[8] = aA[r][g][e];
             }
         }
     }
@@ -724,7 +1014,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // Y[n][j-1] = c_j dt^j Lambda+[n] [n <= nt-2] - c_j (-dt)^j Lambda-[n] [n >= 1].  grid (ceil(panel/256), nt)
 __global__ __launch_bounds__(256) void k_yinit(const double *__restrict__ T, const double *__restrict__ cw, double *__restrict__ Y,
-                                               size_t panel, int m, int nt)
+                                               size_t panel, int m, int nt, double *__restrict__ Yfrag, int Np)
 {
     const int n = blockIdx.y;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -732,6 +1022,10 @@ __global__ __launch_bounds__(256) void k_yinit(const double *__restrict__ T, con
     const double lx = (n <= nt - 2) ? T[((size_t)n * 2) * panel + e] : 0.0;
     const double ln = (n >= 1) ? T[((size_t)n * 2 + 1) * panel + e] : 0.0;
     for (int j = 1; j <= m; j++) Y[((size_t)n * m + (j - 1)) * panel + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+    if (Yfrag) {        // Y_m is never swept: its fragment-order copy here (the others: k_gsweep_f3)
+        const int row = (int)(e / (2 * Np)), w = (int)(e % (2 * Np)), ccol = (w >> 4) * 8 + (w & 7), is_im = (w >> 3) & 1;
+        Yfrag[((size_t)n * m + (m - 1)) * panel + 2 * frag_index(Np, row, ccol) + is_im] = cw[2 * m] * lx - cw[2 * m + 1] * ln;
+    }
 }
 
 // which form the gradient scalars take on the N > 64 path: 0 operator applications (k_ginner_f), 1 outer products with the
@@ -769,8 +1063,12 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
     //  were slower: 7.95 vs 7.2 ms for the six levels.)
     const int grid = dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt);
     for (int j = 0; j < c->m; j++)
-        hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->cw, c->Np, c->m,
-                           c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
+        if (dense_3m())
+            hipLaunchKernelGGL((k_level_f3<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->cw, c->Np, c->m,
+                               c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
+        else
+            hipLaunchKernelGGL((k_level_f<2, 4>), dim3(grid), dim3(256), 0, c->stream, Af, c->D, c->Dfrag, c->L, c->R, c->cw, c->Np, c->m,
+                               c->nt, j, c->cw_host[2 * (j + 1) + 1], c->cw_host[2 * (j + 1)]);
     return (int)hipGetLastError();
 }
 
@@ -806,21 +1104,33 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     const d2 *Af = reinterpret_cast<const d2 *>(c->Afrag);
     double *Gp = c->panel_scratch;
     const int ng = c->cp / 8;
+    const bool m3 = dense_3m() && c->Xfrag;
+    d2 *Xf = reinterpret_cast<d2 *>(c->Xfrag);
+    const d2 *Df = reinterpret_cast<const d2 *>(c->Dfrag);
     if (dense_sigma_form(c) == 3) {      // the sweep on the matrices Y_j = g_j psi_0^H (see k_youter)
         const size_t panel = (size_t)c->Np * 2 * c->Np;
         const int ogrid2 = dense_grid(2, 2, c->Np / 16, c->Np / 16, 2, c->nt), ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
-        hipLaunchKernelGGL((k_youter<2, 2>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
+        if (dense_3m()) hipLaunchKernelGGL((k_youter<2, 2, true>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
+        else hipLaunchKernelGGL((k_youter<2, 2, false>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
         hipLaunchKernelGGL(k_yinit, dim3((unsigned)((panel + 255) / 256), c->nt), dim3(256), 0, c->stream, c->Tlam, c->cw, c->Xouter, panel,
-                           c->m, c->nt);
+                           c->m, c->nt, m3 ? c->Xfrag : nullptr, c->Np);
         const int ngy = c->Np / 8;
         for (int j = c->m; j >= 2; j--) {
 #define CALL_GY(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, \
                                            c->stream, Af, c->Xouter, c->Np, c->Np, c->m, c->nt, j)
-            DISPATCH_SHAPE(ngy, CALL_GY);
+            if (dense_3m() && ngy >= 3)
+                hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, c->stream, Af,
+                                   c->Xouter, c->Np, c->Np, c->m, c->nt, j, m3 ? Xf : nullptr);
+            else
+                DISPATCH_SHAPE(ngy, CALL_GY);
 #undef CALL_GY
         }
-        hipLaunchKernelGGL((k_ginner_d<2, 2, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
-                           c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt);
+        if (m3)
+            hipLaunchKernelGGL((k_ginner_d<2, 2, true, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
+        else
+            hipLaunchKernelGGL((k_ginner_d<2, 2, true, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((hstep + 255) / 256), c->nt), dim3(256), 0, c->stream, c->lam, c->cw, Gp, hstep,
@@ -828,7 +1138,11 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     for (int j = c->m; j >= 2; j--) {
 #define CALL_GS(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, \
                                            c->stream, Af, Gp, c->Np, c->cp, c->m, c->nt, j)
-        DISPATCH_SHAPE(ng, CALL_GS);
+        if (dense_3m() && ng >= 3)
+            hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, c->stream, Af, Gp,
+                               c->Np, c->cp, c->m, c->nt, j, (d2 *)nullptr);
+        else
+            DISPATCH_SHAPE(ng, CALL_GS);
 #undef CALL_GS
     }
 #define CALL_GI(RB, NG) hipLaunchKernelGGL((k_ginner_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), \
@@ -839,15 +1153,25 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     const int form = dense_sigma_form(c);
     const int ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
     if (form == 2) {
-        hipLaunchKernelGGL((k_gouter<2, 2>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt);
-        hipLaunchKernelGGL((k_ginner_d<2, 2, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->Xouter,
-                           c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt);
+        if (m3) {
+            hipLaunchKernelGGL((k_gouter<2, 2, true>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt, Xf);
+            hipLaunchKernelGGL((k_ginner_d<2, 2, false, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
+        } else {
+            hipLaunchKernelGGL((k_gouter<2, 2, false>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt,
+                               (d2 *)nullptr);
+            hipLaunchKernelGGL((k_ginner_d<2, 2, false, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
+        }
         return (int)hipGetLastError();
     }
     if (form == 1) {
-        hipLaunchKernelGGL((k_ginner_m<2, 2>), dim3(ogrid), dim3(256),
-                           (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops, c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,
-                           c->n_ops, c->m, c->nt);
+        if (dense_3m())
+            hipLaunchKernelGGL((k_ginner_m<2, 2, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
+        else
+            hipLaunchKernelGGL((k_ginner_m<2, 2, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+                               c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
         return (int)hipGetLastError();
     }
     DISPATCH_SHAPE(ng, CALL_GI);      // (a 2 x 2 tile at 4 waves per SIMD was slower: 13.2 vs 11.4 ms at config 5)
