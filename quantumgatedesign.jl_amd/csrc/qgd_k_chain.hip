@@ -854,6 +854,137 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
     }
 }
 
+// The same chain with three real products per complex multiply (qgd_k_dense.hip, cgemm3_tile): two column groups form
+// one MFMA operand of 16 complex columns; the state tile lies in LDS as [row][pair][16 re | 16 im] (16-double slots,
+// XOR-ed with row % NGT as above), so the three right operands are two plain 128-byte rows and their sum.
+// Conjugated left operand (ADJ): A^H = ar - i ai with (ar, ai) loaded un-conjugated, hence the sign s below.
+//     P1 = ar Br, P2 = ai Bi, P3 = (ar + s ai)(Br + Bi);   Re = P1 - s P2,  Im = P3 - P1 - s P2,   s = +1 / -1 (ADJ).
+template <int MODE, int RBW, int NGT>
+__global__ __launch_bounds__(512) void k_chain_dense3(const ChainArgs a)
+{
+    static_assert(NGT == 2 || NGT == 4, "pairs of column groups");
+    constexpr bool ADJ = (MODE >= 2);
+    constexpr int NPR = NGT / 2;
+    extern __shared__ double cur[];
+    constexpr int TW = 16 * NGT;                         // doubles per state row of the tile
+    const int Np = a.Np, nrb = Np >> 4, ngt = (a.ngroups + NGT - 1) / NGT;
+    int b, ct;
+    if (MODE == 0) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; b = xcd + 8 * (slot / ngt); ct = slot % ngt; }
+    else { b = blockIdx.x / ngt; ct = blockIdx.x % ngt; }
+    if (b >= a.nblocks) return;
+    const int s0 = b * a.blen, e0 = (s0 + a.blen < a.S) ? s0 + a.blen : a.S;
+    const int PWc = (MODE == 0) ? 2 * Np : 2 * a.cp;
+    const size_t hstep = (size_t)Np * PWc;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    // LDS position of element (row, group g of the tile, c in [8 re | 8 im])
+    auto lds_at = [&](int row, int g, int c) -> int {
+        const int slot = (g >> 1) * 2 + (c >> 3);
+        return row * TW + ((slot ^ (row & (NGT - 1))) << 4) + (g & 1) * 8 + (c & 7);
+    };
+    for (int e = tid; e < Np * TW; e += blockDim.x) {
+        const int row = e / TW, g = (e >> 4) % NGT, c = e & 15, grp = ct * NGT + g;
+        double v = 0.0;
+        if (grp < a.ngroups) {
+            if (MODE == 0) v = (c < 8 && row == grp * 8 + c) ? 1.0 : 0.0;
+            else if (MODE != 2) v = a.start[(size_t)b * a.start_stride + (size_t)row * PWc + grp * 16 + c];
+        }
+        cur[lds_at(row, g, c)] = v;
+    }
+    __syncthreads();
+    int rb[RBW];
+    #pragma unroll
+    for (int r = 0; r < RBW; r++) rb[r] = wave * RBW + r;
+    const double sgn = ADJ ? -1.0 : 1.0;
+    int avr[RBW], avi[RBW];                               // byte offsets of this lane's (row, k = kk) element: chain_a_raw's layouts
+    #pragma unroll
+    for (int r = 0; r < RBW; r++) {
+        const int arow = (rb[r] < nrb ? rb[r] : 0) * 16 + c16;
+        if (!ADJ) { avr[r] = (arow + Np * kk) * 8; avi[r] = avr[r] + Np * Np * 8; }
+        else { avr[r] = (kk * 2 * Np + (arow >> 3) * 16 + (arow & 7)) * 8; avi[r] = avr[r] + 64; }
+    }
+    for (int st = 0; st < e0 - s0; st++) {
+        const int n = ADJ ? e0 - 1 - st : s0 + st;
+        const int nout = ADJ ? n : n + 1;
+        const double *Pn = chain_matrix(a, n);
+        d4 p1[RBW][NPR], p2[RBW][NPR], p3[RBW][NPR];
+        #pragma unroll
+        for (int r = 0; r < RBW; r++)
+            #pragma unroll
+            for (int p = 0; p < NPR; p++) { p1[r][p] = (d4){0, 0, 0, 0}; p2[r][p] = (d4){0, 0, 0, 0}; p3[r][p] = (d4){0, 0, 0, 0}; }
+        // left operand: buffer-addressed (descriptor on the step matrix, per-lane offsets fixed, the k-step in an SGPR)
+        const __amdgpu_buffer_rsrc_t rP = buffer_of(Pn);
+        const int kstep = ADJ ? 2 * Np * 8 : Np * 8;           // bytes per unit of k
+        // four register sets, three k-steps of prefetch, the loop unrolled by four: no register copies, constant LDS offsets
+        double xr[4][RBW], xi[4][RBW];
+#define CD3_LOAD(S, kq) do { _Pragma("unroll") for (int r = 0; r < RBW; r++) {                                         \
+            xr[S][r] = buffer_load_f64(rP, avr[r], (kq) * kstep); xi[S][r] = buffer_load_f64(rP, avi[r], (kq) * kstep); } } while (0)
+#define CD3_STEP(S, kq) do {                                                                                          \
+            const double *brow = cur + (size_t)((kq) + kk) * TW + c16;                                                 \
+            double as[RBW];                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < RBW; r++) as[r] = ADJ ? xr[S][r] - xi[S][r] : xr[S][r] + xi[S][r];     \
+            _Pragma("unroll") for (int p = 0; p < NPR; p++) {                                                          \
+                const double bre = brow[((2 * p) ^ (kk & (NGT - 1))) << 4], bim = brow[((2 * p + 1) ^ (kk & (NGT - 1))) << 4]; \
+                const double bs = bre + bim;                                                                          \
+                _Pragma("unroll") for (int r = 0; r < RBW; r++) {                                                      \
+                    p1[r][p] = MFMA(xr[S][r], bre, p1[r][p]);                                                          \
+                    p2[r][p] = MFMA(xi[S][r], bim, p2[r][p]);                                                          \
+                    p3[r][p] = MFMA(as[r], bs, p3[r][p]);                                                              \
+                } } } while (0)
+        CD3_LOAD(0, 0); CD3_LOAD(1, 4); CD3_LOAD(2, 8);
+        for (int k0 = 0; k0 < Np; k0 += 16) {                  // (Np is a multiple of 16)
+            const int last = Np - 4;
+            CD3_LOAD(3, k0 + 12);                                CD3_STEP(0, k0);
+            CD3_LOAD(0, k0 + 16 <= last ? k0 + 16 : last);       CD3_STEP(1, k0 + 4);
+            CD3_LOAD(1, k0 + 20 <= last ? k0 + 20 : last);       CD3_STEP(2, k0 + 8);
+            CD3_LOAD(2, k0 + 24 <= last ? k0 + 24 : last);       CD3_STEP(3, k0 + 12);
+        }
+#undef CD3_LOAD
+#undef CD3_STEP
+        __syncthreads();            // every wave has read the old state
+        #pragma unroll
+        for (int r = 0; r < RBW; r++) {
+            if (rb[r] >= nrb) continue;
+            #pragma unroll
+            for (int p = 0; p < NPR; p++) {
+                const int g = 2 * p + (c16 >> 3), grp = ct * NGT + g;
+                if (grp >= a.ngroups) continue;
+                #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = rb[r] * 16 + kk + 4 * e;
+                    const double sp2 = sgn * p2[r][p][e];
+                    double vre = p1[r][p][e] - sp2, vim = p3[r][p][e] - p1[r][p][e] - sp2;
+                    const size_t ho = (size_t)nout * hstep + (size_t)row * PWc + grp * 16 + (c16 & 7);
+                    if (ADJ) {
+                        const size_t fo = a.f_bpr ? ho + (size_t)(nout / a.f_bpr) * hstep : ho;
+                        vre += a.forcing[fo]; vim += a.forcing[fo + 8];
+                    }
+                    cur[(size_t)row * TW + (((2 * p) ^ (kk & (NGT - 1))) << 4) + c16] = vre;
+                    cur[(size_t)row * TW + (((2 * p + 1) ^ (kk & (NGT - 1))) << 4) + c16] = vim;
+                    if (MODE == 1 || MODE == 3) { a.out[ho] = vre; a.out[ho + 8] = vim; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 0 || MODE == 2) {
+        const size_t pl = (size_t)Np * Np;
+        double *pc = a.PiC + (size_t)b * 2 * pl, *pr = a.PiR + (size_t)b * 2 * pl;
+        for (int e = tid; e < Np * TW; e += blockDim.x) {
+            const int row = e / TW, g = (e >> 4) % NGT, c = e & 15, grp = ct * NGT + g;
+            if (grp >= a.ngroups) continue;
+            const double v = cur[lds_at(row, g, c)];
+            if (MODE == 0) {
+                const int col = grp * 8 + (c & 7);
+                pc[(c >= 8 ? pl : 0) + (size_t)row + (size_t)Np * col] = v;
+                pr[(size_t)row * 2 * Np + grp * 16 + c] = v;
+            } else {
+                a.phi[(size_t)b * hstep + (size_t)row * PWc + grp * 16 + c] = v;
+            }
+        }
+    }
+}
+
 // Tile width: 4 column groups per workgroup stream the step matrix once per 32 columns -- the right choice when
 // there are more tiles than CUs (config 5: 32 blocks x 8 tiles).  When there are not, the step time of ONE workgroup
 // is what counts and narrower tiles put more CUs on the same chain (N = 100, 32 columns, 54 blocks: one 4-group tile
@@ -865,8 +996,12 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     const int nwg = (MODE == 0) ? 8 * ngt * ((a.nblocks + 7) / 8) : a.nblocks * ngt;
     const size_t shm = (size_t)a.Np * 16 * NGT * sizeof(double);
     if (nwg <= 0) return 0;
-#define CALL_CD(R) do { SET_LDS_ONCE((k_chain_dense<MODE, R, NGT>), shm); \
-        hipLaunchKernelGGL((k_chain_dense<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); } while (0)
+    static const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
+#define CALL_CD(R) do { bool done3_ = false;                                                                                \
+        if constexpr (NGT > 1) { if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
+            hipLaunchKernelGGL((k_chain_dense3<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); done3_ = true; } }      \
+        if (!done3_) { SET_LDS_ONCE((k_chain_dense<MODE, R, NGT>), shm);                                                     \
+            hipLaunchKernelGGL((k_chain_dense<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); } } while (0)
     if (nrb <= 8) CALL_CD(1); else if (nrb <= 16) CALL_CD(2); else CALL_CD(3);
 #undef CALL_CD
     return (int)hipGetLastError();
@@ -876,8 +1011,10 @@ template <int MODE>
 static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 {
     const long long cus = 256;      // (thresholds of 128 .. 1024 tiles give the same times within 2 %)
-    if ((long long)a.nblocks * a.ngroups <= 2 * cus) return launch_chain_dense_w<MODE, 1>(a, stream);
-    if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= 2 * cus) return launch_chain_dense_w<MODE, 2>(a, stream);
+    static const long long t1 = getenv("QGD_CHAIN_T1") ? atoll(getenv("QGD_CHAIN_T1")) : cus - 1;     // (tuning; 8-column tiles only while they are fewer than the CUs)
+    static const long long t2 = getenv("QGD_CHAIN_T2") ? atoll(getenv("QGD_CHAIN_T2")) : 2 * cus;
+    if ((long long)a.nblocks * a.ngroups <= t1) return launch_chain_dense_w<MODE, 1>(a, stream);
+    if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= t2) return launch_chain_dense_w<MODE, 2>(a, stream);
     return launch_chain_dense_w<MODE, 4>(a, stream);
 }
 
