@@ -996,7 +996,7 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     const int nwg = (MODE == 0) ? 8 * ngt * ((a.nblocks + 7) / 8) : a.nblocks * ngt;
     const size_t shm = (size_t)a.Np * 16 * NGT * sizeof(double);
     if (nwg <= 0) return 0;
-    static const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
+    const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
 #define CALL_CD(R) do { bool done3_ = false;                                                                                \
         if constexpr (NGT > 1) { if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
             hipLaunchKernelGGL((k_chain_dense3<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); done3_ = true; } }      \

@@ -292,8 +292,7 @@ __device__ __forceinline__ void cgemm3_tile(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)
 // 3M switch of the N > 64 kernels (QGD_DENSE_4M=1 keeps the four-product tiles: A/B timing and tests)
 static bool dense_3m()
 {
-    static const bool on = getenv("QGD_DENSE_4M") == nullptr;
-    return on;
+    return getenv("QGD_DENSE_4M") == nullptr;       // (read per call: tests switch it inside one process; noise beside these launches)
 }
 
 // ---------------------------------------------------------------------------

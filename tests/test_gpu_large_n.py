@@ -205,3 +205,31 @@ def test_sigma_forms_agree(qgd, N, c, n_ops, order, monkeypatch):
         assert np.abs(grads[f] - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max(), f
     for f in ("1", "2", "3"):
         assert np.abs(grads["0"] - grads[f]).max() <= 1e-12 * np.abs(ref["grad"]).max(), f
+
+
+@pytest.mark.parametrize("N,c,n_ops,order,form", [(128, 128, 4, 12, "3"), (128, 128, 2, 8, "2"), (144, 64, 4, 8, "1"),
+                                                  (100, 32, 2, 8, "0"), (80, 24, 1, 4, "0")])
+def test_three_product_tiles_against_four(qgd, N, c, n_ops, order, form, monkeypatch):
+    """Since round 3 the N > 64 kernels form a complex product from THREE real ones (cgemm3_tile, outer_tile3, outer_frag3,
+    k_chain_dense3: Re = P1 - P2, Im = P3 - P1 - P2).  The four-product kernels stay in the library (QGD_DENSE_4M=1): both
+    against the numpy statement (1e-10) and against each other (history 1e-12, gradient 1e-11 -- 3M is exact to
+    eps |A||B| norm-wise, not component-wise), on shapes with an odd number of column groups (c = 24) and partial tiles."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=12, tf=0.12, seed=N + c)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    monkeypatch.setenv("QGD_GINNER", form)
+    out = {}
+    for four in (False, True):
+        if four:
+            monkeypatch.setenv("QGD_DENSE_4M", "1")
+        else:
+            monkeypatch.delenv("QGD_DENSE_4M", raising=False)
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        hist = np.zeros(dp._hist_shape(), order="F")
+        g, o = dp.discrete_adjoint(pcof, False, hist)
+        dp.close()
+        assert np.abs(g - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max(), four
+        out[four] = (g, np.asarray(o), hist)
+    assert np.abs(out[False][2] - out[True][2]).max() <= 1e-12 * np.abs(out[True][2]).max()
+    assert np.abs(out[False][0] - out[True][0]).max() <= 1e-11 * np.abs(out[True][0]).max()
+    assert np.abs(out[False][1] - out[True][1]).max() <= 1e-12 * max(1.0, np.abs(out[True][1]).max())
