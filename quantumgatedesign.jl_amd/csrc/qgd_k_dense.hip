@@ -545,7 +545,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gsweep_f3(const d2 *__restrict__ Afrag, double *__restrict__ Gp, int Np, int cp,
-                                                  int m, int nt, int j, d2 *__restrict__ Gfrag)
+                                                  int m, int nt, int j, d2 *__restrict__ Gfrag, const double *__restrict__ Tseed,
+                                                  const double *__restrict__ cw)
 {
     DenseTile<DN_RB, DN_NG> t;
     if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
@@ -569,7 +570,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int row = t.rb[r] * 16 + t.kk + 4 * e;
                 double *o = out + (size_t)row * PWc + g * 16 + (t.c16 & 7);
                 const double s12 = p1[r][p][e] + p2[r][p][e];
-                const double vre = o[0] + sc * (p1[r][p][e] - p2[r][p][e]), vim = o[8] + sc * (p3[r][p][e] - s12);
+                double bre, bim;
+                if (Tseed) {     // first level (j = m) of the third gradient form: the seed Y_i = c_i dt^i Lambda+ - c_i (-dt)^i Lambda- is
+                                 // formed here from the two outer products instead of being written and read back (k_yinit)
+                    const size_t to = (size_t)t.n * 2 * hstep + (size_t)row * PWc + g * 16 + (t.c16 & 7);
+                    const double wx = (t.n <= nt - 2) ? cw[2 * i] : 0.0, wn = (t.n >= 1) ? cw[2 * i + 1] : 0.0;
+                    bre = wx * Tseed[to] - wn * Tseed[to + hstep];
+                    bim = wx * Tseed[to + 8] - wn * Tseed[to + hstep + 8];
+                } else { bre = o[0]; bim = o[8]; }
+                const double vre = bre + sc * (p1[r][p][e] - p2[r][p][e]), vim = bim + sc * (p3[r][p][e] - s12);
                 o[0] = vre; o[8] = vim;
                 // level j is the last one that touches g_{j-1}: its final value also in fragment order (square panels only:
                 // the matrices Y_j of the third gradient form, left operands of k_ginner_d)
@@ -1012,15 +1021,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // Y[n][j-1] = c_j dt^j Lambda+[n] [n <= nt-2] - c_j (-dt)^j Lambda-[n] [n >= 1].  grid (ceil(panel/256), nt)
+// only_last: just Y_m (right operand of the first sweep level); the other seeds are formed by that level's epilogue (k_gsweep_f3)
 __global__ __launch_bounds__(256) void k_yinit(const double *__restrict__ T, const double *__restrict__ cw, double *__restrict__ Y,
-                                               size_t panel, int m, int nt, double *__restrict__ Yfrag, int Np)
+                                               size_t panel, int m, int nt, double *__restrict__ Yfrag, int Np, int only_last)
 {
     const int n = blockIdx.y;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= panel) return;
     const double lx = (n <= nt - 2) ? T[((size_t)n * 2) * panel + e] : 0.0;
     const double ln = (n >= 1) ? T[((size_t)n * 2 + 1) * panel + e] : 0.0;
-    for (int j = 1; j <= m; j++) Y[((size_t)n * m + (j - 1)) * panel + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
+    for (int j = only_last ? m : 1; j <= m; j++) Y[((size_t)n * m + (j - 1)) * panel + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
     if (Yfrag) {        // Y_m is never swept: its fragment-order copy here (the others: k_gsweep_f3)
         const int row = (int)(e / (2 * Np)), w = (int)(e % (2 * Np)), ccol = (w >> 4) * 8 + (w & 7), is_im = (w >> 3) & 1;
         Yfrag[((size_t)n * m + (m - 1)) * panel + 2 * frag_index(Np, row, ccol) + is_im] = cw[2 * m] * lx - cw[2 * m + 1] * ln;
@@ -1107,19 +1117,20 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     d2 *Xf = reinterpret_cast<d2 *>(c->Xfrag);
     const d2 *Df = reinterpret_cast<const d2 *>(c->Dfrag);
     if (dense_sigma_form(c) == 3) {      // the sweep on the matrices Y_j = g_j psi_0^H (see k_youter)
+        const bool lazy = dense_3m() && c->m >= 2 && !getenv("QGD_YINIT_ALL");      // seeds formed inside the first sweep level
         const size_t panel = (size_t)c->Np * 2 * c->Np;
         const int ogrid2 = dense_grid(2, 2, c->Np / 16, c->Np / 16, 2, c->nt), ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
         if (dense_3m()) hipLaunchKernelGGL((k_youter<2, 2, true>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
         else hipLaunchKernelGGL((k_youter<2, 2, false>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);
         hipLaunchKernelGGL(k_yinit, dim3((unsigned)((panel + 255) / 256), c->nt), dim3(256), 0, c->stream, c->Tlam, c->cw, c->Xouter, panel,
-                           c->m, c->nt, m3 ? c->Xfrag : nullptr, c->Np);
+                           c->m, c->nt, m3 ? c->Xfrag : nullptr, c->Np, lazy ? 1 : 0);
         const int ngy = c->Np / 8;
         for (int j = c->m; j >= 2; j--) {
 #define CALL_GY(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, \
                                            c->stream, Af, c->Xouter, c->Np, c->Np, c->m, c->nt, j)
             if (dense_3m() && ngy >= 3)
                 hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, c->stream, Af,
-                                   c->Xouter, c->Np, c->Np, c->m, c->nt, j, m3 ? Xf : nullptr);
+                                   c->Xouter, c->Np, c->Np, c->m, c->nt, j, m3 ? Xf : nullptr, (lazy && j == c->m) ? c->Tlam : nullptr, c->cw);
             else
                 DISPATCH_SHAPE(ngy, CALL_GY);
 #undef CALL_GY
@@ -1139,7 +1150,7 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
                                            c->stream, Af, Gp, c->Np, c->cp, c->m, c->nt, j)
         if (dense_3m() && ng >= 3)
             hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, c->stream, Af, Gp,
-                               c->Np, c->cp, c->m, c->nt, j, (d2 *)nullptr);
+                               c->Np, c->cp, c->m, c->nt, j, (d2 *)nullptr, (const double *)nullptr, c->cw);
         else
             DISPATCH_SHAPE(ng, CALL_GS);
 #undef CALL_GS
