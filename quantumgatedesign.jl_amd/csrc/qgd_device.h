@@ -139,6 +139,7 @@ int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
+int qgdk_dense_propagator(const qgdk_ctx *c);     // 1: launched P = Linv R on the three-product tiles, 0: not taken
 int qgdk_dense_derivs(const qgdk_ctx *c);
 int qgdk_dense_gradient(const qgdk_ctx *c);
 int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c);

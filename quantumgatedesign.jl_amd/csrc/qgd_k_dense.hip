@@ -288,6 +288,54 @@ __device__ __forceinline__ void cgemm3_tile(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)
 #undef C3_MFMA
 }
 
+// ... with the left operand given as two column-major planes, element (row, k) at [row + Np k] (the inverse as the blocked
+// elimination writes it); CONJ: the operand is conj(planes), i.e. s = -1 in
+//     P1 = ar Br,  P2 = ai Bi,  P3 = (ar + s ai)(Br + Bi);   Re = P1 - s P2,  Im = P3 - P1 - s P2.
+template <bool CONJ, int DN_RB, int DN_NG>
+__device__ __forceinline__ void cgemm3_tile_planes(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)[DN_RB][DN_NG / 2], d4 (&p3)[DN_RB][DN_NG / 2],
+                                                   const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ Are,
+                                                   const double *__restrict__ Aim, const double *__restrict__ B, size_t ldb, int Np)
+{
+    constexpr int NP = DN_NG / 2;
+    const __amdgpu_buffer_rsrc_t rr = buffer_of(Are), ri = buffer_of(Aim), rb_ = buffer_of(B);
+    int av[DN_RB], bv[NP];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) av[r] = ((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16 + Np * t.kk) * 8;
+    #pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int g = lane_group(t, p);
+        if (g < 0) g = t.g[0];
+        bv[p] = (t.kk * (int)ldb + g * 16 + (t.c16 & 7)) * 8;
+    }
+    const int nk4 = Np >> 2, astep = 4 * Np * 8, bstep = 4 * (int)ldb * 8;
+    double ar0[DN_RB], ai0[DN_RB], ar1[DN_RB], ai1[DN_RB], br0[NP], bi0[NP], br1[NP], bi1[NP];
+#define CP_LOAD(ar, ai, br, bi, k) do {                                                                        \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) { ar[r] = buffer_load_f64(rr, av[r], (k) * astep);     \
+                                                            ai[r] = buffer_load_f64(ri, av[r], (k) * astep); }   \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) { br[p] = buffer_load_f64(rb_, bv[p], (k) * bstep);       \
+                                                         bi[p] = buffer_load_f64(rb_, bv[p] + 64, (k) * bstep); } } while (0)
+#define CP_MFMA(ar, ai, br, bi) do {                                                                           \
+        double as[DN_RB], bs[NP];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) as[r] = CONJ ? ar[r] - ai[r] : ar[r] + ai[r];          \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) bs[p] = br[p] + bi[p];                                   \
+        _Pragma("unroll") for (int p = 0; p < NP; p++)                                                         \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++) {                                                \
+                p1[r][p] = MFMA(ar[r], br[p], p1[r][p]);                                                       \
+                p2[r][p] = MFMA(ai[r], bi[p], p2[r][p]);                                                       \
+                p3[r][p] = MFMA(as[r], bs[p], p3[r][p]);                                                       \
+            } } while (0)
+    CP_LOAD(ar0, ai0, br0, bi0, 0);
+    for (int k4 = 0; k4 < nk4; k4 += 2) {
+        CP_LOAD(ar1, ai1, br1, bi1, k4 + 1);
+        CP_MFMA(ar0, ai0, br0, bi0);
+        const int kn = (k4 + 2 < nk4) ? k4 + 2 : k4;
+        CP_LOAD(ar0, ai0, br0, bi0, kn);
+        CP_MFMA(ar1, ai1, br1, bi1);
+    }
+#undef CP_LOAD
+#undef CP_MFMA
+}
+
 #define ZERO_ACC3(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG / 2; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
 // 3M switch of the N > 64 kernels (QGD_DENSE_4M=1 keeps the four-product tiles: A/B timing and tests)
 static bool dense_3m()
@@ -496,6 +544,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             #pragma unroll
             for (int e = 0; e < 4; e++)
                 out[(size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + t.g[g] * 16 + t.c16] = acc[r][g][e];
+        }
+    }
+}
+
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lambda_f3(const double *__restrict__ LinvT, const double *__restrict__ yhist,
+                                                  double *__restrict__ lam, int Np, int cp, int nt,
+                                                  double *__restrict__ zero_a, int n_a, double *__restrict__ zero_b, int n_b)
+{
+    {
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        for (int e = gid; e < n_a; e += gsz) zero_a[e] = 0.0;
+        for (int e = gid; e < n_b; e += gsz) zero_b[e] = 0.0;
+    }
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, 1, nt - 1)) return;
+    const int n = t.n + 1, PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, pl = (size_t)Np * Np;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    cgemm3_tile_planes<true>(p1, p2, p3, t, LinvT + (size_t)n * 2 * pl, LinvT + (size_t)n * 2 * pl + pl, yhist + (size_t)n * hstep, PWc, Np);
+    double *out = lam + (size_t)n * hstep;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + g * 16 + (t.c16 & 7);
+                o[0] = p1[r][p][e] + p2[r][p][e];                       // conjugated operand: s = -1
+                o[8] = p3[r][p][e] - p1[r][p][e] + p2[r][p][e];
+            }
+        }
+    }
+}
+
+// P[n] = Linv[n+1] R[n] on the three-product tiles (k_propagator in qgd_k_inverse.hip is the four-product kernel): panel and
+// column-major planes as the chains want them
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_propagator3(const double *__restrict__ LinvA, const double *__restrict__ R,
+                                                  double *__restrict__ Pr, double *__restrict__ Pc, int Np, int nt)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, Np >> 3, 1, nt - 1)) return;
+    const int n = t.n, PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    cgemm3_tile_planes<false>(p1, p2, p3, t, LinvA + (size_t)(n + 1) * 2 * pl, LinvA + (size_t)(n + 1) * 2 * pl + pl, R + (size_t)n * panel, PW, Np);
+    double *Prn = Pr + (size_t)n * panel, *Pcn = Pc + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            const int ccol = g * 8 + (t.c16 & 7);
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t.rb[r] * 16 + t.kk + 4 * e;
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                const double vre = p1[r][p][e] - p2[r][p][e], vim = p3[r][p][e] - s12;
+                double *o = Prn + (size_t)row * PW + g * 16 + (t.c16 & 7);
+                o[0] = vre; o[8] = vim;
+                Pcn[(size_t)row + (size_t)Np * ccol] = vre;
+                Pcn[pl + (size_t)row + (size_t)Np * ccol] = vim;
+            }
         }
     }
 }
@@ -1084,6 +1203,15 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
 // tile shape by the number of column groups of the state panels
 #define DISPATCH_SHAPE(ngroups, CALL) do { if ((ngroups) >= 3) CALL(2, 4); else if ((ngroups) == 2) CALL(4, 2); else CALL(4, 1); } while (0)
 
+// returns 1 when the three-product propagator kernel took the launch (else the caller runs k_propagator)
+int qgdk_dense_propagator(const qgdk_ctx *c)
+{
+    if (!dense_3m() || c->nt < 2) return 0;
+    hipLaunchKernelGGL((k_propagator3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, c->Np / 8, 1, c->nt - 1)), dim3(256), 0, c->stream, c->LinvA,
+                       c->R, c->Pr, c->Pc, c->Np, c->nt);
+    return 1;
+}
+
 int qgdk_dense_derivs(const qgdk_ctx *c)
 {
     const int ng = c->cp / 8;
@@ -1100,7 +1228,11 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
 #define CALL_LF(RB, NG) hipLaunchKernelGGL((k_lambda_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, 1, c->nt - 1)), dim3(256), 0, \
                                            c->stream, c->LinvT, c->yhist, c->lam, c->Np, c->cp, c->nt, c->sigma,                       \
                                            c->nt * c->n_ops * c->m * 2, c->grad, c->grad_accumulate ? 0 : c->n_pcof)
-    DISPATCH_SHAPE(ng, CALL_LF);
+    if (dense_3m() && ng >= 3)
+        hipLaunchKernelGGL((k_lambda_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, 1, c->nt - 1)), dim3(256), 0, c->stream, c->LinvT, c->yhist,
+                           c->lam, c->Np, c->cp, c->nt, c->sigma, c->nt * c->n_ops * c->m * 2, c->grad, c->grad_accumulate ? 0 : c->n_pcof);
+    else
+        DISPATCH_SHAPE(ng, CALL_LF);
 #undef CALL_LF
     return (int)hipGetLastError();
 }

@@ -1710,6 +1710,7 @@ int qgdk_propagator_is_fused(const qgdk_ctx *c) { return (c->Np == 16 || c->Np =
 int qgdk_propagator(const qgdk_ctx *c)
 {
     if (qgdk_propagator_is_fused(c)) return 0;                    // k_inverse_mfma produced P_n already
+    if (c->Np > 64 && c->dense_gemm && qgdk_dense_propagator(c)) return (int)hipGetLastError();      // three-product tiles (qgd_k_dense.hip)
     const int ngroups = c->Np / 8;
     const int gtiles = (ngroups + LV_NG - 1) / LV_NG;
     const int rtiles = (c->Np + 63) / 64;
