@@ -291,7 +291,7 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
     // (faster than the LDS-panel kernels at every size measured, scripts/mid_n_timing.py), which keep the m seed
     // panels g_j of a time point in HBM.  QGD_DENSE_OLD=1 keeps the older kernels (LDS panels, or HBM slabs when
     // they do not fit) for comparison.
-    if (!dry) { k.panel_scratch = nullptr; k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr; k.Xouter = k.Tlam = k.Xfrag = nullptr; }
+    if (!dry) { k.panel_scratch = nullptr; k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr; k.Xouter = k.Tlam = k.Xfrag = nullptr; k.binv = nullptr; }
     const bool lds_too_small = qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS");
     if (Np > 64 && !getenv("QGD_DENSE_OLD")) {
         if (!A(&k.panel_scratch, nt * m * hstep) || !A(&k.Afrag, nt * m * 2 * pl) || !A(&k.Dfrag, nt * m * 2 * pl) ||
@@ -299,6 +299,7 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
         // the m panels X_j of the outer-product form of the gradient scalars, where it pays (qgd_k_dense.hip: dense_sigma_form)
         if (Np >= 128 && k.cp >= 64 && (size_t)(m - 1) * Np < (size_t)(m + 1) * k.cp && m >= 1 &&
             (!A(&k.Xouter, nt * m * panel) || !A(&k.Tlam, nt * 2 * panel) || !A(&k.Xfrag, nt * m * panel))) return rc;
+        if (!getenv("QGD_BINV_OFF") && !A(&k.binv, qgdk_dense_inverse_words(k.Np, (int)nt))) return rc;      // block Gauss-Jordan inverse
         if (!dry) {
             if (qgdk_dense_operator_frag(&k)) return fail(h, QGD_ERR_NO_DEVICE, "operator fragment kernel failed to launch");
             k.dense_gemm = 1;

@@ -50,6 +50,7 @@ typedef struct qgdk_ctx {
     double *grad;       // [n_pcof]
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
+    double *binv;       // work space of the block Gauss-Jordan inverse for N > 64 (qgdk_dense_inverse), or null
     double *inv_scratch;
     double *panel_scratch; // large N: per-workgroup panel slabs of k_derivs/k_gradsweep in HBM instead of LDS
     // large N, GEMM-style kernels (qgd_k_dense.hip): A_d(t_n), D_j(t_n) and {S_o, K_o} in MFMA fragment order
@@ -139,6 +140,10 @@ int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
+int qgdk_dense_inverse(const qgdk_ctx *c);        // 1: the block Gauss-Jordan inverse took the launch, 0: not taken
+size_t qgdk_dense_inverse_words(int Np, int nt);  // doubles of work space it needs
+int qgdk_inverse_diag(const qgdk_ctx *c, const double *Win, size_t mstride, int ldw, size_t off, int bs, double *DkC, int *flags);
+int qgdk_inverse_redo(const qgdk_ctx *c, const int *flags);
 int qgdk_dense_propagator(const qgdk_ctx *c);     // 1: launched P = Linv R on the three-product tiles, 0: not taken
 int qgdk_dense_derivs(const qgdk_ctx *c);
 int qgdk_dense_gradient(const qgdk_ctx *c);

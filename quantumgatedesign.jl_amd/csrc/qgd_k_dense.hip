@@ -294,10 +294,12 @@ __device__ __forceinline__ void cgemm3_tile(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)
 template <bool CONJ, int DN_RB, int DN_NG>
 __device__ __forceinline__ void cgemm3_tile_planes(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)[DN_RB][DN_NG / 2], d4 (&p3)[DN_RB][DN_NG / 2],
                                                    const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ Are,
-                                                   const double *__restrict__ Aim, const double *__restrict__ B, size_t ldb, int Np)
+                                                   const double *__restrict__ Aim, const double *__restrict__ B, size_t ldb, int Np,
+                                                   int K = -1)        // Np: leading dimension of the planes; K: contraction length (default Np)
 {
     constexpr int NP = DN_NG / 2;
     const __amdgpu_buffer_rsrc_t rr = buffer_of(Are), ri = buffer_of(Aim), rb_ = buffer_of(B);
+    if (K < 0) K = Np;
     int av[DN_RB], bv[NP];
     #pragma unroll
     for (int r = 0; r < DN_RB; r++) av[r] = ((t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16 + Np * t.kk) * 8;
@@ -307,7 +309,7 @@ __device__ __forceinline__ void cgemm3_tile_planes(d4 (&p1)[DN_RB][DN_NG / 2], d
         if (g < 0) g = t.g[0];
         bv[p] = (t.kk * (int)ldb + g * 16 + (t.c16 & 7)) * 8;
     }
-    const int nk4 = Np >> 2, astep = 4 * Np * 8, bstep = 4 * (int)ldb * 8;
+    const int nk4 = K >> 2, astep = 4 * Np * 8, bstep = 4 * (int)ldb * 8;      // (K is a multiple of 16: nk4 is even)
     double ar0[DN_RB], ai0[DN_RB], ar1[DN_RB], ai1[DN_RB], br0[NP], bi0[NP], br1[NP], bi1[NP];
 #define CP_LOAD(ar, ai, br, bi, k) do {                                                                        \
         _Pragma("unroll") for (int r = 0; r < DN_RB; r++) { ar[r] = buffer_load_f64(rr, av[r], (k) * astep);     \
@@ -615,6 +617,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 Pcn[(size_t)row + (size_t)Np * ccol] = vre;
                 Pcn[pl + (size_t)row + (size_t)Np * ccol] = vim;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Inverse of the N x N step matrices (N > 64) as BLOCK Gauss-Jordan over 64-column blocks, the block operations spread over
+// the whole chip as batched three-product GEMM tiles (k_inverse_blocked2 keeps one matrix on one CU: 201 matrices at config
+// 5 are 201 CUs running a pivot-latency-bound kernel for 1.8 ms, on any number of GPUs).  Step k = 0, 1, ... on W (W = L first):
+//     D    = inv(W_kk)                                   k_inverse_diag: partial pivoting INSIDE the 64 x 64 block
+//     W'_k. = D [W_k. with block k replaced by I]         k_binv_row    (64 x 64 x N)
+//     W'_i. = [W_i. with block k zeroed] - W_ik W'_k.      k_binv_rest   ((N - 64) x 64 x N)
+// and W is the inverse after the last block.  Out of place (two panel-layout buffers alternate); the left operands W_ik
+// are read from column-major planes that k_binv_planes transposes out of the panel layout for the 64 columns a step
+// needs (LinvA serves as that buffer until the final transpose fills it).  No pivoting ACROSS blocks: fine when the
+// block multipliers W_ik D stay small -- L = I + i dt/2 H - ... has leading blocks as well conditioned as itself for
+// the time steps these schemes are accurate at -- and checked: an entry of a multiplier block beyond `thresh` (or a zero
+// pivot inside a diagonal block) marks the matrix, and marked matrices are redone by k_inverse_blocked2 with full partial
+// pivoting from the untouched L in the same stream (a launch that ends at once for the others).
+// ---------------------------------------------------------------------------
+#define BINV_B 64
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_binv_row(const double *__restrict__ DkC, const double *__restrict__ Win,
+                                                  size_t in_stride, double *__restrict__ Wout, int Np, int nmat, int kb0, int bs)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, bs >> 4, Np >> 3, 1, nmat)) return;
+    const int n = t.n + 1, PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW;
+    const double *A = DkC + (size_t)n * 2 * BINV_B * BINV_B;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    cgemm3_tile_planes<false>(p1, p2, p3, t, A, A + BINV_B * BINV_B, Win + (size_t)n * in_stride + (size_t)kb0 * PW, PW, BINV_B, bs);
+    double *out = Wout + (size_t)n * panel;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            const int ccol = g * 8 + (t.c16 & 7);
+            const bool in_blk = ccol >= kb0 && ccol < kb0 + bs;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int lrow = t.rb[r] * 16 + t.kk + 4 * e;
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                double vre = p1[r][p][e] - p2[r][p][e], vim = p3[r][p][e] - s12;
+                if (in_blk) { vre = A[lrow + BINV_B * (ccol - kb0)]; vim = A[BINV_B * BINV_B + lrow + BINV_B * (ccol - kb0)]; }
+                double *o = out + (size_t)(kb0 + lrow) * PW + g * 16 + (t.c16 & 7);
+                o[0] = vre; o[8] = vim;
+            }
+        }
+    }
+}
+
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_binv_rest(const double *__restrict__ Cin, const double *__restrict__ Win,
+                                                  size_t in_stride, double *__restrict__ Wout, int Np, int nmat, int kb0, int bs,
+                                                  int *__restrict__ flags, double thresh)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, (Np - bs) >> 4, Np >> 3, 1, nmat)) return;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) if (t.rb[r] >= (kb0 >> 4)) t.rb[r] += bs >> 4;       // the row blocks outside block k
+    const int n = t.n + 1, PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
+    const double *Are = Cin + (size_t)n * 2 * pl + (size_t)Np * kb0;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    double *out = Wout + (size_t)n * panel;
+    cgemm3_tile_planes<false>(p1, p2, p3, t, Are, Are + pl, out + (size_t)kb0 * PW, PW, Np, bs);
+    const double *in = Win + (size_t)n * in_stride;
+    bool bad = false;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            const int ccol = g * 8 + (t.c16 & 7);
+            const bool in_blk = ccol >= kb0 && ccol < kb0 + bs;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const size_t o = (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PW + g * 16 + (t.c16 & 7);
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                const double bre = in_blk ? 0.0 : in[o], bim = in_blk ? 0.0 : in[o + 8];
+                const double vre = bre - (p1[r][p][e] - p2[r][p][e]), vim = bim - (p3[r][p][e] - s12);
+                if (in_blk) bad = bad || !(fabs(vre) <= thresh && fabs(vim) <= thresh);      // multiplier block -W_ik D (NaN counts)
+                out[o] = vre; out[o + 8] = vim;
+            }
+        }
+    }
+    if (bad) flags[n] = 1;
+}
+
+// panel layout -> column-major planes C[row + Np col] (+ Np^2: imaginary parts) for the columns [col0, col0 + nc) of every
+// matrix, and (T != null) row-major planes T[row Np + col].  32 x 32 tiles through LDS, both sides in runs of 8-32 doubles.
+// grid (ceil(Np/32) * ceil(nc/32), nmat)
+__global__ __launch_bounds__(256) void k_binv_planes(const double *__restrict__ Win, size_t in_stride, double *__restrict__ C, double *__restrict__ T,
+                                                     int Np, int col0, int nc)
+{
+    __shared__ double tre[32][33], tim[32][33];
+    const int n = blockIdx.y + 1, PW = 2 * Np;
+    const size_t pl = (size_t)Np * Np;
+    const int ctiles = (nc + 31) / 32, r0 = (blockIdx.x / ctiles) * 32, c0 = col0 + (blockIdx.x % ctiles) * 32;
+    const double *in = Win + (size_t)n * in_stride;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = threadIdx.x + k * 256, rl = idx >> 5, cl = idx & 31, row = r0 + rl, col = c0 + cl;
+        if (row < Np && col < col0 + nc) {
+            const size_t o = (size_t)row * PW + (col >> 3) * 16 + (col & 7);
+            tre[rl][cl] = in[o]; tim[rl][cl] = in[o + 8];
+        }
+    }
+    __syncthreads();
+    double *Cn = C + (size_t)n * 2 * pl;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = threadIdx.x + k * 256;
+        {
+            const int cl = idx >> 5, rl = idx & 31, row = r0 + rl, col = c0 + cl;
+            if (row < Np && col < col0 + nc) { Cn[(size_t)row + (size_t)Np * col] = tre[rl][cl]; Cn[pl + (size_t)row + (size_t)Np * col] = tim[rl][cl]; }
+        }
+        if (T) {
+            const int rl = idx >> 5, cl = idx & 31, row = r0 + rl, col = c0 + cl;
+            if (row < Np && col < col0 + nc) { T[(size_t)n * 2 * pl + (size_t)row * Np + col] = tre[rl][cl]; T[(size_t)n * 2 * pl + pl + (size_t)row * Np + col] = tim[rl][cl]; }
         }
     }
 }
@@ -1202,6 +1331,42 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
 
 // tile shape by the number of column groups of the state panels
 #define DISPATCH_SHAPE(ngroups, CALL) do { if ((ngroups) >= 3) CALL(2, 4); else if ((ngroups) == 2) CALL(4, 2); else CALL(4, 1); } while (0)
+
+size_t qgdk_dense_inverse_words(int Np, int nt)
+{
+    return (size_t)nt * (2 * (size_t)Np * 2 * Np + 2 * BINV_B * BINV_B) + (size_t)nt / 2 + 8;      // two panel buffers, D, flags
+}
+
+int qgdk_dense_inverse(const qgdk_ctx *c)
+{
+    if (!c->binv || !c->inv_scratch || !dense_3m() || getenv("QGD_BINV_OFF") || c->nt < 2) return 0;
+    const int Np = c->Np, nt = c->nt, nmat = nt - 1, PW = 2 * Np;
+    const size_t panel = (size_t)Np * PW;
+    double *PA = c->binv, *PB = PA + (size_t)nt * panel, *DkC = PB + (size_t)nt * panel;
+    int *flags = reinterpret_cast<int *>(DkC + (size_t)nt * 2 * BINV_B * BINV_B);
+    const double thresh = getenv("QGD_BINV_THRESH") ? atof(getenv("QGD_BINV_THRESH")) : 2.0;
+    if (hipMemsetAsync(flags, 0, (size_t)nt * sizeof(int), c->stream) != hipSuccess) return -1;
+    const double *Win = c->L;
+    double *outs[2] = {PA, PB};
+    int s = 0;
+    for (int kb0 = 0; kb0 < Np; kb0 += BINV_B, s++) {
+        const int bs = (Np - kb0 < BINV_B) ? Np - kb0 : BINV_B;
+        double *Wout = outs[s & 1];
+        hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((bs + 31) / 32), nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA,
+                           (double *)nullptr, Np, kb0, bs);
+        if (qgdk_inverse_diag(c, Win, panel, PW, (size_t)kb0 * PW + 2 * (size_t)kb0, bs, DkC, flags)) return -1;
+        hipLaunchKernelGGL((k_binv_row<1, 4>), dim3(dense_grid(1, 4, bs / 16, Np / 8, 1, nmat)), dim3(256), 0, c->stream, DkC, Win, panel, Wout,
+                           Np, nmat, kb0, bs);
+        if (Np > bs)
+            hipLaunchKernelGGL((k_binv_rest<2, 4>), dim3(dense_grid(2, 4, (Np - bs) / 16, Np / 8, 1, nmat)), dim3(256), 0, c->stream, c->LinvA,
+                               Win, panel, Wout, Np, nmat, kb0, bs, flags, thresh);
+        Win = Wout;
+    }
+    hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((Np + 31) / 32), nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA, c->LinvT,
+                       Np, 0, Np);
+    if (qgdk_inverse_redo(c, flags)) return -1;
+    return hipGetLastError() == hipSuccess ? 1 : -1;
+}
 
 // returns 1 when the three-product propagator kernel took the launch (else the caller runs k_propagator)
 int qgdk_dense_propagator(const qgdk_ctx *c)

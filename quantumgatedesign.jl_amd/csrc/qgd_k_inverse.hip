@@ -1092,6 +1092,65 @@ void k_inverse_multi(const double *__restrict__ L, const double *__restrict__ R,
 }
 
 // ---------------------------------------------------------------------------
+// Inverse of a diagonal block (bs = NP <= 64 rows) of the N > 64 work matrix, for the block Gauss-Jordan inverse of
+// qgd_k_dense.hip (qgdk_dense_inverse): the elimination of k_inverse_mfma (gj_panels: partial pivoting inside the block,
+// rank-4 MFMA steps, matrix in registers) on a block read with the row stride of the big matrix; the result goes out as
+// column-major planes D[i + 64 c] (+ 64*64: imaginary parts), the left operand of the block-row step.  A zero pivot marks the
+// matrix in flags[] (it is then redone with full pivoting) instead of raising the status word.
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_inverse_diag(const double *__restrict__ Win, size_t mstride, int ldw, size_t off, double *__restrict__ DkC, int n0,
+                    int *__restrict__ flags)
+{
+    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
+    constexpr int WORK = 8 * PW + 16 * NP + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
+    __shared__ double smem[SM];
+    __shared__ int rho[NP], rinv[NP];
+    __shared__ int sing;
+    const int n = n0 + blockIdx.x;
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int c16 = lane & 15, kk = lane >> 4;
+    const double *Ln = Win + (size_t)n * mstride + off;
+    d4 M[NG];
+    #pragma unroll
+    for (int g = 0; g < NG; g++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * ldw + 16 * g + c16];
+    if (t == 0) sing = 0;
+    __syncthreads();
+#ifdef QGD_INVM_PROFILE
+    long long prof_last = clock64();
+#endif
+    (void)gj_panels<NP, false>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, (int)(blockIdx.x % NW), &sing);
+    __syncthreads();
+    if (t == 0 && sing) flags[n] = 1;
+    // A^-1[rinv[x]][rho[j]] = M[x][j], one plane at a time through LDS (row-major staging), written column-major
+    int orow[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) orow[r] = rinv[16 * w + kk + 4 * r] * LDP;
+    double *D = DkC + (size_t)n * 2 * 64 * 64;
+    #pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((c16 >> 3) == pass) {
+            #pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int oc = rho[8 * g + (c16 & 7)];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) smem[orow[r] + oc] = M[g][r];
+            }
+        }
+        lds_barrier();
+        #pragma unroll
+        for (int q = 0; q < NP * NP / NTH; q++) {
+            const int e = t + q * NTH, c = e / NP, i = e % NP;
+            D[pass * 64 * 64 + i + 64 * c] = smem[i * LDP + c];
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2 (any Np > 64 whose panels fit in LDS, Np <= 288): blocked Gauss-Jordan with the matrix in an
 // HBM/L2 work slab (panel layout) and 16 pivots per panel.  The same scheme as k_inverse_mfma --
 // implicit pivoting, the pivoted in-place elimination of the Np x 16 panel yields the multipliers,
@@ -1259,9 +1318,13 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
                                                           double *__restrict__ LinvA,
                                                           double *__restrict__ LinvT,
                                                           double *__restrict__ scratch, int Np, int n0,
-                                                          int *__restrict__ status)
+                                                          int *__restrict__ status, const int *__restrict__ redo = nullptr)
 {
     constexpr int NB = INVB_NB, SB = INVB_SB;
+    if (redo) {                                      // fallback pass of the block Gauss-Jordan inverse: only the marked matrices
+        if (!redo[n0 + blockIdx.x]) return;
+        if (threadIdx.x == 0) atomicAdd(status + 1, 1);      // (counted: qgd_get_intermediate "repivoted")
+    }
     extern __shared__ double smem[];
     const int PW = 2 * Np;
     double *Fre = smem, *Fim = Fre + (size_t)Np * NB;          // panel columns -> multipliers
@@ -1665,13 +1728,17 @@ int qgdk_inverse(const qgdk_ctx *c)
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
     }
+    if (c->Np > 64 && c->dense_gemm && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {
+        const int took = qgdk_dense_inverse(c);              // block Gauss-Jordan as batched GEMM launches (qgd_k_dense.hip)
+        if (took) return took < 0 ? (int)hipErrorUnknown : (int)hipGetLastError();
+    }
     if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {
         const size_t shm = inverse_blocked2_lds(c->Np);      // two block levels: 64-column super-panels
         HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
             const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
             hipLaunchKernelGGL(k_inverse_blocked2, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch,
-                               c->Np, n0, c->status);
+                               c->Np, n0, c->status, (const int *)nullptr);
         }
         return (int)hipGetLastError();
     }
@@ -1701,6 +1768,31 @@ int qgdk_inverse(const qgdk_ctx *c)
             hipLaunchKernelGGL(k_inverse, dim3(nb), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT,
                                c->inv_scratch, c->Np, n0, 0, c->status);
         }
+    }
+    return (int)hipGetLastError();
+}
+
+int qgdk_inverse_diag(const qgdk_ctx *c, const double *Win, size_t mstride, int ldw, size_t off, int bs, double *DkC, int *flags)
+{
+    const int nmat = c->nt - 1;
+    switch (bs) {
+#define CALL_ID(N) case N: hipLaunchKernelGGL((k_inverse_diag<N>), dim3(nmat), dim3(N * 4), 0, c->stream, Win, mstride, ldw, off, DkC, 1, flags); break
+        CALL_ID(16); CALL_ID(32); CALL_ID(48); CALL_ID(64);
+#undef CALL_ID
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+// the matrices marked in flags[] again, by k_inverse_blocked2 (partial pivoting over whole columns) from the untouched L
+int qgdk_inverse_redo(const qgdk_ctx *c, const int *flags)
+{
+    const size_t shm = inverse_blocked2_lds(c->Np);
+    HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+        const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+        hipLaunchKernelGGL(k_inverse_blocked2, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch, c->Np, n0,
+                           c->status, flags);
     }
     return (int)hipGetLastError();
 }

@@ -233,3 +233,49 @@ def test_three_product_tiles_against_four(qgd, N, c, n_ops, order, form, monkeyp
     assert np.abs(out[False][2] - out[True][2]).max() <= 1e-12 * np.abs(out[True][2]).max()
     assert np.abs(out[False][0] - out[True][0]).max() <= 1e-11 * np.abs(out[True][0]).max()
     assert np.abs(out[False][1] - out[True][1]).max() <= 1e-12 * max(1.0, np.abs(out[True][1]).max())
+
+
+@pytest.mark.parametrize("N,c,order", [(256, 32, 8), (144, 24, 8), (80, 16, 4), (272, 16, 6)])
+def test_block_gauss_jordan_inverse_and_its_fallback(qgd, N, c, order, monkeypatch):
+    """Round 3: for N > 64 the step matrices are inverted by block Gauss-Jordan over 64-column blocks -- pivoting inside
+    the diagonal blocks only, the block operations as batched GEMM tiles (qgdk_dense_inverse) -- and a matrix whose block
+    multipliers exceed a threshold (or whose diagonal block meets a zero pivot) is redone by k_inverse_blocked2 with
+    partial pivoting over whole columns.  Three routes must agree: the default (nothing redone on these matrices), every
+    matrix forced through the fallback (QGD_BINV_THRESH=0), and the round-2 kernel alone (QGD_BINV_OFF=1, a new handle);
+    N = 80, 144, 272: last blocks of 16 columns."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=6, tf=0.06, seed=3 * N)
+    out = {}
+    for tag, env in (("default", {}), ("forced_fallback", {"QGD_BINV_THRESH": "0"}), ("off", {"QGD_BINV_OFF": "1"})):
+        for k in ("QGD_BINV_THRESH", "QGD_BINV_OFF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        g, o = dp.discrete_adjoint(pcof)
+        out[tag] = (g, np.asarray(o), dp.intermediate("Linv"), dp.intermediate("L"), int(dp.intermediate("repivoted")))
+        dp.close()
+    Linv, L = out["default"][2], out["default"][3]
+    eye = np.eye(N)
+    for n in range(1, prob.nsteps + 1):
+        assert np.abs(Linv[n][:N, :N] @ L[n][:N, :N] - eye).max() <= 1e-12
+    assert out["default"][4] == 0 and out["off"][4] == 0
+    assert out["forced_fallback"][4] == prob.nsteps                 # every matrix of the grid went through the fallback
+    for tag in ("forced_fallback", "off"):
+        assert np.abs(out[tag][2] - Linv).max() <= 1e-12 * np.abs(Linv).max(), tag
+        assert np.abs(out[tag][0] - out["default"][0]).max() <= 1e-11 * np.abs(out["default"][0]).max(), tag
+
+
+def test_block_gauss_jordan_falls_back_on_large_time_steps(qgd, monkeypatch):
+    """With time steps far beyond what the scheme is accurate at (dt |H| ~ 30: scripts/explore_binv.py prints the sweep) the
+    leading blocks of L = sum_j c_j (-dt)^j D_j lose their conditioning (cond(L_11) ~ 1e4), some block multipliers pass the
+    threshold, those matrices are redone with partial pivoting, and L^-1 L = I holds for every time point either way."""
+    N = 128
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=16, n_ops=2, nsteps=8, tf=8 * 64.0, seed=77)
+    dp = qgd.DeviceProblem(prob, 4); dp.set_controls(ctrl); dp.set_target(target)
+    dp.discrete_adjoint(pcof)
+    Linv, L, redone = dp.intermediate("Linv"), dp.intermediate("L"), int(dp.intermediate("repivoted"))
+    dp.close()
+    assert redone > 0, "the case was meant to trip the multiplier check"
+    for n in range(1, prob.nsteps + 1):
+        r = np.abs(Linv[n][:N, :N] @ L[n][:N, :N] - np.eye(N)).max()
+        assert r <= 1e-9 * max(1.0, np.linalg.cond(L[n][:N, :N])), (n, r)
