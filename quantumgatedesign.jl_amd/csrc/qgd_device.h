@@ -140,6 +140,7 @@ int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
+int qgdk_dense_chain_step(hipStream_t stream, int adj, const double *P, const double *in, double *out, const double *forcing, int Np, int cp);
 int qgdk_dense_inverse(const qgdk_ctx *c);        // 1: the block Gauss-Jordan inverse took the launch, 0: not taken
 size_t qgdk_dense_inverse_words(int Np, int nt);  // doubles of work space it needs
 int qgdk_inverse_diag(const qgdk_ctx *c, const double *Win, size_t mstride, int ldw, size_t off, int bs, double *DkC, int *flags);

@@ -88,7 +88,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                int write_y, double *__restrict__ y2, double *__restrict__ y3,
                                                double *__restrict__ y4, int given_ab);
 
-__device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
+__host__ __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
 {
     const size_t pl2 = (size_t)2 * a.Np * a.Np;
     if (a.pm_bpr) return a.Pmat + (size_t)(n / a.pm_bpr) * a.pm_chunk + (size_t)(n % a.pm_bpr) * pl2;
@@ -1007,9 +1007,43 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+// A single sequential chain of states (nblocks = 1: the states at the super-block starts, the prefix over the lower ranks'
+// windows) on a big problem: one full-chip GEMM launch per step instead of one chain kernel on cp/8 workgroups
+// (k_chain_step in qgd_k_dense.hip; config 5: 28 -> 10 us per dependent step).  MODE 1: cur = P_n cur, out[n+1] = cur;
+// MODE 3: cur = P_n^H cur + forcing[n], out[n] = cur.
+template <int MODE>
+static bool chain_as_steps(const ChainArgs &a)
+{
+    if (MODE != 1 && MODE != 3) return false;
+    if (a.nblocks != 1 || a.S < 1 || getenv("QGD_CHAIN_NO_STEPS") || getenv("QGD_DENSE_4M")) return false;
+    if (a.fs_mode || a.guard_diag || a.sub_T || a.npre) return false;                  // plain chains only
+    const char *e = getenv("QGD_CHAIN_STEPS_MIN");                                   // (tests: the step path on small shapes)
+    return (long long)a.Np * a.Np * a.cp >= (e ? atoll(e) : 256LL * 256 * 64);
+}
+
+template <int MODE>
+static int launch_chain_steps(const ChainArgs &a, hipStream_t stream)
+{
+    constexpr bool ADJ = (MODE == 3);
+    const size_t hstep = (size_t)a.Np * 2 * a.cp;
+    const int e0 = (a.blen < a.S) ? a.blen : a.S;
+    const double *cur = a.start;
+    for (int st = 0; st < e0; st++) {
+        const int n = ADJ ? e0 - 1 - st : st, nout = ADJ ? n : n + 1;
+        const double *f = nullptr;
+        if (ADJ) f = a.forcing + (size_t)(a.f_bpr ? nout + nout / a.f_bpr : nout) * hstep;
+        double *o = a.out + (size_t)nout * hstep;
+        const int rc = qgdk_dense_chain_step(stream, ADJ ? 1 : 0, chain_matrix(a, n), cur, o, f, a.Np, a.cp);
+        if (rc) return rc;
+        cur = o;
+    }
+    return 0;
+}
+
 template <int MODE>
 static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 {
+    if (chain_as_steps<MODE>(a)) return launch_chain_steps<MODE>(a, stream);
     const long long cus = 256;      // (thresholds of 128 .. 1024 tiles give the same times within 2 %)
     static const long long t1 = getenv("QGD_CHAIN_T1") ? atoll(getenv("QGD_CHAIN_T1")) : cus - 1;     // (tuning; 8-column tiles only while they are fewer than the CUs)
     static const long long t2 = getenv("QGD_CHAIN_T2") ? atoll(getenv("QGD_CHAIN_T2")) : 2 * cus;

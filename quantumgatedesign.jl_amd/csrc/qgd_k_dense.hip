@@ -338,6 +338,58 @@ __device__ __forceinline__ void cgemm3_tile_planes(d4 (&p1)[DN_RB][DN_NG / 2], d
 #undef CP_MFMA
 }
 
+// ... with the left operand P^H taken from P's PANEL layout (row k of P holds [8 re | 8 im] groups over its columns):
+// element (row, k) of the operand = conj(P(k, row)), the eight lanes c16 & 7 read eight consecutive doubles (chain_a_raw<ADJ>
+// of qgd_k_chain.hip).  s = -1:  P1 = ar Br, P2 = ai Bi, P3 = (ar - ai)(Br + Bi);  Re = P1 + P2,  Im = P3 - P1 + P2.
+template <int DN_RB, int DN_NG>
+__device__ __forceinline__ void cgemm3_tile_panelH(d4 (&p1)[DN_RB][DN_NG / 2], d4 (&p2)[DN_RB][DN_NG / 2], d4 (&p3)[DN_RB][DN_NG / 2],
+                                                   const DenseTile<DN_RB, DN_NG> &t, const double *__restrict__ P,
+                                                   const double *__restrict__ B, size_t ldb, int Np, int K = -1)
+{
+    constexpr int NP = DN_NG / 2;
+    const __amdgpu_buffer_rsrc_t rp = buffer_of(P), rb_ = buffer_of(B);
+    if (K < 0) K = Np;
+    int av[DN_RB], bv[NP];
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        const int arow = (t.rb[r] >= 0 ? t.rb[r] : t.rb[0]) * 16 + t.c16;
+        av[r] = (t.kk * 2 * Np + (arow >> 3) * 16 + (arow & 7)) * 8;
+    }
+    #pragma unroll
+    for (int p = 0; p < NP; p++) {
+        int g = lane_group(t, p);
+        if (g < 0) g = t.g[0];
+        bv[p] = (t.kk * (int)ldb + g * 16 + (t.c16 & 7)) * 8;
+    }
+    const int nk4 = K >> 2, astep = 4 * 2 * Np * 8, bstep = 4 * (int)ldb * 8;
+    double ar0[DN_RB], ai0[DN_RB], ar1[DN_RB], ai1[DN_RB], br0[NP], bi0[NP], br1[NP], bi1[NP];
+#define CH_LOAD(ar, ai, br, bi, k) do {                                                                        \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) { ar[r] = buffer_load_f64(rp, av[r], (k) * astep);     \
+                                                            ai[r] = buffer_load_f64(rp, av[r] + 64, (k) * astep); } \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) { br[p] = buffer_load_f64(rb_, bv[p], (k) * bstep);       \
+                                                         bi[p] = buffer_load_f64(rb_, bv[p] + 64, (k) * bstep); } } while (0)
+#define CH_MFMA(ar, ai, br, bi) do {                                                                           \
+        double as[DN_RB], bs[NP];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < DN_RB; r++) as[r] = ar[r] - ai[r];                                \
+        _Pragma("unroll") for (int p = 0; p < NP; p++) bs[p] = br[p] + bi[p];                                   \
+        _Pragma("unroll") for (int p = 0; p < NP; p++)                                                         \
+            _Pragma("unroll") for (int r = 0; r < DN_RB; r++) {                                                \
+                p1[r][p] = MFMA(ar[r], br[p], p1[r][p]);                                                       \
+                p2[r][p] = MFMA(ai[r], bi[p], p2[r][p]);                                                       \
+                p3[r][p] = MFMA(as[r], bs[p], p3[r][p]);                                                       \
+            } } while (0)
+    CH_LOAD(ar0, ai0, br0, bi0, 0);
+    for (int k4 = 0; k4 < nk4; k4 += 2) {
+        CH_LOAD(ar1, ai1, br1, bi1, k4 + 1);
+        CH_MFMA(ar0, ai0, br0, bi0);
+        const int kn = (k4 + 2 < nk4) ? k4 + 2 : k4;
+        CH_LOAD(ar0, ai0, br0, bi0, kn);
+        CH_MFMA(ar1, ai1, br1, bi1);
+    }
+#undef CH_LOAD
+#undef CH_MFMA
+}
+
 #define ZERO_ACC3(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG / 2; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
 // 3M switch of the N > 64 kernels (QGD_DENSE_4M=1 keeps the four-product tiles: A/B timing and tests)
 static bool dense_3m()
@@ -1299,6 +1351,64 @@ static int dense_sigma_form(const qgdk_ctx *c)
     return ((m + 1) / 2 < c->n_ops) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------
+// ONE step of a state chain as a GEMM over the whole chip:  out = P in  (ADJ: out = P^H in + forcing).  The chain kernels
+// (qgd_k_chain.hip) keep a column tile of the state in LDS over all the steps of a block and so put (blocks x column
+// tiles) workgroups on a chain; for the single sequential chains of the scan -- the states at the super-block starts,
+// the prefix over the windows of the lower ranks: nblocks = 1, 32 workgroups at config 5, 28 us per dependent step --
+// one launch per step with one 16 x 16 output tile per workgroup, its four waves splitting the contraction (256 workgroups
+// at config 5, 48 MFMAs per wave), is the shorter path.
+// ---------------------------------------------------------------------------
+template <bool ADJ>
+__global__ __launch_bounds__(256) void k_chain_step(const double *__restrict__ P, const double *__restrict__ in, double *__restrict__ out,
+                                                    const double *__restrict__ forcing, int Np, int cp)
+{
+    // workgroup = one 16 x 16 tile of the output (row block, pair of column groups); its four waves split the contraction
+    // (a quarter of K each: the dependent chain of loads is what a step costs, not its 192 MFMAs) and add up through LDS
+    __shared__ double part[3][64][8];
+    constexpr int DN_RB = 1, DN_NG = 2;
+    const int nrb = Np >> 4, npair = (cp + 15) >> 4, ngroups = cp >> 3;
+    const int rb = blockIdx.x / npair, pr = blockIdx.x % npair;
+    if (rb >= nrb) return;
+    DenseTile<1, 2> t;
+    t.n = 0; t.sub = 0; t.rb[0] = rb; t.g[0] = 2 * pr; t.g[1] = (2 * pr + 1 < ngroups) ? 2 * pr + 1 : -1;
+    t.lane = threadIdx.x & 63; t.c16 = t.lane & 15; t.kk = t.lane >> 4; t.sign_hi = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int PWc = 2 * cp;
+    // K = Np split in four ranges of whole 16-column chunks (Np is a multiple of 16)
+    const int chunks = Np >> 4, c0 = (chunks * wave) >> 2, c1 = (chunks * (wave + 1)) >> 2;
+    const int kbeg = c0 * 16, klen = (c1 - c0) * 16;
+    d4 p1[1][1], p2[1][1], p3[1][1];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    if (klen > 0) {
+        const double *inb = in + (size_t)kbeg * PWc;
+        if (ADJ) cgemm3_tile_panelH(p1, p2, p3, t, P + (size_t)kbeg * 2 * Np, inb, PWc, Np, klen);
+        else cgemm3_tile_planes<false>(p1, p2, p3, t, P + (size_t)Np * kbeg, P + (size_t)Np * Np + (size_t)Np * kbeg, inb, PWc, Np, klen);
+    }
+    double v[8];
+    #pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (ADJ) { v[2 * e] = p1[0][0][e] + p2[0][0][e]; v[2 * e + 1] = p3[0][0][e] - p1[0][0][e] + p2[0][0][e]; }
+        else { v[2 * e] = p1[0][0][e] - p2[0][0][e]; v[2 * e + 1] = p3[0][0][e] - p1[0][0][e] - p2[0][0][e]; }
+    }
+    if (wave > 0) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) part[wave - 1][t.lane][q] = v[q];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int g = lane_group(t, 0);
+    if (g < 0) return;
+    #pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const size_t o = (size_t)(rb * 16 + t.kk + 4 * e) * PWc + g * 16 + (t.c16 & 7);
+        double vre = v[2 * e] + part[0][t.lane][2 * e] + part[1][t.lane][2 * e] + part[2][t.lane][2 * e];
+        double vim = v[2 * e + 1] + part[0][t.lane][2 * e + 1] + part[1][t.lane][2 * e + 1] + part[2][t.lane][2 * e + 1];
+        if (forcing) { vre += forcing[o]; vim += forcing[o + 8]; }
+        out[o] = vre; out[o + 8] = vim;
+    }
+}
+
 extern "C" {
 
 int qgdk_dense_operator_frag(const qgdk_ctx *c)
@@ -1331,6 +1441,15 @@ int qgdk_dense_build_LR(const qgdk_ctx *c)
 
 // tile shape by the number of column groups of the state panels
 #define DISPATCH_SHAPE(ngroups, CALL) do { if ((ngroups) >= 3) CALL(2, 4); else if ((ngroups) == 2) CALL(4, 2); else CALL(4, 1); } while (0)
+
+// one chain step on the whole chip (see k_chain_step): P = column-major planes (forward) or the panel of P (adjoint, P^H)
+int qgdk_dense_chain_step(hipStream_t stream, int adj, const double *P, const double *in, double *out, const double *forcing, int Np, int cp)
+{
+    const int grid = (Np / 16) * ((cp + 15) / 16);
+    if (adj) hipLaunchKernelGGL((k_chain_step<true>), dim3(grid), dim3(256), 0, stream, P, in, out, forcing, Np, cp);
+    else hipLaunchKernelGGL((k_chain_step<false>), dim3(grid), dim3(256), 0, stream, P, in, out, forcing, Np, cp);
+    return (int)hipGetLastError();
+}
 
 size_t qgdk_dense_inverse_words(int Np, int nt)
 {

@@ -279,3 +279,39 @@ def test_block_gauss_jordan_falls_back_on_large_time_steps(qgd, monkeypatch):
     for n in range(1, prob.nsteps + 1):
         r = np.abs(Linv[n][:N, :N] @ L[n][:N, :N] - np.eye(N)).max()
         assert r <= 1e-9 * max(1.0, np.linalg.cond(L[n][:N, :N])), (n, r)
+
+
+@pytest.mark.parametrize("N,c,world", [(128, 64, 1), (144, 24, 3), (80, 40, 2)])
+def test_sequential_chains_as_full_chip_steps(qgd, N, c, world, monkeypatch):
+    """The single sequential chains of the scan on big problems (states at the super-block starts, the prefix over the
+    lower ranks' windows, and their adjoint counterparts) run one full-chip GEMM launch per step (k_chain_step: 16 x 16
+    output tiles, the four waves of a workgroup split the contraction) instead of one chain kernel on c/8 workgroups.
+    The switch depends on the size (N^2 c >= 256^2 64); here the step path is forced on small shapes (QGD_CHAIN_STEPS_MIN=1)
+    -- partial column pairs (c = 24, 40: 3 and 5 groups), N not a multiple of 64, a time partition of 2 and 3 ranks --
+    against the chain kernels (QGD_CHAIN_NO_STEPS=1) and the numpy statement."""
+    import torch
+    order = 8
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=40, tf=0.4, seed=N + world)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for tag, env in (("steps", {"QGD_CHAIN_STEPS_MIN": "1"}), ("chains", {"QGD_CHAIN_NO_STEPS": "1"})):
+        for k in ("QGD_CHAIN_STEPS_MIN", "QGD_CHAIN_NO_STEPS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        if world == 1:
+            dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+            dp.set_timing(1)
+            g, o = dp.discrete_adjoint(pcof)
+            dp.close()
+        else:
+            backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, world, device=0, stream=stream) for r in range(world)]
+            g, o = qgd.LocalGroup(backs).discrete_adjoint(pcof)[world - 1]
+            for b in backs:
+                b.close()
+        assert np.abs(g - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max(), tag
+        res[tag] = (g, np.asarray(o))
+    assert np.abs(res["steps"][0] - res["chains"][0]).max() <= 1e-11 * np.abs(res["chains"][0]).max()
+    assert np.abs(res["steps"][1] - res["chains"][1]).max() <= 1e-12 * max(1.0, np.abs(res["chains"][1]).max())
