@@ -207,7 +207,9 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
 /* Diagnostics: copy a named intermediate of the last evaluation to the host.
  * Names: "L", "R", "Linv", "P" (complex, returned as [nt][N][N][2] C-order),
  * "sigma" ([nt][n_ops][m][2]), "tables" ([nt][m][n_ops][2]), "repivoted" (1 value: how many step matrices of the last
- * evaluation needed partial pivoting after the static-pivot attempt, N = 64 only).  Returns the number
+ * evaluation were redone with full partial pivoting -- N > 64: after the block Gauss-Jordan inverse, which pivots inside its
+ * 64-column diagonal blocks only, found a block multiplier above its threshold; N = 64: after the optional static-pivot
+ * attempt).  Returns the number
  * of doubles the buffer needs through *needed when out == NULL. */
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);
