@@ -268,6 +268,7 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
     const size_t panel = Np * PW, pl = Np * Np, hstep = Np * PWc;
     const size_t nb = (size_t)k.scan_blocks, W = (size_t)k.part_world, nb2 = (size_t)k.scan_blocks2;
     k.sigma_planes = k.cp / 8;
+    if (Np > 64 && !getenv("QGD_DENSE_OLD")) k.sigma_planes = std::max(k.sigma_planes, qgdk_dense_sigma_planes_max(k.Np, k.cp, k.m));
     bool ok = A(&k.tab, nt * (m + 1) * (size_t)std::max(k.n_ops, 1) * 2) && A(&k.D, nt * m * panel) && A(&k.L, nt * panel) &&
               A(&k.R, nt * panel) && A(&k.LinvA, nt * 2 * pl) && A(&k.LinvT, nt * 2 * pl) && A(&k.Pr, nt * panel) &&
               A(&k.Pc, nt * 2 * pl) && A(&k.hist, nt * hstep) && A(&k.dpsi, nt * m * hstep) && A(&k.forcing, nt * hstep) &&
@@ -1220,6 +1221,8 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     CREATE_TRY(hipMemset(k.target, 0, Np * PWc * sizeof(double)));
     CREATE_RC(dev_alloc(h, h->static_bufs, &h->scal_static, (size_t)8));
     k.scal = h->scal_static;
+    CREATE_RC(dev_alloc(h, h->static_bufs, &k.term_part, (size_t)2 * 1024 + 2));
+    (void)hipMemset(k.term_part, 0, ((size_t)2 * 1024 + 2) * sizeof(double));       // (the ticket counter behind the partial sums)
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.cw, (size_t)2 * 20));
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.status, (size_t)2));
     h->status_static = k.status;
@@ -1772,10 +1775,11 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         return QGD_OK;
     }
     if (s == "sigma") {      // (the column groups' planes of the N <= 64 gradient kernels are summed here)
-        const bool planes = k.use_sparse || (k.Np == 64 && k.m <= 5 && k.n_ops >= 1);
+        const bool planes = k.use_sparse || (k.Np == 64 && k.m <= 5 && k.n_ops >= 1) || k.dense_gemm;
+        const int nplanes = k.dense_gemm ? qgdk_dense_sigma_planes(&k) : k.sigma_planes;
         HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> pl_(need);
-        for (int g = 1; planes && g < k.sigma_planes; g++) {
+        for (int g = 1; planes && g < nplanes; g++) {
             HIP_TRY(h, hipMemcpy(pl_.data(), k.sigma + (size_t)g * need, need * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t e = 0; e < need; e++) out[e] += pl_[e];
         }

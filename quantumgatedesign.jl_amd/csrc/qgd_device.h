@@ -45,10 +45,11 @@ typedef struct qgdk_ctx {
     double *sigma;      // [sigma_planes][nt][n_ops][m][2]: one plane per column group for the kernels whose grid is
                         // (column group, time point) -- each workgroup STORES its plane, k_contract adds the planes in
                         // order (no atomics: the gradient is bitwise reproducible); the other kernels add into plane 0
-    int sigma_planes;   // planes allocated (cp / 8)
+    int sigma_planes;   // planes allocated (cp / 8; N > 64: one per contributing tile, qgdk_dense_sigma_planes_max)
     double *cpart;      // [time chunks of k_contract][n_pcof] partial sums, added in chunk order by k_contract_sum
     double *grad;       // [n_pcof]
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
+    double *term_part;  // [2 * 1024 + 1]: per-workgroup partial overlaps of k_terminal_sum and its ticket counter (zeroed at creation)
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *binv;       // work space of the block Gauss-Jordan inverse for N > 64 (qgdk_dense_inverse), or null
     double *inv_scratch;
@@ -140,6 +141,8 @@ int qgdk_guard_kernel(const qgdk_ctx *c);
 int qgdk_build_LR_sparse(const qgdk_ctx *c);
 int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
+int qgdk_dense_sigma_planes(const qgdk_ctx *c);   // planes of sigma the N > 64 gradient kernels write for the form in use
+int qgdk_dense_sigma_planes_max(int Np, int cp, int m);
 int qgdk_dense_chain_step(hipStream_t stream, int adj, const double *P, const double *in, double *out, const double *forcing, int Np, int cp);
 int qgdk_dense_inverse(const qgdk_ctx *c);        // 1: the block Gauss-Jordan inverse took the launch, 0: not taken
 size_t qgdk_dense_inverse_words(int Np, int nt);  // doubles of work space it needs

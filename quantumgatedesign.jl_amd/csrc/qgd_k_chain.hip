@@ -1353,13 +1353,17 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
 }
 
 
-// the same in two launches of many workgroups, for panels of >= 32768 elements: partial overlaps by atomics, then y_N
+// the same in two launches of many workgroups, for panels of >= 32768 elements: partial overlaps per workgroup, then y_N.
+// The partial sums are STORED (part[2 b], part[2 b + 1]); the workgroup that draws the last ticket adds them in index order
+// and writes scal[0..1] -- the same bits whichever workgroup that is (the gradient depends on these two numbers through
+// the terminal condition: with atomicAdd here the N > 64 gradient differed in its last bits from run to run).
 __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__ w, const double *__restrict__ target,
-                                                      double *__restrict__ scal, int hstep, int PWc, int cost)
+                                                      double *__restrict__ scal, int hstep, int PWc, int cost, double *__restrict__ part, int chunk)
 {
     __shared__ double red[8];
+    __shared__ int last;
     double a = 0.0, b = 0.0;
-    for (int e = blockIdx.x * 2048 + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * 2048); e += 256) {
+    for (int e = blockIdx.x * chunk + threadIdx.x; e < min(hstep, (int)(blockIdx.x + 1) * chunk); e += 256) {
         if (cost) { const double d = (cost == 1) ? w[e] - target[e] : w[e]; a += 0.5 * d * d; continue; }   // :Tracking / :Norm
         const int c16 = (e % PWc) & 15;
         const double tp = target[e ^ 8];
@@ -1369,10 +1373,20 @@ __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
+    int *ticket = reinterpret_cast<int *>(part + 2 * 1024);
     if (threadIdx.x == 0) {
-        atomicAdd(&scal[0], red[0] + red[1] + red[2] + red[3]);
-        atomicAdd(&scal[1], red[4] + red[5] + red[6] + red[7]);
+        part[2 * blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        part[2 * blockIdx.x + 1] = ((red[4] + red[5]) + red[6]) + red[7];
+        __threadfence();                                          // release: the partial sums before the ticket
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
     }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();                                              // acquire: every other workgroup's partial sums
+    double A = 0.0, B = 0.0;
+    for (int g = 0; g < (int)gridDim.x; g++) { A += __builtin_nontemporal_load(part + 2 * g); B += __builtin_nontemporal_load(part + 2 * g + 1); }
+    scal[0] = A; scal[1] = B;
+    *ticket = 0;                                                  // for the next evaluation (same stream: ordered)
 }
 
 __global__ __launch_bounds__(256) void k_terminal_y(const double *__restrict__ target, const double *__restrict__ f,
@@ -1616,10 +1630,11 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
     if (hstep >= 32768 && !getenv("QGD_TERMINAL_ONE_WG")) {
         // large panels (config 5: 131072 elements): one workgroup took 177 us; many workgroups, two launches
         const int nwg = (int)((hstep + 2047) / 2048);
+        const int tchunk = 2048 * ((nwg + 1023) / 1024), twg = (int)((hstep + tchunk - 1) / tchunk);      // (<= 1024 partial sums)
         const double *w = c->hist + (size_t)(c->nt - 1) * hstep;
         if (!given_ab) {
             HIPCHK(hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
-            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(nwg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type);
+            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(twg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type, c->term_part, tchunk);
         }
         if (write_y)
             hipLaunchKernelGGL(k_terminal_y, dim3(nwg), dim3(256), 0, c->stream, c->target, c->forcing + (size_t)(c->nt - 1) * hstep,

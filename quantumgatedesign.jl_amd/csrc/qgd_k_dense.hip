@@ -23,6 +23,7 @@
 // id%8 selects the XCD and all tiles of one time point (which share A_d(t_n) and the panels of t_n)
 // are given ids that land on the same XCD, i.e. in the same L2.
 #include "qgd_kernels_common.h"
+#include <algorithm>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -47,6 +48,7 @@ __device__ __forceinline__ size_t frag_index(int Np, int row, int k)
 template <int DN_RB, int DN_NG>
 struct DenseTile {
     int n, sub, rb[DN_RB], g[DN_NG];     // time point, sub-index (level / source), row blocks and groups (-1 = outside)
+    int slot, ntile;                     // index of the workgroup's tile among the T = ntile * nsub tiles of its time point (ntile = rtiles * ctiles)
     int lane, c16, kk, sign_hi;
 };
 
@@ -70,6 +72,7 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
         r = q % T;
     }
     if (t.n >= nt) return false;
+    t.slot = r; t.ntile = rtiles * ctiles;
     t.sub = r / (rtiles * ctiles);
     r %= rtiles * ctiles;
     const int rt = r / ctiles, ct = r % ctiles;
@@ -888,14 +891,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// Fixed-order reduction of the gradient scalars (round 3: the N > 64 kernels are bitwise reproducible too).  Every wave adds
+// into its OWN LDS slots sigw[wave][.] (wave_sig); after the barrier thread e adds the four slots in order and STORES the
+// sum into the workgroup's own plane of sigma -- plane = the tile's slot inside its time point -- and k_contract adds the
+// planes in order.  No atomics: every (plane, n, o, d) entry has exactly one writer.
+__device__ __forceinline__ double *wave_sig(double *sig, int nvals) { return sig + (threadIdx.x >> 6) * nvals; }
+__device__ __forceinline__ double sum_wave_sig(const double *sig, int nvals, int e)
+{
+    return ((sig[e] + sig[nvals + e]) + sig[2 * nvals + e]) + sig[3 * nvals + e];
+}
+
 // sigma[n][o][d][2] += (1/j) < (dA_d/d{p,q}_o) psi_i, g_j >, j = i+1+d, for the source level i (sub-index)
 template <int DN_RB, int DN_NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ginner_f(const d2 *__restrict__ OpFrag, const double *__restrict__ hist,
                                                   const double *__restrict__ dpsi, const double *__restrict__ Gp,
                                                   double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
 {
-    extern __shared__ double sig[];          // [n_ops][m][2]
-    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    extern __shared__ double sig[];          // [4 waves][n_ops][m][2]
+    for (int e = threadIdx.x; e < 4 * n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
     __syncthreads();
     DenseTile<DN_RB, DN_NG> t;
     const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt);
@@ -931,17 +944,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
                 if (t.lane == 0) {
                     const int d = j - 1 - i;
-                    atomicAdd(&sig[(o * m + d) * 2], sp / (double)j);
-                    atomicAdd(&sig[(o * m + d) * 2 + 1], sq / (double)j);
+                    double *sw = wave_sig(sig, n_ops * m * 2);       // this wave's own slots
+                    sw[(o * m + d) * 2] += sp / (double)j;
+                    sw[(o * m + d) * 2 + 1] += sq / (double)j;
                 }
             }
         }
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
-    const int dmax = m - t.sub;              // only d = 0 .. m-1-i were touched
+    // plane = the tile's slot (source level i included): entries d >= m - i of it are zero (sum_wave_sig of untouched slots)
+    const size_t plane = (size_t)nt * n_ops * m * 2;
     for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x)
-        if ((e >> 1) % m < dmax) atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + e], sig[e]);
+        sigma[(size_t)t.slot * plane + (size_t)t.n * n_ops * m * 2 + e] = sum_wave_sig(sig, n_ops * m * 2, e);
 }
 
 // The same scalars from OUTER products over the columns instead of operator applications:
@@ -1143,7 +1158,7 @@ __device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], co
             }
         }
         for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
-        if (t.lane == 0) { atomicAdd(&sig[o * 2], sp * w); atomicAdd(&sig[o * 2 + 1], sq * w); }
+        if (t.lane == 0) { sig[o * 2] += sp * w; sig[o * 2 + 1] += sq * w; }      // (sig: this wave's own slots)
     }
 }
 
@@ -1161,8 +1176,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                   const double *__restrict__ dpsi, const double *__restrict__ Gp,
                                                   double *__restrict__ sigma, int Np, int cp, int n_ops, int m, int nt)
 {
-    extern __shared__ double sig[];          // [n_ops][2] of this workgroup's d
-    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x) sig[e] = 0.0;
+    extern __shared__ double sig[];          // [4 waves][n_ops][2] of this workgroup's d
+    for (int e = threadIdx.x; e < 4 * n_ops * 2; e += blockDim.x) sig[e] = 0.0;
     __syncthreads();
     DenseTile<DN_RB, DN_NG> t;
     const bool active = dense_tile(t, Np >> 4, Np >> 4, m, nt);      // "groups" = 16-row blocks r2 of psi
@@ -1185,12 +1200,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                           (i == 0) ? hist + (size_t)t.n * hstep : dpsi + ((size_t)t.n * m + (i - 1)) * hstep, (size_t)PWc, cp >> 3);
         }
         outer_finish<M3>(aR, aA, aB);
-        frobenius_sigma(aR, aA, t, ops, Np, n_ops, 1.0 / (double)m, sig);      // (the last pair of every d has j = m)
+        frobenius_sigma(aR, aA, t, ops, Np, n_ops, 1.0 / (double)m, wave_sig(sig, n_ops * 2));      // (the last pair of every d has j = m)
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
+    const int tile = t.slot - t.sub * t.ntile;       // plane = position of the tile inside its (n, d)
+    const size_t plane = (size_t)nt * n_ops * m * 2;
     for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x)
-        atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)], sig[e]);
+        sigma[(size_t)tile * plane + (size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)] = sum_wave_sig(sig, n_ops * 2, e);
 }
 
 // ... and without the stage derivatives psi_i = D_i psi_0 at all:  M(i, j) = g_j psi_0^H D_i^H, so
@@ -1238,8 +1255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                                                   const double *__restrict__ D, double *__restrict__ sigma, int Np, int n_ops, int m, int nt,
                                                   const d2 *__restrict__ Xfrag, const d2 *__restrict__ Dfrag)
 {
-    extern __shared__ double sig[];          // [n_ops][2] of this workgroup's d
-    for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x) sig[e] = 0.0;
+    extern __shared__ double sig[];          // [4 waves][n_ops][2] of this workgroup's d
+    for (int e = threadIdx.x; e < 4 * n_ops * 2; e += blockDim.x) sig[e] = 0.0;
     __syncthreads();
     DenseTile<DN_RB, DN_NG> t;
     const bool active = dense_tile(t, Np >> 4, Np >> 4, m, nt);
@@ -1275,12 +1292,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             else outer_tile(aR, aA, aB, t, Xn + (size_t)(i + d) * panel, Dn + (size_t)(i - 1) * panel, (size_t)PW, Np >> 3);
         }
         outer_finish<M3>(aR, aA, aB);
-        frobenius_sigma(aR, aA, t, ops, Np, n_ops, WEIGHTED ? 1.0 / (double)m : 1.0, sig);
+        frobenius_sigma(aR, aA, t, ops, Np, n_ops, WEIGHTED ? 1.0 / (double)m : 1.0, wave_sig(sig, n_ops * 2));
     }
     __syncthreads();
     if (!active && t.n >= nt) return;
+    const int tile = t.slot - t.sub * t.ntile;       // plane = position of the tile inside its (n, d): one writer per entry
+    const size_t plane = (size_t)nt * n_ops * m * 2;
     for (int e = threadIdx.x; e < n_ops * 2; e += blockDim.x)
-        atomicAdd(&sigma[(size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)], sig[e]);
+        sigma[(size_t)tile * plane + (size_t)t.n * n_ops * m * 2 + ((e >> 1) * m + d) * 2 + (e & 1)] = sum_wave_sig(sig, n_ops * 2, e);
 }
 
 // Third form: the reverse sweep itself on N x N matrices.  g_j enters the scalars only through Y_j = g_j psi_0^H, the sweep
@@ -1521,6 +1540,17 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
+// planes of sigma the form in use writes (one per tile of a time point that contributes to an entry; k_contract adds them in order)
+static int sigma_planes_of(int form, int Np, int cp, int m)
+{
+    const int nrb = Np / 16, ng = cp / 8;
+    if (form >= 1) return ((nrb + 7) / 8) * ((nrb + 1) / 2);                       // <2,2> tiles over (row blocks, row blocks)
+    const int RB = ng >= 3 ? 2 : 4, NG = ng >= 3 ? 4 : (ng == 2 ? 2 : 1);            // DISPATCH_SHAPE
+    return ((nrb + 4 * RB - 1) / (4 * RB)) * ((ng + NG - 1) / NG) * m;
+}
+int qgdk_dense_sigma_planes(const qgdk_ctx *c) { return sigma_planes_of(dense_sigma_form(c), c->Np, c->cp, c->m); }
+int qgdk_dense_sigma_planes_max(int Np, int cp, int m) { return std::max(sigma_planes_of(0, Np, cp, m), sigma_planes_of(1, Np, cp, m)); }
+
 int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c) { return dense_sigma_form(c) < 2; }
 
 int qgdk_dense_gradient(const qgdk_ctx *c)
@@ -1552,10 +1582,10 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
 #undef CALL_GY
         }
         if (m3)
-            hipLaunchKernelGGL((k_ginner_d<2, 2, true, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_d<2, 2, true, true>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
         else
-            hipLaunchKernelGGL((k_ginner_d<2, 2, true, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_d<2, 2, true, false>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
         return (int)hipGetLastError();
     }
@@ -1572,7 +1602,7 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
 #undef CALL_GS
     }
 #define CALL_GI(RB, NG) hipLaunchKernelGGL((k_ginner_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), \
-                                           (size_t)c->n_ops * c->m * 2 * sizeof(double), c->stream,                             \
+                                           (size_t)4 * c->n_ops * c->m * 2 * sizeof(double), c->stream,                         \
                                            reinterpret_cast<const d2 *>(c->OpFrag), c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,  \
                                            c->n_ops, c->m, c->nt)
     // outer-product forms when they are fewer GEMM units and the contraction is long enough (dense_sigma_form)
@@ -1581,22 +1611,22 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     if (form == 2) {
         if (m3) {
             hipLaunchKernelGGL((k_gouter<2, 2, true>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt, Xf);
-            hipLaunchKernelGGL((k_ginner_d<2, 2, false, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_d<2, 2, false, true>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
         } else {
             hipLaunchKernelGGL((k_gouter<2, 2, false>), dim3(ogrid), dim3(256), 0, c->stream, c->hist, Gp, c->Xouter, c->Np, c->cp, c->m, c->nt,
                                (d2 *)nullptr);
-            hipLaunchKernelGGL((k_ginner_d<2, 2, false, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_d<2, 2, false, false>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->Xouter, c->D, c->sigma, c->Np, c->n_ops, c->m, c->nt, Xf, Df);
         }
         return (int)hipGetLastError();
     }
     if (form == 1) {
         if (dense_3m())
-            hipLaunchKernelGGL((k_ginner_m<2, 2, true>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_m<2, 2, true>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
         else
-            hipLaunchKernelGGL((k_ginner_m<2, 2, false>), dim3(ogrid), dim3(256), (size_t)c->n_ops * 2 * sizeof(double), c->stream, c->ops,
+            hipLaunchKernelGGL((k_ginner_m<2, 2, false>), dim3(ogrid), dim3(256), (size_t)4 * c->n_ops * 2 * sizeof(double), c->stream, c->ops,
                                c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp, c->n_ops, c->m, c->nt);
         return (int)hipGetLastError();
     }

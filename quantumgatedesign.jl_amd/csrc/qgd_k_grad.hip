@@ -625,7 +625,8 @@ int qgdk_contract(const qgdk_ctx *c)
     const int chunks = (c->nt + CT_CHUNK - 1) / CT_CHUNK;
     hipLaunchKernelGGL(k_contract, dim3(chunks, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
                        c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->nt, c->m, c->n_ops, c->status, c->scal,
-                       (c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)) ? c->sigma_planes : 1, c->cpart, c->n_pcof,
+                       c->dense_gemm ? qgdk_dense_sigma_planes(c) : (c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)) ? c->sigma_planes : 1,
+                       c->cpart, c->n_pcof,
                        c->g_nt ? c->g_nt : c->nt, c->g_n0);
     hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof, chunks,
                        c->grad_accumulate, (const int *)nullptr, (double *)nullptr);

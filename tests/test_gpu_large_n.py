@@ -315,3 +315,21 @@ def test_sequential_chains_as_full_chip_steps(qgd, N, c, world, monkeypatch):
         res[tag] = (g, np.asarray(o))
     assert np.abs(res["steps"][0] - res["chains"][0]).max() <= 1e-11 * np.abs(res["chains"][0]).max()
     assert np.abs(res["steps"][1] - res["chains"][1]).max() <= 1e-12 * max(1.0, np.abs(res["chains"][1]).max())
+
+
+@pytest.mark.parametrize("N,c,n_ops,order,form", [(128, 128, 4, 8, "3"), (128, 128, 2, 8, "2"), (144, 64, 4, 8, "1"), (100, 32, 2, 8, "0"),
+                                                  (80, 8, 1, 4, "0")])
+def test_gradient_is_bitwise_reproducible_large_n(qgd, N, c, n_ops, order, form, monkeypatch):
+    """The N > 64 gradient kernels add their scalars in a fixed order too (round 3: per-wave LDS slots, one plane of sigma per
+    contributing tile, planes added in order by k_contract -- no atomicAdd left on the gradient path): the same inputs give the
+    same bits, for every form of the gradient scalars, from one handle five times and from a fresh handle."""
+    monkeypatch.setenv("QGD_GINNER", form)
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=10, tf=0.1, seed=N)
+    grads = []
+    for fresh in range(2):
+        dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+        for _ in range(5 if not fresh else 1):
+            grads.append(dp.discrete_adjoint(pcof)[0])
+        dp.close()
+    for g in grads[1:]:
+        assert np.array_equal(g, grads[0])
