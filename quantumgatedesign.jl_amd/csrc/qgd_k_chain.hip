@@ -998,7 +998,8 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     if (nwg <= 0) return 0;
     const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
 #define CALL_CD(R) do { bool done3_ = false;                                                                                \
-        if constexpr (NGT > 1) { if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
+        if constexpr (NGT > 1 && !(NGT == 4 && R == 3)) {    /* (<.,3,4>: 18 accumulator tiles, spills: the four-product kernel there) */ \
+            if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
             hipLaunchKernelGGL((k_chain_dense3<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); done3_ = true; } }      \
         if (!done3_) { SET_LDS_ONCE((k_chain_dense<MODE, R, NGT>), shm);                                                     \
             hipLaunchKernelGGL((k_chain_dense<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); } } while (0)

@@ -570,6 +570,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+template <int DN_RB, int DN_NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_derivs_f3(const d2 *__restrict__ Dfrag, const double *__restrict__ hist,
+                                                  double *__restrict__ dpsi, int Np, int cp, int m, int nt)
+{
+    DenseTile<DN_RB, DN_NG> t;
+    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt)) return;
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
+    d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
+    ZERO_ACC3(p1); ZERO_ACC3(p2); ZERO_ACC3(p3);
+    cgemm3_tile(p1, p2, p3, t, Dfrag + ((size_t)t.n * m + t.sub) * fr, hist + (size_t)t.n * hstep, PWc, Np);
+    double *out = dpsi + ((size_t)t.n * m + t.sub) * hstep;
+    #pragma unroll
+    for (int r = 0; r < DN_RB; r++) {
+        if (t.rb[r] < 0) continue;
+        #pragma unroll
+        for (int p = 0; p < DN_NG / 2; p++) {
+            const int g = lane_group(t, p);
+            if (g < 0) continue;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                double *o = out + (size_t)(t.rb[r] * 16 + t.kk + 4 * e) * PWc + g * 16 + (t.c16 & 7);
+                const double s12 = p1[r][p][e] + p2[r][p][e];
+                o[0] = p1[r][p][e] - p2[r][p][e];
+                o[8] = p3[r][p][e] - s12;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // lambda_n = L_n^{-H} y_n, n = 1..nt-1 (the time point of a tile is n-1); also clears sigma and grad, which the
 // gradient kernels accumulate into.  LinvT: planes with L^{-1}(k, row) at [row + Np*k].
@@ -895,7 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // into its OWN LDS slots sigw[wave][.] (wave_sig); after the barrier thread e adds the four slots in order and STORES the
 // sum into the workgroup's own plane of sigma -- plane = the tile's slot inside its time point -- and k_contract adds the
 // planes in order.  No atomics: every (plane, n, o, d) entry has exactly one writer.
-__device__ __forceinline__ double *wave_sig(double *sig, int nvals) { return sig + (threadIdx.x >> 6) * nvals; }
+__device__ __forceinline__ double *wave_sig(double *sig, int nvals) { return sig + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * nvals; }
 __device__ __forceinline__ double sum_wave_sig(const double *sig, int nvals, int e)
 {
     return ((sig[e] + sig[nvals + e]) + sig[2 * nvals + e]) + sig[3 * nvals + e];
@@ -913,6 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     DenseTile<DN_RB, DN_NG> t;
     const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt);
     if (active) {
+        double *sw = wave_sig(sig, n_ops * m * 2);
         const int i = t.sub;
         const int PWc = 2 * cp;
         const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
@@ -944,9 +975,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
                 if (t.lane == 0) {
                     const int d = j - 1 - i;
-                    double *sw = wave_sig(sig, n_ops * m * 2);       // this wave's own slots
-                    sw[(o * m + d) * 2] += sp / (double)j;
-                    sw[(o * m + d) * 2 + 1] += sq / (double)j;
+                    atomicAdd(&sw[(o * m + d) * 2], sp / (double)j);       // this wave's own slots: one writer, and LDS executes a wave's
+                    atomicAdd(&sw[(o * m + d) * 2 + 1], sq / (double)j);   // operations in order (the add without a return value does not stall)
                 }
             }
         }
@@ -1158,7 +1188,7 @@ __device__ __forceinline__ void frobenius_sigma(const d4 (&aR)[DN_RB][DN_NG], co
             }
         }
         for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
-        if (t.lane == 0) { sig[o * 2] += sp * w; sig[o * 2 + 1] += sq * w; }      // (sig: this wave's own slots)
+        if (t.lane == 0) { atomicAdd(&sig[o * 2], sp * w); atomicAdd(&sig[o * 2 + 1], sq * w); }      // (sig: this wave's own slots -- one writer, in order)
     }
 }
 
@@ -1520,7 +1550,11 @@ int qgdk_dense_derivs(const qgdk_ctx *c)
     const int ng = c->cp / 8;
 #define CALL_DF(RB, NG) hipLaunchKernelGGL((k_derivs_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), 0, \
                                            c->stream, reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt)
-    DISPATCH_SHAPE(ng, CALL_DF);
+    if (dense_3m() && ng >= 3)
+        hipLaunchKernelGGL((k_derivs_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, c->m, c->nt)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt);
+    else
+        DISPATCH_SHAPE(ng, CALL_DF);
 #undef CALL_DF
     return (int)hipGetLastError();
 }
