@@ -192,7 +192,7 @@ static void plan_scan(const qgdk_ctx &k, int S_w, int &B0)
     if (B0 > 64) B0 = 64;
     if (getenv("QGD_SCAN_B0")) B0 = atoi(getenv("QGD_SCAN_B0"));      // (tuning experiments)
     if (B0 < 1) B0 = 1;
-    if (k.Np > 64 && k.Np <= 288) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile
+    if (k.Np > 64 && k.Np <= 640) {     // large-N chains: one workgroup (128 KB of LDS) per CU and 32-column tile (16 beyond Np = 288)
         const int ngt = std::max(k.Np / 32, k.cp / 32);
         B0 = std::min(B0, std::max(8, 256 / std::max(ngt, 1)));
     }
@@ -1070,7 +1070,7 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps; k.nt = d->nsteps + 1;
     if ((size_t)2 * k.Np * 16 * sizeof(double) > 150 * 1024) {
         delete h;
-        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N too large for the sweep kernels of this version (N <= 4608)");
+        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N too large for the sweep kernels of this version (N <= 600)");
     }
 #define CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e__); qgd_destroy(h); return fail(nullptr, QGD_ERR_NO_DEVICE, m_); } } while (0)
 #define CREATE_RC(expr) do { int rc__ = (expr); if (rc__) { std::string m_ = h->err; qgd_destroy(h); return fail(nullptr, rc__, m_); } } while (0)

@@ -998,12 +998,14 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     if (nwg <= 0) return 0;
     const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
 #define CALL_CD(R) do { bool done3_ = false;                                                                                \
-        if constexpr (NGT > 1 && !(NGT == 4 && R == 3)) {    /* (<.,3,4>: 18 accumulator tiles, spills: the four-product kernel there) */ \
+        if constexpr (NGT > 1 && !(NGT == 4 && R == 3) && R < 5) {    /* (<.,3,4>, <.,5,2>: spills -- the four-product kernel there) */ \
             if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
             hipLaunchKernelGGL((k_chain_dense3<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); done3_ = true; } }      \
         if (!done3_) { SET_LDS_ONCE((k_chain_dense<MODE, R, NGT>), shm);                                                     \
             hipLaunchKernelGGL((k_chain_dense<MODE, R, NGT>), dim3(nwg), dim3(512), shm, stream, a); } } while (0)
-    if (nrb <= 8) CALL_CD(1); else if (nrb <= 16) CALL_CD(2); else CALL_CD(3);
+    if (nrb <= 8) CALL_CD(1); else if (nrb <= 16) CALL_CD(2); else if (nrb <= 24) CALL_CD(3);
+    else if constexpr (NGT <= 2) { if (nrb <= 32) CALL_CD(4); else CALL_CD(5); }      // (288 < Np <= 640: tiles of at most 16 columns fit the LDS)
+    else return -1;
 #undef CALL_CD
     return (int)hipGetLastError();
 }
@@ -1049,7 +1051,7 @@ static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
     static const long long t1 = getenv("QGD_CHAIN_T1") ? atoll(getenv("QGD_CHAIN_T1")) : cus - 1;     // (tuning; 8-column tiles only while they are fewer than the CUs)
     static const long long t2 = getenv("QGD_CHAIN_T2") ? atoll(getenv("QGD_CHAIN_T2")) : 2 * cus;
     if ((long long)a.nblocks * a.ngroups <= t1) return launch_chain_dense_w<MODE, 1>(a, stream);
-    if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= t2) return launch_chain_dense_w<MODE, 2>(a, stream);
+    if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= t2 || a.Np > 288) return launch_chain_dense_w<MODE, 2>(a, stream);     // (32-column tiles: Np <= 288, LDS)
     return launch_chain_dense_w<MODE, 4>(a, stream);
 }
 
@@ -1057,7 +1059,7 @@ static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 static bool chain_is_dense(const ChainArgs &a)
 {
     const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;     // (comparison path; a getenv per launch is noise at these sizes)
-    return !off && a.Np > 64 && a.Np <= 288;
+    return !off && a.Np > 64 && a.Np <= 640;
 }
 
 template <int MODE, int NG>

@@ -13,9 +13,13 @@ __global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
                                                  double *__restrict__ LinvA,
                                                  double *__restrict__ LinvT,
                                                  double *__restrict__ scratch, int Np, int n0,
-                                                 int use_lds, int *__restrict__ status)
+                                                 int use_lds, int *__restrict__ status, const int *__restrict__ redo = nullptr)
 {
     extern __shared__ double smem[];
+    if (redo) {                                      // fallback pass of the block Gauss-Jordan inverse (sizes beyond k_inverse_blocked2's LDS)
+        if (!redo[n0 + blockIdx.x]) return;
+        if (threadIdx.x == 0) atomicAdd(status + 1, 1);
+    }
     const int n = n0 + blockIdx.x;
     const int t = threadIdx.x, nth = blockDim.x;
     const int PW = 2 * Np;
@@ -1728,7 +1732,7 @@ int qgdk_inverse(const qgdk_ctx *c)
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;
     }
-    if (c->Np > 64 && c->dense_gemm && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {
+    if (c->Np > 64 && c->dense_gemm && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {    // (any size: no LDS limit)
         const int took = qgdk_dense_inverse(c);              // block Gauss-Jordan as batched GEMM launches (qgd_k_dense.hip)
         if (took) return took < 0 ? (int)hipErrorUnknown : (int)hipGetLastError();
     }
@@ -1787,6 +1791,15 @@ int qgdk_inverse_diag(const qgdk_ctx *c, const double *Win, size_t mstride, int 
 // the matrices marked in flags[] again, by k_inverse_blocked2 (partial pivoting over whole columns) from the untouched L
 int qgdk_inverse_redo(const qgdk_ctx *c, const int *flags)
 {
+    if (inverse_blocked_lds(c->Np) > 150 * 1024) {       // N > ~280: the generic kernel (matrix in a global slab) is the pivoting fallback
+        const size_t shm = (size_t)(3 * c->Np + 16) * sizeof(double);
+        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
+            const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
+            hipLaunchKernelGGL(k_inverse, dim3(nb), dim3(256), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch, c->Np, n0, 0,
+                               c->status, flags);
+        }
+        return (int)hipGetLastError();
+    }
     const size_t shm = inverse_blocked2_lds(c->Np);
     HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {

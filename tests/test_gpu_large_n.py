@@ -333,3 +333,27 @@ def test_gradient_is_bitwise_reproducible_large_n(qgd, N, c, n_ops, order, form,
         dp.close()
     for g in grads[1:]:
         assert np.array_equal(g, grads[0])
+
+
+@pytest.mark.parametrize("N,c,order,nsteps", [(300, 12, 4, 12), (320, 40, 8, 10), (512, 16, 6, 9), (592, 8, 4, 11)])
+def test_sizes_beyond_288(qgd, N, c, order, nsteps):
+    """Until the end of round 3 the GEMM-style chain kernels and the blocked inverse stopped at Np = 288 (their LDS), and a
+    problem one size up fell onto the generic kernels: N = 288 took 72 ms where N = 256 took 5 (scripts/big_n_timing.py).
+    The block Gauss-Jordan inverse has no such limit and the chains run on 16-column tiles up to Np = 640
+    (k_chain_dense3<.,4,2>, four-product <.,5,2> beyond Np = 512): history and gradient against the numpy statement, and
+    L^-1 L = I, at N = 300 (Np = 304), 320, 512 and 592."""
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=nsteps, tf=0.01 * nsteps, seed=N)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    hist = np.zeros(dp._hist_shape(), order="F")
+    g, o = dp.discrete_adjoint(pcof, False, hist)
+    Linv, L = dp.intermediate("Linv"), dp.intermediate("L")
+    redone = int(dp.intermediate("repivoted"))
+    dp.close()
+    href = pp.history_real(ref["ws"])
+    assert np.abs(hist - href).max() <= 1e-11 * np.abs(href).max()
+    assert np.abs(g - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
+    assert redone == 0
+    for n in (1, nsteps):
+        assert np.abs(Linv[n][:N, :N] @ L[n][:N, :N] - np.eye(N)).max() <= 1e-12
