@@ -1070,7 +1070,7 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     h->nsteps = d->nsteps; k.tf = d->tf; k.dt = d->tf / d->nsteps; k.nt = d->nsteps + 1;
     if ((size_t)2 * k.Np * 16 * sizeof(double) > 150 * 1024) {
         delete h;
-        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N too large for the sweep kernels of this version (N <= 600)");
+        return fail(nullptr, QGD_ERR_UNSUPPORTED, "N too large for the sweep kernels of this version (N <= 592: padded to 16 rows, two 16-column panels in LDS)");
     }
 #define CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e__); qgd_destroy(h); return fail(nullptr, QGD_ERR_NO_DEVICE, m_); } } while (0)
 #define CREATE_RC(expr) do { int rc__ = (expr); if (rc__) { std::string m_ = h->err; qgd_destroy(h); return fail(nullptr, rc__, m_); } } while (0)
