@@ -776,6 +776,13 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
     int rb[RBW];
     #pragma unroll
     for (int r = 0; r < RBW; r++) rb[r] = wave * RBW + r;
+    int avr[RBW], avi[RBW];                               // byte offsets of this lane's (row, k = kk) element: chain_a_raw's layouts
+    #pragma unroll
+    for (int r = 0; r < RBW; r++) {
+        const int arow = (rb[r] < nrb ? rb[r] : 0) * 16 + c16;
+        if (!ADJ) { avr[r] = (arow + Np * kk) * 8; avi[r] = avr[r] + Np * Np * 8; }
+        else { avr[r] = (kk * 2 * Np + (arow >> 3) * 16 + (arow & 7)) * 8; avi[r] = avr[r] + 64; }
+    }
     for (int st = 0; st < e0 - s0; st++) {
         const int n = ADJ ? e0 - 1 - st : s0 + st;
         const int nout = ADJ ? n : n + 1;
@@ -785,36 +792,35 @@ __global__ __launch_bounds__(512) void k_chain_dense(const ChainArgs a)
         for (int r = 0; r < RBW; r++)
             #pragma unroll
             for (int g = 0; g < NGT; g++) acc[r][g] = (d4){0, 0, 0, 0};
-        int arow[RBW];
-        #pragma unroll
-        for (int r = 0; r < RBW; r++) arow[r] = (rb[r] < nrb ? rb[r] : 0) * 16 + c16;
-        // A fragments two k-steps ahead (a k-step is 8*RBW MFMAs, ~0.2 us per wave; L2 latency is several of those)
-        double are[RBW], aim[RBW], n1re[RBW], n1im[RBW], n2re[RBW], n2im[RBW];
-        #pragma unroll
-        for (int r = 0; r < RBW; r++) {
-            chain_a_raw<ADJ>(Pn, Np, arow[r], kk, are[r], aim[r]);
-            chain_a_raw<ADJ>(Pn, Np, arow[r], 4 + kk, n1re[r], n1im[r]);
+        // left operand buffer-addressed (descriptor on the step matrix, per-lane offsets fixed, the k-step in an SGPR); four
+        // register sets, three k-steps of prefetch, the loop unrolled by four: no address arithmetic or register copies
+        // beside the MFMAs (as k_chain_dense3 below; this kernel serves the 8-column tiles and the sizes 3M would spill at)
+        const __amdgpu_buffer_rsrc_t rP = buffer_of(Pn);
+        const int kstep = ADJ ? 2 * Np * 8 : Np * 8;           // bytes per unit of k
+        double xr[4][RBW], xi[4][RBW];
+#define CD4_LOAD(S, kq) do { _Pragma("unroll") for (int r = 0; r < RBW; r++) {                                         \
+            xr[S][r] = buffer_load_f64(rP, avr[r], (kq) * kstep); xi[S][r] = buffer_load_f64(rP, avi[r], (kq) * kstep); } } while (0)
+#define CD4_STEP(S, kq) do {                                                                                          \
+            const double *brow = cur + (size_t)((kq) + kk) * TW + c16;                                                 \
+            _Pragma("unroll") for (int g = 0; g < NGT; g++) {                                                          \
+                const double b1 = brow[(g ^ (kk & (NGT - 1))) << 4];                                                   \
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);             \
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);             \
+                const double b2 = __hiloint2double(hi ^ sign_hi, lo);                                                  \
+                _Pragma("unroll") for (int r = 0; r < RBW; r++) {                                                      \
+                    acc[r][g] = MFMA(xr[S][r], b1, acc[r][g]);                                                         \
+                    acc[r][g] = MFMA(xi[S][r], b2, acc[r][g]);                                                         \
+                } } } while (0)
+        CD4_LOAD(0, 0); CD4_LOAD(1, 4); CD4_LOAD(2, 8);
+        for (int k0 = 0; k0 < Np; k0 += 16) {                  // (Np is a multiple of 16)
+            const int last = Np - 4;
+            CD4_LOAD(3, k0 + 12);                                CD4_STEP(0, k0);
+            CD4_LOAD(0, k0 + 16 <= last ? k0 + 16 : last);       CD4_STEP(1, k0 + 4);
+            CD4_LOAD(1, k0 + 20 <= last ? k0 + 20 : last);       CD4_STEP(2, k0 + 8);
+            CD4_LOAD(2, k0 + 24 <= last ? k0 + 24 : last);       CD4_STEP(3, k0 + 12);
         }
-        for (int k0 = 0; k0 < Np; k0 += 4) {
-            const int kn = (k0 + 8 < Np) ? k0 + 8 : k0;
-            #pragma unroll
-            for (int r = 0; r < RBW; r++) chain_a_raw<ADJ>(Pn, Np, arow[r], kn + kk, n2re[r], n2im[r]);
-            const double *brow = cur + (size_t)(k0 + kk) * TW + c16;
-            #pragma unroll
-            for (int g = 0; g < NGT; g++) {
-                const double b1 = brow[(g ^ (kk & (NGT - 1))) << 4];
-                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(b1), 0x128, 0xF, 0xF, false);
-                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(b1), 0x128, 0xF, 0xF, false);
-                const double b2 = __hiloint2double(hi ^ sign_hi, lo);
-                #pragma unroll
-                for (int r = 0; r < RBW; r++) {
-                    acc[r][g] = MFMA(are[r], b1, acc[r][g]);
-                    acc[r][g] = MFMA(aim[r], b2, acc[r][g]);
-                }
-            }
-            #pragma unroll
-            for (int r = 0; r < RBW; r++) { are[r] = n1re[r]; aim[r] = n1im[r]; n1re[r] = n2re[r]; n1im[r] = n2im[r]; }
-        }
+#undef CD4_LOAD
+#undef CD4_STEP
         __syncthreads();            // every wave has read the old state
         #pragma unroll
         for (int r = 0; r < RBW; r++) {
