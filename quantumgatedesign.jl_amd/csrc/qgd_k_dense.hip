@@ -48,16 +48,21 @@ __device__ __forceinline__ size_t frag_index(int Np, int row, int k)
 template <int DN_RB, int DN_NG>
 struct DenseTile {
     int n, sub, rb[DN_RB], g[DN_NG];     // time point, sub-index (level / source), row blocks and groups (-1 = outside)
-    int slot, ntile;                     // index of the workgroup's tile among the T = ntile * nsub tiles of its time point (ntile = rtiles * ctiles)
+    int slot, ntile;                     // index of the workgroup among the T = ntile * nsub workgroups of its time point (ntile per sub-index)
     int lane, c16, kk, sign_hi;
 };
 
-// grid = 8 * T * ceil(nt / 8) workgroups, T = tiles * nsub per time point
+// grid = 8 * T * ceil(nt / 8) workgroups, T = workgroups per time point.  A WAVE owns one item = (group of DN_RB row blocks,
+// tile of DN_NG column groups); the items of one sub-index are dealt to the workgroups four at a time, row-block groups
+// fastest (the waves of a workgroup mostly share their right operand through the L1, and share nothing else).  Round 3,
+// last change: before, a workgroup was 4 * DN_RB consecutive row blocks of ONE column tile, and Np = 144 (9 row blocks)
+// paid for two 128-row tiles; now its 5 row-block pairs x ctiles items fill ceil(5 ctiles / 4) workgroups.
 template <int DN_RB, int DN_NG>
 __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, int ngroups, int nsub, int nt)
 {
-    const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
-    const int T = rtiles * ctiles * nsub;
+    const int nrp = (nrb + DN_RB - 1) / DN_RB, ctiles = (ngroups + DN_NG - 1) / DN_NG;
+    const int per_sub = nrp * ctiles, wgs = (per_sub + 3) >> 2;
+    const int T = wgs * nsub;
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
     t.n = (s / T) * 8 + xcd;
     int r = s % T;
@@ -72,15 +77,17 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
         r = q % T;
     }
     if (t.n >= nt) return false;
-    t.slot = r; t.ntile = rtiles * ctiles;
-    t.sub = r / (rtiles * ctiles);
-    r %= rtiles * ctiles;
-    const int rt = r / ctiles, ct = r % ctiles;
+    t.slot = r; t.ntile = wgs;
+    t.sub = r / wgs;
+    r %= wgs;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     t.lane = threadIdx.x & 63; t.c16 = t.lane & 15; t.kk = t.lane >> 4;
     t.sign_hi = (t.c16 < 8) ? (int)0x80000000 : 0;
+    const int item = r * 4 + wave;
+    const bool on = item < per_sub;
+    const int rp = on ? item % nrp : 0, ct = on ? item / nrp : 0;
     #pragma unroll
-    for (int i = 0; i < DN_RB; i++) { const int rb = (rt * 4 + wave) * DN_RB + i; t.rb[i] = rb < nrb ? rb : -1; }
+    for (int i = 0; i < DN_RB; i++) { const int rb = rp * DN_RB + i; t.rb[i] = (on && rb < nrb) ? rb : -1; }
     #pragma unroll
     for (int i = 0; i < DN_NG; i++) { const int g = ct * DN_NG + i; t.g[i] = g < ngroups ? g : -1; }
     return t.rb[0] >= 0;
@@ -88,8 +95,8 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
 
 static inline int dense_grid(int DN_RB, int DN_NG, int nrb, int ngroups, int nsub, int nt)
 {
-    const int rtiles = (nrb + 4 * DN_RB - 1) / (4 * DN_RB), ctiles = (ngroups + DN_NG - 1) / DN_NG;
-    return 8 * rtiles * ctiles * nsub * ((nt + 7) / 8);
+    const int nrp = (nrb + DN_RB - 1) / DN_RB, ctiles = (ngroups + DN_NG - 1) / DN_NG;
+    return 8 * ((nrp * ctiles + 3) / 4) * nsub * ((nt + 7) / 8);
 }
 
 // acc += A * B for the wave's tile.  A: fragment order (complex); B: panel with row stride ldb.
@@ -1578,9 +1585,9 @@ int qgdk_dense_lambda(const qgdk_ctx *c)
 static int sigma_planes_of(int form, int Np, int cp, int m)
 {
     const int nrb = Np / 16, ng = cp / 8;
-    if (form >= 1) return ((nrb + 7) / 8) * ((nrb + 1) / 2);                       // <2,2> tiles over (row blocks, row blocks)
+    if (form >= 1) return (((nrb + 1) / 2) * ((nrb + 1) / 2) + 3) / 4;               // <2,2> tiles over (row blocks, row blocks): workgroups per (n, d)
     const int RB = ng >= 3 ? 2 : 4, NG = ng >= 3 ? 4 : (ng == 2 ? 2 : 1);            // DISPATCH_SHAPE
-    return ((nrb + 4 * RB - 1) / (4 * RB)) * ((ng + NG - 1) / NG) * m;
+    return ((((nrb + RB - 1) / RB) * ((ng + NG - 1) / NG) + 3) / 4) * m;
 }
 int qgdk_dense_sigma_planes(const qgdk_ctx *c) { return sigma_planes_of(dense_sigma_form(c), c->Np, c->cp, c->m); }
 int qgdk_dense_sigma_planes_max(int Np, int cp, int m) { return std::max(sigma_planes_of(0, Np, cp, m), sigma_planes_of(1, Np, cp, m)); }
