@@ -2,7 +2,7 @@
   * the bounded-memory time grid (random budgets -> 2..12 windows): gradient, scalars, the three reference-layout arrays;
   * the in-library RCCL route with one rank, both shard kinds;
   * the stepping adjoint history pass (QGD_NO_SUFFIX=1) against the suffix-product pass;
-on dispersive (sparse kernels, guard levels) and random dense problems, N = 2..100, orders 2..12, 20..900 steps.
+on dispersive (sparse kernels, guard levels) and random dense problems, N = 2..300, orders 2..12, 20..900 steps.
 Usage: python scripts/fuzz_windows.py [n_cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,10 +27,10 @@ for it in range(ncases):
                 for k in range(prob.N_operators)]
         kind = f"dispersive {sizes}/{ess}"
     else:
-        N = int(rng.choice([3, 9, 20, 33, 64, 72, 100])); n_ops = int(rng.integers(1, 4))
+        N = int(rng.choice([3, 9, 20, 33, 64, 72, 100, 130, 160, 260, 300])); n_ops = int(rng.integers(1, 4))
         nsteps = min(nsteps, 200 if N > 64 else nsteps)
         prob = qgd.construct_rand_prob(N, n_ops, tf=0.02 * nsteps, nsteps=nsteps, scale=1.0 / max(N, 4))
-        c = int(rng.integers(1, min(N, 20) + 1))
+        c = int(rng.integers(1, min(N, 20) + 1)) if N <= 100 else int(rng.choice([8, 24, 40, 72]))
         prob.u0 = np.asfortranarray(prob.u0[:, :c]); prob.v0 = np.asfortranarray(prob.v0[:, :c]); prob.N_initial_conditions = c
         ctrl = [qgd.FortranBSplineControl(int(rng.choice([2, 16])), 20, prob.tf) for _ in range(n_ops)]
         kind = f"random dense N={N} ops={n_ops}"
