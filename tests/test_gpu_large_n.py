@@ -357,3 +357,37 @@ def test_sizes_beyond_288(qgd, N, c, order, nsteps):
     assert redone == 0
     for n in (1, nsteps):
         assert np.abs(Linv[n][:N, :N] @ L[n][:N, :N] - np.eye(N)).max() <= 1e-12
+
+
+def test_physical_four_qutrit_problem_vs_oracle(qgd, orc):
+    """A problem of the reference's own kind beyond N = 64: four dispersively coupled qutrits (two essential + one guard
+    level each: N = 81, 16 initial conditions, guard projector, rotating frame, B-splines with carrier waves) -- drift
+    diagonal with entries of very different size, sparse couplings: the matrices the three-product tiles and the block
+    Gauss-Jordan inverse were NOT tuned on.  Whole path against the oracle (matrix-free GMRES at 1e-15): history, lambda,
+    guard forcing, gradient."""
+    nsteps, order = 24, 8
+    sizes, ess = (3, 3, 3, 3), (2, 2, 2, 2)
+    freqs = 2 * np.pi * np.array([4.10, 4.35, 4.60, 4.85])
+    kerr = 2 * np.pi * np.array([[0.20, 0.004, 0.003, 0.002], [0.004, 0.22, 0.005, 0.003], [0.003, 0.005, 0.21, 0.004], [0.002, 0.003, 0.004, 0.19]])
+    prob = qgd.DispersiveProblem(sizes, ess, freqs, freqs, kerr, 0.5 * nsteps, nsteps, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    ctrl = [qgd.CarrierControl(qgd.FortranBSplineControl(2, 6, prob.tf), [0.0, -float(kerr[k, k])]) for k in range(prob.N_operators)]
+    rng = np.random.default_rng(81)
+    pcof = 0.05 * (rng.random(qgd.get_number_of_control_parameters(ctrl)) - 0.5)
+    N, c = prob.N_tot_levels, prob.N_initial_conditions
+    assert N == 81 and c == 16
+    target = np.linalg.qr(rng.standard_normal((N, c)) + 1j * rng.standard_normal((N, c)))[0]
+    orc.set_converged_terminal(True)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    finally:
+        orc.set_converged_terminal(False)
+    hist = np.zeros(h_ref.shape, order="F"); lam = np.zeros(h_ref.shape, order="F")
+    forcing = np.zeros(f_ref.shape, order="F")
+    grad = np.zeros_like(g_ref)
+    qgd.discrete_adjoint_(grad, hist, lam, forcing, prob, ctrl, pcof, target, order=order)
+    for j in range(order // 2 + 1):
+        assert np.abs(hist[:, j] - h_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(h_ref[:, j]).max()), j
+    assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, 0]).max())
+    assert np.abs(forcing - f_ref).max() <= 1e-11 * max(1.0, np.abs(f_ref).max())
+    assert np.abs(grad - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
+    qgd.clear_cache()
