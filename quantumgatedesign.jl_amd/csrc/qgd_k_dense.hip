@@ -65,11 +65,13 @@ struct DenseTile {
 // last change: before, a workgroup was 4 * DN_RB consecutive row blocks of ONE column tile, and Np = 144 (9 row blocks)
 // paid for two 128-row tiles; now its 5 row-block pairs x ctiles items fill ceil(5 ctiles / 4) workgroups.
 template <int DN_RB, int DN_NG>
-__device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, int ngroups, int nsub, int nt)
+__device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, int ngroups, int nsub, int nt, bool sub_per_wave = false)
 {
+    // sub_per_wave: the sub-index belongs to the ITEM, not to the workgroup (kernels whose waves share nothing that depends on
+    // it): nsub * per_sub items are dealt four to a workgroup -- with few columns per_sub is 1-3 and half the waves idled
     const int nrp = (nrb + DN_RB - 1) / DN_RB, ctiles = (ngroups + DN_NG - 1) / DN_NG;
-    const int per_sub = nrp * ctiles, wgs = (per_sub + 3) >> 2;
-    const int T = wgs * nsub;
+    const int per_sub = nrp * ctiles, total = sub_per_wave ? per_sub * nsub : per_sub, wgs = (total + 3) >> 2;
+    const int T = sub_per_wave ? wgs : wgs * nsub;
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
     t.n = (s / T) * 8 + xcd;
     int r = s % T;
@@ -85,14 +87,16 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
     }
     if (t.n >= nt) return false;
     t.slot = r; t.ntile = wgs;
-    t.sub = r / wgs;
-    r %= wgs;
+    t.sub = 0;
+    if (!sub_per_wave) { t.sub = r / wgs; r %= wgs; }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     t.lane = threadIdx.x & 63; t.c16 = t.lane & 15; t.kk = t.lane >> 4;
     t.sign_hi = (t.c16 < 8) ? (int)0x80000000 : 0;
-    const int item = r * 4 + wave;
-    const bool on = item < per_sub;
-    const int rp = on ? item % nrp : 0, ct = on ? item / nrp : 0;
+    int item = r * 4 + wave;
+    const bool on = item < total;
+    if (!on) item = 0;
+    if (sub_per_wave) { t.sub = item / per_sub; item %= per_sub; }
+    const int rp = item % nrp, ct = item / nrp;
     #pragma unroll
     for (int i = 0; i < DN_RB; i++) { const int rb = rp * DN_RB + i; t.rb[i] = (on && rb < nrb) ? rb : -1; }
     #pragma unroll
@@ -100,10 +104,11 @@ __device__ __forceinline__ bool dense_tile(DenseTile<DN_RB, DN_NG> &t, int nrb, 
     return t.rb[0] >= 0;
 }
 
-static inline int dense_grid(int DN_RB, int DN_NG, int nrb, int ngroups, int nsub, int nt)
+static inline int dense_grid(int DN_RB, int DN_NG, int nrb, int ngroups, int nsub, int nt, bool sub_per_wave = false)
 {
-    const int nrp = (nrb + DN_RB - 1) / DN_RB, ctiles = (ngroups + DN_NG - 1) / DN_NG;
-    return 8 * ((nrp * ctiles + 3) / 4) * nsub * ((nt + 7) / 8);
+    const int nrp = (nrb + DN_RB - 1) / DN_RB, ctiles = (ngroups + DN_NG - 1) / DN_NG, per_sub = nrp * ctiles;
+    const int T = sub_per_wave ? (per_sub * nsub + 3) / 4 : ((per_sub + 3) / 4) * nsub;
+    return 8 * T * ((nt + 7) / 8);
 }
 
 // acc += A * B for the wave's tile.  A: fragment order (complex); B: panel with row stride ldb.
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                   double *__restrict__ dpsi, int Np, int cp, int m, int nt)
 {
     DenseTile<DN_RB, DN_NG> t;
-    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt)) return;
+    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt, true)) return;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
     d4 acc[DN_RB][DN_NG];
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                   double *__restrict__ dpsi, int Np, int cp, int m, int nt)
 {
     DenseTile<DN_RB, DN_NG> t;
-    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt)) return;
+    if (!dense_tile(t, Np >> 4, cp >> 3, m, nt, true)) return;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
     d4 p1[DN_RB][DN_NG / 2], p2[DN_RB][DN_NG / 2], p3[DN_RB][DN_NG / 2];
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                   int m, int nt, int j)
 {
     DenseTile<DN_RB, DN_NG> t;
-    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
+    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt, true)) return;
     const int i = t.sub + 1;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                   const double *__restrict__ cw)
 {
     DenseTile<DN_RB, DN_NG> t;
-    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt)) return;
+    if (!dense_tile(t, Np >> 4, cp >> 3, j - 1, nt, true)) return;
     const int i = t.sub + 1;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc, fr = (size_t)Np * Np;
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int e = threadIdx.x; e < 4 * n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
     __syncthreads();
     DenseTile<DN_RB, DN_NG> t;
-    const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt);
+    const bool active = dense_tile(t, Np >> 4, cp >> 3, m, nt, true);
     if (active) {
         double *sw = wave_sig(sig, n_ops * m * 2);
         const int i = t.sub;
@@ -1562,10 +1567,10 @@ int qgdk_dense_propagator(const qgdk_ctx *c)
 int qgdk_dense_derivs(const qgdk_ctx *c)
 {
     const int ng = c->cp / 8;
-#define CALL_DF(RB, NG) hipLaunchKernelGGL((k_derivs_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), 0, \
+#define CALL_DF(RB, NG) hipLaunchKernelGGL((k_derivs_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt, true)), dim3(256), 0, \
                                            c->stream, reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt)
     if (dense_3m() && ng >= 3)
-        hipLaunchKernelGGL((k_derivs_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, c->m, c->nt)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL((k_derivs_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, c->m, c->nt, true)), dim3(256), 0, c->stream,
                            reinterpret_cast<const d2 *>(c->Dfrag), c->hist, c->dpsi, c->Np, c->cp, c->m, c->nt);
     else
         DISPATCH_SHAPE(ng, CALL_DF);
@@ -1594,7 +1599,7 @@ static int sigma_planes_of(int form, int Np, int cp, int m)
     const int nrb = Np / 16, ng = cp / 8;
     if (form >= 1) return (((nrb + 1) / 2) * ((nrb + 1) / 2) + 3) / 4;               // <2,2> tiles over (row blocks, row blocks): workgroups per (n, d)
     const int RB = ng >= 3 ? 2 : 4, NG = ng >= 3 ? 4 : (ng == 2 ? 2 : 1);            // DISPATCH_SHAPE
-    return ((((nrb + RB - 1) / RB) * ((ng + NG - 1) / NG) + 3) / 4) * m;
+    return (((nrb + RB - 1) / RB) * ((ng + NG - 1) / NG) * m + 3) / 4;        // (k_ginner_f: the source level belongs to the wave's item)
 }
 int qgdk_dense_sigma_planes(const qgdk_ctx *c) { return sigma_planes_of(dense_sigma_form(c), c->Np, c->cp, c->m); }
 int qgdk_dense_sigma_planes_max(int Np, int cp, int m) { return std::max(sigma_planes_of(0, Np, cp, m), sigma_planes_of(1, Np, cp, m)); }
@@ -1620,10 +1625,10 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
                            c->m, c->nt, m3 ? c->Xfrag : nullptr, c->Np, lazy ? 1 : 0);
         const int ngy = c->Np / 8;
         for (int j = c->m; j >= 2; j--) {
-#define CALL_GY(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, \
+#define CALL_GY(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ngy, j - 1, c->nt, true)), dim3(256), 0, \
                                            c->stream, Af, c->Xouter, c->Np, c->Np, c->m, c->nt, j)
             if (dense_3m() && ngy >= 3)
-                hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ngy, j - 1, c->nt)), dim3(256), 0, c->stream, Af,
+                hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ngy, j - 1, c->nt, true)), dim3(256), 0, c->stream, Af,
                                    c->Xouter, c->Np, c->Np, c->m, c->nt, j, m3 ? Xf : nullptr, (lazy && j == c->m) ? c->Tlam : nullptr, c->cw);
             else
                 DISPATCH_SHAPE(ngy, CALL_GY);
@@ -1640,16 +1645,16 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     hipLaunchKernelGGL(k_ginit, dim3((unsigned)((hstep + 255) / 256), c->nt), dim3(256), 0, c->stream, c->lam, c->cw, Gp, hstep,
                        c->m, c->nt);
     for (int j = c->m; j >= 2; j--) {
-#define CALL_GS(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, \
+#define CALL_GS(RB, NG) hipLaunchKernelGGL((k_gsweep_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, j - 1, c->nt, true)), dim3(256), 0, \
                                            c->stream, Af, Gp, c->Np, c->cp, c->m, c->nt, j)
         if (dense_3m() && ng >= 3)
-            hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, j - 1, c->nt)), dim3(256), 0, c->stream, Af, Gp,
+            hipLaunchKernelGGL((k_gsweep_f3<2, 4>), dim3(dense_grid(2, 4, c->Np / 16, ng, j - 1, c->nt, true)), dim3(256), 0, c->stream, Af, Gp,
                                c->Np, c->cp, c->m, c->nt, j, (d2 *)nullptr, (const double *)nullptr, c->cw);
         else
             DISPATCH_SHAPE(ng, CALL_GS);
 #undef CALL_GS
     }
-#define CALL_GI(RB, NG) hipLaunchKernelGGL((k_ginner_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt)), dim3(256), \
+#define CALL_GI(RB, NG) hipLaunchKernelGGL((k_ginner_f<RB, NG>), dim3(dense_grid(RB, NG, c->Np / 16, ng, c->m, c->nt, true)), dim3(256), \
                                            (size_t)4 * c->n_ops * c->m * 2 * sizeof(double), c->stream,                         \
                                            reinterpret_cast<const d2 *>(c->OpFrag), c->hist, c->dpsi, Gp, c->sigma, c->Np, c->cp,  \
                                            c->n_ops, c->m, c->nt)
