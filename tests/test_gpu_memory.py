@@ -23,10 +23,13 @@ def _pair(qgd, prob, ctrl, pcof, target, order, budget):
 
 
 @pytest.mark.parametrize("which,order,nsteps,windows", [("cnot3", 8, 550, 4), ("cnot3", 8, 137, 3), ("cnot2", 8, 100, 3), ("guarded", 6, 90, 2),
-                                                        ("dense_guard", 6, 48, 3), ("synthetic", 12, 240, 3), ("synthetic", 4, 301, 4)])
+                                                        ("dense_guard", 6, 48, 3), ("synthetic", 12, 240, 3), ("synthetic", 4, 301, 4),
+                                                        ("synthetic_square", 8, 48, 3)])
 def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
     if which == "synthetic":
         prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=80, c=16, nsteps=nsteps, tf=0.002 * nsteps)
+    elif which == "synthetic_square":      # as many columns as rows: the gradient on N x N matrices, the full-chip chain steps,
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=176, c=176, n_ops=2, nsteps=nsteps, tf=0.002 * nsteps)   # three blocks in the inverse
     else:
         prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / (1 if which.startswith("cnot") else 2))
     probe = qgd.DeviceProblem(prob, order)
