@@ -340,6 +340,14 @@ int alloc_grid(qgd_handle h)
     int chunks = 1;
     int rc;
     if ((rc = plan_windows(h, 1, 0))) return rc;
+    // several kernels carry the time point in gridDim.y (at most 65535): a window never holds more time points than that
+    const int MAX_WINDOW_STEPS = 65000;
+    if (h->part_world == 1 && !h->comm && h->nsteps > MAX_WINDOW_STEPS) {
+        chunks = (h->nsteps + MAX_WINDOW_STEPS - 1) / MAX_WINDOW_STEPS;
+        if ((rc = plan_windows(h, chunks, 0))) return rc;
+    } else if (k.nt > MAX_WINDOW_STEPS + 500) {
+        return fail(h, QGD_ERR_UNSUPPORTED, "a rank's window of the time grid is limited to 65000 steps (use more ranks or one handle with windows)");
+    }
     if (h->part_world == 1 && !h->comm) {
         size_t budget = h->mem_budget, fr = 0, tot = 0;
         if (!budget && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = (size_t)(0.7 * (double)fr);

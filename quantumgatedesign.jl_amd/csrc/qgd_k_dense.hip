@@ -819,14 +819,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // panel layout -> column-major planes C[row + Np col] (+ Np^2: imaginary parts) for the columns [col0, col0 + nc) of every
 // matrix, and (T != null) row-major planes T[row Np + col].  32 x 32 tiles through LDS, both sides in runs of 8-32 doubles.
-// grid (ceil(Np/32) * ceil(nc/32), nmat)
+// grid ceil(Np/32) * ceil(nc/32) * nmat (flat: a long grid may have more than 65535 matrices)
 __global__ __launch_bounds__(256) void k_binv_planes(const double *__restrict__ Win, size_t in_stride, double *__restrict__ C, double *__restrict__ T,
                                                      int Np, int col0, int nc)
 {
     __shared__ double tre[32][33], tim[32][33];
-    const int n = blockIdx.y + 1, PW = 2 * Np;
+    const int PW = 2 * Np;
     const size_t pl = (size_t)Np * Np;
-    const int ctiles = (nc + 31) / 32, r0 = (blockIdx.x / ctiles) * 32, c0 = col0 + (blockIdx.x % ctiles) * 32;
+    const int ctiles = (nc + 31) / 32, tiles = ((Np + 31) / 32) * ctiles;
+    const int n = (int)(blockIdx.x / tiles) + 1, tl = (int)(blockIdx.x % tiles);
+    const int r0 = (tl / ctiles) * 32, c0 = col0 + (tl % ctiles) * 32;
     const double *in = Win + (size_t)n * in_stride;
     #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1539,7 +1541,7 @@ int qgdk_dense_inverse(const qgdk_ctx *c)
     for (int kb0 = 0; kb0 < Np; kb0 += BINV_B, s++) {
         const int bs = (Np - kb0 < BINV_B) ? Np - kb0 : BINV_B;
         double *Wout = outs[s & 1];
-        hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((bs + 31) / 32), nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA,
+        hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((bs + 31) / 32) * nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA,
                            (double *)nullptr, Np, kb0, bs);
         if (qgdk_inverse_diag(c, Win, panel, PW, (size_t)kb0 * PW + 2 * (size_t)kb0, bs, DkC, flags)) return -1;
         hipLaunchKernelGGL((k_binv_row<1, 4>), dim3(dense_grid(1, 4, bs / 16, Np / 8, 1, nmat)), dim3(256), 0, c->stream, DkC, Win, panel, Wout,
@@ -1549,7 +1551,7 @@ int qgdk_dense_inverse(const qgdk_ctx *c)
                                Win, panel, Wout, Np, nmat, kb0, bs, flags, thresh);
         Win = Wout;
     }
-    hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((Np + 31) / 32), nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA, c->LinvT,
+    hipLaunchKernelGGL(k_binv_planes, dim3(((Np + 31) / 32) * ((Np + 31) / 32) * nmat), dim3(256), 0, c->stream, Win, panel, c->LinvA, c->LinvT,
                        Np, 0, Np);
     if (qgdk_inverse_redo(c, flags)) return -1;
     return hipGetLastError() == hipSuccess ? 1 : -1;

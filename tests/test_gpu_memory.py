@@ -112,3 +112,25 @@ def test_reference_low_order_long_grid(qgd):
     assert np.abs(out["2GB"][1] - out["resident"][1]).max() <= 1e-11
     print(f"\n55000-step cnot3, order 2: resident {out['resident'][3] * 1e3:.1f} ms ({out['resident'][2]['window_bytes'] / 2**30:.1f} GiB), "
           f"2 GB budget {out['2GB'][3] * 1e3:.1f} ms in {out['2GB'][2]['windows']} windows")
+
+
+def test_grid_longer_than_one_launch_dimension(qgd):
+    """Several kernels carry the time point in gridDim.y (at most 65535 on this runtime): a grid of 70 000 steps -- the
+    reference runs such grids at low order (examples/cnot3_optimize_gate.sb:27-40) -- is split into windows by itself even
+    though it fits the memory, and equals the same grid under an explicit budget (more, shorter windows)."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=70000, tf=100.0)
+    dp = qgd.DeviceProblem(prob, 2); dp.set_controls(ctrl); dp.set_target(target)
+    plan = dp.memory_plan()
+    assert plan["windows"] >= 2 and plan["steps_per_window"] <= 65000, plan
+    g, o = dp.discrete_adjoint(pcof)
+    f = dp.eval_forward(pcof)
+    assert np.abs(np.asarray(f) - np.asarray(o)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o)).max())
+    dp.close()
+    dp = qgd.DeviceProblem(prob, 2)
+    dp.set_memory_budget(plan["window_bytes"] // 3)
+    dp.set_controls(ctrl); dp.set_target(target)
+    assert dp.memory_plan()["windows"] > plan["windows"]
+    g2, o2 = dp.discrete_adjoint(pcof)
+    dp.close()
+    assert np.abs(g2 - g).max() <= 1e-11 * np.abs(g).max()
+    assert np.abs(np.asarray(o2) - np.asarray(o)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o)).max())
