@@ -64,10 +64,13 @@ typedef struct qgd_problem_desc {
 } qgd_problem_desc;
 
 #define QGD_MAX_ORDER 16
-#define QGD_MAX_OPS   16
+#define QGD_MAX_OPS   8
 
 /* SchrodingerProb constructor + validation.  On failure *out is NULL and
- * qgd_last_error(NULL) holds the message. */
+ * qgd_last_error(NULL) holds the message.
+ * Limits of this version (QGD_ERR_UNSUPPORTED / QGD_ERR_ARGUMENT beyond them): N <= 592 (the state panels are padded to
+ * 16 rows), at most QGD_MAX_OPS control operators, even orders 2 .. QGD_MAX_ORDER, any number of columns and of time
+ * steps (a grid longer than 65 000 steps, or larger than the memory budget, is processed in windows: qgd_set_memory_budget). */
 int qgd_create(const qgd_problem_desc *desc, qgd_handle *out);
 
 /* The same constructor for sparse operators: SchrodingerProb accepts SparseMatrixCSC
