@@ -274,6 +274,7 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
               A(&k.Pc, nt * 2 * pl) && A(&k.hist, nt * hstep) && A(&k.dpsi, nt * m * hstep) && A(&k.forcing, nt * hstep) &&
               A(&k.yhist, nt * hstep) && A(&k.lam, nt * hstep) &&
               A(&k.sigma, (size_t)k.sigma_planes * nt * (size_t)std::max(k.n_ops, 1) * m * 2) &&
+              A(&k.gpart, (nt + 64) * (size_t)std::max(k.cp / 8, 1)) &&
               // blocked scan of the sweeps: chain length 2*blen + B; exchange buffers hold every rank's chunk
               A(&k.PiX, 2 * nb * 2 * pl) && A(&k.phiX, (nb + 1) * hstep) && A(&k.RX, W * 4 * pl) && A(&k.phiRX, W * 2 * hstep) &&
               A(&k.wbnd, (W + 1) * hstep) && A(&k.wbndY, (W + 1) * hstep) && A(&k.bnd, (nb + 1) * hstep) &&
@@ -293,6 +294,7 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
     // panels g_j of a time point in HBM.  QGD_DENSE_OLD=1 keeps the older kernels (LDS panels, or HBM slabs when
     // they do not fit) for comparison.
     if (!dry) { k.panel_scratch = nullptr; k.dense_gemm = 0; k.Afrag = k.Dfrag = k.OpFrag = nullptr; k.Xouter = k.Tlam = k.Xfrag = nullptr; k.binv = nullptr; }
+    if (!dry) { k.gpart_on = 0; k.gpart_n = 0; }
     const bool lds_too_small = qgdk_lds_needed(k.Np, k.m, k.n_ops) > 150 * 1024 || getenv("QGD_FORCE_GLOBAL_PANELS");
     if (Np > 64 && !getenv("QGD_DENSE_OLD")) {
         if (!A(&k.panel_scratch, nt * m * hstep) || !A(&k.Afrag, nt * m * 2 * pl) || !A(&k.Dfrag, nt * m * 2 * pl) ||
@@ -372,6 +374,7 @@ int alloc_grid(qgd_handle h)
     if ((rc = alloc_window(h, false, &h->window_bytes))) return rc;
     const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt;
     HIP_TRY(h, hipMemsetAsync(k.zero_panel, 0, hstep * sizeof(double), k.stream));
+    HIP_TRY(h, hipMemsetAsync(k.gpart, 0, (nt + 64) * (size_t)std::max(k.cp / 8, 1) * sizeof(double), k.stream));
     HIP_TRY(h, hipMemcpyAsync(k.bnd2, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     HIP_TRY(h, hipMemcpyAsync(k.psi0, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
     HIP_TRY(h, hipMemcpyAsync(k.bnd, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
@@ -571,6 +574,10 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
 {
     qgdk_ctx &k = h->k;
+    // guard penalty: one GPU with the grid resident -> the guard stage stores its workgroups' partial sums and the terminal
+    // stage adds them in index order (the same bits on every run); windows and partitions keep the atomic sum
+    k.gpart_on = (k.gpart && k.part_world == 1 && !h->comm && h->chunks_eff == 1 && !getenv("QGD_GUARD_ATOMIC")) ? 1 : 0;
+    k.gpart_n = qgdk_guard_parts(&k);
     if (pcof) {
         if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
         PhaseTimer t(h, "tables");

@@ -36,6 +36,8 @@ struct ChainArgs {
     // writes the adjoint forcing f_n = -(2 dt/tf) trap_n W w_n and accumulates the guard penalty
     // (dt/tf) sum_n trap_n w_n^T W w_n (infidelity.jl:56-96) of the states it produces
     const double *guard_diag;   // [2N] or null
+    double *gpart;              // MODE 1 with the guard fused: partial penalty of workgroup bid (stored; null: atomicAdd into scal[2])
+    const double *t_gpart; int t_gpart_n;      // t_on: the partial penalties the terminal workgroup adds up in index order
     double *guard_forcing;      // [.][Np][2cp]
     double *scal;               // scal[2] += penalty
     int gN, n_off, nt_glob, count_first;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                const double *__restrict__ forcing, double *__restrict__ yhist,
                                                double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
                                                int write_y, double *__restrict__ y2, double *__restrict__ y3,
-                                               double *__restrict__ y4, int given_ab);
+                                               double *__restrict__ y4, int given_ab, const double *gpart = nullptr, int gpart_n = 0);
 
 __host__ __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
 {
@@ -184,7 +186,7 @@ __device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bi
 
     if (MODE == 2 && a.t_on && bid == nbid - 1) {      // the extra workgroup: k_terminal's work
         terminal_block(a.t_hist, a.t_target, a.t_forcing, a.t_yhist, a.t_scal, NP, a.cp, a.t_nt, a.t_ness, a.t_have_target, 1,
-                       a.t_y2, a.t_y3, a.t_y4, 0);
+                       a.t_y2, a.t_y3, a.t_y4, 0, a.t_gpart, a.t_gpart_n);
         return;
     }
     int b, grp0;
@@ -199,7 +201,10 @@ __device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bi
     const int blk_end = ((bb + 1) * a.blen < a.S) ? (bb + 1) * a.blen : a.S;
     const int s0 = bb * a.blen + (subs ? tsub * a.sub_len : 0);
     const int e0 = subs ? ((s0 + a.sub_len < blk_end) ? s0 + a.sub_len : blk_end) : blk_end;
-    if (subs && s0 >= blk_end) return;                   // (a short last block has fewer sub-blocks)
+    if (subs && s0 >= blk_end) {                         // (a short last block has fewer sub-blocks)
+        if (MODE == 1 && a.guard_diag && a.gpart && threadIdx.x == 0) a.gpart[bid] = 0.0;      // ... whose guard partials are zero, not stale
+        return;
+    }
     const int PWc = MAT ? 2 * NP : 2 * a.cp;
     const size_t hstep = (size_t)NP * PWc;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -524,7 +529,7 @@ __device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bi
         if (tid == 0) {
             double tot = 0.0;
             for (int q = 0; q < NTH / 16; q++) tot += pred[q];
-            atomicAdd(&a.scal[2], tot * a.dt / a.tf);
+            if (a.gpart) a.gpart[bid] = tot * a.dt / a.tf; else atomicAdd(&a.scal[2], tot * a.dt / a.tf);
         }
     }
     if (MODE == 5 && a.fs_gf) {                          // NG == 1: one parameter per workgroup
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
                                                double *__restrict__ forcing,
                                                double *__restrict__ scal, int N, int Np, int c,
                                                int cp, int n_off, int nt_glob, int count_first, double dt, double tf,
-                                               int have_guard)
+                                               int have_guard, double *__restrict__ gpart)
 {
     __shared__ double red[4];
     const int n = blockIdx.x, ng = n + n_off;
@@ -1165,9 +1170,10 @@ __global__ __launch_bounds__(256) void k_guard(const double *__restrict__ W,
     for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
     __syncthreads();
-    if (threadIdx.x == 0 && (n > 0 || count_first)) {
-        double tot = red[0] + red[1] + red[2] + red[3];
-        atomicAdd(&scal[2], tot * trap * dt / tf);
+    if (threadIdx.x == 0) {
+        const double tot = (n > 0 || count_first) ? (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf : 0.0;
+        if (gpart) gpart[n] = tot;                       // added in index order by the terminal stage
+        else if (n > 0 || count_first) atomicAdd(&scal[2], tot);
     }
 }
 
@@ -1177,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
                                                     const double *__restrict__ hist,
                                                     double *__restrict__ forcing,
                                                     double *__restrict__ scal, int N, int Np, int cp,
-                                                    int n_off, int nt_glob, int count_first, double dt, double tf)
+                                                    int n_off, int nt_glob, int count_first, double dt, double tf, double *__restrict__ gpart)
 {
     __shared__ double red[4];
     const int n = blockIdx.x, ng = n + n_off;     // local / global time index
@@ -1199,7 +1205,11 @@ __global__ __launch_bounds__(256) void k_guard_diag(const double *__restrict__ w
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
     __syncthreads();
     // the first point of a time window is the last point of the previous rank's window
-    if (threadIdx.x == 0 && (n > 0 || count_first)) atomicAdd(&scal[2], (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf);
+    if (threadIdx.x == 0) {
+        const double tot = (n > 0 || count_first) ? (red[0] + red[1] + red[2] + red[3]) * trap * dt / tf : 0.0;
+        if (gpart) gpart[n] = tot;                       // added in index order by the terminal stage
+        else if (n > 0 || count_first) atomicAdd(&scal[2], tot);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1213,9 +1223,16 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                const double *__restrict__ forcing, double *__restrict__ yhist,
                                                double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
                                                int write_y, double *__restrict__ y2, double *__restrict__ y3,
-                                               double *__restrict__ y4, int given_ab)
+                                               double *__restrict__ y4, int given_ab, const double *gpart, int gpart_n)
 {
     __shared__ double red[32];
+    // guard penalty: the partial sums of the guard stage's workgroups in index order -- the same bits on every run (the
+    // objective an optimizer compares from step to step is infidelity + this number)
+    if (gpart && threadIdx.x == blockDim.x - 1) {
+        double s = 0.0;
+        for (int w = 0; w < gpart_n; w++) s += gpart[w];
+        scal[2] = s;
+    }
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
     const size_t hstep = (size_t)Np * PWc;
     const double *w = hist + (size_t)(nt - 1) * hstep;
@@ -1367,7 +1384,8 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
 // and writes scal[0..1] -- the same bits whichever workgroup that is (the gradient depends on these two numbers through
 // the terminal condition: with atomicAdd here the N > 64 gradient differed in its last bits from run to run).
 __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__ w, const double *__restrict__ target,
-                                                      double *__restrict__ scal, int hstep, int PWc, int cost, double *__restrict__ part, int chunk)
+                                                      double *__restrict__ scal, int hstep, int PWc, int cost, double *__restrict__ part, int chunk,
+                                                      const double *__restrict__ gpart, int gpart_n)
 {
     __shared__ double red[8];
     __shared__ int last;
@@ -1395,6 +1413,7 @@ __global__ __launch_bounds__(256) void k_terminal_sum(const double *__restrict__
     double A = 0.0, B = 0.0;
     for (int g = 0; g < (int)gridDim.x; g++) { A += __builtin_nontemporal_load(part + 2 * g); B += __builtin_nontemporal_load(part + 2 * g + 1); }
     scal[0] = A; scal[1] = B;
+    if (gpart) { double s = 0.0; for (int w = 0; w < gpart_n; w++) s += gpart[w]; scal[2] = s; }      // guard penalty, in index order
     *ticket = 0;                                                  // for the next evaluation (same stream: ordered)
 }
 
@@ -1421,9 +1440,9 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
                                                   double *__restrict__ scal, int Np, int cp, int nt,
                                                   int n_ess, int have_target, int write_y,
                                                   double *__restrict__ y2, double *__restrict__ y3,
-                                                  double *__restrict__ y4, int given_ab)
+                                                  double *__restrict__ y4, int given_ab, const double *__restrict__ gpart, int gpart_n)
 {
-    terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab);
+    terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab, gpart, gpart_n);
 }
 
 extern "C" {
@@ -1566,6 +1585,7 @@ int qgdk_forward_finish(const qgdk_ctx *c)
         }
         if (guard_is_fused(c)) {
             s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
+            s3.gpart = c->gpart_on ? c->gpart : nullptr;
             s3.n_off = c->n_off; s3.nt_glob = c->nt_glob; s3.count_first = (c->n_off == 0) ? 1 : 0; s3.dt = c->dt; s3.tf = c->tf;
         }
         return launch_chain<1>(s3, c->stream);
@@ -1601,12 +1621,21 @@ int qgdk_forward_finish(const qgdk_ctx *c)
     s3.ngroups = c->cp / 8;
     if (guard_is_fused(c)) {
         s3.guard_diag = c->guard_diag; s3.guard_forcing = c->forcing; s3.scal = c->scal; s3.gN = c->N;
+        s3.gpart = c->gpart_on ? c->gpart : nullptr;
         s3.n_off = c->n_off; s3.nt_glob = c->nt_glob; s3.count_first = (c->n_off == 0) ? 1 : 0; s3.dt = c->dt; s3.tf = c->tf;
     }
     return launch_chain<1>(s3, c->stream);
 }
 
 int qgdk_guard_is_fused(const qgdk_ctx *c) { return guard_is_fused(c) ? 1 : 0; }
+// workgroups of the guard stage (= entries of gpart it writes): the history pass when the guard work is fused into it
+// (chain_is_fast sizes: one per (block or sub-block, column group)), else one per time point (k_guard_diag / k_guard)
+int qgdk_guard_parts(const qgdk_ctx *c)
+{
+    if (!guard_is_fused(c)) return c->nt;
+    const int nb = c->sub_hist ? c->scan_blocks * (c->sub_n + 1) : c->scan_blocks;
+    return nb * (c->cp / 8);
+}
 int qgdk_terminal_can_fuse(const qgdk_ctx *c) { return chain_is_fast(c) && !getenv("QGD_TERMINAL_KERNEL"); }
 
 int qgdk_guard(const qgdk_ctx *c)
@@ -1621,11 +1650,12 @@ int qgdk_guard_kernel(const qgdk_ctx *c)
     const int count_first = (c->n_off == 0) ? 1 : 0;
     if (c->have_guard == 2) {   // diagonal projector
         hipLaunchKernelGGL(k_guard_diag, dim3(c->nt), dim3(256), 0, c->stream, c->guard_diag, c->hist, c->forcing,
-                           c->scal, c->N, c->Np, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf);
+                           c->scal, c->N, c->Np, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf, c->gpart_on ? c->gpart : nullptr);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(k_guard, dim3(c->nt), dim3(256), 0, c->stream, c->guard, c->hist, c->forcing, c->scal,
-                       c->N, c->Np, c->c, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf, c->have_guard);
+                       c->N, c->Np, c->c, c->cp, c->n_off, c->nt_glob, count_first, c->dt, c->tf, c->have_guard,
+                       c->gpart_on ? c->gpart : nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1643,7 +1673,11 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
         const double *w = c->hist + (size_t)(c->nt - 1) * hstep;
         if (!given_ab) {
             HIPCHK(hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
-            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(twg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type, c->term_part, tchunk);
+            if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(twg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type, c->term_part, tchunk,
+                                                   (c->gpart_on && c->have_guard) ? c->gpart : nullptr, c->gpart_n);
+            else if (c->gpart_on && c->have_guard)      // no target: only the guard penalty is to be added up
+                hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist, c->scal, c->Np, c->cp, c->nt,
+                                   c->n_ess, 0, 0, slot, slot, slot, 0, c->gpart, c->gpart_n);
         }
         if (write_y)
             hipLaunchKernelGGL(k_terminal_y, dim3(nwg), dim3(256), 0, c->stream, c->target, c->forcing + (size_t)(c->nt - 1) * hstep,
@@ -1653,7 +1687,8 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
     }
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target * (1 + c->cost_type), write_y, slot,
-                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab);
+                       c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab,
+                       (c->gpart_on && c->have_guard && !given_ab) ? c->gpart : nullptr, c->gpart_n);
     return (int)hipGetLastError();
 }
 
@@ -1671,6 +1706,7 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
         const size_t hstep = (size_t)c->Np * 2 * c->cp;
         a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target * (1 + c->cost_type);
         a.t_hist = c->hist; a.t_target = c->target; a.t_forcing = c->forcing; a.t_yhist = c->yhist; a.t_scal = c->scal;
+        a.t_gpart = (c->gpart_on && c->have_guard) ? c->gpart : nullptr; a.t_gpart_n = c->gpart_n;
         a.t_y2 = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
         a.t_y3 = c->bndY + (size_t)c->scan_blocks * hstep; a.t_y4 = c->bndY2 + (size_t)c->scan_blocks2 * hstep;
     }

@@ -64,14 +64,25 @@ def test_gradient_is_bitwise_reproducible(qgd, which, order, cols):
             target = rng.standard_normal((prob.N_tot_levels, cols)) + 1j * rng.standard_normal((prob.N_tot_levels, cols))
     else:
         prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
-    grads = []
+    grads, scalars, fwd = [], [], []
     for fresh in range(2):
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         for _ in range(5 if not fresh else 1):
-            grads.append(dp.discrete_adjoint(pcof)[0])
+            g, o = dp.discrete_adjoint(pcof)
+            grads.append(g); scalars.append(np.asarray(o))
+        for _ in range(2):
+            fwd.append(np.asarray(dp.eval_forward(pcof)))
         dp.close()
     for g in grads[1:]:
         assert np.array_equal(g, grads[0])
+    # ... and so do the scalars of the objective, guard penalty included (end of round 3: its partial sums are stored per
+    # workgroup and added in index order by the terminal stage).  The forward-only call adds the overlaps in its own kernel:
+    # bitwise equal among its own calls, equal to the gradient call's to rounding.
+    for o in scalars[1:]:
+        assert np.array_equal(o, scalars[0]), (o, scalars[0])
+    for o in fwd[1:]:
+        assert np.array_equal(o, fwd[0]), (o, fwd[0])
+    assert np.abs(fwd[0] - scalars[0]).max() <= 1e-13 * max(1.0, np.abs(scalars[0]).max())
 
 
 @pytest.mark.parametrize("zerocopy", [None, "16"])

@@ -325,14 +325,20 @@ def test_gradient_is_bitwise_reproducible_large_n(qgd, N, c, n_ops, order, form,
     same bits, for every form of the gradient scalars, from one handle five times and from a fresh handle."""
     monkeypatch.setenv("QGD_GINNER", form)
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=10, tf=0.1, seed=N)
-    grads = []
+    rng = np.random.default_rng(N)
+    prob.guard_subspace_projector = np.asfortranarray(np.diag(rng.random(2 * N)))      # (a guard penalty to add up as well)
+    grads, scalars = [], []
     for fresh in range(2):
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         for _ in range(5 if not fresh else 1):
-            grads.append(dp.discrete_adjoint(pcof)[0])
+            g, o = dp.discrete_adjoint(pcof)
+            grads.append(g); scalars.append(np.asarray(o))
         dp.close()
+    assert scalars[0][2] > 0
     for g in grads[1:]:
         assert np.array_equal(g, grads[0])
+    for o in scalars[1:]:
+        assert np.array_equal(o, scalars[0])
 
 
 @pytest.mark.parametrize("N,c,order,nsteps", [(300, 12, 4, 12), (320, 40, 8, 10), (512, 16, 6, 9), (592, 8, 4, 11)])
