@@ -1226,13 +1226,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                double *__restrict__ y4, int given_ab, const double *gpart, int gpart_n)
 {
     __shared__ double red[32];
-    // guard penalty: the partial sums of the guard stage's workgroups in index order -- the same bits on every run (the
-    // objective an optimizer compares from step to step is infidelity + this number)
-    if (gpart && threadIdx.x == blockDim.x - 1) {
-        double s = 0.0;
-        for (int w = 0; w < gpart_n; w++) s += gpart[w];
-        scal[2] = s;
-    }
+    __shared__ double gred[16];
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
     const size_t hstep = (size_t)Np * PWc;
     const double *w = hist + (size_t)(nt - 1) * hstep;
@@ -1256,11 +1250,17 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
             b += (c16 < 8) ? w[e] * tp : -w[e] * tp;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[16 + (threadIdx.x >> 6)] = b; }
+    // guard penalty: the partial sums of the guard stage's workgroups, added in a FIXED order (thread t takes the entries
+    // t, t + blockDim, ... in ascending order; then the same shuffle tree and wave order as the overlaps) -- the same bits
+    // on every run: the objective an optimizer compares from step to step is infidelity + this number
+    double gs = 0.0;
+    if (gpart) for (int w = threadIdx.x; w < gpart_n; w += blockDim.x) gs += gpart[w];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); gs += __shfl_down(gs, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[16 + (threadIdx.x >> 6)] = b; gred[threadIdx.x >> 6] = gs; }
     __syncthreads();
     a = 0.0; b = 0.0;
     for (int q = 0; q < nw; q++) { a += red[q]; b += red[16 + q]; }
+    if (gpart && threadIdx.x == 0) { gs = 0.0; for (int q = 0; q < nw; q++) gs += gred[q]; scal[2] = gs; }
     // column shards: the overlaps are GLOBAL sums over all columns (infidelity.jl:13-17); after the ranks' all-reduce
     // they are in scal and the terminal condition is formed from them, not from this rank's columns
     if (given_ab) { a = scal[0]; b = scal[1]; }       // (a column shard's Tracking / Norm cost was reduced like the overlaps)
