@@ -574,10 +574,13 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
 {
     qgdk_ctx &k = h->k;
-    // guard penalty: one GPU with the grid resident -> the guard stage stores its workgroups' partial sums and the terminal
-    // stage adds them in index order (the same bits on every run); windows and partitions keep the atomic sum
-    k.gpart_on = (k.gpart && k.part_world == 1 && !h->comm && h->chunks_eff == 1 && !getenv("QGD_GUARD_ATOMIC")) ? 1 : 0;
+    // guard penalty: the guard stage stores its workgroups' partial sums and a later stage adds them in a fixed order (the
+    // same bits on every run)
+    k.gpart_on = (k.gpart && !getenv("QGD_GUARD_ATOMIC")) ? 1 : 0;
     k.gpart_n = qgdk_guard_parts(&k);
+    // who adds the partials up: the terminal stage where this handle runs one right behind the guard stage (the grid
+    // resident and the final time its own); a window of a long grid and the other ranks of a partition launch k_guard_fold
+    k.gpart_terminal = (h->chunks_eff == 1 && k.part_rank == k.part_world - 1) ? 1 : 0;
     if (pcof) {
         if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
         PhaseTimer t(h, "tables");
@@ -663,6 +666,7 @@ int forward_end(qgd_handle h)
     if (k.part_rank == k.part_world - 1 && !h->defer_terminal) {   // the rank that owns the final time
         PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target));
     }
+    if (k.gpart_on && !k.gpart_terminal && k.have_guard) { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard_fold(&k)); }
     h->forward_valid = true;
     return QGD_OK;
 }
@@ -769,6 +773,7 @@ int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool reru
         if (qgdk_guard(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "guard kernel failed to launch");
         if (k.have_guard == 0) h->forcing_zero = true;
     }
+    if (!rc && k.gpart_on && k.have_guard && qgdk_guard_fold(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "guard fold failed to launch");
     k.scal = scal_real; k.keep_scal = 0;
     if (rc) return rc;
     if (!rerun)

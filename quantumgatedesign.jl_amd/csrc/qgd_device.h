@@ -50,7 +50,7 @@ typedef struct qgdk_ctx {
     double *grad;       // [n_pcof]
     double *scal;       // [4]: <w,R>, <w,T>, guard, spare
     double *gpart;      // per-workgroup partial guard penalties, added in index order by the terminal stage (gpart_on: single GPU, resident grid)
-    int gpart_on, gpart_n;
+    int gpart_on, gpart_n, gpart_terminal;   // gpart_terminal: the terminal stage of this handle adds the partials up (else qgdk_guard_fold does)
     double *term_part;  // [2 * 1024 + 1]: per-workgroup partial overlaps of k_terminal_sum and its ticket counter (zeroed at creation)
     double *cw;         // [2*(m+1)]: c_j dt^j, c_j (-dt)^j
     double *binv;       // work space of the block Gauss-Jordan inverse for N > 64 (qgdk_dense_inverse), or null
@@ -118,7 +118,8 @@ int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t str
 int qgdk_forward_blocks_upper(const qgdk_ctx *c);
 int qgdk_guard(const qgdk_ctx *c);
 int qgdk_guard_is_fused(const qgdk_ctx *c);
-int qgdk_guard_parts(const qgdk_ctx *c);      /* workgroups of the guard stage of this configuration = entries of gpart it writes */
+int qgdk_guard_parts(const qgdk_ctx *c);
+int qgdk_guard_fold(const qgdk_ctx *c);       /* scal[2] += the partials of gpart in a fixed order (windows, ranks without the final time) */      /* workgroups of the guard stage of this configuration = entries of gpart it writes */
 int qgdk_terminal_can_fuse(const qgdk_ctx *c);
 int qgdk_terminal(const qgdk_ctx *c, int write_y);
 int qgdk_terminal_given(const qgdk_ctx *c);   /* y_N from the overlaps already in scal (column shards) */

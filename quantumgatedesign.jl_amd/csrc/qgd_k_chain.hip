@@ -1445,6 +1445,19 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
     terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab, gpart, gpart_n);
 }
 
+// scal[2] += the guard partials in a fixed order (thread-strided ascending sums, shuffle tree, waves in order): where no
+// terminal stage follows the guard stage -- a window of a long grid, a rank that does not own the final time
+__global__ __launch_bounds__(256) void k_guard_fold(const double *__restrict__ gpart, int n, double *__restrict__ scal)
+{
+    __shared__ double red[4];
+    double gs = 0.0;
+    for (int w = threadIdx.x; w < n; w += 256) gs += gpart[w];
+    for (int off = 32; off > 0; off >>= 1) gs += __shfl_down(gs, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gs;
+    __syncthreads();
+    if (threadIdx.x == 0) scal[2] += ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 extern "C" {
 
 #define QGD_SUB_LEN 3      /* steps per sub-block of the forward history pass */
@@ -1628,6 +1641,11 @@ int qgdk_forward_finish(const qgdk_ctx *c)
 }
 
 int qgdk_guard_is_fused(const qgdk_ctx *c) { return guard_is_fused(c) ? 1 : 0; }
+int qgdk_guard_fold(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_guard_fold, dim3(1), dim3(256), 0, c->stream, c->gpart, c->gpart_n, c->scal);
+    return (int)hipGetLastError();
+}
 // workgroups of the guard stage (= entries of gpart it writes): the history pass when the guard work is fused into it
 // (chain_is_fast sizes: one per (block or sub-block, column group)), else one per time point (k_guard_diag / k_guard)
 int qgdk_guard_parts(const qgdk_ctx *c)
@@ -1674,8 +1692,8 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
         if (!given_ab) {
             HIPCHK(hipMemsetAsync(c->scal, 0, 2 * sizeof(double), c->stream));
             if (c->have_target) hipLaunchKernelGGL(k_terminal_sum, dim3(twg), dim3(256), 0, c->stream, w, c->target, c->scal, (int)hstep, 2 * c->cp, c->cost_type, c->term_part, tchunk,
-                                                   (c->gpart_on && c->have_guard) ? c->gpart : nullptr, c->gpart_n);
-            else if (c->gpart_on && c->have_guard)      // no target: only the guard penalty is to be added up
+                                                   (c->gpart_on && c->gpart_terminal && c->have_guard) ? c->gpart : nullptr, c->gpart_n);
+            else if (c->gpart_on && c->gpart_terminal && c->have_guard)      // no target: only the guard penalty is to be added up
                 hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist, c->scal, c->Np, c->cp, c->nt,
                                    c->n_ess, 0, 0, slot, slot, slot, 0, c->gpart, c->gpart_n);
         }
@@ -1688,7 +1706,7 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
     hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target * (1 + c->cost_type), write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab,
-                       (c->gpart_on && c->have_guard && !given_ab) ? c->gpart : nullptr, c->gpart_n);
+                       (c->gpart_on && c->gpart_terminal && c->have_guard && !given_ab) ? c->gpart : nullptr, c->gpart_n);
     return (int)hipGetLastError();
 }
 
@@ -1706,7 +1724,7 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
         const size_t hstep = (size_t)c->Np * 2 * c->cp;
         a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target * (1 + c->cost_type);
         a.t_hist = c->hist; a.t_target = c->target; a.t_forcing = c->forcing; a.t_yhist = c->yhist; a.t_scal = c->scal;
-        a.t_gpart = (c->gpart_on && c->have_guard) ? c->gpart : nullptr; a.t_gpart_n = c->gpart_n;
+        a.t_gpart = (c->gpart_on && c->gpart_terminal && c->have_guard) ? c->gpart : nullptr; a.t_gpart_n = c->gpart_n;
         a.t_y2 = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
         a.t_y3 = c->bndY + (size_t)c->scan_blocks * hstep; a.t_y4 = c->bndY2 + (size_t)c->scan_blocks2 * hstep;
     }

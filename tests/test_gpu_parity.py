@@ -196,6 +196,9 @@ def test_time_partitioned_matches_single_gpu(qgd, which, nsteps, world):
     for g, o in results:
         assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
         assert np.abs(o - o_ref).max() <= 1e-12
+    again = qgd.LocalGroup(backs).discrete_adjoint(pcof)      # every rank adds its guard partials in a fixed order: the same bits again
+    for (g, o), (g2, o2) in zip(results, again):
+        assert np.array_equal(g, g2) and np.array_equal(np.asarray(o), np.asarray(o2))
     for b in backs:
         b.close()
 
