@@ -1795,8 +1795,8 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         return QGD_OK;
     }
     if (s == "sigma") {      // (the column groups' planes of the N <= 64 gradient kernels are summed here)
-        const bool planes = k.use_sparse || (k.Np == 64 && k.m <= 5 && k.n_ops >= 1) || k.dense_gemm;
-        const int nplanes = k.dense_gemm ? qgdk_dense_sigma_planes(&k) : k.sigma_planes;
+        const bool planes = true;      // (every gradient kernel stores one plane per contributing workgroup)
+        const int nplanes = k.dense_gemm ? qgdk_dense_sigma_planes(&k) : k.cp / 8;
         HIP_TRY(h, hipMemcpy(out, k.sigma, need * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<double> pl_(need);
         for (int g = 1; planes && g < nplanes; g++) {

@@ -1904,7 +1904,7 @@ int qgdk_lambda(const qgdk_ctx *c)
 size_t qgdk_lds_needed(int Np, int m, int n_ops)
 {
     size_t a = (size_t)(m + 1) * Np * 16 * sizeof(double);
-    size_t b = ((size_t)2 * m * Np * 16 + (size_t)n_ops * m * 2) * sizeof(double);
+    size_t b = ((size_t)2 * m * Np * 16 + (size_t)4 * n_ops * m * 2) * sizeof(double);      // (k_gradsweep: panels + per-wave scalar slots)
     return a > b ? a : b;
 }
 

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_derivs(const double *__restrict__ ops,
 //   sigma   sigP[k][d] += (1/j) <(dA/dp_k) psi_i, g_j>,  sigQ likewise, d = j-1-i
 // This is the O(m^2) reverse form of accumulate_gradient_arbitrary_fast! /
 // recursive_magic! (eval_grad_discrete_adjoint.jl:582-726); inner products as
-// compute_inner_prod_S!/K! (:764-800).  sigma: [nt][n_ops][m][2] (atomicAdd
-// across column groups).
+// compute_inner_prod_S!/K! (:764-800).  sigma: one plane [nt][n_ops][m][2] per column
+// group, added in order by k_contract.
 // ---------------------------------------------------------------------------
 template <int NOPS>
 __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ ops,
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
         const double lx = (n <= nt - 2) ? lam[(size_t)(n + 1) * hstep + src] : 0.0;
         for (int j = 1; j <= m; j++) gs[(size_t)(j - 1) * ps + e] = cw[2 * j] * lx - cw[2 * j + 1] * ln;
     }
-    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x) sig[e] = 0.0;
+    const int nsig = n_ops * m * 2;        // per-wave slots sig[wave][nsig]: one writer each, added in wave order below (no atomics across waves)
+    for (int e = threadIdx.x; e < nw * nsig; e += blockDim.x) sig[e] = 0.0;
     __threadfence_block();
     __syncthreads();
 
@@ -158,16 +159,20 @@ __global__ __launch_bounds__(256) void k_gradsweep(const double *__restrict__ op
                     for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sq += __shfl_down(sq, off); }
                     if (lane == 0) {
                         const int d = j - 1 - i;
-                        atomicAdd(&sig[(o * m + d) * 2], sp / (double)j);
-                        atomicAdd(&sig[(o * m + d) * 2 + 1], sq / (double)j);
+                        atomicAdd(&sig[wave * nsig + (o * m + d) * 2], sp / (double)j);          // (own slot: LDS executes a wave's adds in order)
+                        atomicAdd(&sig[wave * nsig + (o * m + d) * 2 + 1], sq / (double)j);
                     }
                 }
             }
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n_ops * m * 2; e += blockDim.x)
-        atomicAdd(&sigma[(size_t)n * n_ops * m * 2 + e], sig[e]);
+    // the workgroup's own plane of sigma (plane = column group): stored, k_contract adds the planes in order
+    for (int e = threadIdx.x; e < nsig; e += blockDim.x) {
+        double v = 0.0;
+        for (int q = 0; q < nw; q++) v += sig[q * nsig + e];
+        sigma[((size_t)grp * nt + n) * nsig + e] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -597,9 +602,9 @@ int qgdk_gradient(const qgdk_ctx *c)
         const int rc = qgdk_dense_gradient(c);
         return rc ? rc : qgdk_contract(c);
     }
-    size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)c->n_ops * c->m * 2) * sizeof(double);
+    size_t shm = ((size_t)2 * c->m * c->Np * 16 + (size_t)4 * c->n_ops * c->m * 2) * sizeof(double);
     double *gp = nullptr;
-    if (c->panel_scratch) { gp = c->panel_scratch; shm = (size_t)c->n_ops * c->m * 2 * sizeof(double); }
+    if (c->panel_scratch) { gp = c->panel_scratch; shm = (size_t)4 * c->n_ops * c->m * 2 * sizeof(double); }
     if (c->Np == 64 && c->m <= 5 && c->n_ops >= 1) {
         int rc = 0;
         switch (c->m) {
@@ -625,7 +630,7 @@ int qgdk_contract(const qgdk_ctx *c)
     const int chunks = (c->nt + CT_CHUNK - 1) / CT_CHUNK;
     hipLaunchKernelGGL(k_contract, dim3(chunks, c->n_ops, (c->nc_max + 63) / 64), dim3(256), 0,
                        c->stream, c->G, c->goff, c->ncoef, c->poff, c->sigma, c->nt, c->m, c->n_ops, c->status, c->scal,
-                       c->dense_gemm ? qgdk_dense_sigma_planes(c) : (c->use_sparse || (c->Np == 64 && c->m <= 5 && c->n_ops >= 1)) ? c->sigma_planes : 1,
+                       c->dense_gemm ? qgdk_dense_sigma_planes(c) : c->cp / 8,      // one plane per contributing workgroup, added in order
                        c->cpart, c->n_pcof,
                        c->g_nt ? c->g_nt : c->nt, c->g_n0);
     hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof, chunks,

@@ -45,14 +45,16 @@ def test_csc_constructor_matches_dense(qgd, which, order):
     # bitwise: the same kernels ran on the same operands, and the gradient reductions have a fixed order (k_contract adds
     # its time chunks in chunk order, the column groups' sigma planes in group order -- no atomics on the way to grad)
     assert np.array_equal(out[0][0], out[1][0])
-    assert np.allclose(out[0][1], out[1][1], rtol=1e-14, atol=1e-15)      # (the guard-penalty scalar is still an atomic sum)
+    assert np.array_equal(out[0][1], out[1][1])      # (the scalars too, since the guard penalty is added in a fixed order)
 
 
-@pytest.mark.parametrize("which,order,cols", [("cnot3", 8, 8), ("cnot3", 8, 24), ("cnot2", 8, 4), ("guarded", 6, 4)])
+@pytest.mark.parametrize("which,order,cols", [("cnot3", 8, 8), ("cnot3", 8, 24), ("cnot2", 8, 4), ("guarded", 6, 4), ("dense_guard", 6, 4),
+                                              ("dense20", 8, 12), ("dense48", 4, 20)])
 def test_gradient_is_bitwise_reproducible(qgd, which, order, cols):
     """The reference accumulates the gradient serially (eval_grad_discrete_adjoint.jl:603-643, :148-157): the same
     inputs give the same bits.  So does the device path for N <= 64: five evaluations of one handle and one of a
-    fresh handle, with 1 and with 3 column groups (cnot3 with 24 initial conditions)."""
+    fresh handle, with 1 and with 3 column groups (cnot3 with 24 initial conditions); the dense-operator kernels below
+    N = 64 too (end of round 3: no atomic sum is left on the way to the gradient or the objective)."""
     if which == "cnot3":
         prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=130, tf=130.0)
         if cols != prob.N_initial_conditions:
@@ -62,6 +64,10 @@ def test_gradient_is_bitwise_reproducible(qgd, which, order, cols):
             prob.u0, prob.v0 = np.asfortranarray(z.real), np.asfortranarray(z.imag)
             prob.N_initial_conditions = cols
             target = rng.standard_normal((prob.N_tot_levels, cols)) + 1j * rng.standard_normal((prob.N_tot_levels, cols))
+    elif which.startswith("dense") and which[5:].isdigit():      # dense random operators below N = 64: the generic kernels (k_gradsweep)
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=int(which[5:]), c=cols, n_ops=2, nsteps=30, tf=0.3)
+        rng = np.random.default_rng(7)
+        prob.guard_subspace_projector = np.asfortranarray(np.diag(rng.random(2 * prob.N_tot_levels)))
     else:
         prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
     grads, scalars, fwd = [], [], []
