@@ -68,6 +68,7 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
 
 KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_mfma", "propagator": "k_propagator",
                    "lambda": "k_lambda", "guard": "k_guard_diag"}
+CNOT2_PROFILE = "r04_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
 PMC_PROFILE = "r03_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
 PMC_MFMA_PROFILE = "r03_pmc_mfma_cnot3.json"
 
@@ -296,11 +297,17 @@ def large_n_case(qgd, np, steps=3):
     # units on three-product tiles (level recursion, sweep, D-contraction, outer products, chains) issue 6 N^3, the rest 8 N^3
     units_3m = gemms - 3 if not os.environ.get("QGD_DENSE_4M") else 0.0
     issued = 8.0 * N ** 3 * (0.75 * units_3m + (gemms - units_3m)) * (nsteps + 1) / 1e12
+    # `frac` is the HARDWARE fraction: flops the MFMA pipe issues (three real products per complex multiply on most
+    # units) / time / peak.  The usual complex-GEMM count (8 N^3 per unit) prices the same time higher and is kept as
+    # `effective_*`: an algorithmic ratio, not a utilisation.
     return {"workload": f"C5 synthetic: N={N}, {c} columns, {n_ops} control operators, order {order}, nsteps={nsteps}",
-            "timesteps_per_s": nsteps / sec, "ms_per_evaluation": sec * 1e3, "tflop_per_evaluation": tflop,
-            "bound": "mfma", "achieved": tflop / sec, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": tflop / sec / PEAK_FP64_MATRIX_TFLOPS,
-            "mfma_issued_tflop_per_evaluation": issued, "mfma_issued_frac": issued / sec / PEAK_FP64_MATRIX_TFLOPS,
+            "timesteps_per_s": nsteps / sec, "ms_per_evaluation": sec * 1e3,
+            "bound": "mfma", "tflop_per_evaluation": issued, "achieved": issued / sec, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": issued / sec / PEAK_FP64_MATRIX_TFLOPS,
+            "frac_note": "MFMA-issued flops (3M tiles: 6 N^3 per complex GEMM unit) / time / 78.6 TFLOP/s; the card clocks ~2.1 GHz under this load "
+                         "(peak assumes 2.4): ~0.78 of the clock-adjusted peak",
+            "effective_tflop_per_evaluation": tflop, "effective_achieved": tflop / sec, "effective_frac": tflop / sec / PEAK_FP64_MATRIX_TFLOPS,
+            "effective_note": "the same time priced at 8 N^3 per complex GEMM unit (the usual count); not a hardware utilisation",
             "gemm_units_per_time_point": gemms, "gemm_units_round2_formulation": gemms_r02,
             "frac_at_round2_flop_count": 8.0 * N ** 3 * gemms_r02 * (nsteps + 1) / 1e12 / sec / PEAK_FP64_MATRIX_TFLOPS,
             "grad_norm": float(np.linalg.norm(grad)),
@@ -325,8 +332,33 @@ def cnot2_case_gpu(qgd, np, steps=50):
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / steps
     dp.close()
+    # roofline of this configuration: NEITHER hardware roof binds.  N = 4 pads to one 16 x 16 MFMA tile and 101 time points
+    # are 101 small workgroups: the evaluation is a chain of DEPENDENT kernel launches, each costing its dispatch + one
+    # workgroup's latency.  Stated as such: launches per evaluation (from the committed rocprofv3 kernel statistics of this
+    # very loop, profiles/CNOT2_PROFILE; the count of the launch sequence in DESIGN.md section 7a otherwise), time per
+    # launch, and -- for the record -- the algorithm's history stream against HBM and its applies against the MFMA peak.
+    N_, c_, m_, n_ops_, ns_ = 4, 4, 4, 2, 100
+    launches, src = 12, "DESIGN.md section 7a (launch sequence)"
+    ppath = os.path.join(ROOT, "profiles", CNOT2_PROFILE)
+    if os.path.exists(ppath):
+        try:
+            d = json.load(open(ppath))
+            launches, src = float(d["launches_per_evaluation"]), "profiles/" + CNOT2_PROFILE
+        except Exception:
+            pass
+    b_step = 2 * 16 * N_ * (1 + m_) * c_ + 2 * 16 * N_ * c_
+    M_ = m_ * (m_ + 1) // 2
+    w_step = M_ * 8.0 * N_ * N_ * c_ * 6          # SURVEY 8(d) W_step with the propagator form's k = 0: forward M, adjoint M, gradient 4M applies
     return {"workload": "cnot2 (examples/cnot2_optimization.jl): N=4, 4 columns, 2 controls x 22 coeffs, Hermite order 8, tf=100, nsteps=100",
             "timesteps_per_s": 100 / sec, "ms_per_evaluation": sec * 1e3, "evaluations_timed": steps,
+            "roofline": {"bound": "launch", "launches_per_evaluation": launches, "launch_count_source": src,
+                         "us_per_dependent_launch": sec * 1e6 / launches,
+                         "hbm": {"bytes_per_timestep": b_step, "achieved": b_step * ns_ / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": b_step * ns_ / sec / 1e9 / PEAK_HBM_GBS},
+                         "mfma": {"flop_per_timestep": w_step, "achieved": w_step * ns_ / sec / 1e12, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": w_step * ns_ / sec / 1e12 / PEAK_FP64_MATRIX_TFLOPS},
+                         "note": "launch-bound: a chain of dependent launches over 101 one-tile time points; both hardware fractions are ~1e-4 by "
+                                 "construction (N = 4 is a sixteenth of one MFMA tile) -- the figure of merit is us per dependent launch"},
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2), "grad_norm": float(np.linalg.norm(grad))}
 
 
@@ -377,6 +409,7 @@ def main():
     ap.add_argument("--shard", default="time", choices=["time", "columns"],
                     help="N > 1: how ONE evaluation is split over the ranks -- time windows (default: 2 all-gathers + 1 all-reduce) or the "
                          "reference's thread axis, blocks of initial-condition columns (2 all-reduces; the step matrices are built on every rank)")
+    ap.add_argument("--no-other-split", action="store_true", help="N > 1: do not time the other split (columns beside time windows) in the same line")
     ap.add_argument("--oversubscribe", action="store_true", help="let several ranks share a GPU (test boxes with one GPU; with --comm torch --backend gloo)")
     args = ap.parse_args()
 
@@ -573,6 +606,55 @@ def main():
         except Exception as exc:
             with_hist = {"error": repr(exc)}
 
+    # N > 1: the OTHER split of the same evaluation in the same line.  `value` is the default split (time windows: the one
+    # that can pay); BASELINE.json's north star sketches column blocks + all-reduce -- the reference's
+    # own thread axis (src/forward_evolution.jl:48,332).  One scaling run of the driver answers both: the second split is
+    # timed the same way (W warm-up, K timed steps, barrier + max over ranks, its own communicator) and reported as
+    # `north_star_split` (or `time_window_split` when --shard columns made the columns the headline).
+    other_split = None
+    if use_dist and (world > 1 or args.force_dist) and not args.no_other_split:
+        other = "columns" if args.shard == "time" else "time"
+        try:
+            if other == "columns" and world > prob.N_initial_conditions:
+                raise ValueError(f"{world} ranks for {prob.N_initial_conditions} initial-condition columns")
+            try:
+                dp.close()
+            except Exception:
+                pass
+            saved = args.shard
+            args.shard = other
+            try:
+                dpo = make_partitioned(qgd, args, prob, order, ctrl, target, rank, world, local_rank, uid)
+            finally:
+                args.shard = saved
+            dpo.set_timing(0)
+            for _ in range(max(args.warmup, 2)):
+                dpo.discrete_adjoint(pcof)
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                g_o, _ = dpo.discrete_adjoint(pcof)
+            barrier()
+            to = max_over_ranks(time.perf_counter() - t3)
+            acc = {}
+            if args.comm == "lib":
+                dpo.set_timing(1)
+                for _ in range(5):
+                    dpo.discrete_adjoint(pcof)
+                    for k, v in dpo.timings().items():
+                        if k.startswith("comm_"):
+                            acc[k] = acc.get(k, 0.0) + v / 5
+                dpo.set_timing(0)
+            dpo.close()
+            other_split = {"shard": other, "value": args.nsteps * args.steps / to, "unit": "timesteps/s", "ms_per_step": to / args.steps * 1e3,
+                           "scaling": "strong", "steps": args.steps,
+                           "parallelism": (f"column blocks over {n_gpus} GPUs, 2 all-reduces per evaluation (step matrices built on every rank)" if other == "columns"
+                                           else f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation"),
+                           "collectives_ms": {k: round(v, 4) for k, v in acc.items()} or None,
+                           "grad_rel_diff_vs_headline_split": float(np.abs(g_o - grad).max() / np.abs(grad).max())}
+        except Exception as exc:      # the secondary number must never cost the headline one
+            other_split = {"shard": other, "error": repr(exc)}
+
     # N > 1: C5 under the same partition (every rank takes part; secondary number, must never cost the headline one)
     large_dist = None
     if use_dist and world > 1 and not args.no_large_n:
@@ -637,6 +719,7 @@ def main():
             "phases_ms_all_events": {k: round(v, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1])},
             "operator_path": path[0],
             "collectives_ms": comm_ms,
+            ("north_star_split" if args.shard == "time" else "time_window_split"): other_split,
             "weak_in_time": weak,
             "with_history_ms_per_step": None if not with_hist else with_hist.get("pinned_ms_per_step"),
             "with_history": with_hist,

@@ -60,8 +60,14 @@ typedef struct qgd_problem_desc {
     const double *u0, *v0;      /* N x n_cols */
     const double *guard;        /* 2N x 2N guard_subspace_projector, or NULL (= zeros) */
     int32_t device;             /* HIP device ordinal */
-    int32_t reserved;
+    int32_t reserved;           /* flags: 0, or QGD_CREATE_DEFER_GRID */
 } qgd_problem_desc;
+
+/* qgd_problem_desc.reserved, bit 0: do not allocate the time grid in qgd_create.  For a handle whose layout is about to
+ * change -- a rank of a time partition (qgd_comm_init_rccl / qgd_set_partition), a memory budget, another nsteps -- so that
+ * it never holds the WHOLE grid first (the reason to shard by time is that the whole grid does not fit).  The first entry
+ * point that needs the grid allocates it. */
+#define QGD_CREATE_DEFER_GRID 1
 
 #define QGD_MAX_ORDER 16
 #define QGD_MAX_OPS   8
@@ -103,9 +109,11 @@ int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
  * bytes = 0 (default): 70 % of the device memory that is free when the grid is allocated; a grid whose single time step
  * does not fit returns QGD_ERR_MEMORY.  Re-allocates the grid (set the control basis afterwards, for the WHOLE grid).
  * With more than one window the reference-layout outputs (uv_history, lambda_history, adjoint_forcing) are filled window
- * by window into the caller's full arrays; the forced sweeps, qgd_eval_adjoint, qgd_set_control_tables,
- * qgd_get_intermediate, qgd_set_save_every != 1 and the derivative columns of lambda_history return QGD_ERR_UNSUPPORTED
- * (they need the grid resident).
+ * by window into the caller's full arrays -- uv_history with qgd_set_save_every's stride, lambda_history with its
+ * derivative columns after qgd_set_lambda_derivatives, as on a resident grid; the forced sweeps, qgd_eval_adjoint,
+ * qgd_set_control_tables and qgd_get_intermediate return QGD_ERR_UNSUPPORTED (they need the grid resident).
+ * qgd_get_partition on such a handle reports the WHOLE grid (first point 0, last point nsteps): the windows are the
+ * library's business, the caller's control basis and output arrays cover every time point.
  * qgd_get_memory_plan: out4 = { windows, time steps per window, bytes of the per-window buffers, budget (0 = automatic) }. */
 int qgd_set_memory_budget(qgd_handle h, size_t bytes);
 int qgd_get_memory_plan(qgd_handle h, int64_t *out4);
@@ -212,7 +220,9 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
  * "sigma" ([nt][n_ops][m][2]), "tables" ([nt][m][n_ops][2]), "repivoted" (1 value: how many step matrices of the last
  * evaluation were redone with full partial pivoting -- N > 64: after the block Gauss-Jordan inverse, which pivots inside its
  * 64-column diagonal blocks only, found a block multiplier above its threshold; N = 64: after the optional static-pivot
- * attempt).  Returns the number
+ * attempt), "selection" (4 values: operator path -- 2 sparse ELL kernels, 1 the N > 64 GEMM-style kernels, 0 dense N <= 64 --,
+ * form of the gradient scalars on the N > 64 path 0..3 or -1, block Gauss-Jordan inverse in use 0/1, windows of the time
+ * grid).  Returns the number
  * of doubles the buffer needs through *needed when out == NULL. */
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);
@@ -222,9 +232,10 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
  * MPI.jl, torch.distributed -- drives them itself.)
  * The reference's only parallel axis is the column loop (Threads.@threads,
  * src/forward_evolution.jl:48,332); this implementation's parallel axis is time, so ranks own
- * contiguous windows of the time grid.  The library never communicates: between the phases the
- * caller all-gathers two exchange buffers and all-reduces one (RCCL through torch.distributed
- * in bench.py; MPI.jl from Julia).  Sequence per evaluation, on every rank:
+ * contiguous windows of the time grid.  With THESE entry points the library does not communicate: between the
+ * phases the caller all-gathers two exchange buffers and all-reduces one (torch.distributed in
+ * bench.py --comm torch; MPI.jl from Julia).  (qgd_comm_init_rccl further down is the other route: the
+ * library issues the same collectives itself, over RCCL.)  Sequence per evaluation, on every rank:
  *   qgd_dist_forward_begin -> all_gather(buffer 0) -> qgd_dist_forward_end
  *   qgd_dist_adjoint_begin -> all_gather(buffer 1) -> qgd_dist_adjoint_end
  *   all_reduce_sum(buffer 2) -> qgd_dist_finish
@@ -286,6 +297,20 @@ int qgd_comm_unique_id(void *id128);
 int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_t world, int32_t shard);
 int qgd_comm_destroy(qgd_handle h);
 int qgd_comm_info(qgd_handle h, int32_t *out3);
+/* Failure mode of the collective calls.  A collective that one rank never enters would block the others inside an RCCL
+ * kernel for good (the reference's thread loop has no such state: a failing column throws out of Threads.@threads,
+ * src/forward_evolution.jl:48).  Therefore: the one host wait of a collective qgd_discrete_adjoint / qgd_eval_forward is
+ * bounded (default 30 000 ms; QGD_COMM_TIMEOUT_MS in the environment, or this setter); when it expires, when RCCL
+ * reports an asynchronous error, or when THIS rank fails between two collectives (HIP / launch / memory / RCCL error),
+ * the library aborts the handle's communicator (ncclCommAbort -- RCCL's kernels leave the stream), and the call returns
+ * QGD_ERR_COMM with the cause in qgd_last_error.  The handle then has no communicator (qgd_comm_info: rank -1): the host
+ * ends the job or calls qgd_comm_init_rccl again with a fresh id on every rank.  Argument and call-order errors are
+ * raised before anything is launched, and a singular step matrix is summed into the reductions: those fail on every
+ * rank alike, with their own codes, and leave the communicator intact.
+ * qgd_comm_debug_fail_at(h, n) is a TEST HOOK: the next collective call fails locally in front of its exchange n-1
+ * (n = 1..4: window products, affine parts, [grad | scalars], scalars); 0 = off. */
+int qgd_set_comm_timeout(qgd_handle h, double milliseconds);
+int qgd_comm_debug_fail_at(qgd_handle h, int32_t collective);
 
 /* Per-phase device time of the last evaluation (HIP events), milliseconds.
  * names/ms hold up to cap entries; returns the number of phases through *n. */

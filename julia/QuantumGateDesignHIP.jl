@@ -50,7 +50,7 @@ end
 "One handle per (prob, order).  Operators stored as SparseMatrixCSC (DispersiveProblem's default, sparse_rep=true)
 go to the library as they are (qgd_create_csc: colptr/rowval/nzval, 1-based); dense ones as column-major copies made
 for the call only."
-function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
+function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0, defer_grid::Bool=false)
     N = prob.N_tot_levels
     u0, v0 = Matrix{Float64}(reshape(prob.u0, N, :)), Matrix{Float64}(reshape(prob.v0, N, :))
     W = Matrix{Float64}(prob.guard_subspace_projector)
@@ -61,7 +61,7 @@ function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
             csc = [CSC(pointer(a.colptr), pointer(a.rowval), pointer(a.nzval), 1, 0) for a in mats]
             nop = prob.N_operators
             d = ProblemDesc(N, size(u0, 2), nop, prob.N_ess_levels, order, prob.nsteps, prob.tf,
-                            C_NULL, C_NULL, C_NULL, C_NULL, pointer(u0), pointer(v0), pointer(W), device, 0)
+                            C_NULL, C_NULL, C_NULL, C_NULL, pointer(u0), pointer(v0), pointer(W), device, defer_grid ? 1 : 0)
             rc = ccall((:qgd_create_csc, libqgd), Cint,
                        (Ref{ProblemDesc}, Ref{CSC}, Ref{CSC}, Ptr{CSC}, Ptr{CSC}, Ref{Ptr{Cvoid}}),
                        d, csc[1], csc[2], pointer(csc, 3), pointer(csc, 3 + nop), h)
@@ -73,7 +73,7 @@ function DeviceProblem(prob::SchrodingerProb, order::Integer; device::Integer=0)
         GC.@preserve ssym sasym sym asym u0 v0 W begin
             d = ProblemDesc(N, size(u0, 2), prob.N_operators, prob.N_ess_levels, order, prob.nsteps, prob.tf,
                             pointer(ssym), pointer(sasym), pointer(sym), pointer(asym),
-                            pointer(u0), pointer(v0), pointer(W), device, 0)
+                            pointer(u0), pointer(v0), pointer(W), device, defer_grid ? 1 : 0)
             rc = ccall((:qgd_create, libqgd), Cint, (Ref{ProblemDesc}, Ref{Ptr{Cvoid}}), d, h)
         end
     end
@@ -187,7 +187,8 @@ function hip_eval_forward!(uv_history::Array{Float64,4}, prob::SchrodingerProb, 
     dp = device_problem(prob, order)
     set_cost_type!(dp, :Infidelity)
     pc_ptr, pc_len = set_controls!(dp, prob, controls, pcof)
-    size(uv_history, 3) == 1 + div(prob.nsteps, saveEveryNsteps) || throw(DimensionMismatch("uv_history: $(size(uv_history, 3)) time slots for saveEveryNsteps=$saveEveryNsteps"))
+    n_lo, n_hi = time_window(dp)           # (a time-partitioned handle fills the slots of its own window)
+    size(uv_history, 3) == 1 + div(n_hi - n_lo, saveEveryNsteps) || throw(DimensionMismatch("uv_history: $(size(uv_history, 3)) time slots for saveEveryNsteps=$saveEveryNsteps over time points $n_lo:$n_hi"))
     check(dp.handle, ccall((:qgd_set_save_every, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, saveEveryNsteps))
     try
         GC.@preserve pcof check(dp.handle, ccall((:qgd_eval_forward, libqgd), Cint,
@@ -298,7 +299,8 @@ rank; the controls' basis is then built for the rank's own window by the next se
 this rank's columns of u0, v0 -- and the caller passes its columns of the target -- with the global N_ess_levels)."
 function comm_init!(prob::SchrodingerProb, order::Integer, id::Vector{UInt8}, rank::Integer, world::Integer; shard::Symbol=:time, device::Integer=rank)
     i = findfirst(e -> e[1] === prob && e[2] == order, _cache)
-    i === nothing && push!(_cache, (prob, order, DeviceProblem(prob, order; device=device)))
+    # (QGD_CREATE_DEFER_GRID: a rank of a time partition never allocates the whole grid -- qgd_comm_init_rccl allocates its window)
+    i === nothing && push!(_cache, (prob, order, DeviceProblem(prob, order; device=device, defer_grid=(shard == :time))))
     dp = device_problem(prob, order)
     check(dp.handle, ccall((:qgd_comm_init_rccl, libqgd), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Int32),
           dp.handle, id, rank, world, shard == :columns ? 1 : 0))
@@ -306,10 +308,14 @@ function comm_init!(prob::SchrodingerProb, order::Integer, id::Vector{UInt8}, ra
     return dp
 end
 
-"First and last global time point of this rank's window (qgd_get_partition); (0, nsteps) without a time partition."
+"First and last global time point of this rank's window (qgd_get_partition); (0, nsteps) without a time partition.
+A handle that works through a long grid in windows on ONE GPU (qgd_set_memory_budget, or more than 65 000 steps) owns
+the whole grid as far as its caller is concerned -- control basis and output arrays cover every time point -- so only a
+handle whose partition has more than one rank (out[7] = world) reports a window of its own."
 function time_window(dp::DeviceProblem)
     out = zeros(Int32, 8)
     check(dp.handle, ccall((:qgd_get_partition, libqgd), Cint, (Ptr{Cvoid}, Ptr{Int32}), dp.handle, out))
+    Int(out[7]) <= 1 && return 0, Int(out[8]) - 1
     return Int(out[1]), Int(out[2])
 end
 

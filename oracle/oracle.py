@@ -195,6 +195,12 @@ def set_converged_terminal(on: bool):
     lib().qo_set_converged_terminal(1 if on else 0)
 
 
+def set_parallel_gradient(on: bool):
+    """Large test problems: the per-column gradient accumulation on threads, summed in column order -- bit-identical to
+    the reference's serial loop (qgd_oracle.c: qo_set_parallel_gradient).  Never on for the cpu_baseline."""
+    lib().qo_set_parallel_gradient(1 if on else 0)
+
+
 COST_TYPES = {"Infidelity": 0, ":Infidelity": 0, "Tracking": 1, ":Tracking": 1, "Norm": 2, ":Norm": 2}
 
 

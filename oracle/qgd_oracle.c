@@ -28,6 +28,15 @@ void qo_set_num_threads(int n) { g_threads = n; }
 static int g_converged_terminal = 0;
 void qo_set_converged_terminal(int on) { g_converged_terminal = on; }
 
+/* 0 (default): the gradient accumulation runs over the columns one after the other, as the reference does
+ * (eval_grad_discrete_adjoint.jl:148-157) -- this is also what the cpu_baseline times.
+ * 1 (large test problems only): the columns go to the threads of qo_set_num_threads, each into its OWN zero-initialised
+ * gradient vector, and the vectors are added in column order.  The serial loop does grad = grad - contrib_c per control
+ * and column, and 0 - contrib_c is exact, so the result is bit-identical to the serial loop
+ * (tests/test_oracle.py::test_parallel_gradient_columns_are_bit_identical). */
+static int g_parallel_gradient = 0;
+void qo_set_parallel_gradient(int on) { g_parallel_gradient = on; }
+
 /* cost_type of discrete_adjoint / eval_grad_forced / eval_grad_finite_difference
  * (eval_grad_discrete_adjoint.jl:26-35, eval_grad_forced.jl:155-165, eval_grad_finite_difference.jl:48-59):
  * 0 :Infidelity (default), 1 :Tracking (0.5 |w_N - target|^2), 2 :Norm (0.5 |w_N|^2). */
@@ -1086,6 +1095,22 @@ int qo_discrete_adjoint(const qo_prob *pr, const qo_control *const *controls, co
     qo_compute_terminal_condition(pr, controls, pcof, order, target_real, final_state, forcing_end, terminal); /* :137-141 */
     qo_eval_adjoint(pr, controls, pcof, order, terminal, adjoint_forcing, lambda_history, st); /* :144-146 */
     for (int l = 0; l < n_pcof; l++) grad[l] = 0.0;                                       /* :149 */
+    if (g_parallel_gradient && nc > 1) {       /* test switch, see qo_set_parallel_gradient: same bits, columns on threads */
+        double *gc = (double *)calloc((size_t)nc * (n_pcof > 0 ? n_pcof : 1), sizeof(double));
+        int nth = g_threads;
+#ifdef _OPENMP
+        if (nth <= 0) nth = omp_get_max_threads();
+#else
+        nth = 1;
+#endif
+        #pragma omp parallel for num_threads(nth) schedule(dynamic, 1)
+        for (int c = 0; c < nc; c++)
+            accumulate_gradient_column(pr, controls, pcof, order, history + (size_t)c * hcol,
+                                       lambda_history + (size_t)c * hcol, gc + (size_t)c * n_pcof);
+        for (int c = 0; c < nc; c++)
+            for (int l = 0; l < n_pcof; l++) grad[l] += gc[(size_t)c * n_pcof + l];
+        free(gc);
+    } else
     for (int c = 0; c < nc; c++)                                                          /* serial, :150-157 */
         accumulate_gradient_column(pr, controls, pcof, order, history + (size_t)c * hcol,
                                    lambda_history + (size_t)c * hcol, grad);

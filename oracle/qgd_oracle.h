@@ -150,6 +150,7 @@ int  qo_eval_grad_finite_difference(const qo_prob *pr, const qo_control *const *
 
 void qo_set_num_threads(int n);
 void qo_set_converged_terminal(int on);
+void qo_set_parallel_gradient(int on);   /* test switch: gradient accumulation with the columns on threads, bit-identical */
 void qo_set_cost_type(int type);   /* 0 :Infidelity, 1 :Tracking, 2 :Norm */
 
 #ifdef __cplusplus

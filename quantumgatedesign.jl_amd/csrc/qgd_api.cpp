@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types only: the library is bound at run time (dlopen), see RcclApi
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <cmath>
 #include <cstdio>
@@ -98,6 +99,15 @@ struct qgd_handle_s {
     // collectives issued on the handle's stream between the phases (no host synchronisation in between).
     ncclComm_t comm = nullptr;
     int comm_shard = QGD_SHARD_TIME, comm_rank = 0, comm_world = 1;
+    // failure mode of the collective calls (qgd_set_comm_timeout): the one host wait of a collective evaluation is bounded;
+    // when it expires, when RCCL reports an asynchronous error, or when this rank fails locally between two collectives,
+    // the communicator is ABORTED (ncclCommAbort: its kernels leave the stream) and the call returns QGD_ERR_COMM --
+    // the other ranks then run into their own bound instead of waiting for this one forever.
+    double comm_timeout_ms = getenv("QGD_COMM_TIMEOUT_MS") ? atof(getenv("QGD_COMM_TIMEOUT_MS")) : 30000.0;
+    int comm_fail_at = 0;               // qgd_comm_debug_fail_at (test hook): pretend a local failure in front of collective #n
+    bool grid_ready = false;            // QGD_CREATE_DEFER_GRID: the time grid is allocated by the first entry point that needs it
+    bool comm_pending = false;          // qgd_comm_init_rccl is re-allocating the grid for the communicator it is about to
+                                        // create: the grid stays resident (comm_discrete_adjoint does not walk windows)
     // bounded-memory time grid (qgd_set_memory_budget): chunks_eff windows of the grid share the per-time-point buffers
     size_t mem_budget = 0;              // bytes; 0 = 70 % of the free device memory when the grid is allocated
     int chunks_eff = 1;                 // windows the grid is processed in (1: everything resident)
@@ -329,6 +339,7 @@ int alloc_grid(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     drop_graph(h);
+    h->grid_ready = false;
     free_pool(h->grid_bufs);
     free_pool(h->forced_bufs); h->forced_key = 0;
     free_pool(h->forcing_bufs); h->forcing_key = 0;
@@ -344,13 +355,13 @@ int alloc_grid(qgd_handle h)
     if ((rc = plan_windows(h, 1, 0))) return rc;
     // several kernels carry the time point in gridDim.y (at most 65535): a window never holds more time points than that
     const int MAX_WINDOW_STEPS = 65000;
-    if (h->part_world == 1 && !h->comm && h->nsteps > MAX_WINDOW_STEPS) {
+    if (h->part_world == 1 && !h->comm && !h->comm_pending && h->nsteps > MAX_WINDOW_STEPS) {
         chunks = (h->nsteps + MAX_WINDOW_STEPS - 1) / MAX_WINDOW_STEPS;
         if ((rc = plan_windows(h, chunks, 0))) return rc;
     } else if (k.nt > MAX_WINDOW_STEPS + 500) {
         return fail(h, QGD_ERR_UNSUPPORTED, "a rank's window of the time grid is limited to 65000 steps (use more ranks or one handle with windows)");
     }
-    if (h->part_world == 1 && !h->comm) {
+    if (h->part_world == 1 && !h->comm && !h->comm_pending) {
         size_t budget = h->mem_budget, fr = 0, tot = 0;
         if (!budget && hipMemGetInfo(&fr, &tot) == hipSuccess) budget = (size_t)(0.7 * (double)fr);
         size_t need = 0;
@@ -397,8 +408,13 @@ int alloc_grid(qgd_handle h)
     h->have_basis = h->have_tables = h->forward_valid = h->derivs_valid = false;
     free_pool(h->basis_bufs);
     k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr; if (h->status_static) k.status = h->status_static;
+    h->grid_ready = true;
     return QGD_OK;
 }
+
+// (QGD_CREATE_DEFER_GRID) entry points that read or size anything by the time grid allocate it first
+#define NEED_GRID(h)                                                                           \
+    do { if (!(h)->grid_ready) { int rg__ = alloc_grid(h); if (rg__) return rg__; } } while (0)
 
 #define K_TRY(h, expr)                                                                         \
     do {                                                                                       \
@@ -711,20 +727,53 @@ int adjoint_end(qgd_handle h)
 // The reference-layout outputs of a chunked grid, one window at a time: the window's panels are re-laid out into a compact
 // staging buffer on the device and copied into the caller's FULL array at the window's time offset (a pitched copy per
 // column); the copy is awaited before the next window overwrites the panels.  Windows share their end points (same values).
-int window_history_out(qgd_handle h, double *uv_history)       // [2N, 1+m, nt_glob, c]
+int window_history_out(qgd_handle h, double *uv_history, int save = 1)       // [2N, 1+m, 1 + (nt_glob-1)/save, c]
 {
     qgdk_ctx &k = h->k;
-    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N, ntg = k.nt_glob;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, m = k.m, n2 = 2 * (size_t)k.N, ntg = k.nt_glob;
     const size_t nt0 = std::min<size_t>((size_t)k.bpr * k.scan_blen + 1, ntg);      // the longest window
     int rc = copy_side(h);
     if (rc) return rc;
     if (!h->stage_hist && (rc = dev_alloc(h, h->stage_bufs, &h->stage_hist, n2 * (m + 1) * nt0 * k.c))) return rc;
-    const long long dcol = (long long)(nt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
-    K_TRY(h, qgdk_layout(&k, k.hist, (long long)hstep, 0, h->stage_hist, dcol, dn, dj, 0, (int)nt, 1, 0, k.stream, 0));
-    K_TRY(h, qgdk_layout(&k, k.dpsi, (long long)(m * hstep), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)nt, (int)m, 0, k.stream, 0));
+    // saveEveryNsteps (forward_evolution.jl:104,178,239-241): slot s of the output holds GLOBAL time point s * save; this
+    // window holds the global points n_off .. n_off + nt - 1 (windows share their end points: same values, same slot)
+    const size_t sv = (size_t)save, g_lo = (size_t)k.n_off, g_hi = (size_t)k.n_off + (size_t)k.nt - 1;
+    const size_t s_lo = (g_lo + sv - 1) / sv, s_hi = g_hi / sv;
+    if (s_hi < s_lo) return QGD_OK;                                                  // (no saved point falls into this window)
+    const size_t cnt = s_hi - s_lo + 1, loc = s_lo * sv - g_lo, slots = 1 + (ntg - 1) / sv;
+    const long long dcol = (long long)(cnt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
+    K_TRY(h, qgdk_layout(&k, k.hist + loc * hstep, (long long)(hstep * sv), 0, h->stage_hist, dcol, dn, dj, 0, (int)cnt, 1, 0, k.stream, 0));
+    K_TRY(h, qgdk_layout(&k, k.dpsi + loc * m * hstep, (long long)(m * hstep * sv), (long long)hstep, h->stage_hist + n2, dcol, dn, dj, 0, (int)cnt, (int)m, 0, k.stream, 0));
     if ((rc = hand_over(h))) return rc;
-    const size_t row = nt * (m + 1) * n2 * sizeof(double);
-    HIP_TRY(h, hipMemcpy2DAsync(uv_history + (size_t)k.n_off * (m + 1) * n2, ntg * (m + 1) * n2 * sizeof(double), h->stage_hist, row, row,
+    const size_t row = cnt * (m + 1) * n2 * sizeof(double);
+    HIP_TRY(h, hipMemcpy2DAsync(uv_history + s_lo * (m + 1) * n2, slots * (m + 1) * n2 * sizeof(double), h->stage_hist, row, row,
+                                (size_t)k.c, hipMemcpyDeviceToHost, h->copy_stream));
+    return finish_copies(h);
+}
+
+// lambda_history of a window WITH its derivative columns (qgd_set_lambda_derivatives): local time indices 1 .. nt-1 (the
+// window's first point is the previous window's last; global index 0 is never written, as in the reference)
+int window_lambda_full_out(qgd_handle h, double *out)       // [2N, 1+m, nt_glob, c]
+{
+    qgdk_ctx &k = h->k;
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, nt = k.nt, m = k.m, n2 = 2 * (size_t)k.N, ntg = k.nt_glob;
+    const size_t nt0 = std::min<size_t>((size_t)k.bpr * k.scan_blen + 1, ntg);
+    int rc = copy_side(h);
+    if (rc) return rc;
+    if (nt < 2) return QGD_OK;
+    if (!h->dlam) {
+        if ((rc = dev_alloc(h, h->stage_bufs, &h->dlam, nt0 * std::max<size_t>(m, 1) * hstep))) return rc;
+        if ((m + 1) * (size_t)k.Np * 16 * sizeof(double) > 150 * 1024 &&
+            (rc = dev_alloc(h, h->stage_bufs, &h->dlam_scratch, (nt0 - 1) * (size_t)(k.cp / 8) * (m + 1) * k.Np * 16))) return rc;
+        if ((rc = dev_alloc(h, h->stage_bufs, &h->stage_lam_full, n2 * (m + 1) * nt0 * k.c))) return rc;
+    }
+    { PhaseTimer t(h, "lambda_derivs"); K_TRY(h, qgdk_adjoint_derivs(&k, h->dlam, h->dlam_scratch)); }
+    const long long dcol = (long long)(nt * (m + 1) * n2), dn = (long long)((m + 1) * n2), dj = (long long)n2;
+    K_TRY(h, qgdk_layout(&k, k.lam, (long long)hstep, 0, h->stage_lam_full, dcol, dn, dj, 1, (int)nt - 1, 1, 0, k.stream, 0));
+    K_TRY(h, qgdk_layout(&k, h->dlam, (long long)(m * hstep), (long long)hstep, h->stage_lam_full + n2, dcol, dn, dj, 1, (int)nt - 1, (int)m, 0, k.stream, 0));
+    if ((rc = hand_over(h))) return rc;
+    HIP_TRY(h, hipMemcpy2DAsync(out + ((size_t)k.n_off + 1) * (m + 1) * n2, ntg * (m + 1) * n2 * sizeof(double),
+                                h->stage_lam_full + (m + 1) * n2, nt * (m + 1) * n2 * sizeof(double), (nt - 1) * (m + 1) * n2 * sizeof(double),
                                 (size_t)k.c, hipMemcpyDeviceToHost, h->copy_stream));
     return finish_copies(h);
 }
@@ -783,7 +832,7 @@ int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool reru
     return QGD_OK;
 }
 
-int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history = nullptr)
+int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history = nullptr, int save = 1)
 {
     qgdk_ctx &k = h->k;
     if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
@@ -792,7 +841,7 @@ int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_his
         if ((rc = chunk_forward(h, pcof, n_pcof, r, false))) return rc;
         if (uv_history) {      // the window's share of the state history with its stage derivatives
             { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
-            if ((rc = window_history_out(h, uv_history))) return rc;
+            if ((rc = window_history_out(h, uv_history, save))) return rc;
         }
     }
     { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }      // overlaps (and y_N) from the final state
@@ -824,7 +873,8 @@ int chunked_adjoint(qgd_handle h, double *lambda_history = nullptr, double *adjo
         if (!rc) rc = adjoint_end(h);
         k.grad_accumulate = 0;
         if (rc) return rc;
-        if (lambda_history && (rc = window_panels_out(h, k.lam, &h->stage_lam, lambda_history, (size_t)k.m + 1, 1))) return rc;
+        if (lambda_history && (rc = h->lambda_derivs ? window_lambda_full_out(h, lambda_history)
+                                                     : window_panels_out(h, k.lam, &h->stage_lam, lambda_history, (size_t)k.m + 1, 1))) return rc;
         HIP_TRY(h, hipMemcpyAsync(h->carry_y, k.yhist, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
     }
     h->forward_valid = true;          // (the window-boundary states of this pcof are still there for history_precomputed)
@@ -855,6 +905,8 @@ int check_status(qgd_handle h)
     return QGD_OK;
 }
 
+int comm_wait(qgd_handle h);      // (bounded wait of a collective evaluation, defined with the RCCL binding below)
+
 // status + results of an evaluation in one device-to-host copy (the three separate copies cost
 // ~25 us of the 0.5 ms evaluation on cnot3)
 int fetch_results(qgd_handle h, double *grad, double *out3, const double *src = nullptr)
@@ -864,13 +916,21 @@ int fetch_results(qgd_handle h, double *grad, double *out3, const double *src = 
     if (!k.redbuf || !h->host_out) {
         int rc = check_status(h);
         if (rc) return rc;
-        if (grad && k.grad) HIP_TRY(h, hipMemcpy(grad, k.grad, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
-        if (out3) HIP_TRY(h, hipMemcpy(out3, k.scal, 3 * sizeof(double), hipMemcpyDeviceToHost));
+        // (src != redbuf: the reduced [grad | scalars | flag] of a time-sharded collective evaluation -- never the rank's own sums)
+        const double *g = (src && src != k.redbuf) ? src : k.grad, *sc = (src && src != k.redbuf) ? src + k.n_pcof : k.scal;
+        if (src && src != k.redbuf) {
+            double flag = 0.0;
+            HIP_TRY(h, hipMemcpy(&flag, src + k.n_pcof + 3, sizeof(double), hipMemcpyDeviceToHost));
+            if (flag != 0.0) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
+        }
+        if (grad && g) HIP_TRY(h, hipMemcpy(grad, g, sizeof(double) * k.n_pcof, hipMemcpyDeviceToHost));
+        if (out3) HIP_TRY(h, hipMemcpy(out3, sc, 3 * sizeof(double), hipMemcpyDeviceToHost));
         return QGD_OK;
     }
     const size_t np = (size_t)k.n_pcof;
     HIP_TRY(h, hipMemcpyAsync(h->host_out, src, (np + 5) * sizeof(double), hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(h, hipStreamSynchronize(k.stream));      // (spinning on hipStreamQuery instead: no difference, 359 us either way)
+    if (h->comm) { int rcw = comm_wait(h); if (rcw) return rcw; }      // collective evaluation: the wait is bounded
+    else HIP_TRY(h, hipStreamSynchronize(k.stream));      // (spinning on hipStreamQuery instead: no difference, 359 us either way)
     int st = 0;
     if (src == k.redbuf) memcpy(&st, h->host_out + np + 4, sizeof(int));      // (a reduced buffer carries the flag as the double in front of it)
     // (host_out[np + 3]: the same flag as a double, summed over the ranks of a time-partitioned evaluation)
@@ -891,6 +951,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // (optional: older builds fall back to CommDestroy)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;  // (optional)
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -919,6 +981,8 @@ RcclApi load_rccl()
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.lib, "ncclCommAbort"));
+    a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(dlsym(a.lib, "ncclCommGetAsyncError"));
     a.ok = all;
     return a;
 }
@@ -932,12 +996,81 @@ RcclApi &rccl() { static RcclApi a = load_rccl(); return a; }
             return fail((h), QGD_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r__)); \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// Failure mode of the collective calls.  A collective that one rank never enters blocks the others inside an RCCL
+// kernel for good, so (1) the single host wait of a collective evaluation is a bounded hipStreamQuery loop that also
+// polls ncclCommGetAsyncError, and (2) a rank that fails locally between two collectives, sees an asynchronous RCCL
+// error or runs out of time ABORTS its communicator (ncclCommAbort makes the RCCL kernels on the stream return) and
+// reports QGD_ERR_COMM.  The handle is left without a communicator: the host tears the job down (bench.py: the rank
+// process exits non-zero) or builds a fresh communicator.  There is no retry inside the library.
+// ---------------------------------------------------------------------------
+void comm_abort(qgd_handle h)
+{
+    if (!h->comm) return;
+    RcclApi &R = rccl();
+    ncclComm_t c = h->comm;
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+    if (R.CommAbort) (void)R.CommAbort(c); else (void)R.CommDestroy(c);
+    (void)hipStreamSynchronize(h->k.stream);      // the library's own kernels behind the aborted collective drain normally
+    (void)hipGetLastError();
+}
+
+int comm_failed(qgd_handle h, const std::string &why)
+{
+    comm_abort(h);
+    return fail(h, QGD_ERR_COMM, why + "; the communicator of this handle was aborted (ncclCommAbort)");
+}
+
+// errors of a collective call that leave the OTHER ranks waiting in a collective this rank will not enter: device and
+// launch failures, memory, RCCL itself.  Argument / state errors are raised before anything is launched (every rank
+// gets them alike), and a singular step matrix travels with the reductions, so all ranks fail together without help.
+int comm_local_error(qgd_handle h, int rc)
+{
+    if (rc == QGD_OK || !h->comm) return rc;
+    if (rc == QGD_ERR_NO_DEVICE || rc == QGD_ERR_MEMORY || rc == QGD_ERR_COMM) {
+        const std::string local = h->err;
+        return comm_failed(h, "collective evaluation failed on rank " + std::to_string(h->comm_rank) + " (error " + std::to_string(rc) + ": " + local + ")");
+    }
+    return rc;
+}
+
+int comm_wait(qgd_handle h)
+{
+    RcclApi &R = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rank = h->comm_rank;
+    for (unsigned spin = 1;; spin++) {
+        const hipError_t q = hipStreamQuery(h->k.stream);
+        if (q == hipSuccess) return QGD_OK;
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return comm_failed(h, std::string("rank ") + std::to_string(rank) + ": stream error while waiting for a collective evaluation: " + hipGetErrorString(q));
+        }
+        if (spin == 1 || (spin & 63u) == 0) {      // (the first look at the clock comes with the first unfinished query)
+            if (R.CommGetAsyncError) {
+                ncclResult_t ar = ncclSuccess;
+                if (R.CommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                    return comm_failed(h, std::string("rank ") + std::to_string(rank) + ": RCCL reported an asynchronous error: " + R.GetErrorString(ar));
+            }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > h->comm_timeout_ms)
+                return comm_failed(h, "rank " + std::to_string(rank) + ": a collective evaluation did not complete within " + std::to_string((long long)h->comm_timeout_ms) +
+                                      " ms (qgd_set_comm_timeout / QGD_COMM_TIMEOUT_MS): another rank failed or never made the call");
+            if (ms > 2.0) sched_yield();      // (an evaluation takes well under a millisecond: past that, stop burning the core)
+        }
+    }
+}
+
 // which: the exchange buffers of qgd_exchange_buffer -- 0, 1 all-gather in place; 2 all-reduce(sum) of [grad | scalars];
 // 3 all-reduce(sum) of the scalars {<w,R>, <w,T>, guard, flag} alone.  Issued on the handle's stream.
 int comm_collective(qgd_handle h, int which)
 {
     qgdk_ctx &k = h->k;
     RcclApi &R = rccl();
+    if (h->comm_fail_at && h->comm_fail_at == which + 1) {      // (test hook: a local failure in front of this collective)
+        h->comm_fail_at = 0;
+        return fail(h, QGD_ERR_NO_DEVICE, "injected failure in front of collective " + std::to_string(which) + " (qgd_comm_debug_fail_at)");
+    }
     const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp;
     static const char *names[4] = {"comm_gather_fwd", "comm_gather_adj", "comm_reduce", "comm_reduce_scal"};
     PhaseTimer t(h, names[which]);
@@ -989,8 +1122,21 @@ int comm_forward(qgd_handle h, const double *pcof, int n_pcof)
 // src/eval_grad_discrete_adjoint.jl:26-28 are what the collectives carry).  Every rank returns the full gradient and
 // the global scalars.  The optional outputs cover what the rank owns: its window of time points (time shards,
 // qgd_get_partition) or its columns (column shards).
+int comm_discrete_adjoint_body(qgd_handle h, const double *pcof, int n_pcof, int history_precomputed, double *grad,
+                               double *uv_history, double *lambda_history, double *adjoint_forcing, double *out3);
+
 int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int history_precomputed, double *grad,
                           double *uv_history, double *lambda_history, double *adjoint_forcing, double *out3)
+{
+    // what every rank gets alike is refused before anything is launched (no collective is left half-entered)
+    if (pcof && n_pcof != h->k.n_pcof) return fail(h, QGD_ERR_ARGUMENT, "length of pcof does not match the control basis");
+    if (!pcof && !h->have_tables && h->k.n_ops > 0) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
+    if (history_precomputed && !h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+    return comm_local_error(h, comm_discrete_adjoint_body(h, pcof, n_pcof, history_precomputed, grad, uv_history, lambda_history, adjoint_forcing, out3));
+}
+
+int comm_discrete_adjoint_body(qgd_handle h, const double *pcof, int n_pcof, int history_precomputed, double *grad,
+                               double *uv_history, double *lambda_history, double *adjoint_forcing, double *out3)
 {
     qgdk_ctx &k = h->k;
     int rc;
@@ -1029,7 +1175,17 @@ int comm_discrete_adjoint(qgd_handle h, const double *pcof, int n_pcof, int hist
     return finish_copies(h);
 }
 
+int comm_eval_forward_body(qgd_handle h, const double *pcof, int n_pcof, double *uv_history, double *out3);
+
 int comm_eval_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history, double *out3)
+{
+    if (pcof && n_pcof != h->k.n_pcof) return fail(h, QGD_ERR_ARGUMENT, "length of pcof does not match the control basis");
+    if (pcof && !h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
+    if (!pcof && !h->have_tables && h->k.n_ops > 0) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
+    return comm_local_error(h, comm_eval_forward_body(h, pcof, n_pcof, uv_history, out3));
+}
+
+int comm_eval_forward_body(qgd_handle h, const double *pcof, int n_pcof, double *uv_history, double *out3)
 {
     qgdk_ctx &k = h->k;
     int rc = comm_forward(h, pcof, n_pcof);
@@ -1246,7 +1402,9 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.cw, (size_t)2 * 20));
     CREATE_RC(dev_alloc(h, h->static_bufs, &k.status, (size_t)2));
     h->status_static = k.status;
-    CREATE_RC(alloc_grid(h));
+    // QGD_CREATE_DEFER_GRID: the caller is about to change the grid's layout (qgd_comm_init_rccl / qgd_set_partition /
+    // qgd_set_nsteps / qgd_set_memory_budget) -- a rank of a time partition never allocates the WHOLE grid first
+    if (!(d->reserved & QGD_CREATE_DEFER_GRID)) CREATE_RC(alloc_grid(h));
     *out = h;
     return QGD_OK;
 }
@@ -1353,6 +1511,7 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     if (h) drop_graph(h);
     if (!h || (h->k.n_ops && (!n_coeff || !Gp || !Gq))) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     free_pool(h->basis_bufs);
     free_pool(h->forced_bufs); h->forced_key = 0;
@@ -1415,6 +1574,7 @@ int qgd_set_control_tables(qgd_handle h, const double *pt, const double *qt)
     if (h) drop_graph(h);
     if (!h || !pt || !qt) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     NEEDS_RESIDENT_GRID(h, "qgd_set_control_tables");
     const size_t cnt = (size_t)k.nt * (k.m + 1) * k.n_ops;
@@ -1434,11 +1594,11 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
 {
     if (!h) return QGD_ERR_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (h->comm) return comm_eval_forward(h, pcof, n_pcof, uv_history, out3);
     if (h->chunks_eff > 1 && uv_history) {      // the history of a chunked grid comes out window by window
-        if (h->save_every != 1) return fail(h, QGD_ERR_UNSUPPORTED, "saveEveryNsteps with a time grid processed in windows: raise qgd_set_memory_budget");
-        int rcw = chunked_forward(h, pcof, n_pcof, uv_history);
+        int rcw = chunked_forward(h, pcof, n_pcof, uv_history, h->save_every);
         return rcw ? rcw : fetch_results(h, nullptr, out3);
     }
     int rc = run_forward(h, pcof, n_pcof);
@@ -1458,6 +1618,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
 {
     if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_discrete_adjoint");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_discrete_adjoint");
@@ -1465,7 +1626,6 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points, or give the handle a communicator (qgd_comm_init_rccl)");
     int rc;
     if (h->chunks_eff > 1) {      // bounded-memory time grid: forward pass over the windows, adjoint pass back over them
-        if (lambda_history && h->lambda_derivs) NEEDS_RESIDENT_GRID(h, "the derivative columns of lambda_history");
         if (history_precomputed && !h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
         // (uv_history is an output: a reused forward pass would have nothing to copy it from, so the pass is redone)
         if ((uv_history || !(history_precomputed && same_pcof(h, pcof, n_pcof))) && (rc = chunked_forward(h, pcof, n_pcof, uv_history))) return rc;
@@ -1564,6 +1724,7 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
     if (h) drop_graph(h);
     if (!h || !forcing) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced forward sweep is single-GPU");
     NEEDS_RESIDENT_GRID(h, "eval_forward with a forcing");
@@ -1617,6 +1778,7 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
     if (h) drop_graph(h);
     if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");     // (pcof may be NULL when the tables were set directly)
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
@@ -1684,6 +1846,7 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
     if (h) drop_graph(h);
     if (!h || !terminal_condition || !lambda_history) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: eval_adjoint is single-GPU");
     NEEDS_RESIDENT_GRID(h, "eval_adjoint");
@@ -1744,6 +1907,7 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
     if (h) drop_graph(h);
     if (!h || !in || !out) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     NEEDS_RESIDENT_GRID(h, "qgd_apply_hamiltonian");
     if (time_index < 0 || time_index >= k.nt || deriv_order < 0 || deriv_order > k.m)
@@ -1774,6 +1938,7 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
 {
     if (!h || !name) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     qgdk_ctx &k = h->k;
     const size_t Np = k.Np, N = k.N, nt = k.nt, PW = 2 * Np, panel = Np * PW, pl = Np * Np;
     std::string s(name);
@@ -1782,11 +1947,19 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     else if (s == "sigma") need = nt * (size_t)k.n_ops * k.m * 2;
     else if (s == "tables") need = nt * (size_t)(k.m + 1) * k.n_ops * 2;
     else if (s == "repivoted") need = 1;
+    else if (s == "selection") need = 4;
     else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
     if (needed) *needed = need;
     if (!out) return QGD_OK;
-    NEEDS_RESIDENT_GRID(h, "qgd_get_intermediate");
     if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
+    if (s == "selection") {      // which kernel families this problem runs on (tests assert that a shape selects what it is meant to)
+        out[0] = k.use_sparse ? 2.0 : (k.dense_gemm ? 1.0 : 0.0);      // 2 sparse (ELL), 1 N > 64 GEMM-style kernels, 0 dense N <= 64
+        out[1] = (k.dense_gemm && !k.use_sparse) ? (double)qgdk_dense_sigma_form(&k) : -1.0;
+        out[2] = (k.dense_gemm && k.binv) ? 1.0 : 0.0;               // block Gauss-Jordan inverse over 64-column blocks
+        out[3] = (double)h->chunks_eff;
+        return QGD_OK;
+    }
+    NEEDS_RESIDENT_GRID(h, "qgd_get_intermediate");
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     if (s == "repivoted") {     // workgroups of the last inverse launch whose static-pivot attempt was redone with partial pivoting
         int v[2] = {0, 0};
@@ -1846,8 +2019,13 @@ int qgd_set_partition(qgd_handle h, int32_t rank, int32_t world)
 int qgd_get_partition(qgd_handle h, int32_t *out8)
 {
     if (!h || !out8) return QGD_ERR_ARGUMENT;
+    NEED_GRID(h);
     const qgdk_ctx &k = h->k;
     out8[0] = k.n_off; out8[1] = k.n_off + k.nt - 1;   // first / last global time point of the window
+    // One GPU working through the grid in windows (qgd_set_memory_budget): the windows are the library's business -- the
+    // caller owns ALL time points (control basis and reference-layout outputs cover the whole grid); k.n_off / k.nt are
+    // whichever window was processed last.
+    if (h->chunks_eff > 1 && h->part_world == 1) { out8[0] = 0; out8[1] = k.nt_glob - 1; }
     out8[2] = k.blocks_glob; out8[3] = k.bpr; out8[4] = k.scan_blen; out8[5] = k.part_rank; out8[6] = k.part_world;
     out8[7] = k.nt_glob;
     return QGD_OK;
@@ -1869,6 +2047,7 @@ int qgd_exchange_buffer(qgd_handle h, int32_t which, void **dev_ptr, size_t *tot
                         size_t *own_doubles)
 {
     if (!h || !dev_ptr || !total_doubles || !own_offset || !own_doubles) return QGD_ERR_ARGUMENT;
+    NEED_GRID(h);
     const qgdk_ctx &k = h->k;
     const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp, W = (size_t)k.part_world;
     if (which == 0) {          // block propagators, all-gather
@@ -1891,6 +2070,7 @@ int qgd_dist_forward_begin(qgd_handle h, const double *pcof, int32_t n_pcof)
 {
     if (!h) return QGD_ERR_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called first");
     return forward_begin(h, pcof, n_pcof);
 }
@@ -1963,23 +2143,55 @@ int qgd_comm_init_rccl(qgd_handle h, const void *unique_id, int32_t rank, int32_
     if (!h || !unique_id) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(h, QGD_ERR_ARGUMENT, "rank/world out of range");
     if (shard != QGD_SHARD_TIME && shard != QGD_SHARD_COLUMNS) return fail(h, QGD_ERR_ARGUMENT, "shard: 0 time windows, 1 column blocks");
-    if (shard == QGD_SHARD_COLUMNS && h->chunks_eff > 1)
-        return fail(h, QGD_ERR_UNSUPPORTED, "a time grid processed in windows (memory budget) cannot also be sharded by columns: raise the budget, "
-                                            "or shard by time -- every rank then holds only its own window");
     RcclApi &R = rccl();
     if (!R.ok) return fail(h, QGD_ERR_COMM, R.err);
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = qgd_comm_destroy(h);
     if (rc) return rc;
     // time windows: the rank's window of the grid (invalidates control basis and histories, like qgd_set_nsteps);
-    // column blocks: the handle was created from the rank's columns, the grid stays whole
-    if (shard == QGD_SHARD_TIME) { if ((rc = qgd_set_partition(h, rank, world))) return rc; }
-    else if (h->part_world != 1 && (rc = qgd_set_partition(h, 0, 1))) return rc;
+    // column blocks: the handle was created from the rank's columns, the grid stays whole.
+    // A handle with a communicator keeps its window RESIDENT (the collective protocol does not walk the windows of a
+    // bounded-memory grid): comm_pending makes this allocation skip the window planner -- a grid that was being
+    // processed in windows (memory budget, > 65 000 steps) is allocated whole here, or the call fails with
+    // QGD_ERR_MEMORY / QGD_ERR_UNSUPPORTED and the handle keeps the layout it had.
+    const int prev_rank = h->part_rank, prev_world = h->part_world;
+    const bool deferred = !h->grid_ready;
+    auto restore = [&]() {
+        h->comm_pending = false;
+        h->part_rank = prev_rank; h->part_world = prev_world;
+        if (deferred) { free_pool(h->grid_bufs); h->grid_ready = false; }
+        else (void)alloc_grid(h);                // (best effort: the caller's error is the one already recorded)
+    };
+    h->comm_pending = true;
+    if (shard == QGD_SHARD_TIME) rc = qgd_set_partition(h, rank, world);
+    else if (h->part_world != 1 || h->chunks_eff > 1 || !h->grid_ready) rc = qgd_set_partition(h, 0, 1);
+    if (rc) { const std::string e = h->err; const int code = rc; restore(); h->err = e; return code; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t comm = nullptr;
-    NCCL_TRY(h, R.CommInitRank(&comm, world, id, rank));
+    const ncclResult_t nr = R.CommInitRank(&comm, world, id, rank);
+    if (nr != ncclSuccess) {
+        restore();
+        return fail(h, QGD_ERR_COMM, std::string("ncclCommInitRank: ") + R.GetErrorString(nr));
+    }
     h->comm = comm; h->comm_shard = shard; h->comm_rank = rank; h->comm_world = world;
+    h->comm_pending = false;
+    return QGD_OK;
+}
+
+int qgd_set_comm_timeout(qgd_handle h, double milliseconds)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (!(milliseconds > 0)) return fail(h, QGD_ERR_ARGUMENT, "the time limit of a collective evaluation must be positive (milliseconds)");
+    h->comm_timeout_ms = milliseconds;
+    return QGD_OK;
+}
+
+int qgd_comm_debug_fail_at(qgd_handle h, int32_t collective)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    if (collective < 0 || collective > 4) return fail(h, QGD_ERR_ARGUMENT, "collective: 0 off, 1..4 = in front of exchange 0..3");
+    h->comm_fail_at = collective;
     return QGD_OK;
 }
 
@@ -2029,6 +2241,7 @@ int qgd_cols_forward(qgd_handle h, const double *pcof, int32_t n_pcof)
 {
     if (!h || !pcof) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
     if (!h->k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called first");
     if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called first");
     return run_forward(h, pcof, n_pcof);        // scal = this rank's <w,R>, <w,T>, guard: exchange buffer 3
@@ -2090,6 +2303,7 @@ int qgd_set_memory_budget(qgd_handle h, size_t bytes)
 int qgd_get_memory_plan(qgd_handle h, int64_t *out4)
 {
     if (!h || !out4) return QGD_ERR_ARGUMENT;
+    NEED_GRID(h);
     const qgdk_ctx &k = h->k;
     out4[0] = h->chunks_eff; out4[1] = (int64_t)k.bpr * k.scan_blen; out4[2] = (int64_t)h->window_bytes; out4[3] = (int64_t)h->mem_budget;
     return QGD_OK;

@@ -147,6 +147,7 @@ int qgdk_dense_operator_frag(const qgdk_ctx *c);
 int qgdk_dense_build_LR(const qgdk_ctx *c);
 int qgdk_dense_sigma_planes(const qgdk_ctx *c);   // planes of sigma the N > 64 gradient kernels write for the form in use
 int qgdk_dense_sigma_planes_max(int Np, int cp, int m);
+int qgdk_dense_sigma_form(const qgdk_ctx *c);     // 0..3: which form of the gradient scalars the N > 64 path takes (qgd_k_dense.hip)
 int qgdk_dense_chain_step(hipStream_t stream, int adj, const double *P, const double *in, double *out, const double *forcing, int Np, int cp);
 int qgdk_dense_inverse(const qgdk_ctx *c);        // 1: the block Gauss-Jordan inverse took the launch, 0: not taken
 size_t qgdk_dense_inverse_words(int Np, int nt);  // doubles of work space it needs

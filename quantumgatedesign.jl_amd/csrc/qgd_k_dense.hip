@@ -1604,6 +1604,7 @@ static int sigma_planes_of(int form, int Np, int cp, int m)
     return (((nrb + RB - 1) / RB) * ((ng + NG - 1) / NG) * m + 3) / 4;        // (k_ginner_f: the source level belongs to the wave's item)
 }
 int qgdk_dense_sigma_planes(const qgdk_ctx *c) { return sigma_planes_of(dense_sigma_form(c), c->Np, c->cp, c->m); }
+int qgdk_dense_sigma_form(const qgdk_ctx *c) { return dense_sigma_form(c); }      // (diagnostic: qgd_get_intermediate("selection"))
 int qgdk_dense_sigma_planes_max(int Np, int cp, int m) { return std::max(sigma_planes_of(0, Np, cp, m), sigma_planes_of(1, Np, cp, m)); }
 
 int qgdk_dense_gradient_needs_derivs(const qgdk_ctx *c) { return dense_sigma_form(c) < 2; }

@@ -484,11 +484,13 @@ __global__ __launch_bounds__(256) void k_adjoint_derivs(const double *__restrict
                                                         const double *__restrict__ tab,
                                                         const double *__restrict__ lam,
                                                         double *__restrict__ dlam, int Np, int cp,
-                                                        int n_ops, int m, double *__restrict__ gpanels)
+                                                        int n_ops, int m, double *__restrict__ gpanels, int n_off)
 {
     extern __shared__ double lds_panels[];              // g_0 .. g_m
     const int n = blockIdx.y + 1, grp = blockIdx.x;
-    const int tn = (n >= 2) ? n - 1 : 1;
+    // (n_off: global index of this grid's first time point -- a window of a long grid, a rank's window: only GLOBAL
+    //  time index 1 takes the controls of its own time point, forward_evolution.jl:423,472)
+    const int tn = (n + n_off >= 2) ? n - 1 : 1;
     double *smem = gpanels ? gpanels + ((size_t)blockIdx.y * gridDim.x + grp) * (size_t)(m + 1) * Np * 16 : lds_panels;
     const int PWc = 2 * cp;
     const size_t hstep = (size_t)Np * PWc;
@@ -657,7 +659,7 @@ int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch)
     if (scratch) shm = 0;
 #define CALL_AD(N) do { if (shm > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_derivs<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
         hipLaunchKernelGGL((k_adjoint_derivs<N>), dim3(c->cp / 8, c->nt - 1), dim3(256), shm, c->stream, c->ops, c->tab, c->lam, dlam, \
-                           c->Np, c->cp, c->n_ops, c->m, scratch); } while (0)
+                           c->Np, c->cp, c->n_ops, c->m, scratch, c->n_off); } while (0)
     DISPATCH_NOPS(c->n_ops, CALL_AD)
 #undef CALL_AD
     return (int)hipGetLastError();

@@ -52,7 +52,9 @@ class RcclEvaluation:
             self.dp.set_controls(controls)
             self.dp.set_target(target[:, lo:hi])
         else:
-            self.dp = DeviceProblem(prob, order, device)
+            # (the grid is allocated by comm_init, for the rank's window only: a problem that is sharded by time because
+            #  its whole grid does not fit one GPU must not be allocated whole first)
+            self.dp = DeviceProblem(prob, order, device, defer_grid=True)
             self.dp.comm_init(unique_id, rank, world, "time")
             self.partition = self.dp.partition
             self.dp.set_controls(controls)

@@ -61,9 +61,11 @@ COST_TYPES = {"Infidelity": 0, ":Infidelity": 0, "Tracking": 1, ":Tracking": 1, 
 class DeviceProblem:
     """One qgd handle: a SchrodingerProb resident on one GPU for one Hermite order."""
 
-    def __init__(self, prob, order: int, device: int = 0, csc: bool = False):
+    def __init__(self, prob, order: int, device: int = 0, csc: bool = False, defer_grid: bool = False):
         """``csc=True`` hands the operators to the library as SparseMatrixCSC triples (qgd_create_csc), the
-        form DispersiveProblem(sparse_rep=true) produces in the reference."""
+        form DispersiveProblem(sparse_rep=true) produces in the reference.  ``defer_grid=True`` (QGD_CREATE_DEFER_GRID):
+        the time grid is not allocated by the constructor -- for a handle that is about to become a rank of a time
+        partition (``comm_init``) and must never hold the whole grid first."""
         self.lib = _lib.lib()
         self.N = prob.N_tot_levels
         self.c = prob.N_initial_conditions
@@ -80,7 +82,8 @@ class DeviceProblem:
             u0=_f(prob.u0), v0=_f(prob.v0), guard=_f(prob.guard_subspace_projector))
         d = _lib.ProblemDesc(N, self.c, self.n_ops, prob.N_ess_levels, self.order, prob.nsteps, prob.tf,
                              _vp(bufs["ssym"]), _vp(bufs["sasym"]), _vp(bufs["sym"]), _vp(bufs["asym"]),
-                             _vp(bufs["u0"]), _vp(bufs["v0"]), _vp(bufs["guard"]), device, 0)
+                             _vp(bufs["u0"]), _vp(bufs["v0"]), _vp(bufs["guard"]), device,
+                             _lib.QGD_CREATE_DEFER_GRID if defer_grid else 0)
         h = C.c_void_p()
         if csc:
             from scipy.sparse import csc_matrix
@@ -214,6 +217,15 @@ class DeviceProblem:
 
     def comm_destroy(self):
         _lib.check(self.h, self.lib.qgd_comm_destroy(self.h))
+
+    def set_comm_timeout(self, milliseconds):
+        """qgd_set_comm_timeout: the bound on the host wait of a collective evaluation; past it the communicator is
+        aborted and the call raises QGDError(QGD_ERR_COMM)."""
+        _lib.check(self.h, self.lib.qgd_set_comm_timeout(self.h, float(milliseconds)))
+
+    def comm_debug_fail_at(self, collective):
+        """Test hook (qgd_comm_debug_fail_at): the next collective call fails locally in front of its exchange."""
+        _lib.check(self.h, self.lib.qgd_comm_debug_fail_at(self.h, int(collective)))
 
     def comm_info(self):
         out = (C.c_int32 * 3)()
@@ -355,6 +367,8 @@ class DeviceProblem:
             return z[..., 0] + 1j * z[..., 1]
         if name == "repivoted":
             return int(out[0])
+        if name == "selection":
+            return out
         if name == "sigma":
             return out.reshape(nt, self.n_ops, self.m, 2)
         return out.reshape(nt, self.m + 1, self.n_ops, 2)

@@ -10,7 +10,11 @@
  *      test/GradientTests/compare_gradients.jl:47-65), to 1e-7 relative;
  *   4. the same problem through qgd_create_csc gives the same gradient;
  *   5. qgd_comm_unique_id / qgd_comm_init_rccl (one rank, both shard kinds): the collective qgd_discrete_adjoint gives it too;
- *   6. qgd_set_memory_budget: the grid in windows gives it too, and an impossible budget is QGD_ERR_MEMORY.
+ *   6. qgd_set_memory_budget: the grid in windows gives it too, qgd_get_partition reports the whole grid, and an
+ *      impossible budget is QGD_ERR_MEMORY;
+ *   7. the failure mode of the collective calls: an injected local failure and an expired time limit are QGD_ERR_COMM with
+ *      the communicator aborted, and a fresh communicator on the same handle works;
+ *   8. QGD_CREATE_DEFER_GRID, and a communicator on a handle that was working in windows (one resident window).
  * Exit code 0 and "C_CONSUMER_OK" on success; 3 when there is no GPU (the library has no CPU path).
  */
 #include <math.h>
@@ -149,7 +153,75 @@ int main(void)
         fprintf(stderr, "windowed grid differs: %.15g %.15g vs %.15g %.15g\n", gw[0], gw[1], grad[0], grad[1]);
         return 1;
     }
+    /* (qgd_get_partition on a handle that works in windows: the caller owns the WHOLE grid -- first point 0, last point
+     *  NSTEPS, one rank -- whichever window the library processed last; a shim sizes its basis and outputs by this) */
+    int32_t part[8];
+    if ((rc = qgd_get_partition(h, part)) || part[0] != 0 || part[1] != NSTEPS || part[6] != 1 || part[7] != NT) {
+        fprintf(stderr, "qgd_get_partition on a windowed grid: [%d, %d], world %d, %d points\n", part[0], part[1], part[6], part[7]);
+        return 1;
+    }
     if (qgd_set_memory_budget(h, 64) != QGD_ERR_MEMORY) { fprintf(stderr, "a 64-byte budget must be QGD_ERR_MEMORY\n"); return 1; }
+    /* 7. the failure mode of a collective call: a rank that fails locally in front of an exchange aborts its communicator and
+     *    reports QGD_ERR_COMM (it does not leave the call half-entered); so does a collective call that outlives its time
+     *    limit.  Afterwards the handle has no communicator (rank -1) and takes a fresh one. */
+    for (int trial = 0; trial < 2; trial++) {
+        if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);
+        if ((rc = qgd_comm_init_rccl(hc, id, 0, 1, QGD_SHARD_TIME))) return die("qgd_comm_init_rccl(7)", hc, rc);
+        if ((rc = qgd_set_control_basis(hc, ncoef, gp, gq))) return die("qgd_set_control_basis(7)", hc, rc);
+        if ((rc = qgd_set_target(hc, target))) return die("qgd_set_target(7)", hc, rc);
+        if (trial == 0) { if ((rc = qgd_comm_debug_fail_at(hc, 2))) return die("qgd_comm_debug_fail_at", hc, rc); }
+        else if ((rc = qgd_set_comm_timeout(hc, 1e-6))) return die("qgd_set_comm_timeout", hc, rc);
+        double gm[2], om3[3];
+        rc = qgd_discrete_adjoint(hc, theta, 2, 0, gm, NULL, NULL, NULL, om3);
+        if (rc != QGD_ERR_COMM || !strstr(qgd_last_error(hc), "aborted")) {
+            fprintf(stderr, "failure mode %d: expected QGD_ERR_COMM, got %d (%s)\n", trial, rc, qgd_last_error(hc));
+            return 1;
+        }
+        if ((rc = qgd_comm_info(hc, info)) || info[0] != -1) { fprintf(stderr, "the communicator must be gone after a failure\n"); return 1; }
+        if ((rc = qgd_set_comm_timeout(hc, 30000.0))) return die("qgd_set_comm_timeout", hc, rc);
+    }
+    /*    ... and a healthy communicator on the same handle works again */
+    if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);
+    if ((rc = qgd_comm_init_rccl(hc, id, 0, 1, QGD_SHARD_TIME))) return die("qgd_comm_init_rccl(7b)", hc, rc);
+    if ((rc = qgd_set_control_basis(hc, ncoef, gp, gq))) return die("qgd_set_control_basis(7b)", hc, rc);
+    if ((rc = qgd_set_target(hc, target))) return die("qgd_set_target(7b)", hc, rc);
+    if ((rc = qgd_discrete_adjoint(hc, theta, 2, 0, gc, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(7b)", hc, rc);
+    if (fabs(gc[0] - grad[0]) > 1e-13 || fabs(gc[1] - grad[1]) > 1e-13) { fprintf(stderr, "after a recovered communicator: gradient differs\n"); return 1; }
+    /* 8. QGD_CREATE_DEFER_GRID: no grid until an entry point needs one; a communicator on a handle that had a memory
+     *    budget keeps its window resident (one window), and the result is the same */
+    qgd_handle hd = NULL;
+    d.reserved = QGD_CREATE_DEFER_GRID;
+    if ((rc = qgd_create(&d, &hd))) return die("qgd_create(deferred)", NULL, rc);
+    d.reserved = 0;
+    if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);
+    if ((rc = qgd_comm_init_rccl(hd, id, 0, 1, QGD_SHARD_TIME))) return die("qgd_comm_init_rccl(deferred)", hd, rc);
+    if ((rc = qgd_get_memory_plan(hd, plan)) || plan[0] != 1) { fprintf(stderr, "a communicator handle must be resident: %d windows\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_control_basis(hd, ncoef, gp, gq))) return die("qgd_set_control_basis(deferred)", hd, rc);
+    if ((rc = qgd_set_target(hd, target))) return die("qgd_set_target(deferred)", hd, rc);
+    if ((rc = qgd_discrete_adjoint(hd, theta, 2, 0, gc, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(deferred)", hd, rc);
+    if (fabs(gc[0] - grad[0]) > 1e-13 || fabs(gc[1] - grad[1]) > 1e-13) { fprintf(stderr, "deferred-grid handle: gradient differs\n"); return 1; }
+    /*    a handle that works in windows because of its memory budget cannot take a communicator (the collective protocol
+     *    keeps a rank's window resident): QGD_ERR_MEMORY -- not window 0 of several, silently -- and the handle keeps the
+     *    layout it had; with the budget lifted the communicator is accepted and the grid is one resident window */
+    if ((rc = qgd_set_memory_budget(h, 0))) return die("qgd_set_memory_budget(0)", h, rc);
+    if ((rc = qgd_get_memory_plan(h, plan)) || plan[0] != 1) { fprintf(stderr, "automatic budget: %d windows\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_memory_budget(h, (size_t)plan[2] / 2))) return die("qgd_set_memory_budget(half)", h, rc);
+    if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);
+    if (qgd_comm_init_rccl(h, id, 0, 1, QGD_SHARD_TIME) != QGD_ERR_MEMORY) { fprintf(stderr, "communicator on a windowed handle: %s\n", qgd_last_error(h)); return 1; }
+    if ((rc = qgd_comm_info(h, info)) || info[0] != -1) { fprintf(stderr, "no communicator may be left behind\n"); return 1; }
+    if ((rc = qgd_get_memory_plan(h, plan)) || plan[0] < 2) { fprintf(stderr, "the refused handle must keep its windows: %d\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_control_basis(h, ncoef, gp, gq))) return die("qgd_set_control_basis(refused)", h, rc);
+    if ((rc = qgd_set_target(h, target))) return die("qgd_set_target(refused)", h, rc);
+    if ((rc = qgd_discrete_adjoint(h, theta, 2, 0, gw, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(refused)", h, rc);
+    if (fabs(gw[0] - grad[0]) > 1e-12 || fabs(gw[1] - grad[1]) > 1e-12) { fprintf(stderr, "refused handle: gradient differs\n"); return 1; }
+    if ((rc = qgd_set_memory_budget(h, 0))) return die("qgd_set_memory_budget(0)", h, rc);
+    if ((rc = qgd_comm_init_rccl(h, id, 0, 1, QGD_SHARD_TIME))) return die("qgd_comm_init_rccl(budget lifted)", h, rc);
+    if ((rc = qgd_get_memory_plan(h, plan)) || plan[0] != 1) { fprintf(stderr, "communicator handle: %d windows\n", (int)plan[0]); return 1; }
+    if ((rc = qgd_set_control_basis(h, ncoef, gp, gq))) return die("qgd_set_control_basis(comm)", h, rc);
+    if ((rc = qgd_set_target(h, target))) return die("qgd_set_target(comm)", h, rc);
+    if ((rc = qgd_discrete_adjoint(h, theta, 2, 0, gw, NULL, NULL, NULL, out3))) return die("qgd_discrete_adjoint(comm)", h, rc);
+    if (fabs(gw[0] - grad[0]) > 1e-12 || fabs(gw[1] - grad[1]) > 1e-12) { fprintf(stderr, "communicator handle: gradient differs\n"); return 1; }
+    qgd_destroy(hd);
     qgd_destroy(hc);
     qgd_destroy(h);
     printf("infidelity(0.4, 0.1) = %.12f  grad = [%.12f, %.12f]  fd = [%.12f, %.12f]\nC_CONSUMER_OK\n", infid0, grad[0], grad[1], fd[0], fd[1]);

@@ -34,6 +34,39 @@ def test_large_n_kernels_vs_oracle(qgd, orc, N, c, n_ops, nsteps, order):
     qgd.clear_cache()
 
 
+def test_config5_kernel_selection_vs_oracle(qgd, orc):
+    """BASELINE.json configs[4] at the shape that SELECTS its kernels -- N = 256, 256 columns (the 16-column chain tiles, the
+    outer-product gradient form "3" on N x N matrices: it needs 15 N < 19 c, block Gauss-Jordan over four 64-column blocks),
+    4 control operators, order 12 -- against the ORACLE itself (per-column matrix-free GMRES at 1e-15, the exponential adjoint
+    recursion and recursive_magic! of the reference), not the numpy statement of the device algorithm: 2 time steps,
+    state history with all six stage derivatives, lambda, guard forcing and gradient.  The oracle's gradient loop runs
+    its columns on threads for this one (bit-identical to the serial loop: tests/test_oracle.py); ~1 minute of host time.
+    Reference shape: src/ProblemConstructors/random_problem.jl:15-35; contract: test/GradientTests/compare_gradients.jl:47-65."""
+    import os
+    N, c, n_ops, nsteps, order = 256, 256, 4, 2, 12
+    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=nsteps, tf=0.01 * nsteps, seed=N)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    shape = (2 * N, 1 + order // 2, 1 + nsteps, c)
+    hist, lam = np.zeros(shape, order="F"), np.zeros(shape, order="F")
+    forcing = np.zeros((2 * N, 1 + nsteps, c), order="F")
+    grad, _ = dp.discrete_adjoint(pcof, False, hist, lam, forcing)
+    sel = dp.intermediate("selection")
+    dp.close()
+    assert list(sel) == [1.0, 3.0, 1.0, 1.0], sel      # GEMM-style kernels, gradient form 3, block inverse, one window
+    orc.set_converged_terminal(True); orc.set_parallel_gradient(True)
+    orc.set_num_threads(min(16, os.cpu_count() or 1))      # (the GPU box's CPU share for one GPU)
+    try:
+        g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)
+    finally:
+        orc.set_converged_terminal(False); orc.set_parallel_gradient(False); orc.set_num_threads(0)
+    for j in range(order // 2 + 1):      # relative per Taylor index: the high coefficients of a random problem are large
+        assert np.abs(hist[:, j] - h_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(h_ref[:, j]).max()), j
+    assert np.abs(lam[:, 0] - lam_ref[:, 0]).max() <= 1e-10 * max(1.0, np.abs(lam_ref[:, 0]).max())
+    assert np.abs(forcing - f_ref).max() <= 1e-11 * max(1.0, np.abs(f_ref).max())
+    assert np.abs(grad - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
+
+
 @pytest.mark.parametrize("N,c,n_ops,nsteps,order", [(80, 4, 2, 6, 12), (180, 9, 2, 4, 12)])
 def test_large_n_lambda_derivative_columns(qgd, orc, N, c, n_ops, nsteps, order):
     """qgd_set_lambda_derivatives beyond N = 64 (the second case keeps the m+1 work panels of k_adjoint_derivs in HBM:

@@ -73,10 +73,37 @@ def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
     hist = np.full(shape, np.nan, order="F")
     dp.eval_forward(pcof, hist)
     assert np.abs(hist[:, 0] - ref[0][:, 0]).max() <= 1e-11
-    # what needs the grid resident says so
+    # the derivative columns of lambda_history (forward_evolution.jl:427-433) window by window: equal to the resident call's
+    chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl); chk.set_target(target)
+    chk.set_lambda_derivatives(True)
+    lam_ref = np.zeros(shape, order="F")
+    chk.discrete_adjoint(pcof, False, None, lam_ref, None)
     dp.set_lambda_derivatives(True)
+    lam = np.full(shape, np.nan, order="F")
+    dp.discrete_adjoint(pcof, False, None, lam, None)
+    for j in range(shape[1]):
+        assert np.isfinite(lam[:, j]).all() and np.abs(lam[:, j] - lam_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(lam_ref[:, j]).max()), ("lambda derivatives", j)
+    assert np.abs(lam_ref[:, 1:, 1:]).max() > 0 and np.abs(lam[:, :, 0]).max() == 0      # (filled; time index 0 never written)
+    dp.set_lambda_derivatives(False)
+    # eval_forward's saveEveryNsteps (forward_evolution.jl:104,239-241) window by window: slot s = global time point s * save,
+    # whatever the windows' boundaries are (strides that divide the window length, that do not, and one longer than a window)
+    for save in (2, 3, 7, plan["steps_per_window"] + 1):
+        if save > prob.nsteps:
+            continue
+        slots = 1 + prob.nsteps // save
+        chk.set_save_every(save); dp.set_save_every(save)
+        h_ref = np.zeros((shape[0], shape[1], slots, shape[3]), order="F")
+        chk.eval_forward(pcof, h_ref)
+        h_win = np.full_like(h_ref, np.nan, order="F")
+        dp.eval_forward(pcof, h_win)
+        for j in range(shape[1]):
+            assert np.isfinite(h_win[:, j]).all() and np.abs(h_win[:, j] - h_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(h_ref[:, j]).max()), ("save", save, j)
+        assert np.abs(h_ref[:, 0, 1] - ref[0][:, 0, save]).max() <= 1e-11
+    chk.set_save_every(1); dp.set_save_every(1)
+    chk.close()
+    # what still needs the grid resident says so
     with pytest.raises(qgd._lib.QGDError) as e:
-        dp.discrete_adjoint(pcof, False, None, got[1], None)
+        dp.eval_adjoint(pcof, np.zeros((shape[0], shape[3])))
     assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
     dp.close()
 

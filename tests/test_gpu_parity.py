@@ -687,6 +687,46 @@ def test_legacy_controls_on_device(qgd):
     qgd.clear_cache()
 
 
+def test_legacy_controls_on_device_vs_oracle(qgd, orc):
+    """SURVEY 8 row f3 on the DEVICE against the oracle (not device against device): the hard-coded quadratic B-spline
+    under carrier waves (BSpline2Control, my_bspline_controls: bspline_control.jl:21-270, :52-64) at orders 2-6, and
+    the reference's BSplineControl -- the product builds it as CarrierControl(BSpline2Control), the oracle evaluates it
+    through its own restatement of bcarrier2 / gradbcarrier2 (bspline_backend.jl:381-955; derivative orders 0 and 1,
+    i.e. Hermite order 2, all the reference implements).  Gradient against the oracle's discrete_adjoint AND
+    eval_grad_forced (the reference's parity contract, test/GradientTests/compare_gradients.jl:47-65), state history with
+    every stage derivative, lambda and the guard forcing: 1e-10 / 1e-11."""
+    from oracle.oracle import BCarrier2Control
+    prob = qgd.construct_rand_prob(5, 2, tf=1.5, nsteps=30, scale=0.5, gmres_abstol=1e-15, gmres_reltol=1e-15)
+    target = cases.rand_target(prob)
+    rng = np.random.default_rng(44)
+    omega = [-2.5, 0.0, 1.7]
+    cases_ = [([qgd.CarrierControl(qgd.BSpline2Control(6, prob.tf), omega), qgd.CarrierControl(qgd.BSpline2Control(4, prob.tf), [0.0, 3.1])],
+               None, (2, 4, 6)),
+              ([qgd.BSplineControl(prob.tf, 6, omega), qgd.BSplineControl(prob.tf, 5, [1.1])],
+               [BCarrier2Control(prob.tf, 6, omega), BCarrier2Control(prob.tf, 5, [1.1])], (2,))]
+    orc.set_converged_terminal(True)
+    try:
+        for dev_ctrl, orc_ctrl, orders in cases_:
+            orc_ctrl = dev_ctrl if orc_ctrl is None else orc_ctrl
+            pcof = 0.4 * rng.standard_normal(qgd.get_number_of_control_parameters(dev_ctrl))
+            for order in orders:
+                g_ref, h_ref, lam_ref, f_ref, _ = orc.discrete_adjoint(prob, orc_ctrl, pcof, target, order=order, return_all=True)
+                gf_ref = orc.eval_grad_forced(prob, orc_ctrl, pcof, target, order=order)
+                dp = qgd.DeviceProblem(prob, order); dp.set_controls(dev_ctrl); dp.set_target(target)
+                hist, lam = np.zeros(h_ref.shape, order="F"), np.zeros(h_ref.shape, order="F")
+                forcing = np.zeros(f_ref.shape, order="F")
+                g, _ = dp.discrete_adjoint(pcof, False, hist, lam, forcing)
+                gf = dp.eval_grad_forced(pcof)
+                dp.close()
+                scale = np.abs(g_ref).max()
+                assert np.abs(g - g_ref).max() <= 1e-10 * scale, (type(orc_ctrl[0]).__name__, order)
+                assert np.abs(g - gf_ref).max() <= 1e-10 * scale, (type(orc_ctrl[0]).__name__, order)
+                assert np.abs(gf - gf_ref).max() <= 1e-10 * scale, (type(orc_ctrl[0]).__name__, order)
+                assert close(hist, h_ref) and close(lam[:, 0], lam_ref[:, 0]) and close(forcing, f_ref), (type(orc_ctrl[0]).__name__, order)
+    finally:
+        orc.set_converged_terminal(False)
+
+
 @pytest.mark.parametrize("which,order", [("cnot2", 4), ("guarded", 6), ("cnot3", 8)])
 def test_eval_forward_with_forcing(qgd, orc, which, order):
     """eval_forward(...; forcing) (forward_evolution.jl:118-129,167-206): the whole derivative history and the

@@ -87,3 +87,65 @@ def test_rccl_errors(qgd):
     assert e.value.code == qgd._lib.QGD_ERR_ARGUMENT
     assert dp.comm_info()["rank"] == -1
     dp.close()
+
+
+@pytest.mark.parametrize("shard,where", [("time", 1), ("time", 2), ("time", 3), ("columns", 4), ("columns", 3), ("time", "timeout")])
+def test_rccl_failure_mode(qgd, shard, where):
+    """A collective call that cannot complete must END, with QGD_ERR_COMM and the communicator aborted (ncclCommAbort) --
+    not leave this rank's stream, or the other ranks, waiting inside a collective: (a) a local failure injected in front
+    of each exchange of both protocols (qgd_comm_debug_fail_at), (b) a time limit that expires (qgd_set_comm_timeout).
+    Afterwards the handle has no communicator and accepts a fresh one, with which the evaluation is right again.
+    (The reference's thread loop has no such state: an exception leaves Threads.@threads, src/forward_evolution.jl:48.)"""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=60, tf=60.0)
+    order = 8
+    g_ref, o_ref, _ = _reference(qgd, prob, ctrl, pcof, target, order)
+    ev = qgd.RcclEvaluation(prob, order, ctrl, target, 0, 1, qgd.comm_unique_id(), shard=shard)
+    g, _ = ev.discrete_adjoint(pcof)
+    assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+    if where == "timeout":
+        ev.dp.set_comm_timeout(1e-6)
+    else:
+        ev.dp.comm_debug_fail_at(where)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        ev.discrete_adjoint(pcof)
+    assert e.value.code == qgd._lib.QGD_ERR_COMM and "aborted" in str(e.value), str(e.value)
+    assert ev.dp.comm_info()["rank"] == -1
+    # argument errors are raised before anything is launched and leave a communicator alone
+    ev.dp.set_comm_timeout(30000.0)
+    ev.dp.comm_init(qgd.comm_unique_id(), 0, 1, shard)
+    ev.dp.set_controls(ctrl); ev.dp.set_target(target)
+    with pytest.raises(qgd._lib.QGDError) as e:
+        ev.dp.discrete_adjoint(pcof[:-1], False, None, None, np.zeros((prob.real_system_size, 1 + prob.nsteps, prob.N_initial_conditions), order="F"))
+    assert e.value.code == qgd._lib.QGD_ERR_ARGUMENT
+    assert ev.dp.comm_info()["rank"] == 0
+    g, o = ev.discrete_adjoint(pcof)
+    assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+    assert np.abs(np.asarray(o) - o_ref).max() <= 1e-12 * max(1.0, np.abs(o_ref).max())
+    ev.close()
+
+
+def test_rccl_handle_never_walks_windows(qgd):
+    """A handle with a communicator keeps its window resident (comm_discrete_adjoint does not walk the windows of a
+    bounded-memory grid): a budget that would cut the grid into windows makes qgd_comm_init_rccl fail with QGD_ERR_MEMORY
+    and leaves the handle as it was; a deferred-grid handle (QGD_CREATE_DEFER_GRID) allocates its window in comm_init."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=96, tf=96.0)
+    order = 4
+    g_ref, o_ref, _ = _reference(qgd, prob, ctrl, pcof, target, order)
+    dp = qgd.DeviceProblem(prob, order)
+    dp.set_memory_budget(dp.memory_plan()["window_bytes"] // 3)
+    assert dp.memory_plan()["windows"] >= 3
+    with pytest.raises(qgd._lib.QGDError) as e:
+        dp.comm_init(qgd.comm_unique_id(), 0, 1, "time")
+    assert e.value.code == qgd._lib.QGD_ERR_MEMORY
+    assert dp.comm_info()["rank"] == -1 and dp.memory_plan()["windows"] >= 3
+    dp.set_controls(ctrl); dp.set_target(target)
+    g, _ = dp.discrete_adjoint(pcof)                    # (still a working single-GPU handle, in windows)
+    assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    dp.close()
+    dp = qgd.DeviceProblem(prob, order, defer_grid=True)
+    dp.comm_init(qgd.comm_unique_id(), 0, 1, "time")
+    assert dp.memory_plan()["windows"] == 1 and dp.window == (0, prob.nsteps)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g, _ = dp.discrete_adjoint(pcof)
+    assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+    dp.close()

@@ -326,3 +326,24 @@ def test_legacy_controls_three_way_contract(qgd, orc):
             scale = np.abs(ga).max()
             assert np.abs(ga - gf).max() <= 1e-13 * scale, (type(ctrl).__name__, order)
             assert np.abs(ga - gd).max() <= 3e-8 * scale, (type(ctrl).__name__, order)
+
+
+def test_parallel_gradient_columns_are_bit_identical(qgd, orc):
+    """The oracle's test switch for large problems (qo_set_parallel_gradient: the per-column gradient accumulation of
+    eval_grad_discrete_adjoint.jl:148-157 with the columns on threads, each into its own vector, added in column order)
+    gives the SAME BITS as the reference's serial loop -- so the N = 256 device comparison that uses it is a comparison
+    with the serial oracle."""
+    prob = qgd.construct_rand_prob(6, 2, tf=1.0, nsteps=8, gmres_abstol=1e-14, gmres_reltol=1e-14)
+    ctrl = [qgd.FortranBSplineControl(3, 6, prob.tf) for _ in range(2)]
+    rng = np.random.default_rng(3)
+    pcof = rng.standard_normal(qgd.get_number_of_control_parameters(ctrl))
+    target = cases.rand_target(prob)
+    orc.set_num_threads(4)
+    try:
+        g_serial = orc.discrete_adjoint(prob, ctrl, pcof, target, order=6)
+        orc.set_parallel_gradient(True)
+        g_par = orc.discrete_adjoint(prob, ctrl, pcof, target, order=6)
+    finally:
+        orc.set_parallel_gradient(False)
+        orc.set_num_threads(0)
+    assert np.array_equal(g_serial, g_par) and np.abs(g_serial).max() > 0
