@@ -99,6 +99,14 @@ typedef struct qgdk_ctx {
     double *ff_F, *ff_E, *ff_XR, *ff_XL, *ff_Q, *ff_phi, *ff_bnd;
     int *status;
     double cw_host[2 * 20];
+    // Result mirror (single GPU, resident grid): the last kernel of a gradient evaluation, k_contract_sum, also writes
+    // [grad | scal(4) | status] into pinned host memory and then a sequence number the host is polling -- no copy packet
+    // behind the kernel and no wait for the stream's completion signal (qgd_api.cpp: fetch_results).  mirror_dev: the
+    // device-visible address of that host buffer ([n_pcof + 6] doubles, the sequence number in the last one as a 64-bit
+    // integer), or null for this launch; mirror_ticket: a zeroed device counter.
+    double *mirror_dev;
+    unsigned long long mirror_seq;
+    unsigned int *mirror_ticket;
 } qgdk_ctx;
 
 #ifdef __cplusplus
@@ -133,6 +141,7 @@ int qgdk_contract(const qgdk_ctx *c);
 int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
 int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch);
+int qgdk_mirror_scalars(const qgdk_ctx *c);      // result mirror of an evaluation without a gradient: [scal | status | sequence number]
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);
 size_t qgdk_forced_lds(int Np, int m);

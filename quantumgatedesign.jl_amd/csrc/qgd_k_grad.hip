@@ -442,8 +442,11 @@ __global__ __launch_bounds__(256) void k_contract(const double *__restrict__ G, 
 // coefficients x 64 row slots; a slot adds its rows (slot, slot + 64, ...) in order with the loads issued four at a time
 // (a rolled loop waited one memory round trip per row: 11 us for the 551 rows of the benchmark grid), then a fixed binary
 // tree over the 64 slots.  Same shape on every run => same bits.
+struct ResultMirror { double *host; unsigned long long seq; unsigned int *ticket; const double *scal; const int *status; };
+
 __global__ __launch_bounds__(1024) void k_contract_sum(const double *__restrict__ cpart, double *__restrict__ grad, int n_pcof, int rows,
-                                                       int accumulate, const int *__restrict__ status, double *__restrict__ scal)
+                                                       int accumulate, const int *__restrict__ status, double *__restrict__ scal,
+                                                       const ResultMirror mir)
 {
     __shared__ double red[64][17];
     // the singularity flag also travels as a double in the spare scalar slot, INSIDE the range the ranks all-reduce
@@ -466,7 +469,29 @@ __global__ __launch_bounds__(1024) void k_contract_sum(const double *__restrict_
         if (slot < w) red[slot][pl] += red[slot + w][pl];
         __syncthreads();
     }
-    if (slot == 0 && p < n_pcof) grad[p] = accumulate ? grad[p] + red[0][pl] : red[0][pl];
+    if (slot == 0 && p < n_pcof) {
+        const double v = accumulate ? grad[p] + red[0][pl] : red[0][pl];
+        grad[p] = v;
+        if (mir.host) { mir.host[p] = v; __threadfence_system(); }      // (this thread's own posted write, ordered before the ticket below)
+    }
+    // Result mirror: the workgroup that draws the last ticket adds the scalars and the status word and then publishes the
+    // sequence number the host polls (system-scope release: every workgroup's values are in host memory before it).
+    if (mir.host) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned int t = atomicAdd(mir.ticket, 1u);
+            if (t == gridDim.x - 1) {
+                __threadfence();
+                #pragma unroll
+                for (int q = 0; q < 4; q++) mir.host[n_pcof + q] = __hip_atomic_load(mir.scal + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mir.host[n_pcof + 4] = (double)__hip_atomic_load(mir.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *mir.ticket = 0u;
+                __threadfence_system();
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(mir.host + n_pcof + 5), mir.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -590,6 +615,32 @@ int qgdk_derivs(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
+// the result mirror of an evaluation WITHOUT a gradient (qgd_eval_forward): one small workgroup behind the last kernel
+// publishes [scal(4) | status] and the sequence number
+__global__ void k_mirror_scalars(const ResultMirror mir, int n_pcof)
+{
+    if (threadIdx.x == 0) {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) mir.host[n_pcof + q] = mir.scal[q];
+        mir.host[n_pcof + 4] = (double)*mir.status;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mir.host + n_pcof + 5), mir.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+static inline ResultMirror mirror_of(const qgdk_ctx *c)
+{
+    ResultMirror m;
+    m.host = c->mirror_dev; m.seq = c->mirror_seq; m.ticket = c->mirror_ticket; m.scal = c->scal; m.status = c->status;
+    return m;
+}
+
+int qgdk_mirror_scalars(const qgdk_ctx *c)
+{
+    hipLaunchKernelGGL(k_mirror_scalars, dim3(1), dim3(64), 0, c->stream, mirror_of(c), c->n_pcof);
+    return (int)hipGetLastError();
+}
+
 int qgdk_gradient(const qgdk_ctx *c)
 {
     if (c->n_ops == 0) return 0;                       // no control parameters: nothing to differentiate
@@ -597,7 +648,7 @@ int qgdk_gradient(const qgdk_ctx *c)
         const int rc = qgdk_gradient_sparse(c);
         if (rc) return rc;
         hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof,
-                           (c->cp / 8) * c->nt, c->grad_accumulate, c->status, c->scal);
+                           (c->cp / 8) * c->nt, c->grad_accumulate, c->status, c->scal, mirror_of(c));
         return (int)hipGetLastError();
     }
     if (c->dense_gemm) {
@@ -636,7 +687,7 @@ int qgdk_contract(const qgdk_ctx *c)
                        c->cpart, c->n_pcof,
                        c->g_nt ? c->g_nt : c->nt, c->g_n0);
     hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof, chunks,
-                       c->grad_accumulate, (const int *)nullptr, (double *)nullptr);
+                       c->grad_accumulate, (const int *)nullptr, (double *)nullptr, mirror_of(c));
     return (int)hipGetLastError();
 }
 

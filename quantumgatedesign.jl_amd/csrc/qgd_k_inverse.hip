@@ -408,17 +408,36 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 #else
             #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
+                const double m2 = xr[s] * xr[s] + xi[s] * xi[s];
+                const unsigned mag = (unsigned)__double2hiint(m2);
                 unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
+#ifdef QGD_INV_RCP_HOIST
+                // (round 4 experiment, off: every lane inverts its OWN candidate while the arg-max runs, so that the reciprocal
+                //  and its two Newton steps leave the serial pivot chain; same bits.  Measured with
+                //  scripts/ubench/inverse_bench.hip: 66.6 / 91.3 / 109.2 us for 256 / 512 / 550 matrices against 65.7 / 91.1 /
+                //  109.0 -- the chain is not waiting on that dependency; not kept.)
+                const double den_own = fast_rcp(m2);
+                double yr[4], yi[4];
+                yr[s] = xr[s] * den_own; yi[s] = -xi[s] * den_own;
+#endif
                 key = wave_max_u32(key);
                 const int pr = 63 - (int)(key & 63u);
                 if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
                 used = used || (lane == pr);
+#ifdef QGD_INV_RCP_HOIST
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q == s) { yr[q] = lane_read(yr[q], pr); yi[q] = lane_read(yi[q], pr); }
+                    else { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
+                }
+                const double ir = yr[s], ii = yi[s];
+#else
                 double yr[4], yi[4];
                 #pragma unroll
                 for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
                 const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
                 const double ir = yr[s] * den, ii = -yi[s] * den;
+#endif
                 const double fr = xr[s], fi = xi[s];
                 #pragma unroll
                 for (int q = 0; q < 4; q++) {

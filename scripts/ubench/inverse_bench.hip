@@ -4,6 +4,9 @@
 // Prints the mean launch time over 50 launches of nmat matrices, the max |Linv*L - I|, and (with
 // -DQGD_INV_PROFILE) the cycles one workgroup spent in each phase of the blocked elimination.
 #include "../../quantumgatedesign.jl_amd/csrc/qgd_k_inverse.hip"
+// (the launcher at the end of that file refers to the N > 64 path, which this stand-alone bench does not link)
+extern "C" int qgdk_dense_inverse(const qgdk_ctx *) { return 0; }
+extern "C" int qgdk_dense_propagator(const qgdk_ctx *) { return 0; }
 #ifndef KERNEL
 #define KERNEL k_inverse_mfma      // -DKERNEL=k_inverse_aug: the augmented elimination
 #endif

@@ -287,3 +287,40 @@ def test_save_every_nsteps_in_the_c_abi(qgd, which, order):
     qgd.eval_forward_(again, prob, ctrl, pcof, order=order)
     assert np.array_equal(again, full)
     qgd.clear_cache()
+
+
+def test_result_mirror_equals_the_copy_path(qgd):
+    """Round 4: the last kernel of an evaluation writes [grad | scalars | status] into pinned host memory itself and
+    publishes a sequence number the host polls (no copy packet, no wait for the stream's completion signal).  Same bits
+    as the copy + hipStreamSynchronize path (QGD_RESULT_MIRROR=0, read when the handle is created), for the gradient
+    evaluation, the forward-only evaluation, history_precomputed reuse, the reference-shaped call with the three output
+    arrays, a changing pcof (no stale sequence number) and an evaluation with event bracketing on."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=130, tf=130.0)
+    order = 8
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    out = {}
+    for label in ("copy", "mirror"):
+        if label == "copy":
+            os.environ["QGD_RESULT_MIRROR"] = "0"
+        try:
+            dp = qgd.DeviceProblem(prob, order)
+        finally:
+            os.environ.pop("QGD_RESULT_MIRROR", None)
+        dp.set_controls(ctrl); dp.set_target(target)
+        res = []
+        for scale in (1.0, 0.5, 1.0, -0.25):
+            g, o = dp.discrete_adjoint(scale * pcof)
+            f = dp.eval_forward(scale * pcof)
+            g2, o2 = dp.discrete_adjoint(scale * pcof, history_precomputed=True)
+            res += [g, np.asarray(o), np.asarray(f), g2, np.asarray(o2)]
+        arrays = [np.zeros(shape, order="F"), np.zeros(shape, order="F"), np.zeros((shape[0], shape[2], shape[3]), order="F")]
+        g, o = dp.discrete_adjoint(pcof, False, *arrays)
+        res += [g, np.asarray(o)] + arrays
+        dp.set_timing(1)
+        g, o = dp.discrete_adjoint(pcof)
+        assert "inverse" in dp.timings()
+        res += [g, np.asarray(o)]
+        dp.close()
+        out[label] = res
+    for a, b in zip(out["copy"], out["mirror"]):
+        assert np.array_equal(a, b)
