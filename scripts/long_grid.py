@@ -80,10 +80,16 @@ def main():
     t4 = time.perf_counter()
     fd = (obj(pcof + eps * d) - obj(pcof - eps * d)) / (2 * eps)
     t5 = time.perf_counter()
-    rel = abs(fd - g @ d) / abs(fd)
+    # the carriers make the objective oscillate on the scale of the coefficients: the truncation error of the centred
+    # difference (~eps^2 f''' / 6) is visible at eps = 1e-4.  Second difference at eps / 2 and Richardson's combination
+    # (error ~eps^4) separate it from an error of the gradient.
+    fd2 = (obj(pcof + 0.5 * eps * d) - obj(pcof - 0.5 * eps * d)) / eps
+    fdr = (4.0 * fd2 - fd) / 3.0
+    rel, rel2, relr = (abs(x - g @ d) / abs(g @ d) for x in (fd, fd2, fdr))
     print(f"RESULT nsteps {nsteps} order {order}: {sec:.3f} s per gradient evaluation = {nsteps / sec / 1e6:.2f} M timesteps/s in {plan['windows']} windows "
           f"({plan['window_bytes'] / 2**30:.1f} GiB each); forward only {(t5 - t4) / 2:.3f} s; |grad| {np.linalg.norm(g):.6g}; "
-          f"directional derivative: adjoint {g @ d:.10g}, centred difference {fd:.10g}, relative difference {rel:.2e}", flush=True)
+          f"directional derivative: adjoint {g @ d:.12g}; centred differences eps={eps:g}: {fd:.12g} (rel. diff. {rel:.2e}), eps={eps / 2:g}: {fd2:.12g} ({rel2:.2e}), "
+          f"Richardson: {fdr:.12g} ({relr:.2e})", flush=True)
     dp.close()
 
 
