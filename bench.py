@@ -489,46 +489,66 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Untimed: warm-up with every phase bracketed by HIP events -> per-phase breakdown and the
-    # dominant phase.  Bracketing all 13 phases costs ~0.17 ms per evaluation (26 event records),
-    # so the timed region keeps only the pair around the dominant phase (what `roofline` needs).
+    # The W warm-up steps.  The first one has every phase bracketed by HIP events: it pays the one-time launch costs anyway
+    # and names the dominant phase (the only thing the timed region needs to know: which launch gets the live event pair);
+    # the other W-1 are the plain evaluation, exactly what the timed steps are.  The per-phase breakdown of the JSON line
+    # (`phases_ms_all_events`: all 13 phases bracketed, ~0.17 ms of event records per evaluation) is taken AFTER the timed
+    # region -- round 3 took it from the warm-up steps, which made them 1.5x as long as a timed step and mostly idle.
     merge = (("sweep_forward2", "sweep_forward"), ("sweep_adjoint2", "sweep_adjoint"))
-    breakdown = {}
     dp.set_timing(1)
-    nwarm = max(args.warmup, 2)
-    for it in range(nwarm):
-        dp.discrete_adjoint(pcof)
-        if it == 0:
-            continue                      # first call pays one-time launch/JIT costs
-        for k, v in dp.timings().items():
-            breakdown[k] = breakdown.get(k, 0.0) + v / (nwarm - 1)
+    dp.discrete_adjoint(pcof)
+    first = dp.timings()
+    dp.set_timing(0)
     inner = getattr(dp, "dp", dp)
     path = inner.operator_path() if hasattr(inner, "operator_path") else ("sparse", 0, 0)
     model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1,
-                        sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in breakdown))
-    dom_raw = max((k for k in breakdown if k in model), key=breakdown.get)
-    # (these warm-up evaluations ARE the contract's W: the breakdown is read from them, no further untimed work follows
-    # unless --run-in asks for it)
-    dp.set_timing(0)
-    for _ in range(args.run_in):
+                        sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in first))
+    dom_raw = max((k for k in first if k in model), key=first.get)
+    for _ in range(max(args.warmup, 1) - 1 + args.run_in):
         dp.discrete_adjoint(pcof)
     phase_ms = {}
+    step_times = [] if os.environ.get("QGD_BENCH_STEP_TIMES") else None      # (diagnostic: wall time of every timed step on stderr)
     barrier()
     t0 = time.perf_counter()
     nsamp = 0
+    # The live sample of the dominant kernel (an event pair on the library's stream around its launch) is not free: per-step
+    # wall times (QGD_BENCH_STEP_TIMES=1) show +30 us on the bracketed evaluation (the two event records drain the queue
+    # between kernels) and +30 us for reading the pair back (stream synchronisation + elapsed-time query).  Round 3
+    # bracketed every 8th step and read inside the loop: 9 us per step on average over 20 steps.  Now: one bracketed step
+    # per 16 (the middle one of a 20-step region), read back only when the next bracketed step is about to overwrite the
+    # pair -- the last one after the timed region.
+    pending = False
+
+    def read_sample():
+        for k, v in dp.timings().items():
+            phase_ms[k] = phase_ms.get(k, 0.0) + v
+
     for i in range(args.steps):
-        # the event pair around the dominant kernel costs ~20 us per evaluation (it drains the queue between two
-        # kernels): it brackets every 8th step of the timed region, the kernel's duration is the mean of those
-        sample = (i % 8 == 0)
-        if sample or i % 8 == 1:
+        sample = (i % 16 == min(10, args.steps // 2))
+        if sample and pending:
+            read_sample(); pending = False
+        if sample or (i > 0 and (i - 1) % 16 == min(10, args.steps // 2)):
             dp.set_timing(2 if sample else 0, dom_raw)
         grad, out3 = dp.discrete_adjoint(pcof)
+        if step_times is not None:
+            step_times.append(time.perf_counter())
         if sample:
             nsamp += 1
-            for k, v in dp.timings().items():
-                phase_ms[k] = phase_ms.get(k, 0.0) + v
+            pending = True
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    if pending:
+        read_sample(); pending = False
+    # per-phase breakdown: three evaluations with every phase bracketed (untimed, after the timed region)
+    breakdown = {}
+    dp.set_timing(1)
+    for _ in range(3):
+        dp.discrete_adjoint(pcof)
+        for k, v in dp.timings().items():
+            breakdown[k] = breakdown.get(k, 0.0) + v / 3
+    dp.set_timing(0)
+    if step_times:
+        print("[bench] us per timed step:", " ".join(f"{(b - a) * 1e6:.0f}" for a, b in zip([t0] + step_times[:-1], step_times)), file=sys.stderr)
     part_info = getattr(inner, "partition", None)
     # the collectives of one evaluation, timed by HIP events on the library's stream (--comm lib)
     comm_ms = None
@@ -752,6 +772,9 @@ def main():
         }
         if not use_dist:
             dp.close()
+            # (round 4 tried these two BEFORE the headline, to start its timed region on a card that had been working: `value`
+            #  did not move -- 0.3328 against 0.3314 ms -- and the pinned downloads of `with_history` behind a C5 evaluation in
+            #  the same process took 3.3-3.9 ms instead of 0.87; the order of round 3 stays)
             if not args.no_cnot2:
                 try:
                     out["cnot2"] = cnot2_case_gpu(qgd, np)

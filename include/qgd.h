@@ -316,7 +316,8 @@ int qgd_comm_debug_fail_at(qgd_handle h, int32_t collective);
  * names/ms hold up to cap entries; returns the number of phases through *n. */
 int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, int32_t *n);
 /* Event bracketing costs ~0.17 ms per evaluation on cnot3 (26 event records): mode 0 = off,
- * (default; QGD_PHASE_TIMING=1 in the environment turns it on), 1 = every phase, 2 = only the named phase. */
+ * (default; QGD_PHASE_TIMING=1 in the environment turns it on), 1 = every phase, 2 = only the named phase.
+ * Switching off keeps the times of the last bracketed evaluation readable (qgd_get_timings). */
 int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 
 

@@ -133,3 +133,4 @@ def check(handle, rc):
     if rc != QGD_OK:
         msg = lib().qgd_last_error(handle)
         raise QGDError(rc, msg.decode() if msg else "unknown error")
+

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <sched.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,7 +80,7 @@ struct qgd_handle_s {
     bool lambda_derivs = false;
     double *dlam = nullptr, *dlam_scratch = nullptr, *stage_lam_full = nullptr;
     hipStream_t copy_stream = nullptr;
-    hipStream_t copy_stream2 = nullptr;   // QGD_COPY_SPLIT=1: the second half of a large pinned download on a second DMA engine
+    hipStream_t copy_stream2 = nullptr;   // the second half of a large pinned download goes to a second DMA engine (QGD_COPY_SPLIT=0: off)
     hipEvent_t ev_ready = nullptr;
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
     std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
@@ -442,7 +443,9 @@ qgd_handle_s::HostReg *find_reg(qgd_handle h, const void *p, size_t bytes)
 int copy_side(qgd_handle h)
 {
     if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    if (!h->copy_stream2 && getenv("QGD_COPY_SPLIT")) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream2, hipStreamNonBlocking));
+    // (two DMA engines for a large pinned download: 1.24 -> 0.87 ms for the reference-shaped cnot3 call on a box whose single
+    //  engine path was slow, gpurun_out/r4e; QGD_COPY_SPLIT=0 keeps one stream)
+    if (!h->copy_stream2 && !(getenv("QGD_COPY_SPLIT") && atoi(getenv("QGD_COPY_SPLIT")) == 0)) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream2, hipStreamNonBlocking));
     if (!h->ev_ready) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     return QGD_OK;
 }
@@ -2397,7 +2400,9 @@ int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase)
     if (!h) return QGD_ERR_ARGUMENT;
     h->timing = (mode != 0);
     h->timing_only = (mode == 2 && phase) ? phase : "";
-    for (auto &p : h->phases) p.used = false;
+    // (turning the bracketing OFF keeps the last recorded pairs readable: a caller can sample one evaluation, switch off and
+    //  read the times later, outside its own timed region -- bench.py)
+    if (mode != 0) for (auto &p : h->phases) p.used = false;
     return QGD_OK;
 }
 

@@ -69,9 +69,9 @@ def main():
         t3 = time.perf_counter(); g, o = dp.discrete_adjoint(pcof); ts.append(time.perf_counter() - t3)
     sec = min(ts)
     d = np.random.default_rng(1).standard_normal(len(pcof)); d /= np.linalg.norm(d)
-    # the objective is smooth in pcof on the scale of the coefficients (2 pi * 0.005 ~ 0.03): a centred difference with
-    # eps = 1e-4 has a truncation error ~1e-8 relative and a rounding error ~1e-16 * |J| / eps
-    eps = 1e-4
+    # a coefficient acts over the whole gate time (tf = 550): eps * tf is the expansion parameter of the difference quotient,
+    # eps = 1e-4 gave 1e-5 relative (truncation); eps = 2e-5 and 1e-5 and their Richardson combination are used
+    eps = 2e-5
 
     def obj(p):
         a, b, gd = dp.eval_forward(p)

@@ -219,6 +219,12 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert "error" not in j2["large_n"], j2["large_n"]
     assert j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10
     assert j2["weak_in_time"] is None or "error" not in j2["weak_in_time"], j2["weak_in_time"]
+    # one run answers both questions: the other split of the same evaluation rides in the same line
+    other = j2["north_star_split" if shard == "time" else "time_window_split"]
+    assert other and "error" not in other, other
+    assert other["shard"] == ("columns" if shard == "time" else "time") and other["value"] > 0
+    assert other["grad_rel_diff_vs_headline_split"] <= 1e-10
+    assert j1["settled"] and j1["settled"]["ms_per_step"] > 0 and j1["cnot2"]["roofline"]["bound"] == "launch"
 
 
 @pytest.mark.parametrize("shard", ["time", "columns"])
@@ -240,6 +246,9 @@ def test_bench_in_library_rccl_one_rank(shard):
     assert abs(j2["grad_norm"] - j1["grad_norm"]) <= 1e-11 * j1["grad_norm"]
     assert abs(j2["infidelity"] - j1["infidelity"]) <= 1e-12
     assert j2["collectives_ms"] and all(v >= 0 for v in j2["collectives_ms"].values()), j2["collectives_ms"]
+    other = j2["north_star_split" if shard == "time" else "time_window_split"]
+    assert other and "error" not in other, other
+    assert other["grad_rel_diff_vs_headline_split"] <= 1e-10 and other["collectives_ms"], other
 
 
 @pytest.mark.parametrize("which,order,world", [("cnot2", 4, 2), ("cnot2", 8, 4), ("guarded", 6, 2), ("cnot3", 8, 2), ("cnot3", 8, 8),
