@@ -316,29 +316,40 @@ def large_n_case(qgd, np, steps=3):
 
 def cnot2_case_gpu(qgd, np, steps=50):
     """BASELINE.json configs[1] (C2: 2-qubit CNOT of examples/cnot2_optimization.jl:10-47, N=4, 4 columns, order 8,
-    tf=100, nsteps=100) on the GPU: north_star asks for the cnot2 rate beside the cnot3 one.  A 12-launch chain of
-    latency-bound kernels on 101 time points (bring-up configuration, not a throughput one)."""
+    tf=100, nsteps=100) on the GPU: north_star asks for the cnot2 rate beside the cnot3 one.  The library's default for a
+    problem this small is the four-launch path of csrc/qgd_k_tiny.hip (fp64 vector ALU, one thread per (time point,
+    column)); the general path -- a 12-launch chain of padded 16 x 16 MFMA tiles on 101 time points -- is timed beside it
+    (bring-up configuration, not a throughput one)."""
     import torch
     import cases
     prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=100, tf=100.0, amp=1e-2)
-    dp = qgd.DeviceProblem(prob, 8, device=0)
-    dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(0)
-    for _ in range(5):
-        dp.discrete_adjoint(pcof)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        grad, out3 = dp.discrete_adjoint(pcof)
-    torch.cuda.synchronize()
-    sec = (time.perf_counter() - t0) / steps
-    dp.close()
+
+    def timed(small):
+        dp = qgd.DeviceProblem(prob, 8, device=0)
+        if not small:
+            dp.set_small_path(False)
+        dp.set_controls(ctrl); dp.set_target(target); dp.set_timing(0)
+        for _ in range(5):
+            dp.discrete_adjoint(pcof)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            grad, out3 = dp.discrete_adjoint(pcof)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        taken = bool(dp.small_path_taken())
+        dp.close()
+        return sec, taken, grad, out3
+
+    sec_gen, _, grad_gen, _ = timed(False)
+    sec, small_taken, grad, out3 = timed(True)
     # roofline of this configuration: NEITHER hardware roof binds.  N = 4 pads to one 16 x 16 MFMA tile and 101 time points
     # are 101 small workgroups: the evaluation is a chain of DEPENDENT kernel launches, each costing its dispatch + one
     # workgroup's latency.  Stated as such: launches per evaluation (from the committed rocprofv3 kernel statistics of this
     # very loop, profiles/CNOT2_PROFILE; the count of the launch sequence in DESIGN.md section 7a otherwise), time per
     # launch, and -- for the record -- the algorithm's history stream against HBM and its applies against the MFMA peak.
     N_, c_, m_, n_ops_, ns_ = 4, 4, 4, 2, 100
-    launches, src = 12, "DESIGN.md section 7a (launch sequence)"
+    launches, src = (4, "csrc/qgd_k_tiny.hip (front, scan, gradient, sum)") if small_taken else (12, "DESIGN.md section 7a (launch sequence)")
     ppath = os.path.join(ROOT, "profiles", CNOT2_PROFILE)
     if os.path.exists(ppath):
         try:
@@ -351,14 +362,18 @@ def cnot2_case_gpu(qgd, np, steps=50):
     w_step = M_ * 8.0 * N_ * N_ * c_ * 6          # SURVEY 8(d) W_step with the propagator form's k = 0: forward M, adjoint M, gradient 4M applies
     return {"workload": "cnot2 (examples/cnot2_optimization.jl): N=4, 4 columns, 2 controls x 22 coeffs, Hermite order 8, tf=100, nsteps=100",
             "timesteps_per_s": 100 / sec, "ms_per_evaluation": sec * 1e3, "evaluations_timed": steps,
+            "path": "small-problem path (qgd_k_tiny.hip, 4 launches)" if small_taken else "general path",
+            "general_path": {"timesteps_per_s": 100 / sec_gen, "ms_per_evaluation": sec_gen * 1e3,
+                             "max_rel_gradient_difference": float(np.abs(grad - grad_gen).max() / np.abs(grad_gen).max())},
             "roofline": {"bound": "launch", "launches_per_evaluation": launches, "launch_count_source": src,
                          "us_per_dependent_launch": sec * 1e6 / launches,
                          "hbm": {"bytes_per_timestep": b_step, "achieved": b_step * ns_ / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": b_step * ns_ / sec / 1e9 / PEAK_HBM_GBS},
                          "mfma": {"flop_per_timestep": w_step, "achieved": w_step * ns_ / sec / 1e12, "peak": PEAK_FP64_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                   "frac": w_step * ns_ / sec / 1e12 / PEAK_FP64_MATRIX_TFLOPS},
-                         "note": "launch-bound: a chain of dependent launches over 101 one-tile time points; both hardware fractions are ~1e-4 by "
-                                 "construction (N = 4 is a sixteenth of one MFMA tile) -- the figure of merit is us per dependent launch"},
+                         "note": "launch-bound: a chain of dependent launches over 101 time points whose work is 2-8 us each; both hardware fractions "
+                                 "are ~1e-4 by construction (N = 4 is a sixteenth of one MFMA tile; the small-problem path does not use MFMA at all) -- "
+                                 "the figure of merit is us per dependent launch"},
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2), "grad_norm": float(np.linalg.norm(grad))}
 
 

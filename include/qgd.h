@@ -215,6 +215,18 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
 int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
                           int32_t use_adjoint, const double *in, double *out);
 
+/* Small problems in four launches.  N <= 4 levels, <= 4 initial conditions, 1..4 control operators, order <= 12, <= 64
+ * coefficients, no dense guard projector, <= 128 time points: the reference's Rabi oscillator and its two-qubit CNOT
+ * (examples/cnot2_optimization.jl).  For such a problem qgd_discrete_adjoint / qgd_eval_forward WITHOUT output arrays run
+ * on the fp64 vector ALU with one thread per (time point, column) -- csrc/qgd_k_tiny.hip: front (tables, step matrices,
+ * inverses: one workgroup per time point), scan (both sweeps and lambda: one workgroup), gradient scalars (one workgroup
+ * per time point), fixed-order sum -- instead of twelve dependent launches of padded 16 x 16 MFMA tiles: same discrete
+ * quantities (1e-12 of the general path, 1e-10 of the oracle: tests/test_gpu_tiny.py; the same bits on every run).  Calls
+ * with output arrays, event bracketing (qgd_set_timing), windows or a communicator take the general path; a
+ * history_precomputed call after a small-path evaluation simply redoes the sweep.  on = 0 turns the path off for this
+ * handle (QGD_TINY=0 in the environment: for every handle). */
+int qgd_set_small_path(qgd_handle h, int32_t on);
+
 /* Diagnostics: copy a named intermediate of the last evaluation to the host.
  * Names: "L", "R", "Linv", "P" (complex, returned as [nt][N][N][2] C-order),
  * "sigma" ([nt][n_ops][m][2]), "tables" ([nt][m][n_ops][2]), "repivoted" (1 value: how many step matrices of the last
@@ -222,7 +234,7 @@ int qgd_apply_hamiltonian(qgd_handle h, int32_t time_index, int32_t deriv_order,
  * 64-column diagonal blocks only, found a block multiplier above its threshold; N = 64: after the optional static-pivot
  * attempt), "selection" (4 values: operator path -- 2 sparse ELL kernels, 1 the N > 64 GEMM-style kernels, 0 dense N <= 64 --,
  * form of the gradient scalars on the N > 64 path 0..3 or -1, block Gauss-Jordan inverse in use 0/1, windows of the time
- * grid).  Returns the number
+ * grid), "small_path" (1 value: whether the last evaluation ran on the small-problem path of qgd_set_small_path).  Returns the number
  * of doubles the buffer needs through *needed when out == NULL. */
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);

@@ -62,6 +62,14 @@ struct qgd_handle_s {
     unsigned int *mirror_ticket = nullptr;
     unsigned long long mirror_seq = 0;
     bool mirror_armed = false;          // the evaluation in flight ends with a mirrored k_contract_sum
+    // Small problems (N <= 4, <= 4 columns, <= 128 time points: Rabi, the two-qubit CNOT) take the four-launch path of
+    // qgd_k_tiny.hip for calls that return only [grad | scalars].  That path leaves none of the general path's intermediates
+    // behind: history_stale makes a later call that needs them (history_precomputed with output arrays, qgd_get_intermediate)
+    // redo the evaluation on the general path first.  QGD_TINY=0 / qgd_set_small_path(h, 0): off.
+    bool small_path = !(getenv("QGD_TINY") && atoi(getenv("QGD_TINY")) == 0);
+    bool history_stale = false;
+    std::vector<double> tiny_pcof;      // pcof of the last small-path evaluation
+    bool tiny_was_gradient = false;
     bool mirror_off = (getenv("QGD_RESULT_MIRROR") && atoi(getenv("QGD_RESULT_MIRROR")) == 0);
     // the launch sequence of one full gradient evaluation as a hipGraph, opt-in (QGD_GRAPH=1).  Measured: no gain
     // on cnot3 (420 us either way) and 5 % on cnot2 (98 vs 104 us) -- an evaluation is a chain of ~15 DEPENDENT
@@ -913,7 +921,34 @@ int run_forward(qgd_handle h, const double *pcof, int n_pcof)
     if (rc) return rc;
     if ((rc = forward_end(h))) return rc;
     if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
+    h->history_stale = false;
     return QGD_OK;
+}
+
+int fetch_results(qgd_handle h, double *grad, double *out3, const double *src);
+
+// the small-problem evaluation (qgd_k_tiny.hip); results through the mirror when there is one
+bool tiny_applies(qgd_handle h, const double *pcof, int n_pcof)
+{
+    const qgdk_ctx &k = h->k;
+    return h->small_path && pcof && h->have_basis && n_pcof == k.n_pcof && !h->timing && h->graph_off && !h->comm && h->part_world == 1 &&
+           h->chunks_eff == 1 && k.redbuf && h->host_out && qgdk_tiny_supported(&k, n_pcof) != 0;
+}
+
+int tiny_evaluate(qgd_handle h, const double *pcof, int n_pcof, bool gradient, double *grad, double *out3)
+{
+    qgdk_ctx &k = h->k;
+    const bool mirror = h->mirror_dev != nullptr && h->mirror_ticket != nullptr;
+    if (mirror) { k.mirror_dev = h->mirror_dev; k.mirror_ticket = h->mirror_ticket; k.mirror_seq = ++h->mirror_seq; }
+    int e = qgdk_tiny_eval(&k, pcof, n_pcof, gradient ? 1 : 0);
+    if (!e && gradient) e = qgdk_contract_rows(&k, k.nt);
+    k.mirror_dev = nullptr;
+    if (e) return fail(h, QGD_ERR_NO_DEVICE, std::string("small-problem evaluation failed to launch: ") + hipGetErrorString((hipError_t)e));
+    h->mirror_armed = mirror;
+    h->forward_valid = true; h->derivs_valid = false; h->history_stale = true; h->forcing_zero = false;
+    h->fwd_pcof.clear();
+    h->tiny_pcof.assign(pcof, pcof + n_pcof); h->tiny_was_gradient = gradient;
+    return fetch_results(h, gradient ? grad : nullptr, out3, nullptr);
 }
 
 int check_status(qgd_handle h)
@@ -1146,6 +1181,7 @@ const double *comm_result(qgd_handle h) { return h->comm_shard == QGD_SHARD_TIME
 
 bool same_pcof(qgd_handle h, const double *pcof, int n_pcof)
 {
+    if (h->history_stale) return false;     // (the last evaluation ran on the small-problem path: no stored history to reuse)
     return pcof ? ((size_t)n_pcof == h->fwd_pcof.size() && n_pcof > 0 && !memcmp(pcof, h->fwd_pcof.data(), sizeof(double) * n_pcof))
                 : h->fwd_pcof.empty();
 }
@@ -1580,6 +1616,7 @@ int qgd_set_control_basis(qgd_handle h, const int32_t *n_coeff, const double *co
     for (int o = 0; o < k.n_ops; o++) {
         if (n_coeff[o] < 0) return fail(h, QGD_ERR_ARGUMENT, "negative coefficient count");
         h->ncoef[o] = n_coeff[o]; h->poff[o] = np; h->goff[o] = (int64_t)total;
+        if (o < QGD_MAX_OPS_DEV) { k.ncoef_host[o] = n_coeff[o]; k.poff_host[o] = np; k.goff_host[o] = (int64_t)total; }
         np += n_coeff[o]; total += 2 * per * n_coeff[o];
         if (n_coeff[o] > ncmax) ncmax = n_coeff[o];
     }
@@ -1674,6 +1711,7 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
         int rcw = chunked_forward(h, pcof, n_pcof, uv_history, h->save_every);
         return rcw ? rcw : fetch_results(h, nullptr, out3);
     }
+    if (!uv_history && tiny_applies(h, pcof, n_pcof)) return tiny_evaluate(h, pcof, n_pcof, false, nullptr, out3);
     int rc = run_forward(h, pcof, n_pcof);
     if (rc) return rc;
     if (uv_history) {
@@ -1704,6 +1742,10 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
         if ((uv_history || !(history_precomputed && same_pcof(h, pcof, n_pcof))) && (rc = chunked_forward(h, pcof, n_pcof, uv_history))) return rc;
         if ((rc = chunked_adjoint(h, lambda_history, adjoint_forcing))) return rc;
         return fetch_results(h, grad, out3);
+    }
+    if (!uv_history && !lambda_history && !adjoint_forcing && tiny_applies(h, pcof, n_pcof)) {
+        if (history_precomputed && !h->forward_valid) return fail(h, QGD_ERR_STATE, "history_precomputed without a previous forward evaluation");
+        return tiny_evaluate(h, pcof, n_pcof, true, grad, out3);      // (four launches redo the sweep faster than the stored one could be reused)
     }
     // full evaluation, nothing but [grad | scalars] coming back, no event bracketing: replay the captured launch sequence
     const bool graph_ok = !h->graph_off && !history_precomputed && !uv_history && !lambda_history && !adjoint_forcing &&
@@ -2026,10 +2068,12 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     else if (s == "tables") need = nt * (size_t)(k.m + 1) * k.n_ops * 2;
     else if (s == "repivoted") need = 1;
     else if (s == "selection") need = 4;
+    else if (s == "small_path") need = 1;
     else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
     if (needed) *needed = need;
     if (!out) return QGD_OK;
     if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
+    if (s == "small_path") { out[0] = h->history_stale ? 1.0 : 0.0; return QGD_OK; }      // did the LAST evaluation run on the small-problem path
     if (s == "selection") {      // which kernel families this problem runs on (tests assert that a shape selects what it is meant to)
         out[0] = k.use_sparse ? 2.0 : (k.dense_gemm ? 1.0 : 0.0);      // 2 sparse (ELL), 1 N > 64 GEMM-style kernels, 0 dense N <= 64
         out[1] = (k.dense_gemm && !k.use_sparse) ? (double)qgdk_dense_sigma_form(&k) : -1.0;
@@ -2038,6 +2082,14 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         return QGD_OK;
     }
     NEEDS_RESIDENT_GRID(h, "qgd_get_intermediate");
+    if (h->history_stale && s != "repivoted" && !h->tiny_pcof.empty()) {
+        // the last evaluation ran on the small-problem path, which keeps no intermediates: the same evaluation once more on
+        // the general path (diagnostics only)
+        const std::vector<double> pc = h->tiny_pcof;
+        int rcs = run_forward(h, pc.data(), (int)pc.size());
+        if (!rcs && h->tiny_was_gradient && k.have_target) { rcs = adjoint_begin(h); if (!rcs) rcs = adjoint_end(h); }
+        if (rcs) return rcs;
+    }
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     if (s == "repivoted") {     // workgroups of the last inverse launch whose static-pivot attempt was redone with partial pivoting
         int v[2] = {0, 0};
@@ -2356,6 +2408,13 @@ int qgd_get_operator_path(qgd_handle h, int32_t *out3)
 {
     if (!h || !out3) return QGD_ERR_ARGUMENT;
     out3[0] = h->k.use_sparse ? 2 : 1; out3[1] = h->k.ell_z; out3[2] = h->k.op_z;
+    return QGD_OK;
+}
+
+int qgd_set_small_path(qgd_handle h, int32_t on)
+{
+    if (!h) return QGD_ERR_ARGUMENT;
+    h->small_path = (on != 0);
     return QGD_OK;
 }
 

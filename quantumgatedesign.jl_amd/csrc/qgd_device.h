@@ -99,6 +99,8 @@ typedef struct qgdk_ctx {
     double *ff_F, *ff_E, *ff_XR, *ff_XL, *ff_Q, *ff_phi, *ff_bnd;
     int *status;
     double cw_host[2 * 20];
+    int32_t ncoef_host[QGD_MAX_OPS_DEV], poff_host[QGD_MAX_OPS_DEV];      // host copies of ncoef / poff / goff (kernel arguments of qgd_k_tiny.hip)
+    int64_t goff_host[QGD_MAX_OPS_DEV];
     // Result mirror (single GPU, resident grid): the last kernel of a gradient evaluation, k_contract_sum, also writes
     // [grad | scal(4) | status] into pinned host memory and then a sequence number the host is polling -- no copy packet
     // behind the kernel and no wait for the stream's completion signal (qgd_api.cpp: fetch_results).  mirror_dev: the
@@ -141,6 +143,9 @@ int qgdk_contract(const qgdk_ctx *c);
 int qgdk_gradient_needs_derivs(const qgdk_ctx *c);
 int qgdk_apply(const qgdk_ctx *c, const double *in_dev, double *out_dev, int n, int d, double sign);
 int qgdk_adjoint_derivs(const qgdk_ctx *c, double *dlam, double *scratch);
+int qgdk_tiny_supported(const qgdk_ctx *c, int n_pcof);      // small problems (N <= 4): four launches instead of twelve (qgd_k_tiny.hip)
+int qgdk_tiny_eval(const qgdk_ctx *c, const double *pcof_host, int n_pcof, int gradient);
+int qgdk_contract_rows(const qgdk_ctx *c, int rows);         // cpart rows -> grad (+ host mirror), fixed order
 int qgdk_mirror_scalars(const qgdk_ctx *c);      // result mirror of an evaluation without a gradient: [scal | status | sequence number]
 size_t qgdk_lds_needed(int Np, int m, int n_ops);
 int qgdk_sparse_supported(int Np, int m, int n_ops, int Z);

@@ -641,6 +641,14 @@ int qgdk_mirror_scalars(const qgdk_ctx *c)
     return (int)hipGetLastError();
 }
 
+// rows of cpart added in a fixed order -> grad (and the host mirror): the tail of the small-problem path (qgd_k_tiny.hip)
+int qgdk_contract_rows(const qgdk_ctx *c, int rows)
+{
+    hipLaunchKernelGGL(k_contract_sum, dim3((c->n_pcof + 15) / 16), dim3(1024), 0, c->stream, c->cpart, c->grad, c->n_pcof, rows,
+                       0, c->status, c->scal, mirror_of(c));
+    return (int)hipGetLastError();
+}
+
 int qgdk_gradient(const qgdk_ctx *c)
 {
     if (c->n_ops == 0) return 0;                       // no control parameters: nothing to differentiate

@@ -1,0 +1,876 @@
+// qgd_k_tiny.hip -- small problems (N <= 4 levels, <= 4 initial conditions, <= 128 time points) in FOUR launches (round 4).
+//
+// The reference's Rabi oscillator (src/ProblemConstructors/rabi_oscillator.jl) and its two-qubit CNOT
+// (examples/cnot2_optimization.jl: N = 4, 4 columns, 100 steps; BASELINE.json configs[0..1]).  On the general path such a
+// problem is a chain of twelve dependent launches over 101 one-tile time points -- 81 us per gradient evaluation, all of it
+// launch and dispatch latency (bench.py: cnot2.roofline).  A 4 x 4 problem is a sixteenth of one MFMA tile: here the same
+// discrete computation (tests/proto_propagator.py::evaluate is the statement it follows) runs on the
+// fp64 vector ALU with one thread per (time point, column):
+//
+//   k_tiny_front   one workgroup per TIME POINT: control tables tab[n] = G[n] . pcof (16 lanes per entry), column j of
+//                  D_1..D_m(t_n), L_n, R_n by the Taylor recursion on e_j (hermite.jl:56-101, :389-427), L_n^-1 by a
+//                  4 x 4 complex Gauss-Jordan with partial pivoting                                   -> tab, R, L^-1
+//   k_tiny_scan    ONE workgroup: P_{n-1} = L_n^-1 R_{n-1}; forward sweep, guard penalty / forcing, overlaps, terminal
+//                  condition, adjoint sweep (two-level blocked scans in LDS), lambda_n = L_n^-H y_n
+//                  (forward_evolution.jl:88-245, :352-483; infidelity.jl; eval_grad_discrete_adjoint.jl:1-67, :732-752)
+//                                                                                                      -> psi, lambda, scalars
+//   k_tiny_grad    one workgroup per time point: seeds g_j, reverse sweep, state derivatives source-major, the scalars
+//                  sigma^{P,Q}_{k,d} (eval_grad_discrete_adjoint.jl:582-726 in the O(m^2) order of DESIGN.md section 2),
+//                  contracted with the basis rows of the time point                                    -> cpart[n][:]
+//   k_contract_sum (qgd_k_grad.hip) the rows in a fixed order -> grad, and the results into the host mirror
+//
+// A_d(t_n) x is never formed from an assembled matrix: with u_o = Asym_o x, v_o = Sym_o x, h = (K_sys - i S_sys) x computed
+// once per source vector, A_d x = [d = 0] h + sum_o (q_o^(d) u_o - i p_o^(d) v_o) for every d ("source-major").
+// All sums have a fixed order: the same bits on every run.  A first version did ALL of this in one workgroup: correct, and
+// 107 us -- one compute unit can neither stream the control basis (300 KB) nor do the per-time-point work of 101 points
+// fast enough ("Round 4" (4)).  The general path's device buffers hold this path's compact arrays
+// afterwards, not its own intermediates: the host side marks the handle's stored history stale (qgd_api.cpp).
+#include "qgd_kernels_common.h"
+#include <string.h>
+#include <algorithm>
+
+struct cx { double re, im; };
+__device__ __forceinline__ cx cmul(const cx a, const cx b) { return (cx){a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cx cmulc(const cx a, const cx b) { return (cx){a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re}; }   // conj(a) * b
+__device__ __forceinline__ void cfma_(cx &acc, const cx a, const cx b)
+{
+    acc.re = __builtin_fma(a.re, b.re, acc.re); acc.re = __builtin_fma(-a.im, b.im, acc.re);
+    acc.im = __builtin_fma(a.re, b.im, acc.im); acc.im = __builtin_fma(a.im, b.re, acc.im);
+}
+__device__ __forceinline__ void cfmac_(cx &acc, const cx a, const cx b)      // acc += conj(a) * b
+{
+    acc.re = __builtin_fma(a.re, b.re, acc.re); acc.re = __builtin_fma(a.im, b.im, acc.re);
+    acc.im = __builtin_fma(a.re, b.im, acc.im); acc.im = __builtin_fma(-a.im, b.re, acc.im);
+}
+
+// The pieces of A_d x, one operator at a time (few live registers): h = (K_sys - i S_sys) x; u = Asym_o x, v = Sym_o x for the
+// real 4 x 4 operators in LDS (row-major, zero padded); acc += s (q u - i p v).
+__device__ __forceinline__ void apply_sys(const double *__restrict__ OPS, const cx (&x)[4], cx (&h)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double kr = 0, ki = 0, sr = 0, si = 0;
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double K = OPS[r * 4 + c], S = OPS[16 + r * 4 + c];
+            kr = __builtin_fma(K, x[c].re, kr); ki = __builtin_fma(K, x[c].im, ki);
+            sr = __builtin_fma(S, x[c].re, sr); si = __builtin_fma(S, x[c].im, si);
+        }
+        h[r] = (cx){kr + si, ki - sr};      // K x - i S x
+    }
+}
+__device__ __forceinline__ void apply_op(const double *__restrict__ OPS, const int o, const cx (&x)[4], cx (&u)[4], cx (&v)[4])
+{
+    const double *Ko = OPS + 32 + 32 * o, *So = Ko + 16;
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double kr = 0, ki = 0, sr = 0, si = 0;
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {
+            kr = __builtin_fma(Ko[r * 4 + c], x[c].re, kr); ki = __builtin_fma(Ko[r * 4 + c], x[c].im, ki);
+            sr = __builtin_fma(So[r * 4 + c], x[c].re, sr); si = __builtin_fma(So[r * 4 + c], x[c].im, si);
+        }
+        u[r] = (cx){kr, ki}; v[r] = (cx){sr, si};
+    }
+}
+__device__ __forceinline__ void add_scaled(cx (&acc)[4], const double s, const cx (&h)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) { acc[r].re = __builtin_fma(s, h[r].re, acc[r].re); acc[r].im = __builtin_fma(s, h[r].im, acc[r].im); }
+}
+__device__ __forceinline__ void add_op(cx (&acc)[4], const double s, const double p, const double q, const cx (&u)[4], const cx (&v)[4])
+{
+    const double sq = s * q, sp = s * p;
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {      // s (q u - i p v)
+        acc[r].re = __builtin_fma(sq, u[r].re, acc[r].re); acc[r].re = __builtin_fma(sp, v[r].im, acc[r].re);
+        acc[r].im = __builtin_fma(sq, u[r].im, acc[r].im); acc[r].im = __builtin_fma(-sp, v[r].re, acc[r].im);
+    }
+}
+
+__device__ __forceinline__ void ld4(const double *p, cx (&x)[4])      // column vector stored as [r][2]
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = (cx){p[2 * r], p[2 * r + 1]};
+}
+__device__ __forceinline__ void st4(double *p, const cx (&x)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) { p[2 * r] = x[r].re; p[2 * r + 1] = x[r].im; }
+}
+// y = M x  (M: 4 x 4 complex in LDS, stored [col][row][2]: column-major, so that a thread owning column j writes 8 consecutive doubles)
+__device__ __forceinline__ void matvec(const double *__restrict__ Mx, const cx (&x)[4], cx (&y)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) y[r] = (cx){0.0, 0.0};
+    #pragma unroll
+    for (int c = 0; c < 4; c++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) cfma_(y[r], (cx){Mx[(c * 4 + r) * 2], Mx[(c * 4 + r) * 2 + 1]}, x[c]);
+}
+// The same with the matrix in REGISTERS (32 doubles, loaded one step ahead of its use: the steps of a sweep depend on each
+// other through x only, and a load issued behind the previous step's LDS store could not be moved in front of it by the
+// compiler -- same array): mv: y = M x, mvH: y = M^H x.
+__device__ __forceinline__ void ldm(const double *__restrict__ Mx, double (&m)[32])
+{
+    #pragma unroll
+    for (int q = 0; q < 32; q++) m[q] = Mx[q];
+}
+__device__ __forceinline__ void mv(const double (&m)[32], const cx (&x)[4], cx (&y)[4])
+{
+    #pragma unroll
+    for (int r = 0; r < 4; r++) y[r] = (cx){0.0, 0.0};
+    #pragma unroll
+    for (int c = 0; c < 4; c++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) cfma_(y[r], (cx){m[(c * 4 + r) * 2], m[(c * 4 + r) * 2 + 1]}, x[c]);
+}
+__device__ __forceinline__ void mvH(const double (&m)[32], const cx (&x)[4], cx (&y)[4])
+{
+    #pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cx s = (cx){0.0, 0.0};
+        #pragma unroll
+        for (int r = 0; r < 4; r++) cfmac_(s, (cx){m[(c * 4 + r) * 2], m[(c * 4 + r) * 2 + 1]}, x[r]);
+        y[c] = s;
+    }
+}
+// one sweep of `cnt` dependent steps x <- M_k x (ADJ: x <- M_k^H x) (+ f_k), k = k0, k0 + dk, ..., the next matrix (and
+// forcing) in flight while the current step computes; st != null: x after step i is stored at st + i * st_stride
+template <bool ADJ, bool AFF, bool ST>
+__device__ __forceinline__ void sweep(const double *Mbase, const int k0, const int dk, const int cnt, cx (&x)[4],
+                                      const double *fbase, const int foff, double *st, const int st0, const int dst)
+{
+    if (cnt <= 0) return;
+    double ma[32], mb[32];
+    cx fa[4], fb[4];
+    ldm(Mbase + (size_t)k0 * 32, ma);
+    if (AFF) ld4(fbase + (size_t)k0 * 32 + foff, fa);
+    for (int i = 0; i < cnt; i += 2) {
+        const int k = k0 + i * dk;
+        if (i + 1 < cnt) { ldm(Mbase + (size_t)(k + dk) * 32, mb); if (AFF) ld4(fbase + (size_t)(k + dk) * 32 + foff, fb); }
+        {
+            cx y[4];
+            if (ADJ) mvH(ma, x, y); else mv(ma, x, y);
+            #pragma unroll
+            for (int r = 0; r < 4; r++) x[r] = AFF ? (cx){y[r].re + fa[r].re, y[r].im + fa[r].im} : y[r];
+            if (ST) st4(st + (size_t)(st0 + i * dst) * 32, x);
+        }
+        if (i + 1 < cnt) {
+            if (i + 2 < cnt) { ldm(Mbase + (size_t)(k + 2 * dk) * 32, ma); if (AFF) ld4(fbase + (size_t)(k + 2 * dk) * 32 + foff, fa); }
+            cx y[4];
+            if (ADJ) mvH(mb, x, y); else mv(mb, x, y);
+            #pragma unroll
+            for (int r = 0; r < 4; r++) x[r] = AFF ? (cx){y[r].re + fb[r].re, y[r].im + fb[r].im} : y[r];
+            if (ST) st4(st + (size_t)(st0 + (i + 1) * dst) * 32, x);
+        }
+    }
+}
+
+// The sweeps of k_tiny_scan with FOUR lanes per chain (a quad: lane r holds element r of the state column and computes
+// element r of the next one): a step is 4 complex multiply-adds per lane instead of 16 -- the steps of a sweep are issued by ONE
+// wave, so their cost is the instruction count -- and the other three elements come by DPP quad broadcasts, no LDS round trip.
+__device__ __forceinline__ double quad_bcast(const double v, const int c)      // c = 0..3, compile-time after unrolling
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rlo, rhi;
+    switch (c) {
+    case 0: rlo = __builtin_amdgcn_update_dpp(0, lo, 0x00, 0xF, 0xF, false); rhi = __builtin_amdgcn_update_dpp(0, hi, 0x00, 0xF, 0xF, false); break;
+    case 1: rlo = __builtin_amdgcn_update_dpp(0, lo, 0x55, 0xF, 0xF, false); rhi = __builtin_amdgcn_update_dpp(0, hi, 0x55, 0xF, 0xF, false); break;
+    case 2: rlo = __builtin_amdgcn_update_dpp(0, lo, 0xAA, 0xF, 0xF, false); rhi = __builtin_amdgcn_update_dpp(0, hi, 0xAA, 0xF, 0xF, false); break;
+    default: rlo = __builtin_amdgcn_update_dpp(0, lo, 0xFF, 0xF, 0xF, false); rhi = __builtin_amdgcn_update_dpp(0, hi, 0xFF, 0xF, 0xF, false); break;
+    }
+    return __hiloint2double(rhi, rlo);
+}
+// this lane's operand of step matrix M ([col][row][2]): row r of M (forward: y_r = sum_c M[r][c] x_c), or column r of M
+// (adjoint: y_r = sum_q conj(M[q][r]) x_q)
+template <bool ADJ>
+__device__ __forceinline__ void ldq(const double *__restrict__ Mx, const int r, cx (&m)[4])
+{
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int e = ADJ ? (r * 4 + q) * 2 : (q * 4 + r) * 2;
+        m[q] = (cx){Mx[e], Mx[e + 1]};
+    }
+}
+template <bool ADJ>
+__device__ __forceinline__ cx stepq(const cx (&m)[4], const cx x)
+{
+    cx y = (cx){0.0, 0.0};
+    #pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const cx xq = (cx){quad_bcast(x.re, q), quad_bcast(x.im, q)};
+        if (ADJ) cfmac_(y, m[q], xq); else cfma_(y, m[q], xq);
+    }
+    return y;
+}
+// `cnt` dependent steps x <- M_k x (ADJ: M_k^H x) (+ f_k), k = k0, k0 + dk, ...; the next operand (and forcing element) in flight
+// while the current step computes; ST: element r of the state after step i goes to st[(st0 + i * dst) * 32 + 2 r]
+template <bool ADJ, bool AFF, bool ST>
+__device__ __forceinline__ void sweepq(const double *Mbase, const int k0, const int dk, const int cnt, cx &x, const int r,
+                                       const double *fbase, const int foff, double *st, const int st0, const int dst)
+{
+    if (cnt <= 0) return;
+    cx ma[4], mb[4], fa = (cx){0.0, 0.0}, fb = (cx){0.0, 0.0};
+    ldq<ADJ>(Mbase + (size_t)k0 * 32, r, ma);
+    if (AFF) fa = (cx){fbase[(size_t)k0 * 32 + foff + 2 * r], fbase[(size_t)k0 * 32 + foff + 2 * r + 1]};
+    for (int i = 0; i < cnt; i += 2) {
+        const int k = k0 + i * dk;
+        if (i + 1 < cnt) {
+            ldq<ADJ>(Mbase + (size_t)(k + dk) * 32, r, mb);
+            if (AFF) fb = (cx){fbase[(size_t)(k + dk) * 32 + foff + 2 * r], fbase[(size_t)(k + dk) * 32 + foff + 2 * r + 1]};
+        }
+        {
+            const cx y = stepq<ADJ>(ma, x);
+            x = AFF ? (cx){y.re + fa.re, y.im + fa.im} : y;
+            if (ST) { double *o = st + (size_t)(st0 + i * dst) * 32 + 2 * r; o[0] = x.re; o[1] = x.im; }
+        }
+        if (i + 1 < cnt) {
+            if (i + 2 < cnt) {
+                ldq<ADJ>(Mbase + (size_t)(k + 2 * dk) * 32, r, ma);
+                if (AFF) fa = (cx){fbase[(size_t)(k + 2 * dk) * 32 + foff + 2 * r], fbase[(size_t)(k + 2 * dk) * 32 + foff + 2 * r + 1]};
+            }
+            const cx y = stepq<ADJ>(mb, x);
+            x = AFF ? (cx){y.re + fb.re, y.im + fb.im} : y;
+            if (ST) { double *o = st + (size_t)(st0 + (i + 1) * dst) * 32 + 2 * r; o[0] = x.re; o[1] = x.im; }
+        }
+    }
+}
+
+// y = M^H x
+__device__ __forceinline__ void matvecH(const double *__restrict__ Mx, const cx (&x)[4], cx (&y)[4])
+{
+    #pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cx s = (cx){0.0, 0.0};
+        #pragma unroll
+        for (int r = 0; r < 4; r++) cfmac_(s, (cx){Mx[(c * 4 + r) * 2], Mx[(c * 4 + r) * 2 + 1]}, x[r]);
+        y[c] = s;
+    }
+}
+
+template <int NMAX> struct TinyPcof { double v[NMAX]; };
+
+struct TinyArgs {
+    const double *ops;          // [(2+2 n_ops)][Np*Np] column-major planes (K_sys, S_sys, Asym_1, Sym_1, ...)
+    const double *G; const int64_t *goff; const int32_t *ncoef, *poff;
+    const double *psi0, *target;                // panels [Np][2cp]
+    const double *guard_diag;                   // [2N] or null
+    double cwv[2 * 7];                          // c_j dt^j, c_j (-dt)^j, j = 0..m (m <= 6), by value
+    int nc[4], po[4]; long long go[4];          // ncoef, poff, goff of the (<= 4) controls, by value
+    double *tab;                                // [nt][m+1][n_ops][2]
+    double *Rg, *Linv;                          // [nt][32] each: R_n, L_n^-1 as [col][row][2]
+    double *psi, *lam;                          // [nt][32] each: [col][row][2]
+    double *cpart;                              // [nt][n_pcof]
+    double *scal; int *status;
+    double *mirror; unsigned long long mirror_seq;
+    int Np, cp, N, c, n_ops, m, nt, n_ess, n_pcof;
+    int cost;                                   // 0 no target, 1 :Infidelity, 2 :Tracking, 3 :Norm
+    int gradient;                               // 0: forward evaluation only (scalars)
+    int B, blen;                                // blocks of the scan
+    double dt, tf;
+    int o_small, o_P, o_psi, o_y, o_f, o_pib, o_bst, o_phi, o_red;     // LDS offsets of k_tiny_scan (doubles)
+};
+
+// ---------------------------------------------------------------------------
+// front: one workgroup (64 threads) per time point n
+// ---------------------------------------------------------------------------
+template <int M, int NO, int NMAX>
+__global__ __launch_bounds__(64) void k_tiny_front(const TinyArgs a, const TinyPcof<NMAX> pcof)
+{
+    __shared__ double PC[NMAX], OPS[(2 + 2 * NO) * 16], TABS[(M + 1) * NO * 2], CW[2 * (M + 1)], Y[32];
+    __shared__ int NC[4], POFF[4];
+    __shared__ long long GOFF[4];
+    const int tid = threadIdx.x, n = blockIdx.x, j = tid & 3;
+    const int nt = a.nt, n_ops = a.n_ops, N = a.N;
+    const int TE = (M + 1) * n_ops * 2;
+    const bool live = tid < 4;
+    double *TAB = TABS - n * TE;                        // (the phase code below indexes TAB[n * TE + ...])
+    for (int e = tid; e < a.n_pcof; e += 64) PC[e] = pcof.v[e];
+    for (int e = tid; e < (2 + 2 * n_ops) * 16; e += 64) {
+        const int pl = e >> 4, r = (e >> 2) & 3, cc = e & 3;
+        OPS[e] = (r < N && cc < N) ? a.ops[(size_t)pl * a.Np * a.Np + r + (size_t)a.Np * cc] : 0.0;
+    }
+    if (tid < 2 * (M + 1)) CW[tid] = a.cwv[tid];
+    if (tid >= 32 && tid < 36) { const int k = tid - 32; NC[k] = a.nc[k]; POFF[k] = a.po[k]; GOFF[k] = a.go[k]; }
+    if (n == 0) {
+        if (tid < 4) a.scal[tid] = 0.0;
+        if (tid == 4) { a.status[0] = 0; a.status[1] = 0; }
+    }
+    // control tables of this time point: 16 lanes per entry (contiguous reads of the basis row), up to eight entries per
+    // 16-lane group in flight, every load unconditional (clamped indices): one memory round trip
+    {
+        const int sub = tid & 15, grp = tid >> 4, NGp = 4, rows = TE;
+        for (int it = 0; it < (rows + NGp * 8 - 1) / (NGp * 8); it++) {      // (uniform trip count: a barrier sits inside)
+            const int e0 = grp + it * NGp * 8;
+            double gv[8][4];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = min(e0 + q * NGp, rows - 1);
+                const int pq = idx & 1, k = (idx >> 1) % n_ops, d = (idx >> 1) / n_ops;
+                const int nc = (k == 0) ? a.nc[0] : (k == 1) ? a.nc[1] : (k == 2) ? a.nc[2] : a.nc[3];
+                const long long go = (k == 0) ? a.go[0] : (k == 1) ? a.go[1] : (k == 2) ? a.go[2] : a.go[3];
+                const double *g = a.G + go + (((size_t)pq * nt + n) * (M + 1) + d) * nc;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) gv[q][i] = g[min(sub + 16 * i, nc - 1)];
+            }
+            if (it == 0) __syncthreads();               // (PC, NC, POFF in LDS; the basis loads above are already in flight)
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int eq = e0 + q * NGp;
+                const int kq = (eq < rows) ? ((eq >> 1) % n_ops) : 0, poq = POFF[kq], ncq = NC[kq];
+                double sacc = 0.0;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) { const int l = sub + 16 * i; sacc = __builtin_fma(gv[q][i], (l < ncq) ? PC[poq + l] : 0.0, sacc); }
+                sacc = row16_sum(sacc);
+                if (sub == 15 && eq < rows) { TABS[eq] = sacc; a.tab[(size_t)n * TE + eq] = sacc; }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P2: column j of D_1 .. D_M, of L_n and of R_n
+    cx Lc[4], Rc[4];
+    {
+        cx cur[4], Tacc[M + 1][4];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cur[r] = (cx){(r == j && j < N) ? 1.0 : 0.0, 0.0};
+            Lc[r] = cur[r]; Rc[r] = cur[r];
+            #pragma unroll
+            for (int q = 0; q <= M; q++) Tacc[q][r] = (cx){0.0, 0.0};
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++)                     // padding columns: identity (L stays invertible)
+            if (r == j && j >= N) { Lc[r] = (cx){1.0, 0.0}; Rc[r] = (cx){1.0, 0.0}; }
+        if (live) {
+            #pragma unroll
+            for (int s = 0; s < M; s++) {
+                {
+                    cx h[4]; apply_sys(OPS, cur, h);
+                    add_scaled(Tacc[s + 1], 1.0, h);                       // A_0's system part: level s+1 only
+                }
+                #pragma unroll
+                for (int o = 0; o < NO; o++) {
+                    if (o < n_ops) {
+                        cx u[4], v[4]; apply_op(OPS, o, cur, u, v);
+                        #pragma unroll
+                        for (int i = s; i < M; i++) {
+                            const double *t = TAB + n * TE + ((i - s) * n_ops + o) * 2;
+                            add_op(Tacc[i + 1], 1.0, t[0], t[1], u, v);
+                        }
+                    }
+                }
+                const double inv = 1.0 / (double)(s + 1), cR = CW[2 * (s + 1)], cL = CW[2 * (s + 1) + 1];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    cur[r] = (cx){Tacc[s + 1][r].re * inv, Tacc[s + 1][r].im * inv};
+                    Lc[r].re = __builtin_fma(cL, cur[r].re, Lc[r].re); Lc[r].im = __builtin_fma(cL, cur[r].im, Lc[r].im);
+                    Rc[r].re = __builtin_fma(cR, cur[r].re, Rc[r].re); Rc[r].im = __builtin_fma(cR, cur[r].im, Rc[r].im);
+                }
+            }
+            st4(Y + j * 8, Lc);                         // L_n staged in LDS, R_n to global ([col][row][2])
+            st4(a.Rg + (size_t)n * 32 + j * 8, Rc);
+        }
+    }
+    __syncthreads();
+    // ---- P3: L_n^-1 (every thread of the time point, in registers: it serves lambda later) and column j of P_{n-1}
+    cx Lij[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};       // column j of L_n^-1
+    if (live && n >= 1) {
+        // Gauss-Jordan on [A | I] with partial pivoting, plain double arrays with compile-time indices only (row swaps by
+        // selects), fully unrolled: everything stays in registers
+        double Ar[4][4], Ai[4][4], Ir[4][4], Ii[4][4];
+        #pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                Ar[r][cc] = Y[(cc * 4 + r) * 2]; Ai[r][cc] = Y[(cc * 4 + r) * 2 + 1];
+                Ir[r][cc] = (r == cc) ? 1.0 : 0.0; Ii[r][cc] = 0.0;
+            }
+        #pragma unroll
+        for (int p = 0; p < 4; p++) {
+            int piv = p; double best = Ar[p][p] * Ar[p][p] + Ai[p][p] * Ai[p][p];
+            #pragma unroll
+            for (int r = p + 1; r < 4; r++) {
+                const double mg = Ar[r][p] * Ar[r][p] + Ai[r][p] * Ai[r][p];
+                if (mg > best) { best = mg; piv = r; }
+            }
+            if (!(best > 0.0)) { a.status[0] = 1; best = 1.0; }
+            #pragma unroll
+            for (int r = p + 1; r < 4; r++) {
+                const bool sw = (r == piv);
+                #pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    double t;
+                    t = Ar[p][cc]; Ar[p][cc] = sw ? Ar[r][cc] : t; Ar[r][cc] = sw ? t : Ar[r][cc];
+                    t = Ai[p][cc]; Ai[p][cc] = sw ? Ai[r][cc] : t; Ai[r][cc] = sw ? t : Ai[r][cc];
+                    t = Ir[p][cc]; Ir[p][cc] = sw ? Ir[r][cc] : t; Ir[r][cc] = sw ? t : Ir[r][cc];
+                    t = Ii[p][cc]; Ii[p][cc] = sw ? Ii[r][cc] : t; Ii[r][cc] = sw ? t : Ii[r][cc];
+                }
+            }
+            const double den = 1.0 / best;
+            const double pr = Ar[p][p] * den, pi = -Ai[p][p] * den;      // 1 / pivot
+            #pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                double xr = Ar[p][cc], xi = Ai[p][cc];
+                Ar[p][cc] = pr * xr - pi * xi; Ai[p][cc] = pr * xi + pi * xr;
+                xr = Ir[p][cc]; xi = Ii[p][cc];
+                Ir[p][cc] = pr * xr - pi * xi; Ii[p][cc] = pr * xi + pi * xr;
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r != p) {
+                    const double fr = Ar[r][p], fi = Ai[r][p];
+                    #pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        Ar[r][cc] -= fr * Ar[p][cc] - fi * Ai[p][cc]; Ai[r][cc] -= fr * Ai[p][cc] + fi * Ar[p][cc];
+                        Ir[r][cc] -= fr * Ir[p][cc] - fi * Ii[p][cc]; Ii[r][cc] -= fr * Ii[p][cc] + fi * Ir[p][cc];
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {                   // column j of L_n^-1 stays in registers for lambda (P7)
+            Lij[r].re = (j == 0) ? Ir[r][0] : (j == 1) ? Ir[r][1] : (j == 2) ? Ir[r][2] : Ir[r][3];
+            Lij[r].im = (j == 0) ? Ii[r][0] : (j == 1) ? Ii[r][1] : (j == 2) ? Ii[r][2] : Ii[r][3];
+        }
+        st4(a.Linv + (size_t)n * 32 + j * 8, Lij);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan: ONE workgroup, thread (n, j)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_tiny_scan(const TinyArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *SMALL = lds + a.o_small, *Pm = lds + a.o_P, *PSI = lds + a.o_psi, *Y = lds + a.o_y, *F = lds + a.o_f;
+    double *PIB = lds + a.o_pib, *BST = lds + a.o_bst, *PHI = lds + a.o_phi, *RED = lds + a.o_red;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int n = tid >> 2, j = tid & 3;
+#ifdef QGD_TINY_PROFILE
+    long long stamp_[16]; int ns_ = 0;
+#define TP_STAMP() do { if (tid == 0) stamp_[ns_++] = wall_clock64(); } while (0)
+#else
+#define TP_STAMP() do { } while (0)
+#endif
+    TP_STAMP();
+    const int nt = a.nt, S = nt - 1, N = a.N, c = a.c;
+    const bool live = n < nt;
+    const bool guard = a.guard_diag != nullptr;
+    // small inputs through LDS (PSI0 [col][r][2] | TGT [col][r][2] | WD [8]): no load sits under a lane-dependent condition
+    for (int t = tid; t < 72; t += T) {                 // (the workgroup may have only 64 threads)
+        if (t < 64) {
+            const int which = t >> 5, e = t & 31, col = e >> 3, r = (e >> 1) & 3, im = e & 1;
+            const bool on = r < N && col < c;
+            const size_t o = (size_t)(on ? r : 0) * 2 * a.cp + ((on ? col : 0) >> 3) * 16 + ((on ? col : 0) & 7) + (im ? 8 : 0);
+            const double v = which ? a.target[o] : a.psi0[o];
+            SMALL[which * 32 + e] = on ? v : 0.0;
+        } else {
+            const int e = t - 64, r = e & 3;
+            const double v = guard ? a.guard_diag[(r < N ? r : 0) + (e >= 4 ? N : 0)] : 0.0;
+            SMALL[64 + e] = (guard && r < N) ? v : 0.0;
+        }
+    }
+    const double *PSI0 = SMALL, *TGT = SMALL + 32, *WD = SMALL + 64;
+    TP_STAMP();
+    // P_{n-1}[:, j] = L_n^-1 R_{n-1}[:, j]; column j of L_n^-1 stays in registers for lambda
+    cx Lij[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if (live && n >= 1) {
+        double li[32];                                  // (L_n^-1)(r, cc) at [(cc * 4 + r) * 2]
+        cx Rprev[4], Pcol[4];
+        ldm(a.Linv + (size_t)n * 32, li);
+        ld4(a.Rg + (size_t)(n - 1) * 32 + j * 8, Rprev);
+        mv(li, Rprev, Pcol);
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            Lij[r].re = (j == 0) ? li[r * 2] : (j == 1) ? li[(4 + r) * 2] : (j == 2) ? li[(8 + r) * 2] : li[(12 + r) * 2];
+            Lij[r].im = (j == 0) ? li[r * 2 + 1] : (j == 1) ? li[(4 + r) * 2 + 1] : (j == 2) ? li[(8 + r) * 2 + 1] : li[(12 + r) * 2 + 1];
+        }
+        st4(Pm + (n - 1) * 32 + j * 8, Pcol);
+    }
+    __syncthreads();
+
+    TP_STAMP();
+    // ---- P4: forward sweep psi_{n+1} = P_n psi_n: block products, block starts, replay.  Four lanes per chain (sweepq).
+    const int B = a.B, blen = a.blen;
+    const int qb = tid >> 4, qc = (tid >> 2) & 3, qr = tid & 3;      // (block, column, element) of the quad-cooperative phases
+    if (tid < 16 * B) {                                 // column qc of the block product Pi_b = P_{e-1} ... P_s
+        const int s0 = qb * blen, e0 = min(S, s0 + blen);
+        cx x = (cx){Pm[s0 * 32 + qc * 8 + 2 * qr], Pm[s0 * 32 + qc * 8 + 2 * qr + 1]};
+        sweepq<false, false, false>(Pm, s0 + 1, 1, e0 - s0 - 1, x, qr, nullptr, 0, nullptr, 0, 0);
+        PIB[qb * 32 + qc * 8 + 2 * qr] = x.re; PIB[qb * 32 + qc * 8 + 2 * qr + 1] = x.im;
+    }
+    if (tid >= 16 * B && tid < 16 * B + 4) {            // the initial state into psi[0] and the first block start
+        const int col = tid - 16 * B;
+        cx x[4]; ld4(PSI0 + col * 8, x);
+        st4(PSI + col * 8, x); st4(BST + col * 8, x);
+    }
+    __syncthreads();
+    if (tid < 16) {                                     // block starts, sequential over the blocks (column qc)
+        cx x = (cx){BST[qc * 8 + 2 * qr], BST[qc * 8 + 2 * qr + 1]};
+        sweepq<false, false, true>(PIB, 0, 1, B - 1, x, qr, nullptr, 0, BST + qc * 8, 1, 1);
+    }
+    __syncthreads();
+    if (tid < 16 * B) {                                 // replay: block qb, column qc
+        const int s0 = qb * blen, e0 = min(S, s0 + blen);
+        cx x = (cx){BST[qb * 32 + qc * 8 + 2 * qr], BST[qb * 32 + qc * 8 + 2 * qr + 1]};
+        sweepq<false, false, true>(Pm, s0, 1, e0 - s0, x, qr, nullptr, 0, PSI + qc * 8, s0 + 1, 1);
+    }
+    __syncthreads();
+
+    TP_STAMP();
+    // ---- P5: guard penalty / forcing, overlaps, terminal condition.  Thread (n, col = j).
+    {
+        double pen = 0.0;
+        if (live) {
+            cx w[4], f[4]; ld4(PSI + n * 32 + j * 8, w);
+            const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0, sc = -(2.0 * a.dt / a.tf) * trap;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double wu = WD[r], wv = WD[4 + r];
+                f[r] = (cx){sc * wu * w[r].re, sc * wv * w[r].im};
+                pen = __builtin_fma(trap * wu * w[r].re, w[r].re, pen); pen = __builtin_fma(trap * wv * w[r].im, w[r].im, pen);
+            }
+            st4(F + n * 32 + j * 8, f);
+        }
+        // fixed tree: 64 lanes by shuffles, then the waves in order
+        for (int off = 32; off > 0; off >>= 1) pen += __shfl_down(pen, off);
+        if ((tid & 63) == 0) RED[tid >> 6] = pen;
+        // overlaps / cost: thread (col, r) = the first sixteen lanes
+        double av = 0.0, bv = 0.0;
+        if (tid < 16) {
+            const int col = tid >> 2, r = tid & 3;
+            if (col < c && r < N && a.cost) {
+                const double u = PSI[S * 32 + col * 8 + 2 * r], v = PSI[S * 32 + col * 8 + 2 * r + 1], tr = TGT[col * 8 + 2 * r], ti = TGT[col * 8 + 2 * r + 1];
+                if (a.cost == 1) { av = u * tr + v * ti; bv = u * ti - v * tr; }      // <w_N, R>; <w_N, T>, T = [R_im; -R_re]
+                else { const double du = u - (a.cost == 2 ? tr : 0.0), dv = v - (a.cost == 2 ? ti : 0.0); av = 0.5 * (du * du + dv * dv); }
+            }
+        }
+        if (tid < 64) {
+            for (int off = 8; off > 0; off >>= 1) { av += __shfl_down(av, off); bv += __shfl_down(bv, off); }
+            if (tid == 0) { RED[32] = av; RED[33] = bv; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double gs = 0.0;
+        for (int q = 0; q < (T >> 6); q++) gs += RED[q];
+        gs *= a.dt / a.tf;
+        a.scal[0] = RED[32]; a.scal[1] = RED[33]; a.scal[2] = gs;
+        RED[34] = gs;
+    }
+    __syncthreads();
+    if (!a.gradient) {
+        if (tid == 0 && a.mirror) {
+            a.mirror[a.n_pcof] = RED[32]; a.mirror[a.n_pcof + 1] = RED[33]; a.mirror[a.n_pcof + 2] = RED[34]; a.mirror[a.n_pcof + 3] = 0.0;
+            a.mirror[a.n_pcof + 4] = (double)__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.mirror + a.n_pcof + 5), a.mirror_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (tid < 4) {                                      // y_N for column tid -> Y[S] and the top block end
+        const int col = tid;
+        const double av = RED[32], bv = RED[33], sc = 2.0 / ((double)a.n_ess * (double)a.n_ess);
+        cx y[4];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool on = r < N && col < c;
+            const double tr = TGT[col * 8 + 2 * r], ti = TGT[col * 8 + 2 * r + 1];
+            const double fu = F[S * 32 + col * 8 + 2 * r], fv = F[S * 32 + col * 8 + 2 * r + 1];
+            double yu, yv;
+            if (a.cost == 1) { yu = sc * (av * tr + bv * ti) + fu; yv = sc * (av * ti - bv * tr) + fv; }
+            else if (a.cost == 2) { yu = (tr - PSI[S * 32 + col * 8 + 2 * r]) + fu; yv = (ti - PSI[S * 32 + col * 8 + 2 * r + 1]) + fv; }
+            else { yu = -PSI[S * 32 + col * 8 + 2 * r] + fu; yv = -PSI[S * 32 + col * 8 + 2 * r + 1] + fv; }
+            y[r] = on ? (cx){yu, yv} : (cx){0.0, 0.0};
+        }
+        st4(Y + S * 32 + col * 8, y);
+        st4(BST + B * 32 + col * 8, y);                 // y at the end of the last block
+    }
+    __syncthreads();
+
+    TP_STAMP();
+    // ---- P6: adjoint sweep y_n = P_n^H y_{n+1} + f_n, n = S-1 .. 1 (four lanes per chain)
+    if (tid < 16 * B) {                                 // affine part of block qb (zero start at its end), column qc
+        const int s0 = qb * blen, e0 = min(S, s0 + blen);
+        cx z = (cx){0.0, 0.0};
+        if (guard) sweepq<true, true, false>(Pm, e0 - 1, -1, e0 - s0, z, qr, F, qc * 8, nullptr, 0, 0);
+        PHI[qb * 32 + qc * 8 + 2 * qr] = z.re; PHI[qb * 32 + qc * 8 + 2 * qr + 1] = z.im;
+    }
+    __syncthreads();
+    if (tid < 16) {                                     // y at the block ends, from the top: y_{s0(b)} = Pi_b^H y_{e0(b)} + phi_b
+        cx y = (cx){BST[B * 32 + qc * 8 + 2 * qr], BST[B * 32 + qc * 8 + 2 * qr + 1]};
+        sweepq<true, true, true>(PIB, B - 1, -1, B - 1, y, qr, PHI, qc * 8, BST + qc * 8, B - 1, -1);      // BST[b] = y at the end of block b-1
+    }
+    __syncthreads();
+    if (tid < 16 * B) {                                 // replay of block qb, column qc
+        const int s0 = qb * blen, e0 = min(S, s0 + blen);
+        cx y = (cx){BST[(qb + 1) * 32 + qc * 8 + 2 * qr], BST[(qb + 1) * 32 + qc * 8 + 2 * qr + 1]};
+        sweepq<true, true, true>(Pm, e0 - 1, -1, e0 - max(s0, 1), y, qr, F, qc * 8, Y + qc * 8, e0 - 1, -1);
+    }
+    __syncthreads();
+
+    TP_STAMP();
+    // ---- P7: lambda_n = L_n^-H y_n in place (n >= 1; lambda_0 = 0).  Thread (n, j) holds column j of L_n^-1 and forms ROW j of
+    //      lambda_n for all state columns; the four threads of a time point are lanes of one wave: read all, fence, write.
+    if (live) {
+        cx yv[4][4];                                    // [col][r]
+        #pragma unroll
+        for (int col = 0; col < 4; col++) ld4(Y + n * 32 + col * 8, yv[col]);
+        wave_lds_fence();
+        #pragma unroll
+        for (int col = 0; col < 4; col++) {
+            cx sacc = (cx){0.0, 0.0};
+            if (n >= 1) {
+                #pragma unroll
+                for (int r = 0; r < 4; r++) cfmac_(sacc, Lij[r], yv[col][r]);
+            }
+            Y[n * 32 + col * 8 + 2 * j] = sacc.re; Y[n * 32 + col * 8 + 2 * j + 1] = sacc.im;
+        }
+    }
+    __syncthreads();
+
+    TP_STAMP();
+#ifdef QGD_TINY_PROFILE
+    if (tid == 0) { printf("scan phases (x10 ns):"); for (int q = 1; q < ns_; q++) printf(" %lld", stamp_[q] - stamp_[q - 1]); printf("\n"); }
+#endif
+    if (live) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            a.psi[(size_t)n * 32 + j * 8 + q] = PSI[n * 32 + j * 8 + q];
+            a.lam[(size_t)n * 32 + j * 8 + q] = Y[n * 32 + j * 8 + q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// grad: one workgroup (64 threads) per time point n; threads 0..3 = state columns
+// ---------------------------------------------------------------------------
+template <int M, int NO>
+__global__ __launch_bounds__(64) void k_tiny_grad(const TinyArgs a)
+{
+    __shared__ double OPS[(2 + 2 * NO) * 16], TABS[(M + 1) * NO * 2], CW[2 * (M + 1)], SIGS[NO * M * 2], PSI[32], Y[64];
+    __shared__ int NC[4], POFF[4];
+    __shared__ long long GOFF[4];
+    const int tid = threadIdx.x, n = blockIdx.x, j = tid & 3;
+    const int nt = a.nt, n_ops = a.n_ops, N = a.N, c = a.c;
+    const int TE = (M + 1) * n_ops * 2;
+    const bool live = tid < 4;
+    double *TAB = TABS - n * TE, *SIG = SIGS - (size_t)n * n_ops * M * 2;
+    for (int e = tid; e < (2 + 2 * n_ops) * 16; e += 64) {
+        const int pl = e >> 4, r = (e >> 2) & 3, cc = e & 3;
+        OPS[e] = (r < N && cc < N) ? a.ops[(size_t)pl * a.Np * a.Np + r + (size_t)a.Np * cc] : 0.0;
+    }
+    if (tid < TE) TABS[tid] = a.tab[(size_t)n * TE + tid];
+    if (tid < 2 * (M + 1)) CW[tid] = a.cwv[tid];
+    if (tid >= 32 && tid < 36) { const int k = tid - 32; NC[k] = a.nc[k]; POFF[k] = a.po[k]; GOFF[k] = a.go[k]; }
+    if (tid < 32) PSI[tid] = a.psi[(size_t)n * 32 + tid];
+    Y[tid] = (tid < 32) ? a.lam[(size_t)n * 32 + tid] : ((n + 1 < nt) ? a.lam[(size_t)min(n + 1, nt - 1) * 32 + (tid - 32)] : 0.0);
+    __syncthreads();
+    double *PSIq = PSI - n * 32, *Yq = Y - n * 32;      // (the phase code indexes PSI[n * 32 + ...], Y[n * 32 + ...], Y[(n + 1) * 32 + ...])
+    // ---- P8: gradient scalars of (time point n, column j)
+    {
+        double sg[NO][M][2];
+        #pragma unroll
+        for (int o = 0; o < NO; o++)
+            #pragma unroll
+            for (int d = 0; d < M; d++) { sg[o][d][0] = 0.0; sg[o][d][1] = 0.0; }
+        if (live && j < c) {
+            cx lh[4], ln[4], g[M + 1][4];
+            ld4(Yq + n * 32 + j * 8, lh);
+            if (n + 1 < nt) ld4(Yq + (n + 1) * 32 + j * 8, ln);
+            else { ln[0] = ln[1] = ln[2] = ln[3] = (cx){0.0, 0.0}; }
+            #pragma unroll
+            for (int q = 1; q <= M; q++) {
+                const double cR = CW[2 * q], cL = CW[2 * q + 1];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) g[q][r] = (cx){cR * ln[r].re - cL * lh[r].re, cR * ln[r].im - cL * lh[r].im};
+            }
+            // reverse sweep: g_i += (1/q) A_{q-1-i}^H g_q = -(1/q) A_{q-1-i} g_q, i = 1 .. q-1, q = M .. 2
+            #pragma unroll
+            for (int q = M; q >= 2; q--) {
+                const double mq = -1.0 / (double)q;
+                {
+                    cx h[4]; apply_sys(OPS, g[q], h);
+                    add_scaled(g[q - 1], mq, h);                           // d = q-1-i = 0  <=>  i = q-1
+                }
+                #pragma unroll
+                for (int o = 0; o < NO; o++) {
+                    if (o < n_ops) {
+                        cx u[4], v[4]; apply_op(OPS, o, g[q], u, v);
+                        #pragma unroll
+                        for (int i = 1; i < q; i++) {
+                            const double *t = TAB + n * TE + ((q - 1 - i) * n_ops + o) * 2;
+                            add_op(g[i], mq, t[0], t[1], u, v);
+                        }
+                    }
+                }
+            }
+            // state derivatives source-major; the scalars of source w_i against every g_q, q > i
+            cx cur[4], Tacc[M + 1][4];
+            ld4(PSIq + n * 32 + j * 8, cur);
+            #pragma unroll
+            for (int q = 0; q <= M; q++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++) Tacc[q][r] = (cx){0.0, 0.0};
+            #pragma unroll
+            for (int i = 0; i < M; i++) {
+                if (i + 1 < M) {
+                    cx h[4]; apply_sys(OPS, cur, h);
+                    add_scaled(Tacc[i + 1], 1.0, h);
+                }
+                #pragma unroll
+                for (int o = 0; o < NO; o++) {
+                    if (o < n_ops) {
+                        cx u[4], v[4]; apply_op(OPS, o, cur, u, v);
+                        #pragma unroll
+                        for (int q = i + 1; q <= M; q++) {
+                            const int d = q - 1 - i;
+                            const double iq = 1.0 / (double)q;
+                            double sp = 0.0, sq = 0.0;
+                            #pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                // Re<-i Sym w, g> = v_im g_re - v_re g_im ;  Re<Asym w, g> = u_re g_re + u_im g_im
+                                sp = __builtin_fma(v[r].im, g[q][r].re, sp); sp = __builtin_fma(-v[r].re, g[q][r].im, sp);
+                                sq = __builtin_fma(u[r].re, g[q][r].re, sq); sq = __builtin_fma(u[r].im, g[q][r].im, sq);
+                            }
+                            sg[o][d][0] = __builtin_fma(iq, sp, sg[o][d][0]); sg[o][d][1] = __builtin_fma(iq, sq, sg[o][d][1]);
+                        }
+                        #pragma unroll
+                        for (int t = i; t + 1 < M; t++) {
+                            const double *tb = TAB + n * TE + ((t - i) * n_ops + o) * 2;
+                            add_op(Tacc[t + 1], 1.0, tb[0], tb[1], u, v);
+                        }
+                    }
+                }
+                if (i + 1 < M) {
+                    const double inv = 1.0 / (double)(i + 1);
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++) cur[r] = (cx){Tacc[i + 1][r].re * inv, Tacc[i + 1][r].im * inv};
+                }
+            }
+        }
+        // sum over the four columns of the time point (lanes 4q .. 4q+3), fixed order; lane 0 of the quad stores
+        #pragma unroll
+        for (int o = 0; o < NO; o++) {
+            if (o < n_ops) {
+                #pragma unroll
+                for (int d = 0; d < M; d++)
+                    #pragma unroll
+                    for (int pq = 0; pq < 2; pq++) {
+                        double x = sg[o][d][pq];
+                        const double x1 = __shfl_xor(x, 1); x = (j & 1) ? x1 + x : x + x1;
+                        const double x2 = __shfl_xor(x, 2); x = (j & 2) ? x2 + x : x + x2;
+                        if (live && j == 0) SIG[(n * n_ops + o) * M * 2 + d * 2 + pq] = x;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+
+    // this time point's row of the gradient: cpart[n][p] = - sum_{d < M} (Gp[k][n][d][l] sigP[k][d] + Gq[k][n][d][l] sigQ[k][d])
+    for (int p = tid; p < a.n_pcof; p += 64) {
+        int k = 0;
+        while (k + 1 < n_ops && p >= POFF[k + 1]) k++;
+        const int l = p - POFF[k], nc = NC[k];
+        const double *gp = a.G + GOFF[k] + ((size_t)n * (M + 1)) * nc + l, *gq = gp + (size_t)nt * (M + 1) * nc;
+        double gvp[M], gvq[M];
+        #pragma unroll
+        for (int d = 0; d < M; d++) { gvp[d] = gp[(size_t)d * nc]; gvq[d] = gq[(size_t)d * nc]; }
+        double s = 0.0;
+        #pragma unroll
+        for (int d = 0; d < M; d++) { s = __builtin_fma(gvp[d], SIGS[(k * M + d) * 2], s); s = __builtin_fma(gvq[d], SIGS[(k * M + d) * 2 + 1], s); }
+        a.cpart[(size_t)n * a.n_pcof + p] = -s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+#define QGD_TINY_PCOF_MAX 64
+static void tiny_layout(const qgdk_ctx *c, TinyArgs &a, size_t &doubles, int &threads)
+{
+    const int nt = c->nt, S = nt - 1;
+    int B = 1; while (B * B < S) B++;
+    a.blen = (S + B - 1) / B;
+    a.B = (S + a.blen - 1) / a.blen;                    // (non-empty blocks only)
+    threads = ((4 * nt + 63) / 64) * 64;
+    threads = std::max(threads, ((16 * a.B + 4 + 63) / 64) * 64);
+    int o = 0;
+    a.o_small = o; o += 80;
+    a.o_P = o; o += nt * 32;
+    a.o_psi = o; o += nt * 32;
+    a.o_y = o; o += nt * 32;
+    a.o_f = o; o += nt * 32;
+    a.o_pib = o; o += (a.B + 1) * 32;
+    a.o_bst = o; o += (a.B + 2) * 32;
+    a.o_phi = o; o += (a.B + 1) * 32;
+    a.o_red = o; o += 64;
+    doubles = (size_t)o;
+}
+
+template <int M, int NO>
+static int launch_tiny(const qgdk_ctx *c, TinyArgs &a, const TinyPcof<QGD_TINY_PCOF_MAX> &pc, size_t shm, int threads)
+{
+    hipLaunchKernelGGL((k_tiny_front<M, NO, QGD_TINY_PCOF_MAX>), dim3(c->nt), dim3(64), 0, c->stream, a, pc);
+    SET_LDS_ONCE(k_tiny_scan, shm);
+    hipLaunchKernelGGL(k_tiny_scan, dim3(1), dim3(threads), shm, c->stream, a);
+    if (a.gradient) hipLaunchKernelGGL((k_tiny_grad<M, NO>), dim3(c->nt), dim3(64), 0, c->stream, a);
+    return (int)hipGetLastError();
+}
+template <int M>
+static int launch_tiny_m(const qgdk_ctx *c, TinyArgs &a, const TinyPcof<QGD_TINY_PCOF_MAX> &pc, size_t shm, int threads)
+{
+    return c->n_ops <= 2 ? launch_tiny<M, 2>(c, a, pc, shm, threads) : launch_tiny<M, 4>(c, a, pc, shm, threads);
+}
+
+extern "C" {
+
+// whether the small-problem path covers this problem: N <= 4, <= 4 columns, 1..4 control operators, order <= 12, pcof in
+// the kernel arguments, no dense guard projector, the grid within one workgroup's threads and LDS (scan kernel)
+int qgdk_tiny_supported(const qgdk_ctx *c, int n_pcof)
+{
+    if (c->N > 4 || c->c > 4 || c->n_ops < 1 || c->n_ops > 4 || c->m < 1 || c->m > 6 || n_pcof < 1 || n_pcof > QGD_TINY_PCOF_MAX) return 0;
+    if (c->have_guard == 1 || c->nt < 3 || 4 * c->nt > 512) return 0;
+    if (c->part_world != 1 || c->g_nt != 0) return 0;
+    TinyArgs a; size_t d; int th;
+    tiny_layout(c, a, d, th);
+    return d * sizeof(double) <= (size_t)150 * 1024 && th <= 512;
+}
+
+// one evaluation: gradient != 0 -> cpart rows (the caller adds them with qgdk_contract_rows: grad, mirror), scal, status;
+// else the scalars only (and the host mirror, when c->mirror_dev is set)
+int qgdk_tiny_eval(const qgdk_ctx *c, const double *pcof_host, int n_pcof, int gradient)
+{
+    if (!qgdk_tiny_supported(c, n_pcof)) return (int)hipErrorInvalidValue;
+    TinyArgs a;
+    size_t doubles; int threads;
+    tiny_layout(c, a, doubles, threads);
+    a.ops = c->ops; a.G = c->G; a.goff = c->goff; a.ncoef = c->ncoef; a.poff = c->poff;
+    a.psi0 = c->psi0; a.target = c->target; a.guard_diag = (c->have_guard == 2) ? c->guard_diag : nullptr;
+    for (int q = 0; q < 14; q++) a.cwv[q] = (q < 2 * (c->m + 1)) ? c->cw_host[q] : 0.0;
+    for (int q = 0; q < 4; q++) { a.nc[q] = (q < c->n_ops) ? c->ncoef_host[q] : 1; a.po[q] = (q < c->n_ops) ? c->poff_host[q] : 0; a.go[q] = (q < c->n_ops) ? c->goff_host[q] : 0; }
+    // compact arrays in buffers the general path rewrites completely before it reads them (its hist[0] and lam[0] panels hold
+    // the initial state and zeros from the allocation on: not those)
+    a.tab = c->tab; a.Rg = c->R; a.Linv = c->LinvT; a.psi = c->L; a.lam = c->Pr; a.cpart = c->cpart;
+    a.scal = c->scal; a.status = c->status;
+    a.mirror = gradient ? nullptr : c->mirror_dev; a.mirror_seq = c->mirror_seq;
+    a.Np = c->Np; a.cp = c->cp; a.N = c->N; a.c = c->c; a.n_ops = c->n_ops; a.m = c->m; a.nt = c->nt; a.n_ess = c->n_ess; a.n_pcof = n_pcof;
+    a.cost = c->have_target ? 1 + c->cost_type : 0;
+    a.gradient = gradient;
+    a.dt = c->dt; a.tf = c->tf;
+    TinyPcof<QGD_TINY_PCOF_MAX> pc;
+    memset(&pc, 0, sizeof pc);
+    memcpy(pc.v, pcof_host, sizeof(double) * n_pcof);
+    const size_t shm = doubles * sizeof(double);
+    switch (c->m) {
+    case 1: return launch_tiny_m<1>(c, a, pc, shm, threads);
+    case 2: return launch_tiny_m<2>(c, a, pc, shm, threads);
+    case 3: return launch_tiny_m<3>(c, a, pc, shm, threads);
+    case 4: return launch_tiny_m<4>(c, a, pc, shm, threads);
+    case 5: return launch_tiny_m<5>(c, a, pc, shm, threads);
+    default: return launch_tiny_m<6>(c, a, pc, shm, threads);
+    }
+}
+
+} // extern "C"

@@ -343,6 +343,14 @@ class DeviceProblem:
             _lib.check(self.h, self.lib.qgd_set_cost_type(self.h, code))
             self._cost_type = code
 
+    def set_small_path(self, on=True):
+        """qgd_set_small_path: the four-launch evaluation of small problems (N <= 4: Rabi, cnot2) on / off for this handle."""
+        _lib.check(self.h, self.lib.qgd_set_small_path(self.h, 1 if on else 0))
+
+    def small_path_taken(self):
+        """Whether the last evaluation of this handle ran on the small-problem path."""
+        return bool(self.intermediate("small_path")[0])
+
     def set_lambda_derivatives(self, on=True):
         """Fill ``lambda_history[:, 1:, :, :]`` as the reference leaves it (forward_evolution.jl:427-433, :471-480):
         the adjoint derivatives of lambda_n with the controls at t_{n-1} (t_1 for n = 1).  Off by default -- nothing
@@ -367,7 +375,7 @@ class DeviceProblem:
             return z[..., 0] + 1j * z[..., 1]
         if name == "repivoted":
             return int(out[0])
-        if name == "selection":
+        if name in ("selection", "small_path"):
             return out
         if name == "sigma":
             return out.reshape(nt, self.n_ops, self.m, 2)

@@ -14,6 +14,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# The suite exercises the GENERAL kernels on small problems too (cnot2, Rabi, random N = 4: the padded 16 x 16 tiles of the chain,
+# inverse and gradient kernels).  The small-problem path that the library takes by default for such problems (qgd_k_tiny.hip)
+# has its own module, tests/test_gpu_tiny.py, which switches it on per handle.
+os.environ.setdefault("QGD_TINY", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
