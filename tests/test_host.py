@@ -419,3 +419,81 @@ def test_more_problem_constructors(qgd):
     assert d.N_tot_levels == 1 and d.system_sym[0, 0] == -2.0 and d.N_operators == 1 and d.v0[0, 0] == 0.5
     with pytest.raises(ValueError):
         qgd.dahlquist_problem(1.0 + 1.0j)
+
+
+def _header_prototypes():
+    """{name: (return type, [argument types])} of every function include/qgd.h declares, and {struct: [(type, field)]}."""
+    import re
+    src = open(os.path.join(ROOT, "include", "qgd.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s+\w+\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            base = re.match(r"((?:const\s+)?\w+)\s+(.*)", decl)
+            for part in base.group(2).split(","):
+                part = part.strip()
+                fields.append((base.group(1) + (" *" if part.startswith("*") else ""), part.lstrip("* ")))
+        structs[name] = fields
+    protos = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?\w+\s*\*?)\s*(qgd_\w+)\s*\(([^)]*)\)\s*;", src, flags=re.M):
+        al = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if a in ("void", ""):
+                continue
+            m = re.match(r"((?:const\s+)?\w+)\s*((?:\*\s*(?:const\s*)?)*)\s*\w*(\[\w*\])?$", a)
+            assert m, (name, a)
+            stars = m.group(2).count("*") + (1 if m.group(3) else 0)
+            al.append(m.group(1) + (" " + "*" * stars if stars else ""))
+        protos[name] = (" ".join(ret.split()).replace(" *", "*").replace("*", " *"), al)
+    return protos, structs
+
+
+def test_julia_shim_signatures_match_header():
+    """julia/QuantumGateDesignHIP.jl has never run (no Julia in the image): every `ccall` of the shim is parsed here and compared
+    with the prototype in include/qgd.h -- symbol, return type, number of arguments and each argument's C type -- and the two
+    `struct`s the shim passes by reference field by field with their C declarations (same order, same widths)."""
+    import re
+    protos, structs = _header_prototypes()
+    jl = open(os.path.join(ROOT, "julia", "QuantumGateDesignHIP.jl")).read()
+    jl = "\n".join(line.split("#")[0] if "ccall" not in line.split("#")[0] and "#" in line else line for line in jl.splitlines())
+
+    def ctype(j):        # Julia ccall type -> the C types it may stand for
+        j = j.strip()
+        table = {"Cint": {"int", "int32_t"}, "Int32": {"int32_t", "int"}, "Int64": {"int64_t"}, "Clonglong": {"int64_t"},
+                 "Float64": {"double"}, "Cdouble": {"double"}, "Csize_t": {"size_t"}, "Cstring": {"const char *"}, "Cvoid": {"void"},
+                 "Ptr{Cvoid}": {"qgd_handle", "void *", "const void *"}, "Ptr{Float64}": {"double *", "const double *"},
+                 "Ptr{Cdouble}": {"double *", "const double *"}, "Ptr{Int32}": {"int32_t *", "const int32_t *"},
+                 "Ptr{Int64}": {"int64_t *", "const int64_t *"}, "Ptr{UInt8}": {"void *", "const void *", "uint8_t *", "const uint8_t *", "unsigned char *"},
+                 "Ref{Ptr{Cvoid}}": {"qgd_handle *"}, "Ref{ProblemDesc}": {"const qgd_problem_desc *"},
+                 "Ref{CSC}": {"const qgd_csc *"}, "Ptr{CSC}": {"const qgd_csc *"}, "Ptr{Ptr{Float64}}": {"const double **", "double **"}}
+        assert j in table, f"unmapped Julia type {j!r}"
+        return table[j]
+
+    calls = re.findall(r"ccall\(\(:(\w+),\s*libqgd\),\s*([\w{}]+),\s*\(((?:[^()]|\{[^}]*\})*)\)", jl, flags=re.S)
+    assert len(calls) >= 23
+    seen = set()
+    for name, ret, args in calls:
+        assert name in protos, f"the shim calls {name}, which include/qgd.h does not declare"
+        cret, cargs = protos[name]
+        assert cret in ctype(ret), (name, ret, cret)
+        jargs = [a for a in re.split(r",\s*(?![^{]*\})", " ".join(args.split())) if a.strip()]
+        assert len(jargs) == len(cargs), (name, jargs, cargs)
+        for ja, ca in zip(jargs, cargs):
+            assert ca in ctype(ja), (name, ja, ca)
+        seen.add(name)
+    # the evaluation entry points, the constructors and the multi-GPU calls are all bound
+    assert {"qgd_create", "qgd_create_csc", "qgd_destroy", "qgd_set_control_basis", "qgd_eval_forward", "qgd_discrete_adjoint",
+            "qgd_eval_grad_forced", "qgd_comm_unique_id", "qgd_comm_init_rccl", "qgd_get_partition"} <= seen
+    width = {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double", "Ptr{Float64}": "const double *", "Ptr{Int64}": "const int64_t *"}
+    for jname, cname in (("ProblemDesc", "qgd_problem_desc"), ("CSC", "qgd_csc")):
+        body = re.search(r"^struct\s+" + jname + r"\b(.*?)^end", jl, flags=re.S | re.M).group(1)
+        jf = [(f, t) for f, t in re.findall(r"(\w+)::([\w{}]+)", body)]
+        cf = structs[cname]
+        assert [f for f, _ in jf] == [f for _, f in cf], (jname, jf, cf)
+        for (f, jt), (ct, _) in zip(jf, cf):
+            assert width[jt] == ct, (jname, f, jt, ct)
