@@ -110,7 +110,8 @@ int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
  * does not fit returns QGD_ERR_MEMORY.  Re-allocates the grid (set the control basis afterwards, for the WHOLE grid).
  * With more than one window the reference-layout outputs (uv_history, lambda_history, adjoint_forcing) are filled window
  * by window into the caller's full arrays -- uv_history with qgd_set_save_every's stride, lambda_history with its
- * derivative columns after qgd_set_lambda_derivatives, as on a resident grid; the forced sweeps, qgd_eval_adjoint,
+ * derivative columns after qgd_set_lambda_derivatives, as on a resident grid; qgd_eval_adjoint walks the windows in reverse
+ * with the caller's terminal condition and forcing (no forward history is formed); the forced sweeps,
  * qgd_set_control_tables and qgd_get_intermediate return QGD_ERR_UNSUPPORTED (they need the grid resident).
  * qgd_get_partition on such a handle reports the WHOLE grid (first point 0, last point nsteps): the windows are the
  * library's business, the caller's control basis and output arrays cover every time point.

@@ -909,6 +909,68 @@ int chunked_adjoint(qgd_handle h, double *lambda_history = nullptr, double *adjo
     return QGD_OK;
 }
 
+int check_status(qgd_handle h);
+// eval_adjoint on a windowed grid: windows in reverse; each forms its matrices, takes its slice of the caller's forcing and
+// the y the next window ended in (the last one: y_N = L_N^H lambda_N from the given terminal condition), runs the adjoint
+// scan and lambda, and writes its share of lambda_history (global time indices n_off+1 .. n_off+nt-1).  No forward history is
+// needed (forward_evolution.jl:352-483 reads none).
+int chunked_eval_adjoint(qgd_handle h, const double *pcof, int n_pcof, const double *terminal_condition, const double *forcing,
+                         double *lambda_history)
+{
+    qgdk_ctx &k = h->k;
+    if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
+    const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, N = k.N, n2 = 2 * N, m = k.m, ntg = (size_t)h->nsteps + 1;
+    const int W = h->chunks_eff;
+    std::vector<double> lamN(hstep, 0.0), f;
+    for (size_t col = 0; col < (size_t)k.c; col++)
+        for (size_t i = 0; i < N; i++) {
+            const size_t o = panel_index((int)i, (int)col, (int)PWc);
+            lamN[o] = terminal_condition[i + n2 * col];
+            lamN[o + 8] = terminal_condition[N + i + n2 * col];
+        }
+    memset(lambda_history, 0, sizeof(double) * n2 * (m + 1) * ntg * k.c);
+    h->forward_valid = false; h->resident_window = -1;      // (the buffers will hold no window's forward history)
+    int rc;
+    for (int r = W - 1; r >= 0; r--) {
+        if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
+        const size_t nt = k.nt, n_off = k.n_off;
+        if ((rc = forward_begin(h, pcof, n_pcof))) return rc;
+        { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }      // (the super-block propagators)
+        f.assign(nt * hstep, 0.0);
+        if (forcing)
+            for (size_t col = 0; col < (size_t)k.c; col++)
+                for (size_t n = 0; n < nt; n++) {
+                    const double *src = forcing + (col * ntg + n_off + n) * n2;
+                    for (size_t i = 0; i < N; i++) {
+                        const size_t o = n * hstep + panel_index((int)i, (int)col, (int)PWc);
+                        f[o] = src[i]; f[o + 8] = src[N + i];
+                    }
+                }
+        // (on the library's stream: behind the history pass, which writes the guard forcing of the window into this buffer)
+        HIP_TRY(h, hipMemcpyAsync(k.forcing, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, k.stream));
+        HIP_TRY(h, hipStreamSynchronize(k.stream));         // (f is filled again for the next window)
+        h->forcing_zero = false;
+        if (r == W - 1) {
+            HIP_TRY(h, hipMemcpyAsync(k.lam + (nt - 1) * hstep, lamN.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+            K_TRY(h, qgdk_apply_LH(&k));
+        } else {
+            for (double *dst : {k.yhist + (nt - 1) * hstep, k.bndY + (size_t)k.scan_blocks * hstep, k.bndY2 + (size_t)k.scan_blocks2 * hstep})
+                HIP_TRY(h, hipMemcpyAsync(dst, h->carry_y, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+        }
+        if ((rc = adjoint_begin(h))) return rc;
+        { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
+        { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+        if ((rc = check_status(h))) return rc;
+        if (r == W - 1)      // lambda_N is the given one (not L_N^-H L_N^H of it)
+            HIP_TRY(h, hipMemcpyAsync(k.lam + (nt - 1) * hstep, lamN.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));
+        if ((rc = h->lambda_derivs ? window_lambda_full_out(h, lambda_history)
+                                   : window_panels_out(h, k.lam, &h->stage_lam, lambda_history, m + 1, 1))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->carry_y, k.yhist, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    return QGD_OK;
+}
+
 #define NEEDS_RESIDENT_GRID(h, what)                                                                                   \
     do { if ((h)->chunks_eff > 1) return fail((h), QGD_ERR_UNSUPPORTED, std::string(what) + " needs the whole time grid resident: this handle " \
                                                "processes it in " + std::to_string((h)->chunks_eff) + " windows (raise qgd_set_memory_budget)"); } while (0)
@@ -1969,7 +2031,7 @@ int qgd_eval_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, const dou
     NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: eval_adjoint is single-GPU");
-    NEEDS_RESIDENT_GRID(h, "eval_adjoint");
+    if (h->chunks_eff > 1) return chunked_eval_adjoint(h, pcof, n_pcof, terminal_condition, forcing, lambda_history);
     int rc = forward_begin(h, pcof, n_pcof);          // tables, L/R, inverses, propagators, block propagators
     if (rc) return rc;
     // the second scan level (super-block propagators) is produced by the forward boundary phase

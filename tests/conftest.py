@@ -36,3 +36,21 @@ def orc():
     o = import_oracle()
     o.lib()
     return o
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Handles the suite left open (the per-problem cache of evolution.device_problem, handles of failed tests) are closed
+    here, while the HIP runtime is certainly alive, instead of by finalizers at interpreter shutdown."""
+    import gc
+    mod = sys.modules.get("quantumgatedesign.jl_amd.evolution") or sys.modules.get("qgd_amd.evolution")
+    for m in list(sys.modules.values()):
+        if getattr(m, "__name__", "").endswith(".evolution") and hasattr(m, "clear_cache"):
+            mod = m
+    if mod is not None:
+        try:
+            mod.clear_cache()
+        except Exception:
+            pass
+    gc.collect()
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()

@@ -205,7 +205,7 @@ def test_bench_two_processes_share_the_gpu(shard):
     import json
     bench = os.path.join(ROOT, "bench.py")
     common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--nsteps", "120"]
-    env = dict(os.environ, MASTER_PORT="29631")
+    env = dict(os.environ, MASTER_PORT="29631", QGD_TINY="1")      # (conftest.py switches the small-problem path off for the suite; bench.py runs the library's defaults)
     one = subprocess.run([sys.executable, bench, "--gpus", "1", "--no-large-n"] + common, capture_output=True, text=True, timeout=600, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, bench, "--gpus", "2", "--comm", "torch", "--backend", "gloo", "--oversubscribe", "--shard", shard] + common,
@@ -225,6 +225,9 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert other["shard"] == ("columns" if shard == "time" else "time") and other["value"] > 0
     assert other["grad_rel_diff_vs_headline_split"] <= 1e-10
     assert j1["settled"] and j1["settled"]["ms_per_step"] > 0 and j1["cnot2"]["roofline"]["bound"] == "launch"
+    assert j1["cnot2"]["path"].startswith("small-problem") and j1["cnot2"]["general_path"]["max_rel_gradient_difference"] <= 1e-12
+    # the roofline object is about the dominant kernel of the evaluation (the inverse), whatever the first call's one-time costs were
+    assert j1["roofline"]["phase"] == "inverse" and j1["roofline"]["kernel"].startswith("k_inverse"), j1["roofline"]
 
 
 @pytest.mark.parametrize("shard", ["time", "columns"])

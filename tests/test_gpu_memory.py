@@ -101,9 +101,27 @@ def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
         assert np.abs(h_ref[:, 0, 1] - ref[0][:, 0, save]).max() <= 1e-11
     chk.set_save_every(1); dp.set_save_every(1)
     chk.close()
+    # eval_adjoint (forward_evolution.jl:300-315, :352-483) window by window: a given terminal condition and a given forcing,
+    # with and without the derivative columns -- equal to the resident call
+    rng = np.random.default_rng(7)
+    term = rng.standard_normal((shape[0], shape[3]))
+    forc = rng.standard_normal((shape[0], shape[2], shape[3])) * 0.1
+    chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl)
+    for derivs in (False, True):
+        chk.set_lambda_derivatives(derivs); dp.set_lambda_derivatives(derivs)
+        for fo in (None, forc):
+            l_ref = chk.eval_adjoint(pcof, term, fo)
+            l_win = dp.eval_adjoint(pcof, term, fo)
+            for j in range(shape[1]):
+                assert np.isfinite(l_win[:, j]).all() and np.abs(l_win[:, j] - l_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(l_ref[:, j]).max()), ("eval_adjoint", derivs, fo is None, j)
+            assert np.array_equal(l_win[:, 0, -1], term) and np.abs(l_win[:, :, 0]).max() == 0
+    chk.set_lambda_derivatives(False); dp.set_lambda_derivatives(False)
+    chk.close()
+    g, _ = dp.discrete_adjoint(pcof)                     # (the windows' buffers were reused: the next evaluation starts over)
+    assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
     # what still needs the grid resident says so
     with pytest.raises(qgd._lib.QGDError) as e:
-        dp.eval_adjoint(pcof, np.zeros((shape[0], shape[3])))
+        dp.eval_grad_forced(pcof)
     assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
     dp.close()
 
