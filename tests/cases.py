@@ -134,3 +134,32 @@ class PointwiseOnly:
     def eval_q_derivative(self, t, th, d): return self.inner.eval_q_derivative(t, th, d)
     def eval_grad_p_derivative(self, t, th, d): return self.inner.eval_grad_p_derivative(t, th, d)
     def eval_grad_q_derivative(self, t, th, d): return self.inner.eval_grad_q_derivative(t, th, d)
+
+
+def oracle_pins(orc, prob, ctrl, pcof, target, order, ref, tol=1e-10, budget=1.5e8):
+    """Ties a result of tests/proto_propagator.py (the numpy statement of the DEVICE algorithm, which a test compares the device
+    with at 1e-11 .. 1e-13) to the ORACLE (the reference's algorithm: GMRES per step, eval_grad_discrete_adjoint.jl) on the SAME
+    inputs, inside the same test: gradient and state history with its stage derivatives at `tol`.  Skipped (returns False) when
+    the oracle would take more than about ten seconds (N^2 * columns * steps * order^2 above `budget`)."""
+    import numpy as np
+    import proto_propagator as pp
+    N, c = prob.N_tot_levels, prob.N_initial_conditions
+    if float(N) * N * c * prob.nsteps * order * order > budget:
+        return False
+    import os
+    orc.set_num_threads(min(8, os.cpu_count() or 1)); orc.set_converged_terminal(True)
+    tols = (prob.gmres_abstol, prob.gmres_reltol)
+    prob.gmres_abstol = prob.gmres_reltol = 1e-15      # (the oracle's step solves run to convergence: the device inverts L_n directly)
+    try:
+        g, h = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)[:2]
+    finally:
+        orc.set_converged_terminal(False); orc.set_num_threads(1)
+        prob.gmres_abstol, prob.gmres_reltol = tols
+    assert np.abs(ref["grad"] - g).max() <= tol * np.abs(g).max(), "numpy statement vs oracle: gradient"
+    # States at 1e-11.  Their stage derivatives w_j = (1/j) sum_i A_{j-1-i} w_i are a fixed linear map of the state of the
+    # same time point whose norm grows like |A dt|^j / j!: a 2e-13 difference of two correctly rounded states is 1e-10 in w_6
+    # of cnot3 at dt = 1 (measured, with the gradients of the two agreeing to 3e-15) -- hence the looser bound there.
+    hs = pp.history_real(ref["ws"])
+    assert np.abs(hs[:, 0] - h[:, 0]).max() <= 0.1 * tol * max(1.0, np.abs(h[:, 0]).max()), "numpy statement vs oracle: states"
+    assert np.abs(hs - h).max() <= 10 * tol * max(1.0, np.abs(h).max()), "numpy statement vs oracle: stage derivatives"
+    return True

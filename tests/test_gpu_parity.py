@@ -54,7 +54,7 @@ def test_apply_hamiltonian(qgd, orc, which):
 
 @pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 6), ("cnot3", 2), ("cnot3", 4),
                                          ("cnot3", 6), ("cnot3", 8), ("cnot3", 10), ("cnot3", 12)])
-def test_stage_matrices(qgd, which, order):
+def test_stage_matrices(qgd, orc, which, order):
     """L(t_n), R(t_n), L^-1, P_n on the device vs the numpy statement of the same algorithm."""
     prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
     m = order // 2
@@ -63,6 +63,7 @@ def test_stage_matrices(qgd, which, order):
     dp.eval_forward(pcof)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, m)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     L, R, Li, P = (dp.intermediate(k) for k in ("L", "R", "Linv", "P"))
     assert np.abs(L - ref["L"]).max() < 1e-13
     assert np.abs(R - ref["R"]).max() < 1e-13
@@ -237,7 +238,7 @@ def test_graph_replay_matches_plain_launches(qgd, which, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["QGD_ELL_ROW_PACKED", "QGD_BUILD_ELL_NARROW"])
-def test_sparse_kernel_comparison_paths(qgd, switch, monkeypatch):
+def test_sparse_kernel_comparison_paths(qgd, orc, switch, monkeypatch):
     """The alternatives kept beside the default sparse kernels -- row-packed ELL slots instead of diagonal-ordered
     ones, 16-column build workgroups instead of 32-column ones -- give the same gradient (cnot3 order 8, guarded
     two-qutrit problem order 6) as the numpy statement of the algorithm."""
@@ -247,6 +248,7 @@ def test_sparse_kernel_comparison_paths(qgd, switch, monkeypatch):
         prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
         Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
         ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+        cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         assert dp.operator_path()[0] == "sparse"
         grad, _ = dp.discrete_adjoint(pcof)
@@ -256,7 +258,7 @@ def test_sparse_kernel_comparison_paths(qgd, switch, monkeypatch):
 
 
 @pytest.mark.parametrize("n_basis,force_copy", [(10, True), (300, False)])
-def test_pcof_upload_paths(qgd, n_basis, force_copy, monkeypatch):
+def test_pcof_upload_paths(qgd, orc, n_basis, force_copy, monkeypatch):
     """pcof travels in the kernel arguments of k_tables when it fits (<= 448 coefficients) and through a device
     copy otherwise (here 2 x 600) or with QGD_PCOF_COPY=1: both against the numpy statement of the algorithm."""
     if force_copy:
@@ -269,9 +271,11 @@ def test_pcof_upload_paths(qgd, n_basis, force_copy, monkeypatch):
     order = 6
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
     for scale in (1.0, 0.5):            # two different vectors through the same handle
         ref = pp.evaluate(prob, Gp, Gq, off, scale * pcof, target, order)
+        cases.oracle_pins(orc, prob, ctrl, scale * pcof, target, order, ref)
         grad, _ = dp.discrete_adjoint(scale * pcof)
         assert np.abs(grad - ref["grad"]).max() <= 1e-11 * np.abs(ref["grad"]).max()
     dp.close()
@@ -299,13 +303,14 @@ def test_time_partitioned_large_n(qgd, world):
 
 
 @pytest.mark.parametrize("order", [2, 4, 6, 10, 12])
-def test_cnot3_gradient_all_orders(qgd, order):
+def test_cnot3_gradient_all_orders(qgd, orc, order):
     """Every instantiation of the N=64 fast-path kernels (fused L/R build and fused gradient kernel
     for orders 2..10, generic kernels at order 12) against the numpy statement of the algorithm,
     which tests/test_oracle.py ties to the reference-structured oracle."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=30, tf=15.0)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     shape = (128, 1 + order // 2, 31, 8)
     hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((128, 31, 8), order="F")
     grad = np.zeros(len(pcof))
@@ -420,7 +425,7 @@ def test_lambda_history_derivative_columns_cnot3(qgd, orc):
 
 
 @pytest.mark.parametrize("older_kernels", [False, True])
-def test_large_n_fallback_paths(qgd, older_kernels, monkeypatch):
+def test_large_n_fallback_paths(qgd, orc, older_kernels, monkeypatch):
     """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12 -- vs the numpy statement
     of the algorithm.  older_kernels: QGD_DENSE_OLD=1 keeps the pre-GEMM large-N kernels (assembled-at-use
     recursion, panel slabs in HBM, generic chain) alive as a comparison path."""
@@ -432,6 +437,7 @@ def test_large_n_fallback_paths(qgd, older_kernels, monkeypatch):
     order = 12
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     shape = (200, 7, 25, 20)
     hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((200, 25, 20), order="F")
     grad = np.zeros(len(pcof))
@@ -442,7 +448,7 @@ def test_large_n_fallback_paths(qgd, older_kernels, monkeypatch):
 
 
 @pytest.mark.parametrize("c", [8, 16, 32])
-def test_large_n_gemm_kernels(qgd, c):
+def test_large_n_gemm_kernels(qgd, orc, c):
     """N=100 (padded to 112: partial row tiles) with 8, 16 and 32 columns: the three tile shapes of the
     GEMM-style large-N kernels of qgd_k_dense.hip (<4,1>, <4,2>, <2,4>: fragment-ordered A_d / D_j,
     w_j = D_j w_0, level-by-level reverse sweep), order 12 and order 4, against the numpy statement."""
@@ -450,6 +456,7 @@ def test_large_n_gemm_kernels(qgd, c):
         prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=100, c=c, nsteps=nsteps, tf=0.3)
         Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
         ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+        cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
         dp = qgd.DeviceProblem(prob, order)
         dp.set_controls(ctrl); dp.set_target(target)
         grad, _ = dp.discrete_adjoint(pcof)
@@ -462,13 +469,14 @@ def test_large_n_gemm_kernels(qgd, c):
 
 @pytest.mark.parametrize("N,c,order,n_ops,nsteps", [(65, 1, 2, 2, 9), (72, 9, 4, 1, 13), (96, 40, 6, 3, 11), (130, 17, 16, 2, 5),
                                                   (200, 3, 2, 5, 7), (113, 24, 8, 3, 30), (255, 5, 4, 3, 6), (290, 12, 6, 2, 5)])
-def test_large_n_shape_sweep(qgd, N, c, order, n_ops, nsteps):
+def test_large_n_shape_sweep(qgd, orc, N, c, order, n_ops, nsteps):
     """Odd sizes for the N > 64 kernels: partial row tiles and column groups, 1..40 columns, orders 2..16, 1..5
     control operators, N above the 288 limit of the blocked inverse / LDS chain -- history and gradient against
     the numpy statement of the algorithm (scripts/shape_sweep.py prints the errors: 1e-15 / 1e-13)."""
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=nsteps, tf=0.02 * nsteps, seed=N + c)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
     grad, _ = dp.discrete_adjoint(pcof)
     hist = np.zeros((2 * N, order // 2 + 1, nsteps + 1, c), order="F")
@@ -549,13 +557,14 @@ def test_error_behaviour_on_device(qgd):
 
 @pytest.mark.parametrize("which,order", [("cnot3", 2), ("cnot3", 4), ("cnot3", 8), ("cnot3", 10), ("cnot3", 12),
                                          ("cnot3", 14), ("cnot3", 16), ("cnot2", 6), ("guarded", 8)])
-def test_sparse_and_dense_operator_paths_agree(qgd, which, order):
+def test_sparse_and_dense_operator_paths_agree(qgd, orc, which, order):
     """The ELL (sparse-operator) kernels and the dense fp64 MFMA kernels build the same L_n, R_n and
     the same gradient, and both match the numpy statement of the algorithm."""
     kw = dict(nsteps=24, tf=12.0) if which == "cnot3" else {}
     prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, **kw)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     out = {}
     for path in ("sparse", "dense"):
         dp = qgd.DeviceProblem(prob, order)
@@ -595,13 +604,14 @@ def test_operator_path_selection(qgd):
 
 
 @pytest.mark.parametrize("N,c,order", [(20, 4, 6), (40, 12, 4), (64, 8, 8)])
-def test_mid_size_dense_problems(qgd, N, c, order):
+def test_mid_size_dense_problems(qgd, orc, N, c, order):
     """Random dense problems padded to 32, 48 and 64 rows: the register-blocked inverses, the
     team-pipelined sweeps at every compiled size and the dense MFMA operator kernels, against the
     numpy statement of the algorithm."""
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=70, tf=0.7)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     shape = (2 * N, 1 + order // 2, prob.nsteps + 1, c)
     hist = np.zeros(shape, order="F"); lam = np.zeros(shape, order="F"); forcing = np.zeros((2 * N, prob.nsteps + 1, c), order="F")
     grad = np.zeros(len(pcof))
@@ -766,7 +776,7 @@ def test_dahlquist_and_rotating_frame_on_device(qgd):
     qgd.clear_cache()
 
 
-def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
+def test_static_pivot_inverse_and_its_fallback(qgd, orc, monkeypatch):
     """The comparison paths of the N=64 inverse and of the launch order (none is the default: DESIGN.md section 7 has the
     measurements).  k_inverse_multi (QGD_INV_STATIC=1) tries the diagonal as pivot first (L(t_n) of the dispersive models
     is strongly diagonally dominant) and redoes a matrix with partial pivoting when a multiplier exceeds 8.  cnot3: no
@@ -802,6 +812,7 @@ def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
     prob.system_sym = np.asfortranarray(H + 0.1 * prob.system_sym)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, 0.1 * pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, 0.1 * pcof, target, order, ref)
     monkeypatch.setenv("QGD_INV_STATIC", "1")
     dp = qgd.DeviceProblem(prob, order)
     dp.set_controls(ctrl); dp.set_target(target)
@@ -812,7 +823,7 @@ def test_static_pivot_inverse_and_its_fallback(qgd, monkeypatch):
 
 
 @pytest.mark.parametrize("c", [20, 64])
-def test_cnot3_many_columns(qgd, c):
+def test_cnot3_many_columns(qgd, orc, c):
     """The sparse N=64 path with more initial conditions than one MFMA tile (the whole 64-dimensional basis, and a
     ragged 20): several column groups per time point in the sweeps, the gradient scalars summed over groups."""
     prob, ctrl, pcof, _ = cases.cnot3_case(qgd, nsteps=30, tf=30.0)
@@ -823,6 +834,7 @@ def test_cnot3_many_columns(qgd, c):
     order = 8
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     dp = qgd.DeviceProblem(prob, order)
     dp.set_controls(ctrl); dp.set_target(target)
     assert dp.operator_path()[0] == "sparse"
@@ -973,7 +985,7 @@ def test_nonlinear_controls_general_path(qgd, order):
     qgd.clear_cache()
 
 
-def test_long_grid_vs_statement(qgd):
+def test_long_grid_vs_statement(qgd, orc):
     """cnot3 on a grid eight times the headline's (4400 steps at dt = 1: scan blocks of 69 steps, the inverse at 17
     matrices per CU) against the numpy statement of the algorithm: state history, infidelity, guard penalty, gradient."""
     nsteps = 4400
@@ -984,6 +996,7 @@ def test_long_grid_vs_statement(qgd):
     order = 8
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
     dp = qgd.device_problem(prob, order)
     dp.set_controls(ctrl); dp.set_target(target)
     hist = np.zeros((128, 5, nsteps + 1, 8), order="F")
