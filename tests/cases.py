@@ -153,7 +153,7 @@ def oracle_pins(orc, prob, ctrl, pcof, target, order, ref, tol=1e-10, budget=1.5
     try:
         g, h = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order, return_all=True)[:2]
     finally:
-        orc.set_converged_terminal(False); orc.set_num_threads(1)
+        orc.set_converged_terminal(False); orc.set_num_threads(0)      # (0: the default, one thread per column up to the cores)
         prob.gmres_abstol, prob.gmres_reltol = tols
     assert np.abs(ref["grad"] - g).max() <= tol * np.abs(g).max(), "numpy statement vs oracle: gradient"
     # States at 1e-11.  Their stage derivatives w_j = (1/j) sum_i A_{j-1-i} w_i are a fixed linear map of the state of the
