@@ -146,3 +146,29 @@ def test_what_the_single_kernel_path_leaves_to_the_general_one(qgd):
     ga, _ = gen.discrete_adjoint(pcof); gb, _ = tiny.discrete_adjoint(pcof)
     assert not _selected(tiny) and np.array_equal(ga, gb)
     gen.close(); tiny.close()
+
+
+@pytest.mark.parametrize("nsteps,taken", [(1, False), (2, True), (3, True), (4, True), (7, True), (127, True), (128, False)])
+def test_grid_limits(qgd, orc, nsteps, taken):
+    """The shortest grids the scan takes (3 time points: one step on either side of the middle one), odd lengths that leave
+    its last block short, the longest one (128 time points = 512 threads for 4 columns), and the lengths on either side that
+    go to the general path: against the general path (1e-12) and, below 10 steps, against the oracle (1e-10); after
+    qgd_set_nsteps on the same handle too."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=nsteps, tf=0.5 * nsteps, amp=2e-2)
+    order = 6
+    gen, tiny = _handles(qgd, prob, order, ctrl, target)
+    g0, o0 = gen.discrete_adjoint(pcof)
+    g1, o1 = tiny.discrete_adjoint(pcof)
+    assert _selected(tiny) == taken, nsteps
+    assert np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
+    assert np.abs(np.asarray(o1) - np.asarray(o0)).max() <= 1e-12
+    f1 = tiny.eval_forward(pcof)
+    assert np.abs(np.asarray(f1) - np.asarray(o0)).max() <= 1e-12
+    if nsteps < 10:
+        orc.set_converged_terminal(True)
+        try:
+            g_ref = orc.discrete_adjoint(prob, ctrl, pcof, target, order=order)
+        finally:
+            orc.set_converged_terminal(False)
+        assert np.abs(g1 - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
+    gen.close(); tiny.close()
