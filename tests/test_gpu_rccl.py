@@ -1,8 +1,10 @@
 """GPU tests of the multi-GPU path BEHIND the C ABI: after qgd_comm_init_rccl the library itself issues the RCCL
 collectives of a partitioned evaluation (include/qgd.h, "several GPUs behind ONE call").  The test box has one GPU, so
 the communicator has one rank -- every collective is still an RCCL call on the handle's stream -- and the result must
-equal the unpartitioned evaluation.  (Worlds of 2-8 ranks are covered through the phase hooks the protocol is made
-of: test_time_partitioned_matches_single_gpu, test_bench_two_processes_share_the_gpu, tests/test_distributed_cpu.py.)
+equal the unpartitioned evaluation.  Worlds of 2 and 3 ranks run the SAME library path as one process per rank with the
+transport replaced by tests/fake_rccl (test_library_protocol_between_processes, test_failure_on_one_rank_ends_every_rank);
+worlds of 2-8 ranks are also covered through the phase hooks the protocol is made of
+(test_time_partitioned_matches_single_gpu, test_bench_two_processes_share_the_gpu, tests/test_distributed_cpu.py).
 """
 import numpy as np
 import pytest
@@ -149,3 +151,73 @@ def test_rccl_handle_never_walks_windows(qgd):
     g, _ = dp.discrete_adjoint(pcof)
     assert np.abs(g - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
     dp.close()
+
+
+def _fake_transport(tmp_path):
+    """tests/fake_rccl/fake_rccl.cpp compiled into the test's directory: the seven nccl* entry points the library binds, carried
+    over shared memory between processes that share the one GPU of the box (RCCL itself refuses two ranks on one device)."""
+    import os, shutil, subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "fake_rccl.cpp")
+    out = str(tmp_path / "libfake_rccl.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src, "-lrt"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def _run_ranks(tmp_path, lib, case, shard, world, fail_at=0):
+    import os, subprocess, sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_rank_worker.py")
+    env = dict(os.environ, QGD_RCCL_LIB=lib, FAKE_RCCL_TIMEOUT_MS="60000" if not fail_at else "15000")
+    procs = [subprocess.Popen([sys.executable, worker, case, shard, str(r), str(world), str(tmp_path)] + ([str(fail_at)] if fail_at else []),
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.parametrize("case,shard,world", [("cnot3", "time", 2), ("cnot3", "columns", 2), ("cnot3", "time", 3), ("guarded", "columns", 3),
+                                              ("dense", "time", 2), ("dense", "columns", 2)])
+def test_library_protocol_between_processes(qgd, tmp_path, case, shard, world):
+    """World sizes above one through the library's OWN communicator path (comm_discrete_adjoint / comm_eval_forward in
+    csrc/qgd_api.cpp: the in-place all-gathers at the rank's offset, the out-of-place reduction of [grad | scalars], the
+    terminal condition deferred into the last rank's first adjoint launch, the zeroed scalars of column ranks other than 0,
+    history_precomputed across ranks, the rank's share of the three output arrays), one PROCESS per rank on the one GPU of
+    the box, with the transport replaced by tests/fake_rccl (shared memory; QGD_RCCL_LIB): every rank must return the
+    single-GPU gradient and scalars to 1e-12, and all ranks the same bits."""
+    import rccl_rank_worker as w
+    prob, ctrl, pcof, target, order = w.problem(qgd, case)
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    shape = (prob.real_system_size, 1 + order // 2, 1 + prob.nsteps, prob.N_initial_conditions)
+    arrays = [np.zeros(shape, order="F"), np.zeros(shape, order="F"), np.zeros((shape[0], shape[2], shape[3]), order="F")]
+    g, o = dp.discrete_adjoint(pcof, False, *arrays)
+    f = dp.eval_forward(pcof)
+    g_half, o_half = dp.discrete_adjoint(0.5 * pcof)
+    dp.close()
+    np.savez(tmp_path / "ref.npz", g=g, o=np.asarray(o), f=np.asarray(f), hist=arrays[0], lam=arrays[1], forc=arrays[2])
+    lib = _fake_transport(tmp_path)
+    codes, outs = _run_ranks(tmp_path, lib, case, shard, world)
+    assert codes == [0] * world, "\n".join(x[-1500:] for x in outs)
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(1, world):
+        for key in res[0].files:
+            assert np.array_equal(res[r][key], res[0][key]), (r, key)
+    assert np.abs(res[0]["g_half"] - g_half).max() <= 1e-12 * np.abs(g_half).max()
+    assert np.abs(res[0]["o_half"] - np.asarray(o_half)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o_half)).max())
+
+
+@pytest.mark.parametrize("shard,fail_at", [("time", 1), ("time", 2), ("time", 3), ("columns", 4), ("columns", 3)])
+def test_failure_on_one_rank_ends_every_rank(qgd, tmp_path, shard, fail_at):
+    """The failure mode between processes: the last of two ranks fails locally in front of one of the exchanges
+    (qgd_comm_debug_fail_at).  It aborts its communicator and returns QGD_ERR_COMM; the other rank, already waiting in the
+    collective, is released by the abort and returns QGD_ERR_COMM as well -- nobody hangs (exit code 7 from both)."""
+    lib = _fake_transport(tmp_path)
+    codes, outs = _run_ranks(tmp_path, lib, "cnot3", shard, 2, fail_at=fail_at)
+    assert codes == [7, 7], "\n".join(x[-1500:] for x in outs)
