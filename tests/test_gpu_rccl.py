@@ -221,3 +221,31 @@ def test_failure_on_one_rank_ends_every_rank(qgd, tmp_path, shard, fail_at):
     lib = _fake_transport(tmp_path)
     codes, outs = _run_ranks(tmp_path, lib, "cnot3", shard, 2, fail_at=fail_at)
     assert codes == [7, 7], "\n".join(x[-1500:] for x in outs)
+
+
+def test_bench_default_multi_gpu_flow_between_processes(tmp_path):
+    """`python bench.py --gpus 2` as the driver's scaling run launches it (torch.distributed.run, one process per rank,
+    `--comm lib`: the collectives inside the library) on the one GPU of the box (`--oversubscribe`), the transport replaced by
+    tests/fake_rccl: the headline split, the other split in the same line, the weak-in-time figure and the partitioned
+    config 5 all complete, and the partitioned gradients equal the single-GPU ones."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _fake_transport(tmp_path)
+    env = dict(os.environ, QGD_RCCL_LIB=lib, MASTER_PORT="29657", QGD_TINY="1")
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--nsteps", "120"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-large-n"] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["value"] > 0
+    assert abs(j2["grad_norm"] - j1["grad_norm"]) <= 1e-11 * j1["grad_norm"] and abs(j2["infidelity"] - j1["infidelity"]) <= 1e-12
+    assert set(j2["collectives_ms"]) >= {"comm_gather_fwd", "comm_gather_adj", "comm_reduce"}, j2["collectives_ms"]
+    other = j2["north_star_split"]
+    assert other and "error" not in other and other["shard"] == "columns" and other["grad_rel_diff_vs_headline_split"] <= 1e-10, other
+    assert set(other["collectives_ms"]) >= {"comm_reduce_scal", "comm_reduce"}
+    assert j2["weak_in_time"] and "error" not in j2["weak_in_time"], j2["weak_in_time"]
+    assert "error" not in j2["large_n"] and j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10, j2["large_n"]
