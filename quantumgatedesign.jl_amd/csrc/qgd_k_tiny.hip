@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64) void k_tiny_front(const TinyArgs a, const TinyP
                 const double mg = Ar[r][p] * Ar[r][p] + Ai[r][p] * Ai[r][p];
                 if (mg > best) { best = mg; piv = r; }
             }
-            if (!(best > 0.0)) { a.status[0] = 1; best = 1.0; }
+            if (best == 0.0) { a.status[0] = 1; best = 1.0; }      // (an exactly singular pivot column; NaN coefficients propagate as on the general path and in the reference)
             #pragma unroll
             for (int r = p + 1; r < 4; r++) {
                 const bool sw = (r == piv);

@@ -172,3 +172,16 @@ def test_grid_limits(qgd, orc, nsteps, taken):
             orc.set_converged_terminal(False)
         assert np.abs(g1 - g_ref).max() <= 1e-10 * np.abs(g_ref).max()
     gen.close(); tiny.close()
+
+
+def test_nan_coefficients_propagate_like_the_general_path(qgd):
+    """A NaN control coefficient (an optimizer probing outside its trust region) gives NaN results and NO error on both paths --
+    what the reference's GMRES does with it -- and leaves the handle usable."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=40, tf=40.0)
+    bad = pcof.copy(); bad[3] = np.nan
+    for dp in _handles(qgd, prob, 8, ctrl, target):
+        g, o = dp.discrete_adjoint(bad)
+        assert not np.isfinite(g).all() and not np.isfinite(o[0])
+        g, o = dp.discrete_adjoint(pcof)
+        assert np.isfinite(g).all() and np.isfinite(np.asarray(o)).all()
+        dp.close()
