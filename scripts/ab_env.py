@@ -1,5 +1,5 @@
 """A/B of an environment switch on the cnot3 headline evaluation, both variants in ONE process on the same box, interleaved:
-    python3 scripts/ab_env.py QGD_AS_GLOBAL
+    python3 scripts/ab_env.py QGD_AS_GLOBAL          (or VAR=value, e.g. QGD_LIB_PATH=scripts/ubench/bin/libqgd_x.so)
 Each variant: its own handle (the switch is read when the library first needs it, so the variants run in child processes),
 60 untimed evaluations, then the median of 300 timed ones; the gradient of the two variants is compared bit for bit."""
 import os, subprocess, sys, json
@@ -25,12 +25,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     print(json.dumps({"median_us": float(np.median(ts) * 1e6), "min_us": float(np.min(ts) * 1e6), "sha": hashlib.sha1(g.tobytes()).hexdigest()[:12],
                       "phases_us": {k: round(v, 1) for k, v in acc.items()}}))
     sys.exit(0)
-var = sys.argv[1]
+var, _, val = sys.argv[1].partition("=")      # VAR (on = "1") or VAR=value
 for rep in range(2):
     for on in (False, True):
         env = dict(os.environ)
         env.pop(var, None)
-        if on: env[var] = "1"
+        if on: env[var] = val or "1"
         out = subprocess.run([sys.executable, __file__, "--child", var], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         print(var, "on " if on else "off", line[-1] if line else out.stderr[-500:], flush=True)
