@@ -319,4 +319,16 @@ function time_window(dp::DeviceProblem)
     return Int(out[1]), Int(out[2])
 end
 
+"Bound (milliseconds, default 30 000) on the host wait of a collective evaluation: past it the communicator is aborted
+and the call throws with QGD_ERR_COMM instead of waiting for a rank that failed (qgd_set_comm_timeout)."
+function comm_timeout!(dp::DeviceProblem, milliseconds::Real)
+    check(dp.handle, ccall((:qgd_set_comm_timeout, libqgd), Cint, (Ptr{Cvoid}, Float64), dp.handle, milliseconds))
+end
+
+"Problems with N <= 4 levels, <= 4 initial conditions and <= 128 time points (the Rabi oscillator, the two-qubit CNOT) are
+evaluated by a four-launch path of their own (qgd_set_small_path); `on = false` keeps this handle on the general kernels."
+function small_path!(dp::DeviceProblem, on::Bool)
+    check(dp.handle, ccall((:qgd_set_small_path, libqgd), Cint, (Ptr{Cvoid}, Int32), dp.handle, on ? 1 : 0))
+end
+
 end # module
