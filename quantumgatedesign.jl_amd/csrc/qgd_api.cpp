@@ -2418,12 +2418,12 @@ int qgd_register_host_buffer(qgd_handle h, void *ptr, size_t bytes)
     if (!h || !ptr || !bytes) return fail(h, QGD_ERR_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     if (find_reg(h, ptr, bytes)) return QGD_OK;
-    // The host has several NUMA nodes and the process may run on one the card is not attached to: pages of the caller's
-    // array then sit across the socket link and the copy engine writes them at 11 GB/s instead of 56 (bench.py's
-    // with_history: 2.7-2.9 ms instead of 0.89 on such boxes).  Before the pages are pinned they are moved (and the
-    // untouched ones steered) to the card's node: mbind(MPOL_PREFERRED, MPOL_MF_MOVE) on the page-aligned interior of
-    // the array.  QGD_PIN_NUMA=0 leaves the pages where they are.
-    if (!(getenv("QGD_PIN_NUMA") && atoi(getenv("QGD_PIN_NUMA")) == 0)) {
+    // QGD_PIN_NUMA=1 (off by default): before the pages of the caller's array are pinned they are moved (and the untouched
+    // ones steered) to the NUMA node the card is attached to -- mbind(MPOL_PREFERRED, MPOL_MF_MOVE) on the page-aligned
+    // interior of the array -- for hosts whose cross-socket DMA is slow.  On the two-socket MI355X hosts of this pool it makes
+    // no difference (0.88 ms for the 31.6 MB of the reference-shaped call with the arrays on either node,
+    // scripts/numa_pin_check.py), hence opt-in.
+    if (getenv("QGD_PIN_NUMA") && atoi(getenv("QGD_PIN_NUMA")) == 1) {
         const int node = gpu_numa_node(h->device);
         const uintptr_t lo = ((uintptr_t)ptr + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)ptr + bytes) & ~(uintptr_t)4095;
         if (node >= 0 && node < 64 && hi > lo) {

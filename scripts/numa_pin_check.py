@@ -1,6 +1,6 @@
 """Reproduces the slow box on any box: the process's memory policy is bound to the NUMA node the card is NOT attached to
 (set_mempolicy), the three output arrays of the reference-shaped call are created there, pinned, and the call is timed -- with
-the library moving the pages to the card's node at registration (default) and without (QGD_PIN_NUMA=0)."""
+the library moving the pages to the card's node at registration (QGD_PIN_NUMA=1) and without (default)."""
 import os, sys, time, json, subprocess, ctypes, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -42,7 +42,7 @@ node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
 nn = len(glob.glob("/sys/devices/system/node/node[0-9]*"))
 print(f"card {bdf} on NUMA node {node} of {nn}", flush=True)
 far = (node + 1) % nn if nn > 1 and node >= 0 else -1
-for f, env in ((-1, None), (far, "0"), (far, None), (far, "0"), (far, None)):
+for f, env in ((-1, None), (far, None), (far, "1"), (far, None), (far, "1")):
     e = dict(os.environ); e.pop("QGD_PIN_NUMA", None)
     if env is not None: e["QGD_PIN_NUMA"] = env
     out = subprocess.run([sys.executable, __file__, "--child", str(f)], env=e, capture_output=True, text=True)

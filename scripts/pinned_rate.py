@@ -1,6 +1,7 @@
 """The reference-shaped call (three output arrays, 31.6 MB) into arrays pinned in different ways, on THIS box:
-numpy arrays registered as they are (hipHostRegister: what INTEGRATION.md's shim does), the same with transparent huge pages
-requested first (QGD_PIN_HUGEPAGE=1), pageable arrays, and arrays touched before they are pinned.  Prints the box's THP setting."""
+numpy arrays registered as they are (hipHostRegister: what INTEGRATION.md's shim does), the same over one DMA engine
+(QGD_COPY_SPLIT=0), and pageable arrays; the raw D2H / H2D rates into runtime-allocated and into registered memory; the box's
+NUMA layout and THP setting."""
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
