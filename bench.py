@@ -517,26 +517,25 @@ def main():
     def settle():
         gc.collect()
 
-    # The W warm-up steps.  The first two have every phase bracketed by HIP events: the first pays the one-time launch costs,
-    # the second names the dominant phase (the only thing the timed region needs to know: which launch gets the live event
-    # pair); the other W-2 are the plain evaluation, exactly what the timed steps are.  The per-phase breakdown of the JSON line
-    # (`phases_ms_all_events`: all 13 phases bracketed, ~0.17 ms of event records per evaluation) is taken AFTER the timed
-    # region -- round 3 took it from the warm-up steps, which made them 1.5x as long as a timed step and mostly idle.
+    # The W warm-up steps.  The first one has every phase bracketed by HIP events (it pays the one-time launch costs anyway):
+    # it tells which phases exist on this path; the other W-1 are the plain evaluation, exactly what the timed steps are.
+    # Which launch gets the live event pair of the timed region: the inverse where the path has one (the dominant kernel of
+    # every configuration measured so far) -- NOT the largest phase of this first evaluation, whose build phase also loads
+    # code objects (0.4 ms) -- else the largest; the choice is checked against the per-phase breakdown taken AFTER the timed
+    # region (`phases_ms_all_events`: all 13 phases bracketed, ~0.17 ms of event records per evaluation; round 3 took it from
+    # the warm-up steps, which made them 1.5x as long as a timed step and mostly idle) and the line says so
+    # (`roofline.dominant_confirmed`).
     merge = (("sweep_forward2", "sweep_forward"), ("sweep_adjoint2", "sweep_adjoint"))
     dp.set_timing(1)
     dp.discrete_adjoint(pcof)
     first = dp.timings()
     nbr = 1
-    if args.warmup >= 2:      # the very first evaluation also loads code objects (its build phase took 0.4 ms): the second one names the dominant phase
-        dp.discrete_adjoint(pcof)
-        first = dp.timings()
-        nbr = 2
     dp.set_timing(0)
     inner = getattr(dp, "dp", dp)
     path = inner.operator_path() if hasattr(inner, "operator_path") else ("sparse", 0, 0)
     model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1,
                         sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in first))
-    dom_raw = max((k for k in first if k in model), key=first.get)
+    dom_raw = "inverse" if ("inverse" in first and "inverse" in model) else max((k for k in first if k in model), key=first.get)
     for _ in range(max(args.warmup, 1) - nbr + args.run_in):
         dp.discrete_adjoint(pcof)
     phase_ms = {}
@@ -792,6 +791,8 @@ def main():
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work,
+                         # (single-launch phases only: the sweeps are several launches each)
+                         "dominant_confirmed": bool(max((k for k in breakdown if k in model and not k.startswith("sweep")), key=breakdown.get, default=dom) == dom),
                          "history_stream": {"bound": "hbm", "bytes_per_timestep": b_step, "achieved": hs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                             "frac": hs / PEAK_HBM_GBS, "note": "SURVEY 8(d) B_step * nsteps / T_eval: the algorithm's history stream "
                                                                                "(write once, read once) against HBM; the evaluation is latency-bound, not stream-bound"},

@@ -227,7 +227,7 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert j1["settled"] and j1["settled"]["ms_per_step"] > 0 and j1["cnot2"]["roofline"]["bound"] == "launch"
     assert j1["cnot2"]["path"].startswith("small-problem") and j1["cnot2"]["general_path"]["max_rel_gradient_difference"] <= 1e-12
     # the roofline object is about the dominant kernel of the evaluation (the inverse), whatever the first call's one-time costs were
-    assert j1["roofline"]["phase"] == "inverse" and j1["roofline"]["kernel"].startswith("k_inverse"), j1["roofline"]
+    assert j1["roofline"]["phase"] == "inverse" and j1["roofline"]["kernel"].startswith("k_inverse") and j1["roofline"]["dominant_confirmed"], j1["roofline"]
 
 
 @pytest.mark.parametrize("shard", ["time", "columns"])
