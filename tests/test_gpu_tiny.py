@@ -185,3 +185,24 @@ def test_nan_coefficients_propagate_like_the_general_path(qgd):
         g, o = dp.discrete_adjoint(pcof)
         assert np.isfinite(g).all() and np.isfinite(np.asarray(o)).all()
         dp.close()
+
+
+def test_results_by_copy_equal_results_by_mirror(qgd, monkeypatch):
+    """QGD_RESULT_MIRROR=0 (read when the handle is created: results by a device-to-host copy + stream synchronisation instead of
+    the host-memory mirror the last kernel writes): the same bits, gradient evaluations and forward-only ones, changing pcof."""
+    prob, ctrl, pcof, target = cases.cnot2_case(qgd, nsteps=60, tf=60.0)
+    res = {}
+    for label in ("mirror", "copy"):
+        if label == "copy":
+            monkeypatch.setenv("QGD_RESULT_MIRROR", "0")
+        dp = qgd.DeviceProblem(prob, 8)
+        monkeypatch.delenv("QGD_RESULT_MIRROR", raising=False)
+        dp.set_small_path(True); dp.set_controls(ctrl); dp.set_target(target)
+        out = []
+        for s in (1.0, 0.5, 1.0):
+            g, o = dp.discrete_adjoint(s * pcof)
+            assert _selected(dp)
+            out += [g, np.asarray(o), np.asarray(dp.eval_forward(s * pcof))]
+        res[label] = out
+        dp.close()
+    assert all(np.array_equal(a, b) for a, b in zip(res["mirror"], res["copy"]))
