@@ -138,6 +138,7 @@ struct qgd_handle_s {
     int resident_window = 0;            // whose step matrices are in the buffers right now
     double *chunk_state = nullptr;      // [chunks_eff + 1][Np][2cp]: the state at the start of every window (+ the final state)
     double *carry_y = nullptr;          // y at the end of the window the adjoint pass does next
+    std::vector<double> tab_p_host, tab_q_host;      // qgd_set_control_tables on a windowed grid: the caller's tables for the WHOLE grid
     double *scal_scratch = nullptr;     // where a re-run of a window's forward sweep puts its guard sum (already counted)
     int save_every = 1;                 // qgd_set_save_every: uv_history of qgd_eval_forward holds every save_every-th time point
     double *redglob = nullptr;          // [n_pcof + 8] time shards: the reductions are out of place (send = the rank's own
@@ -428,6 +429,7 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipMemcpyAsync(k.cw, k.cw_host, sizeof(double) * 2 * (k.m + 1), hipMemcpyHostToDevice, k.stream));
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     h->have_basis = h->have_tables = h->forward_valid = h->derivs_valid = false;
+    h->tab_p_host.clear(); h->tab_q_host.clear();
     free_pool(h->basis_bufs);
     k.scal = h->scal_static; k.grad = nullptr; k.redbuf = nullptr; if (h->status_static) k.status = h->status_static;
     h->grid_ready = true;
@@ -643,7 +645,7 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
         return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
     }
     if (!pcof) {   // (with pcof, k_tables clears them)
-        HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));
+        if (!k.keep_scal) HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));      // (a later window of a long grid keeps the running guard sum)
         HIP_TRY(h, hipMemsetAsync(k.status, 0, 2 * sizeof(int), k.stream));
     }
     const int C = std::min<int>(h->pipe_chunks, qgd_handle_s::MAX_CHUNKS);
@@ -835,11 +837,30 @@ int window_panels_out(qgd_handle h, const double *panels, double **stage, double
     return finish_copies(h);
 }
 
+// qgd_set_control_tables on a windowed grid: the window's slice of the caller's tables goes to the device before the
+// window's matrices are built (with pcof the tables kernel forms them from the basis, which covers the whole grid)
+int window_tables(qgd_handle h)
+{
+    qgdk_ctx &k = h->k;
+    const size_t per = (size_t)(k.m + 1) * k.n_ops, cnt = (size_t)k.nt * per, off = (size_t)k.n_off * per;
+    if (h->tab_p_host.size() < off + cnt) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
+    double *tmp = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&tmp, 2 * cnt * sizeof(double) + 64));
+    hipError_t e1 = hipMemcpyAsync(tmp, h->tab_p_host.data() + off, cnt * sizeof(double), hipMemcpyHostToDevice, k.stream);
+    hipError_t e2 = hipMemcpyAsync(tmp + cnt, h->tab_q_host.data() + off, cnt * sizeof(double), hipMemcpyHostToDevice, k.stream);
+    int kr = (e1 == hipSuccess && e2 == hipSuccess) ? qgdk_tables_from_host(&k, tmp, tmp + cnt) : 1;
+    (void)hipStreamSynchronize(k.stream);
+    (void)hipFree(tmp);
+    if (kr) return fail(h, QGD_ERR_NO_DEVICE, "uploading control tables failed");
+    return QGD_OK;
+}
+
 int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool rerun)
 {
     qgdk_ctx &k = h->k;
     int rc = plan_windows(h, h->chunks_req, r);
     if (rc) return rc;
+    if (!pcof && k.n_ops > 0 && (rc = window_tables(h))) return rc;
     const size_t hstep = (size_t)k.Np * 2 * k.cp;
     const double *start = h->chunk_state + (size_t)r * hstep;
     for (double *dst : {k.psi0, k.hist, k.bnd, k.bnd2})
@@ -867,7 +888,7 @@ int chunk_forward(qgd_handle h, const double *pcof, int n_pcof, int r, bool reru
 int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_history = nullptr, int save = 1)
 {
     qgdk_ctx &k = h->k;
-    if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
+    if (!pcof && !h->have_tables && k.n_ops > 0) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
     int rc;
     for (int r = 0; r < h->chunks_eff; r++) {
         if ((rc = chunk_forward(h, pcof, n_pcof, r, false))) return rc;
@@ -878,7 +899,7 @@ int chunked_forward(qgd_handle h, const double *pcof, int n_pcof, double *uv_his
     }
     { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }      // overlaps (and y_N) from the final state
     h->forward_valid = true; h->derivs_valid = false;
-    h->fwd_pcof.assign(pcof, pcof + n_pcof);
+    if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
     return QGD_OK;
 }
 
@@ -892,7 +913,7 @@ int chunked_adjoint(qgd_handle h, double *lambda_history = nullptr, double *adjo
         memset(lambda_history, 0, sizeof(double) * 2 * (size_t)k.N * (k.m + 1) * (size_t)k.nt_glob * k.c);
     for (int r = W - 1; r >= 0; r--) {
         if (h->resident_window != r) {
-            if ((rc = chunk_forward(h, h->fwd_pcof.data(), (int)h->fwd_pcof.size(), r, true))) return rc;
+            if ((rc = chunk_forward(h, h->fwd_pcof.empty() ? nullptr : h->fwd_pcof.data(), (int)h->fwd_pcof.size(), r, true))) return rc;
         } else if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
         if (adjoint_forcing && (rc = window_panels_out(h, k.forcing, &h->stage_f, adjoint_forcing, 1, 0))) return rc;
         if (r == W - 1) { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
@@ -922,7 +943,7 @@ int chunked_eval_adjoint(qgd_handle h, const double *pcof, int n_pcof, const dou
                          double *lambda_history)
 {
     qgdk_ctx &k = h->k;
-    if (!pcof) return fail(h, QGD_ERR_UNSUPPORTED, "a chunked time grid needs the control basis + pcof (qgd_set_control_tables holds one resident grid)");
+    if (!pcof && !h->have_tables && k.n_ops > 0) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
     const size_t Np = k.Np, PWc = 2 * k.cp, hstep = Np * PWc, N = k.N, n2 = 2 * N, m = k.m, ntg = (size_t)h->nsteps + 1;
     const int W = h->chunks_eff;
     std::vector<double> lamN(hstep, 0.0), f;
@@ -938,6 +959,7 @@ int chunked_eval_adjoint(qgd_handle h, const double *pcof, int n_pcof, const dou
     for (int r = W - 1; r >= 0; r--) {
         if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
         const size_t nt = k.nt, n_off = k.n_off;
+        if (!pcof && k.n_ops > 0 && (rc = window_tables(h))) return rc;
         if ((rc = forward_begin(h, pcof, n_pcof))) return rc;
         { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }      // (the super-block propagators)
         f.assign(nt * hstep, 0.0);
@@ -973,6 +995,100 @@ int chunked_eval_adjoint(qgd_handle h, const double *pcof, int n_pcof, const dou
     }
     HIP_TRY(h, hipStreamSynchronize(k.stream));
     return QGD_OK;
+}
+
+// buffers of the forced forward sweep for (up to) nt time points and B scan blocks
+int forcing_buffers(qgd_handle h, size_t nt, size_t B)
+{
+    qgdk_ctx &k = h->k;
+    const size_t m = k.m, hstep = (size_t)k.Np * 2 * k.cp;
+    const size_t key = nt * 4099u + B;
+    int rc;
+    if (h->forcing_key != key) {
+        free_pool(h->forcing_bufs); h->forcing_key = 0;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_F, nt * m * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_E, nt * m * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XR, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XL, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_Q, nt * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_phi, (B + 1) * hstep))) return rc;
+        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_bnd, (B + 2) * hstep))) return rc;
+        h->fsc_forcing = nullptr;     // (N > 64 at high order: the m+2 work panels of k_forcing_terms do not fit in LDS)
+        if ((size_t)(m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024 &&
+            (rc = dev_alloc(h, h->forcing_bufs, &h->fsc_forcing, nt * (size_t)(k.cp / 8) * (m + 2) * k.Np * 16))) return rc;
+        h->forcing_key = key;
+    }
+    k.fs_scratch = h->fsc_forcing;
+    return QGD_OK;
+}
+
+// forcing [2N, m, nt_glob, c] (Julia layout, forward_evolution.jl:42-44), time points n_off .. n_off + nt - 1 -> panels [nt][m][Np][2cp]
+int upload_forcing(qgd_handle h, const double *forcing, size_t nt, size_t n_off)
+{
+    qgdk_ctx &k = h->k;
+    const size_t m = k.m, N = k.N, n2 = 2 * N, PWc = 2 * k.cp, hstep = (size_t)k.Np * PWc, ntg = (size_t)h->nsteps + 1;
+    std::vector<double> f(nt * m * hstep, 0.0);
+    for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) for (size_t j = 0; j < m; j++) {
+        const double *src = forcing + ((col * ntg + n_off + n) * m + j) * n2;
+        double *dst = f.data() + (n * m + j) * hstep;
+        for (size_t i = 0; i < N; i++) {
+            const size_t o = panel_index((int)i, (int)col, (int)PWc);
+            dst[o] = src[i]; dst[o + 8] = src[N + i];
+        }
+    }
+    HIP_TRY(h, hipMemcpyAsync(k.ff_F, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, k.stream));
+    HIP_TRY(h, hipStreamSynchronize(k.stream));
+    return QGD_OK;
+}
+
+int fetch_results(qgd_handle h, double *grad, double *out3, const double *src);
+
+// eval_forward(...; forcing) on a windowed grid (forward_evolution.jl:118-129,167-206): windows in order, each from the
+// forced state the previous one ended in, with its slice of the caller's forcing; the guard penalty accumulates over the
+// windows, the overlaps come from the final state; uv_history (stage derivatives w_j = D_j w_0 + E_j included) window by
+// window as in chunked_forward.
+int chunked_forward_forced(qgd_handle h, const double *pcof, int n_pcof, const double *forcing, double *uv_history, double *out3)
+{
+    qgdk_ctx &k = h->k;
+    if (!pcof && !h->have_tables && k.n_ops > 0) return fail(h, QGD_ERR_STATE, "no control tables: call qgd_set_control_tables or pass pcof");
+    const size_t hstep = (size_t)k.Np * 2 * k.cp;
+    int rc;
+    h->forward_valid = false; h->resident_window = -1;       // (the window-boundary states are those of the FORCED sweep from here on)
+    size_t nt0 = 0, B0 = 0;
+    for (int r = 0; r < h->chunks_eff; r++) {
+        if ((rc = plan_windows(h, h->chunks_req, r))) return rc;
+        if (r == 0) { nt0 = (size_t)k.nt; B0 = (size_t)k.scan_blocks; }      // (the first window is the longest)
+        if (!pcof && k.n_ops > 0 && (rc = window_tables(h))) return rc;
+        const double *start = h->chunk_state + (size_t)r * hstep;
+        for (double *dst : {k.psi0, k.hist, k.bnd, k.bnd2})
+            HIP_TRY(h, hipMemcpyAsync(dst, start, hstep * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+        k.keep_scal = (r > 0) ? 1 : 0;
+        rc = forward_begin(h, pcof, n_pcof);
+        if (!rc) rc = forcing_buffers(h, std::max(nt0, (size_t)k.nt), std::max(B0, (size_t)k.scan_blocks));
+        if (!rc) rc = upload_forcing(h, forcing, (size_t)k.nt, (size_t)k.n_off);
+        if (!rc && qgdk_forcing_terms(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "forcing terms failed to launch");
+        if (!rc && qgdk_forcing_sweep(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "forced sweep failed to launch");
+        if (!rc) {
+            k.gpart_n = k.nt;                                 // (one partial penalty per time point: the stand-alone guard kernel)
+            if (qgdk_guard_kernel(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "guard kernel failed to launch");
+            if (k.have_guard == 0) h->forcing_zero = true; else h->forcing_zero = false;
+        }
+        if (!rc && k.gpart_on && k.have_guard && qgdk_guard_fold(&k)) rc = fail(h, QGD_ERR_NO_DEVICE, "guard fold failed to launch");
+        k.keep_scal = 0;
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->chunk_state + (size_t)(r + 1) * hstep, k.hist + (size_t)(k.nt - 1) * hstep, hstep * sizeof(double),
+                                  hipMemcpyDeviceToDevice, k.stream));
+        if (uv_history) {
+            { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+            K_TRY(h, qgdk_forcing_add_derivs(&k));            // w_j = D_j w_0 + E_j
+            if ((rc = window_history_out(h, uv_history, h->save_every))) return rc;
+        }
+    }
+    { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }
+    h->derivs_valid = false;
+    h->fwd_pcof.clear();
+    if ((rc = fetch_results(h, nullptr, out3, nullptr))) { (void)finish_copies(h); return rc; }
+    return finish_copies(h);
 }
 
 #define NEEDS_RESIDENT_GRID(h, what)                                                                                   \
@@ -1752,7 +1868,13 @@ int qgd_set_control_tables(qgd_handle h, const double *pt, const double *qt)
     HIP_TRY(h, hipSetDevice(h->device));
     NEED_GRID(h);
     qgdk_ctx &k = h->k;
-    NEEDS_RESIDENT_GRID(h, "qgd_set_control_tables");
+    if (h->chunks_eff > 1) {      // a windowed grid: the tables of the whole grid stay on the host, each window uploads its slice
+        const size_t all = (size_t)k.nt_glob * (k.m + 1) * k.n_ops;
+        h->tab_p_host.assign(pt, pt + all); h->tab_q_host.assign(qt, qt + all);
+        h->have_tables = true; h->forward_valid = false;
+        return QGD_OK;
+    }
+    h->tab_p_host.clear(); h->tab_q_host.clear();
     const size_t cnt = (size_t)k.nt * (k.m + 1) * k.n_ops;
     double *tmp = nullptr;
     HIP_TRY(h, hipMalloc((void **)&tmp, 2 * cnt * sizeof(double) + 64));
@@ -1913,39 +2035,17 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
     NEED_GRID(h);
     qgdk_ctx &k = h->k;
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced forward sweep is single-GPU");
-    NEEDS_RESIDENT_GRID(h, "eval_forward with a forcing");
+    if (h->chunks_eff > 1) return chunked_forward_forced(h, pcof, n_pcof, forcing, uv_history, out3);
     int rc = forward_begin(h, pcof, n_pcof);
     if (rc) return rc;
-    const size_t nt = k.nt, m = k.m, N = k.N, n2 = 2 * N, PWc = 2 * k.cp, hstep = (size_t)k.Np * PWc, B = k.scan_blocks;
-    if (h->forcing_key != nt) {
-        free_pool(h->forcing_bufs); h->forcing_key = 0;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_F, nt * m * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_E, nt * m * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XR, nt * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_XL, nt * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_Q, nt * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_phi, (B + 1) * hstep))) return rc;
-        if ((rc = dev_alloc(h, h->forcing_bufs, &k.ff_bnd, (B + 2) * hstep))) return rc;
-        h->fsc_forcing = nullptr;     // (N > 64 at high order: the m+2 work panels of k_forcing_terms do not fit in LDS)
-        if ((size_t)(m + 2) * k.Np * 16 * sizeof(double) > 150 * 1024 &&
-            (rc = dev_alloc(h, h->forcing_bufs, &h->fsc_forcing, nt * (size_t)(k.cp / 8) * (m + 2) * k.Np * 16))) return rc;
-        h->forcing_key = nt;
-    }
-    k.fs_scratch = h->fsc_forcing;
-    {   // forcing [2N, m, nt, c] (Julia layout, forward_evolution.jl:42-44) -> panels [nt][m][Np][2cp]
-        std::vector<double> f(nt * m * hstep, 0.0);
-        for (size_t col = 0; col < (size_t)k.c; col++) for (size_t n = 0; n < nt; n++) for (size_t j = 0; j < m; j++) {
-            const double *src = forcing + ((col * nt + n) * m + j) * n2;
-            double *dst = f.data() + (n * m + j) * hstep;
-            for (size_t i = 0; i < N; i++) {
-                const size_t o = panel_index((int)i, (int)col, (int)PWc);
-                dst[o] = src[i]; dst[o + 8] = src[N + i];
-            }
-        }
-        HIP_TRY(h, hipMemcpy(k.ff_F, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    if ((rc = forcing_buffers(h, (size_t)k.nt, (size_t)k.scan_blocks))) return rc;
+    if ((rc = upload_forcing(h, forcing, (size_t)k.nt, 0))) return rc;
     { PhaseTimer t(h, "forcing_terms"); K_TRY(h, qgdk_forcing_terms(&k)); }
     { PhaseTimer t(h, "sweep_forced"); K_TRY(h, qgdk_forcing_sweep(&k)); }
+    // (the stand-alone guard kernel stores ONE partial penalty per time point; forward_begin sized the fixed-order sum for
+    //  the history pass that fuses the guard work -- fewer, per-block partials -- which this sweep does not run: round 3's
+    //  sum added only the first of them and returned a guard penalty that was too small)
+    k.gpart_n = k.nt;
     { PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard_kernel(&k)); }
     { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, k.have_target)); }
     h->forward_valid = false;      // this history is not the one the adjoint sweep differentiates

@@ -119,6 +119,22 @@ def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
     chk.close()
     g, _ = dp.discrete_adjoint(pcof)                     # (the windows' buffers were reused: the next evaluation starts over)
     assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    # eval_forward with a forcing (forward_evolution.jl:118-129,167-206) window by window: scalars (the guard penalty sums
+    # over the windows) and the history with its stage derivatives, equal to the resident call's
+    m = order // 2
+    ff = np.asfortranarray(0.2 * rng.standard_normal((shape[0], m, shape[2], shape[3])))
+    chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl); chk.set_target(target)
+    h_ref = np.zeros(shape, order="F"); h_win = np.full(shape, np.nan, order="F")
+    s_ref = np.asarray(chk.eval_forward_forced(pcof, ff, h_ref))
+    s_win = np.asarray(dp.eval_forward_forced(pcof, ff, h_win))
+    assert np.abs(s_win - s_ref).max() <= 1e-11 * max(1.0, np.abs(s_ref).max()), (s_win, s_ref)
+    for j in range(shape[1]):
+        assert np.isfinite(h_win[:, j]).all() and np.abs(h_win[:, j] - h_ref[:, j]).max() <= 1e-11 * max(1.0, np.abs(h_ref[:, j]).max()), ("forced", j)
+    s_win2 = np.asarray(dp.eval_forward_forced(pcof, ff))          # (without the history)
+    assert np.abs(s_win2 - s_ref).max() <= 1e-11 * max(1.0, np.abs(s_ref).max())
+    chk.close()
+    g, _ = dp.discrete_adjoint(pcof)                     # (and the ordinary evaluation afterwards starts over)
+    assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
     # what still needs the grid resident says so
     with pytest.raises(qgd._lib.QGDError) as e:
         dp.eval_grad_forced(pcof)
@@ -183,3 +199,39 @@ def test_grid_longer_than_one_launch_dimension(qgd):
     dp.close()
     assert np.abs(g2 - g).max() <= 1e-11 * np.abs(g).max()
     assert np.abs(np.asarray(o2) - np.asarray(o)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o)).max())
+
+
+@pytest.mark.parametrize("which,order,nsteps,windows", [("cnot2", 6, 90, 3), ("guarded", 6, 64, 2)])
+def test_control_tables_on_a_windowed_grid(qgd, which, order, nsteps, windows):
+    """Controls that are not linear in their coefficients reach the library as tables + Jacobian per evaluation
+    (qgd_set_control_tables + qgd_set_control_basis, NULL pcof: Control.jl:6-27 leaves the family open).  On a windowed grid the
+    caller's tables cover the WHOLE grid and every window uploads its slice: gradient, scalars, forward-only evaluation and
+    eval_adjoint equal the resident handle's -- for a linear family seen through its pointwise protocol only (which must also
+    reproduce the basis path) and for a sine control."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / (1 if which.startswith("cnot") else 2))
+    for kind in ("pointwise", "sine"):
+        if kind == "pointwise":
+            gctrl, gp = [cases.PointwiseOnly(c) for c in ctrl], pcof
+        else:
+            gctrl = [cases.SineControl(prob.tf) for _ in ctrl]
+            gp = np.concatenate([[0.02 * (k + 1), 0.3 + 0.1 * k, 0.2 * k] for k in range(len(ctrl))])
+        ref = qgd.DeviceProblem(prob, order); ref.set_controls(gctrl); ref.set_target(target)
+        g_ref, o_ref = ref.discrete_adjoint(gp)
+        f_ref = np.asarray(ref.eval_forward(gp))
+        full = ref.memory_plan()["window_bytes"]
+        dp = qgd.DeviceProblem(prob, order); dp.set_memory_budget(int(full / windows * 1.15)); dp.set_controls(gctrl); dp.set_target(target)
+        assert dp.memory_plan()["windows"] >= 2
+        for rep in range(2):
+            g, o = dp.discrete_adjoint(gp)
+            assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max(), (kind, rep)
+            assert np.abs(np.asarray(o) - np.asarray(o_ref)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o_ref)).max())
+        assert np.abs(np.asarray(dp.eval_forward(gp)) - f_ref).max() <= 1e-12 * max(1.0, np.abs(f_ref).max())
+        term = np.random.default_rng(3).standard_normal((prob.real_system_size, prob.N_initial_conditions))
+        l_ref, l_win = ref.eval_adjoint(gp, term), dp.eval_adjoint(gp, term)
+        assert np.abs(l_win[:, 0] - l_ref[:, 0]).max() <= 1e-11 * max(1.0, np.abs(l_ref[:, 0]).max())
+        if kind == "pointwise":      # the general path reproduces the basis path
+            lin = qgd.DeviceProblem(prob, order); lin.set_controls(ctrl); lin.set_target(target)
+            g_lin, _ = lin.discrete_adjoint(pcof)
+            lin.close()
+            assert np.abs(g_ref - g_lin).max() <= 1e-11 * np.abs(g_lin).max()
+        ref.close(); dp.close()

@@ -755,6 +755,14 @@ def test_eval_forward_with_forcing(qgd, orc, which, order):
     # and without forcing the same entry point reproduces the ordinary sweep
     plain = qgd.eval_forward(prob, ctrl, pcof, order=order, forcing=np.zeros_like(forcing))
     assert close(plain, qgd.eval_forward(prob, ctrl, pcof, order=order), 1e-13)
+    # the three scalars too (overlaps and GUARD PENALTY: round 3's fixed-order sum dropped most of it on this entry point)
+    dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
+    s_plain = np.asarray(dp.eval_forward(pcof))
+    s_zero = np.asarray(dp.eval_forward_forced(pcof, np.zeros_like(forcing)))
+    assert np.abs(s_zero - s_plain).max() <= 1e-12 * max(1.0, np.abs(s_plain).max()), (s_zero, s_plain)
+    s_forced = np.asarray(dp.eval_forward_forced(pcof, forcing))
+    assert abs(s_forced[2] - orc.guard_penalty_real(prob, h_ref)) <= 1e-11 * max(1.0, abs(s_forced[2]))
+    dp.close()
     qgd.clear_cache()
 
 
