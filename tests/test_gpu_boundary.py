@@ -336,3 +336,16 @@ def test_result_mirror_equals_the_copy_path(qgd):
         out[label] = res
     for a, b in zip(out["copy"], out["mirror"]):
         assert np.array_equal(a, b)
+
+
+def test_entry_points_agree_on_random_problems():
+    """scripts/fuzz_entry_points.py: on random dispersive and dense problems every quantity that two entry points (or two
+    layouts of one handle: small path / general kernels / windows) return must agree, scalars included -- gradient calls with
+    and without output arrays, eval_forward, the zero-forced and the forced sweep (resident and windowed), eval_adjoint fed
+    with discrete_adjoint's own terminal lambda and forcing, the forced gradient, the three cost types, and the guard penalty
+    and infidelity recomputed on the host from the history.  (Round 4 found the guard penalty of the forced sweep wrong this
+    way.)"""
+    env = dict(os.environ, QGD_TINY="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_entry_points.py"), "24", "11"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
