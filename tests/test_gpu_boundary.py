@@ -349,3 +349,14 @@ def test_entry_points_agree_on_random_problems():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_entry_points.py"), "24", "11"], capture_output=True, text=True,
                        timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
+
+def test_no_state_leaks_between_calls_on_one_handle():
+    """scripts/fuzz_call_sequences.py: random sequences of calls on ONE handle (resident and windowed; cnot2 with the small
+    path toggled, guarded, cnot3, a dense guard matrix) -- gradient with and without output arrays, history_precomputed,
+    forward-only with and without (strided) history, forced sweep, eval_adjoint, forced gradient, switches of cost type /
+    event bracketing / small path / save-every, two coefficient vectors -- each result against a fresh handle's."""
+    env = dict(os.environ, QGD_TINY="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_call_sequences.py"), "120", "7"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
