@@ -1,6 +1,6 @@
 """Cross-checks between the ENTRY POINTS of the C ABI on random problems: every quantity that two different calls (or two
 layouts of the same handle) return must agree -- scalars included, which the kernel-level parity tests look at least.
-    python3 scripts/fuzz_entry_points.py [n_cases] [seed]
+    python3 scripts/fuzz_entry_points.py [n_cases] [seed] [large]
 Per case (dispersive problems with guard levels on the sparse kernels, random dense problems with a diagonal or a dense guard
 projector, N = 2..40, a few N > 64): plain gradient call vs general kernels (small path off) vs a windowed handle vs the
 reference-shaped call; eval_forward scalars and history vs discrete_adjoint's; zero-forced sweep vs plain sweep; random-forced
@@ -31,6 +31,9 @@ for it in range(ncases):
     order = int(rng.choice([2, 4, 6, 8, 12]))
     nsteps = int(rng.choice([3, 7, 16, 33, 60, 97]))
     r = rng.random()
+    if len(sys.argv) > 3 and sys.argv[3] == "large":      # N > 64 only: the GEMM-style kernels
+        r = 0.95
+        nsteps = int(rng.choice([3, 7, 16, 33]))
     if r < 0.5:
         nsub = int(rng.integers(1, 3)); sizes = tuple(int(rng.integers(2, 5)) for _ in range(nsub))
         ess = tuple(max(1, s - int(rng.integers(0, 2))) for s in sizes)
@@ -40,9 +43,9 @@ for it in range(ncases):
                 for k in range(prob.N_operators)]
         kind = f"dispersive {sizes}/{ess}"
     else:
-        N = int(rng.integers(2, 41)) if r < 0.93 else int(rng.choice([72, 100])); n_ops = int(rng.integers(1, 4))
+        N = int(rng.integers(2, 41)) if r < 0.93 else int(rng.choice([72, 100, 130, 180])); n_ops = int(rng.integers(1, 4))
         prob = qgd.construct_rand_prob(N, n_ops, tf=0.02 * nsteps, nsteps=nsteps, gmres_abstol=1e-15, gmres_reltol=1e-15, scale=1.0 / max(N, 4))
-        c = int(rng.integers(1, min(N, 9) + 1))
+        c = int(rng.integers(1, min(N, 9) + 1)) if N <= 64 else int(rng.choice([3, 8, 16, 40, N]))
         prob.u0 = np.asfortranarray(prob.u0[:, :c]); prob.v0 = np.asfortranarray(prob.v0[:, :c]); prob.N_initial_conditions = c
         g = rng.random()
         W = np.zeros((2 * N, 2 * N))
