@@ -360,3 +360,11 @@ def test_no_state_leaks_between_calls_on_one_handle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_call_sequences.py"), "120", "7"], capture_output=True, text=True,
                        timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
+
+def test_random_partitions_match_the_unpartitioned_call():
+    """scripts/fuzz_partitions.py: ONE problem over 2..8 ranks inside one process (time windows and column blocks, step counts
+    the blocks do not divide, sparse / dense / N > 64): every rank's gradient and scalars against the unpartitioned call; a
+    partition that would leave a rank without a step is refused with an error, not evaluated wrongly."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_partitions.py"), "16", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
