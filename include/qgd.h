@@ -113,8 +113,9 @@ int qgd_set_nsteps(qgd_handle h, int32_t nsteps, double tf);
  * derivative columns after qgd_set_lambda_derivatives, as on a resident grid; qgd_eval_adjoint walks the windows in reverse
  * with the caller's terminal condition and forcing (no forward history is formed); qgd_eval_forward_forced walks them in
  * order with its slice of the caller's forcing; qgd_set_control_tables keeps the tables of the whole grid on the host and
- * every window uploads its slice.  qgd_eval_grad_forced, qgd_apply_hamiltonian and qgd_get_intermediate return
- * QGD_ERR_UNSUPPORTED (they need the grid resident).
+ * every window uploads its slice; qgd_eval_grad_forced forms every window's matrices and history again from its stored
+ * start state and carries the sensitivities from window to window.  Only the diagnostics qgd_apply_hamiltonian and
+ * qgd_get_intermediate return QGD_ERR_UNSUPPORTED (they address one resident grid).
  * qgd_get_partition on such a handle reports the WHOLE grid (first point 0, last point nsteps): the windows are the
  * library's business, the caller's control basis and output arrays cover every time point.
  * qgd_get_memory_plan: out4 = { windows, time steps per window, bytes of the per-window buffers, budget (0 = automatic) }. */

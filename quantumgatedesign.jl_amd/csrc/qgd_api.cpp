@@ -2059,23 +2059,14 @@ int qgd_eval_forward_forced(qgd_handle h, const double *pcof, int32_t n_pcof, co
     return finish_copies(h);
 }
 
-int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad)
+// buffers of the forced gradient for (up to) nt time points and B scan blocks
+static int forced_buffers(qgd_handle h, size_t nt, size_t B)
 {
-    if (h) drop_graph(h);
-    if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");     // (pcof may be NULL when the tables were set directly)
-    HIP_TRY(h, hipSetDevice(h->device));
-    NEED_GRID(h);
     qgdk_ctx &k = h->k;
-    if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");
-    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
-    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced gradient is single-GPU");
-    NEEDS_RESIDENT_GRID(h, "eval_grad_forced");
+    const size_t hstep = (size_t)k.Np * 2 * k.cp, NB = (size_t)k.n_ops * 2 * k.m;
+    const size_t cpS = (size_t)k.n_pcof * k.cp, hstepS = (size_t)k.Np * 2 * cpS;
+    const size_t key = (nt * 1000003u + (size_t)k.n_pcof) * 4099u + B;
     int rc;
-    if ((rc = run_forward(h, pcof, n_pcof))) return rc;
-    if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
-    const size_t nt = k.nt, hstep = (size_t)k.Np * 2 * k.cp, NB = (size_t)k.n_ops * 2 * k.m;
-    const size_t cpS = (size_t)k.n_pcof * k.cp, hstepS = (size_t)k.Np * 2 * cpS, B = k.scan_blocks;
-    const size_t key = nt * 1000003u + (size_t)k.n_pcof;
     if (h->forced_key != key) {
         free_pool(h->forced_bufs); h->forced_key = 0;
         if ((rc = dev_alloc(h, h->forced_bufs, &k.fs_BR, nt * NB * hstep))) return rc;
@@ -2089,10 +2080,56 @@ int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, doubl
         h->forced_key = key;
     }
     k.fs_scratch = h->fsc_forced;
-    HIP_TRY(h, hipMemsetAsync(k.fs_bnd, 0, hstepS * sizeof(double), k.stream));
-    HIP_TRY(h, hipMemsetAsync(k.fs_gacc, 0, ((size_t)k.n_pcof + 1) * sizeof(double), k.stream));
-    { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }
-    { PhaseTimer t(h, "forced_sweeps"); K_TRY(h, qgdk_forced_chains(&k)); }
+    return QGD_OK;
+}
+
+int qgd_eval_grad_forced(qgd_handle h, const double *pcof, int32_t n_pcof, double *grad)
+{
+    if (h) drop_graph(h);
+    if (!h || !grad) return fail(h, QGD_ERR_ARGUMENT, "null argument");     // (pcof may be NULL when the tables were set directly)
+    HIP_TRY(h, hipSetDevice(h->device));
+    NEED_GRID(h);
+    qgdk_ctx &k = h->k;
+    if (!k.have_target) return fail(h, QGD_ERR_STATE, "qgd_set_target must be called before qgd_eval_grad_forced");
+    if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before qgd_eval_grad_forced");
+    if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: the forced gradient is single-GPU");
+    int rc;
+    if ((rc = run_forward(h, pcof, n_pcof))) return rc;      // (a windowed grid: every window, the state at each window start kept)
+    const size_t hstep = (size_t)k.Np * 2 * k.cp;
+    const size_t cpS = (size_t)k.n_pcof * k.cp, hstepS = (size_t)k.Np * 2 * cpS;
+    size_t nt = k.nt, B = k.scan_blocks;
+    if (h->chunks_eff == 1) {
+        if (!h->derivs_valid) { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); h->derivs_valid = true; }
+        if ((rc = forced_buffers(h, nt, B))) return rc;
+        HIP_TRY(h, hipMemsetAsync(k.fs_bnd, 0, hstepS * sizeof(double), k.stream));
+        HIP_TRY(h, hipMemsetAsync(k.fs_gacc, 0, ((size_t)k.n_pcof + 1) * sizeof(double), k.stream));
+        { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }
+        { PhaseTimer t(h, "forced_sweeps"); K_TRY(h, qgdk_forced_chains(&k)); }
+    } else {
+        // Windows in order: each forms its matrices and forward history again from its stored start state (as the adjoint pass
+        // does), the sensitivities of all parameters continue from where the previous window left them, the guard part of the
+        // gradient accumulates.  (eval_grad_forced.jl:17-194 keeps no matrices either: one forced sweep per parameter.)
+        const std::vector<double> pc(h->fwd_pcof);
+        const double *pp = pc.empty() ? nullptr : pc.data();
+        size_t nt0 = 0, B0 = 0;
+        for (int r = 0; r < h->chunks_eff; r++) {
+            if ((rc = chunk_forward(h, pp, (int)pc.size(), r, true))) return rc;
+            if (r == 0) {
+                nt0 = (size_t)k.nt; B0 = (size_t)k.scan_blocks;      // (the first window is the longest)
+                if ((rc = forced_buffers(h, nt0, B0))) return rc;
+                HIP_TRY(h, hipMemsetAsync(k.fs_bnd, 0, hstepS * sizeof(double), k.stream));
+                HIP_TRY(h, hipMemsetAsync(k.fs_gacc, 0, ((size_t)k.n_pcof + 1) * sizeof(double), k.stream));
+            }
+            k.fs_scratch = h->fsc_forced;
+            { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
+            { PhaseTimer t(h, "forced_basis"); K_TRY(h, qgdk_forced_basis(&k)); }
+            { PhaseTimer t(h, "forced_sweeps"); K_TRY(h, qgdk_forced_chains(&k)); }
+            nt = k.nt; B = k.scan_blocks;
+            if (r + 1 < h->chunks_eff)      // s at the start of the next window
+                HIP_TRY(h, hipMemcpyAsync(k.fs_bnd, k.fs_bnd + B * hstepS, hstepS * sizeof(double), hipMemcpyDeviceToDevice, k.stream));
+        }
+        h->derivs_valid = false;
+    }
     if ((rc = check_status(h))) return rc;
     std::vector<double> sN(hstepS), gacc(k.n_pcof), scal(4), wN;
     HIP_TRY(h, hipMemcpy(sN.data(), k.fs_bnd + B * hstepS, hstepS * sizeof(double), hipMemcpyDeviceToHost));

@@ -56,6 +56,7 @@ struct ChainArgs {
     // assembled from the 2m basis responses of the parameter's control,
     //   q_n = sum_{tau,d} G^tau_l(n,d) BR[n][b] - G^tau_l(n+1,d) BL[n+1][b],  b = (k*2+tau)*m + d
     int fs_mode, fs_m, fs_nops, fs_gpc, fs_nt;   // gpc: state column groups per parameter
+    int fs_n0;                                  // global index of the local time point 0 in the control basis (a window of a long grid)
     const double *fs_BR, *fs_BL;                 // [nt][NB][Np][2*cp_state], already multiplied by L^-1
     const double *fs_G; const int64_t *fs_goff; const int32_t *fs_ncoef, *fs_poff;
     const double *fs_gf;                         // adjoint forcing f_n [nt][Np][2*cp_state]: guard part = -<f_n, s_n>
@@ -324,8 +325,8 @@ __device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bi
                 for (int tau = 0; tau < 2; tau++)
                     for (int d = 0; d < a.fs_m; d++) {
                         const double *gk = a.fs_G + a.fs_goff[k];
-                        const double g0 = gk[(((size_t)tau * a.fs_nt + n) * (a.fs_m + 1) + d) * nc + l];
-                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + 1) * (a.fs_m + 1) + d) * nc + l];
+                        const double g0 = gk[(((size_t)tau * a.fs_nt + n + a.fs_n0) * (a.fs_m + 1) + d) * nc + l];
+                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + a.fs_n0 + 1) * (a.fs_m + 1) + d) * nc + l];
                         const int bidx = (k * 2 + tau) * a.fs_m + d;
                         const double *br = a.fs_BR + ((size_t)n * NB + bidx) * pstep + cg * 16 + c16;
                         const double *bl = a.fs_BL + ((size_t)(n + 1) * NB + bidx) * pstep + cg * 16 + c16;
@@ -697,8 +698,8 @@ __global__ __launch_bounds__(256) void k_chain_forced_generic(const ChainArgs a)
                 const double *gk = a.fs_G + a.fs_goff[ctl];
                 for (int tau = 0; tau < 2; tau++)
                     for (int d = 0; d < a.fs_m; d++) {
-                        const double g0 = gk[(((size_t)tau * a.fs_nt + n) * (a.fs_m + 1) + d) * ncf + lco];
-                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + 1) * (a.fs_m + 1) + d) * ncf + lco];
+                        const double g0 = gk[(((size_t)tau * a.fs_nt + n + a.fs_n0) * (a.fs_m + 1) + d) * ncf + lco];
+                        const double g1 = gk[(((size_t)tau * a.fs_nt + n + a.fs_n0 + 1) * (a.fs_m + 1) + d) * ncf + lco];
                         const int bidx = (ctl * 2 + tau) * a.fs_m + d;
                         const double *br = a.fs_BR + ((size_t)n * NB + bidx) * pstep + cg * 16 + c16;
                         const double *bl = a.fs_BL + ((size_t)(n + 1) * NB + bidx) * pstep + cg * 16 + c16;
@@ -1839,7 +1840,7 @@ int qgdk_forced_chains(const qgdk_ctx *c)
     const int cpS = c->n_pcof * c->cp, B = c->scan_blocks;
     const size_t hstepS = (size_t)c->Np * 2 * cpS;
     ChainArgs f{};
-    f.Np = c->Np; f.cp = cpS; f.fs_mode = 1; f.fs_m = c->m; f.fs_nops = c->n_ops; f.fs_gpc = c->cp / 8; f.fs_nt = c->nt;
+    f.Np = c->Np; f.cp = cpS; f.fs_mode = 1; f.fs_m = c->m; f.fs_nops = c->n_ops; f.fs_gpc = c->cp / 8; f.fs_nt = c->g_nt ? c->g_nt : c->nt; f.fs_n0 = c->g_n0;
     f.fs_BR = c->fs_BR; f.fs_BL = c->fs_BL; f.fs_G = c->G; f.fs_goff = c->goff; f.fs_ncoef = c->ncoef; f.fs_poff = c->poff;
     ChainArgs a = f;   // (i)
     a.S = c->nt - 1; a.Pmat = c->Pc; a.phi = c->fs_phi; a.nblocks = B; a.blen = c->scan_blen; a.ngroups = cpS / 8;

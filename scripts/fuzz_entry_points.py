@@ -113,6 +113,8 @@ for it in range(ncases):
         hW = np.zeros(shape, order="F"); sW = Wn.eval_forward_forced(pcof, ff, hW)
         check("windows: forced sweep scalars", sW, sF, 1e-11); check("windows: forced sweep history", hW, hF, 1e-10)
         check("windows: eval_adjoint", Wn.eval_adjoint(pcof, arrs[1][:, 0, -1, :], arrs[2])[:, 0], lam[:, 0], 1e-10)
+        if npar <= 40 and N <= 64:
+            check("windows: forced gradient", Wn.eval_grad_forced(pcof), gB, 1e-9, gs)
         Wn.close()
     for cost in ("Tracking", "Norm"):
         A.set_cost_type(cost); B.set_cost_type(cost)

@@ -135,9 +135,20 @@ def test_chunked_grid_matches_resident(qgd, which, order, nsteps, windows):
     chk.close()
     g, _ = dp.discrete_adjoint(pcof)                     # (and the ordinary evaluation afterwards starts over)
     assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
+    # the forced gradient (eval_grad_forced.jl:17-194) window by window: the sensitivities of all parameters continue from
+    # window to window, the guard part accumulates -- equal to the resident call's and to the adjoint gradient
+    if len(pcof) <= 200 and prob.N_initial_conditions * len(pcof) <= 4096:
+        chk = qgd.DeviceProblem(prob, order); chk.set_controls(ctrl); chk.set_target(target)
+        gf_ref = chk.eval_grad_forced(pcof)
+        chk.close()
+        gf = dp.eval_grad_forced(pcof)
+        assert np.abs(gf - gf_ref).max() <= 1e-10 * np.abs(gf_ref).max(), np.abs(gf - gf_ref).max() / np.abs(gf_ref).max()
+        assert np.abs(gf - g_ref).max() <= 1e-9 * np.abs(g_ref).max()
+        g, _ = dp.discrete_adjoint(pcof)
+        assert np.abs(g - g_ref).max() <= 1e-11 * np.abs(g_ref).max()
     # what still needs the grid resident says so
     with pytest.raises(qgd._lib.QGDError) as e:
-        dp.eval_grad_forced(pcof)
+        dp.intermediate("P")
     assert e.value.code == qgd._lib.QGD_ERR_UNSUPPORTED
     dp.close()
 
