@@ -560,6 +560,9 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             }
             #pragma unroll
             for (int rt = 0; rt < NRT; rt++) {
+#ifdef QGD_INV_KO_QUARTER      // (timing experiment, wrong results: a quarter of the product's MFMAs dropped -- what a three-product form would save)
+                if (pass == 1 && rt >= NRT / 2) continue;
+#endif
                 const double af = smem[(16 * rt + c16) * LDP + k];
                 #pragma unroll
                 for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
