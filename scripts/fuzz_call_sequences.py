@@ -41,7 +41,7 @@ def expected(prob, ctrl, target, order, pcofs, forcing, term):
     return exp
 
 
-def run(name, prob, ctrl, pcof, target, order, windows, rng):
+def run(name, prob, ctrl, pcof, target, order, windows, rng, general=False):
     m = order // 2
     shape = (prob.real_system_size, m + 1, prob.nsteps + 1, prob.N_initial_conditions)
     pcofs = [pcof, 0.6 * pcof[::-1].copy()]
@@ -51,7 +51,9 @@ def run(name, prob, ctrl, pcof, target, order, windows, rng):
     dp = qgd.DeviceProblem(prob, order)
     if windows:
         dp.set_memory_budget(int(dp.memory_plan()["window_bytes"] / windows * 1.15))
-    dp.set_controls(ctrl); dp.set_target(target)
+    # general=True: the persistent handle sees the same (linear) controls through their pointwise protocol only -- tables and
+    # Jacobian uploaded per evaluation, NULL pcof (qgd_set_control_tables + qgd_set_control_basis) -- and must reproduce the basis path
+    dp.set_controls([cases.PointwiseOnly(c) for c in ctrl] if general else ctrl); dp.set_target(target)
     cost, save, log = "Infidelity", 1, []
 
     def check(tag, a, b, tol):
@@ -116,6 +118,10 @@ for name, case, order in (("cnot2", cases.cnot2_case(qgd, nsteps=36, tf=36.0), 8
     for windows in (0, 3):
         print(name, "windows", windows, flush=True)
         run(name, *case, order, windows, rng)
+    if name in ("cnot2", "guarded"):
+        for windows in (0, 2):
+            print(name, "general controls, windows", windows, flush=True)
+            run(name + " (general controls)", *case, order, windows, rng, general=True)
 print("mismatches:", len(bad))
 for b in bad: print("  ", b)
 sys.exit(1 if bad else 0)
