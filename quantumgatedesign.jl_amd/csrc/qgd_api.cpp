@@ -64,6 +64,7 @@ struct qgd_handle_s {
     // and the stream's completion signal.  QGD_RESULT_MIRROR=0 keeps the copy + hipStreamSynchronize.
     double *mirror_host = nullptr, *mirror_dev = nullptr;
     unsigned int *mirror_ticket = nullptr;
+    bool status_dirty = false;          // an evaluation ended with the singular-matrix flag set on the device (reset before the small-problem path runs)
     unsigned long long mirror_seq = 0;
     bool mirror_armed = false;          // the evaluation in flight ends with a mirrored k_contract_sum
     // Small problems (N <= 4, <= 4 columns, <= 128 time points: Rabi, the two-qubit CNOT) take the four-launch path of
@@ -151,6 +152,7 @@ namespace {
 int fail(qgd_handle h, int code, const std::string &msg)
 {
     if (h) h->err = msg; else g_create_error = msg;
+    if (h && code == QGD_ERR_NUMERIC) h->status_dirty = true;      // (the device's status word is set: see tiny_evaluate)
     return code;
 }
 
@@ -1122,6 +1124,10 @@ int tiny_evaluate(qgd_handle h, const double *pcof, int n_pcof, bool gradient, d
     qgdk_ctx &k = h->k;
     const bool mirror = h->mirror_dev != nullptr && h->mirror_ticket != nullptr;
     if (mirror) { k.mirror_dev = h->mirror_dev; k.mirror_ticket = h->mirror_ticket; k.mirror_seq = ++h->mirror_seq; }
+    // (the status word: the general path clears it in its first kernel and sets it in a later one; here the kernel that could
+    //  clear it -- the per-time-point front -- is also the one that sets it, so it is cleared from the host, and only after an
+    //  evaluation that left it set)
+    if (h->status_dirty) { HIP_TRY(h, hipMemsetAsync(k.status, 0, 2 * sizeof(int), k.stream)); h->status_dirty = false; }
     int e = qgdk_tiny_eval(&k, pcof, n_pcof, gradient ? 1 : 0);
     if (!e && gradient) e = qgdk_contract_rows(&k, k.nt);
     k.mirror_dev = nullptr;

@@ -295,7 +295,6 @@ __global__ __launch_bounds__(64) void k_tiny_front(const TinyArgs a, const TinyP
     if (tid >= 32 && tid < 36) { const int k = tid - 32; NC[k] = a.nc[k]; POFF[k] = a.po[k]; GOFF[k] = a.go[k]; }
     if (n == 0) {
         if (tid < 4) a.scal[tid] = 0.0;
-        if (tid == 4) { a.status[0] = 0; a.status[1] = 0; }
     }
     // control tables of this time point: 16 lanes per entry (contiguous reads of the basis row), up to eight entries per
     // 16-lane group in flight, every load unconditional (clamped indices): one memory round trip
