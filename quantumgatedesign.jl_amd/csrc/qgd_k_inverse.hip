@@ -330,30 +330,22 @@ __device__ __forceinline__ double fast_rcp(double d)             // v_rcp_f64 + 
     return r;
 }
 
+// LDS of the Np <= 64 kernels (doubles): the working buffers of the elimination, overlaid by the output staging plane
+#define INV_SMEM(NP) (((8 * 2 * (NP) + 16 * (NP) + 8 * (NP)) > (NP) * ((NP) + 1)) ? (8 * 2 * (NP) + 16 * (NP) + 8 * (NP)) : (NP) * ((NP) + 1))
+
 template <int NP>
-__global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
-                    double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status
-#ifdef QGD_INV_PROFILE      // scripts/ubench/inverse_bench.hip: cycles of workgroup 0 / wave 0 per phase
-                    , unsigned long long *prof)
+__device__ __forceinline__ void inverse_mfma_body(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                                                  double *__restrict__ Pr, double *__restrict__ Pc, const int n, int *__restrict__ status,
+                                                  double *__restrict__ smem, int *__restrict__ rho, int *__restrict__ rinv)
 {
-    long long prof_last = clock64();
-#define INV_PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&prof[i], (unsigned long long)(now_ - prof_last)); prof_last = now_; } } while (0)
-#else
-                    )
-{
-#define INV_PROF(i) do { } while (0)
-#endif
     constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
     // LDS: the working buffers of the elimination, overlaid by the output staging plane at the end
     constexpr int O_PROW = 0, O_G = O_PROW + 8 * PW, O_F = O_G + 16 * NP,
                   WORK = O_F + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
-    __shared__ double smem[SM];
-    __shared__ int rho[NP], rinv[NP];                   // rho[p] = row of the p-th pivot
+    static_assert(SM <= INV_SMEM(NP), "INV_SMEM");
     double *Prow = smem + O_PROW;                       // [2][4][PW]   pivot rows (B operand), by panel parity
     double *Gm = smem + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
     double *Fm = smem + O_F;                            // [2][NP][4]   panel columns re/im
-    const int n = n0 + blockIdx.x;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int c16 = lane & 15, kk = lane >> 4;
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
@@ -364,15 +356,10 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
     for (int g = 0; g < NG; g++)
         #pragma unroll
         for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
-    INV_PROF(0);
     bool used = lane >= NP;                             // panel wave: this lane's row has been a pivot row
     // which wave factors the panels (rotating it differently across workgroups that share a CU, e.g. with
     // blockIdx/256, changes nothing: 108-111 us for 550 matrices either way)
-#ifdef QGD_INV_PW_FIXED          // (experiment: the panel wave has the same index in every workgroup)
-    const int pw = QGD_INV_PW_FIXED;
-#else
     const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
-#endif
 
     for (int pn = 0; pn < NP / 4; pn++) {
         const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
@@ -393,7 +380,6 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             }
         }
         __syncthreads();
-        INV_PROF(1);
         // ---- 2. one wave (a different one in neighbouring workgroups, so that the serial phases of
         //         the workgroups sharing a CU sit on different SIMDs): pivoted in-place Gauss-Jordan
         //         on the NP x 4 panel, lane = row
@@ -403,41 +389,20 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             const int lrow = (lane < NP) ? lane : 0;
             #pragma unroll
             for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
-#ifdef QGD_INV_KO_CHAIN
-            if (lane == 0) { for (int s = 0; s < 4; s++) { rho[p0 + s] = p0 + s; rinv[p0 + s] = p0 + s; } }
-#else
             #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const double m2 = xr[s] * xr[s] + xi[s] * xi[s];
                 const unsigned mag = (unsigned)__double2hiint(m2);
                 unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
-#ifdef QGD_INV_RCP_HOIST
-                // (round 4 experiment, off: every lane inverts its OWN candidate while the arg-max runs, so that the reciprocal
-                //  and its two Newton steps leave the serial pivot chain; same bits.  Measured with
-                //  scripts/ubench/inverse_bench.hip: 66.6 / 91.3 / 109.2 us for 256 / 512 / 550 matrices against 65.7 / 91.1 /
-                //  109.0 -- the chain is not waiting on that dependency; not kept.)
-                const double den_own = fast_rcp(m2);
-                double yr[4], yi[4];
-                yr[s] = xr[s] * den_own; yi[s] = -xi[s] * den_own;
-#endif
                 key = wave_max_u32(key);
                 const int pr = 63 - (int)(key & 63u);
                 if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
                 used = used || (lane == pr);
-#ifdef QGD_INV_RCP_HOIST
-                #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (q == s) { yr[q] = lane_read(yr[q], pr); yi[q] = lane_read(yi[q], pr); }
-                    else { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
-                }
-                const double ir = yr[s], ii = yi[s];
-#else
                 double yr[4], yi[4];
                 #pragma unroll
                 for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
                 const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
                 const double ir = yr[s] * den, ii = -yi[s] * den;
-#endif
                 const double fr = xr[s], fi = xi[s];
                 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -448,7 +413,6 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                     xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
                 }
             }
-#endif
             if (lane < NP) {
                 #pragma unroll
                 for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
@@ -456,7 +420,6 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
-        INV_PROF(2);
         // ---- 3. the owners of the pivot rows publish them as the B operand of the block step
         {
             const int s0 = rho[p0], s1 = rho[p0 + 1], s2 = rho[p0 + 2], s3 = rho[p0 + 3];
@@ -471,15 +434,11 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             }
         }
         __syncthreads();
-        INV_PROF(3);
         // ---- 4. rank-4 block step on the MFMA, then the pivot columns take the multipliers
         {
             const int arow = 16 * w + c16;
             const double are = Gre[arow * 4 + kk] - ((arow == rho[p0 + kk]) ? 1.0 : 0.0);
             const double aim = Gim[arow * 4 + kk];
-#ifdef QGD_INV_KO_PW_MFMA         // (timing experiment, wrong results: the panel wave issues no MFMA)
-            if (w != pw)
-#endif
             {
             #pragma unroll
             for (int g = 0; g < NG; g++) {
@@ -501,7 +460,6 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 }
             }
         }
-        INV_PROF(4);
         // no barrier here: the next panel writes F (last read before barrier 2), and the buffers
         // read above (G, Prow) alternate with the panel parity
     }
@@ -544,10 +502,6 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
                 buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
             }
         }
-#ifndef QGD_INV_KO_PRODUCT      // (knock-out experiments of scripts/ubench/inverse_bench.hip: timing only, wrong results)
-#ifdef QGD_INV_KO_PW_MFMA
-        if (w != pw)
-#endif
         #pragma unroll 4
         for (int ks = 0; ks < NP / 4; ks++) {
             const int k = 4 * ks + kk;
@@ -560,15 +514,11 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
             }
             #pragma unroll
             for (int rt = 0; rt < NRT; rt++) {
-#ifdef QGD_INV_KO_QUARTER      // (timing experiment, wrong results: a quarter of the product's MFMAs dropped -- what a three-product form would save)
-                if (pass == 1 && rt >= NRT / 2) continue;
-#endif
                 const double af = smem[(16 * rt + c16) * LDP + k];
                 #pragma unroll
                 for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
             }
         }
-#endif
         lds_barrier();
     }
     // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
@@ -603,236 +553,57 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
         }
         lds_barrier();
     }
-    INV_PROF(5);
-#undef INV_PROF
 }
 
-// ---------------------------------------------------------------------------
-// K2 (Np = 64, comparison path QGD_INV_AUGMENTED=1): the same elimination on the AUGMENTED matrix [L_n | R_{n-1}].  The row
-// operations that turn L into the identity turn R into P_{n-1} = L_n^-1 R_{n-1}, so the step propagator comes out of
-// the rank-4 block steps themselves (8 more column groups per step, same A operand) instead of a separate product
-// phase behind the elimination (k_inverse_mfma: 256 MFMAs per wave at 42 % of the pipe, the A operand re-read from
-// the LDS staging plane, R streamed from global inside the loop).  With implicit pivoting row rho(i) of the
-// augmented matrix ends as the equation of unknown i:  P[i][j] = MR[rho(i)][j].
-// Measured (scripts/ubench/inverse_bench.hip -DKERNEL=k_inverse_aug): SLOWER -- 67.0 / 98.7 / 117.2 / 123.7 us for
-// 256 / 512 / 550 / 768 matrices against 64.8 / 91.1 / 108.7 / 117.9: the 16 extra MFMAs lengthen each of the 16
-// barrier-delimited block steps, in which the four waves of a matrix move in lockstep, by more than the free-running
-// product phase behind the elimination costs -- that phase overlaps with the other workgroups of the CU, the block
-// steps do not.
-// ---------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(NP * 4) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_inverse_aug(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
-                   double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status)
+void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                    double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status)
 {
-    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, PW2 = 2 * PW, LDP = NP + 1;
-    constexpr int O_PROW = 0, O_G = O_PROW + 8 * PW2, O_F = O_G + 16 * NP,
-                  WORK = O_F + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
-    __shared__ double smem[SM];
+    __shared__ double smem[INV_SMEM(NP)];
     __shared__ int rho[NP], rinv[NP];                   // rho[p] = row of the p-th pivot
-    double *Prow = smem + O_PROW;                       // [2][4][2 PW]  pivot rows of [M | MR] (B operand), by panel parity
-    double *Gm = smem + O_G;                            // [2][2][NP][4] multipliers re/im, by panel parity
-    double *Fm = smem + O_F;                            // [2][NP][4]    panel columns re/im
-    const int n = n0 + blockIdx.x;
-    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const int c16 = lane & 15, kk = lane >> 4;
-    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
-    const double *Ln = L + (size_t)n * panel, *Rn = R + (size_t)(n - 1) * panel;
+    inverse_mfma_body<NP>(L, R, LinvT, Pr, Pc, n0 + (int)blockIdx.x, status, smem, rho, rinv);
+}
 
-    d4 M[NG], MR[NG];
-    #pragma unroll
-    for (int g = 0; g < NG; g++)
-        #pragma unroll
-        for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
-    #pragma unroll
-    for (int g = 0; g < NG; g++)
-        #pragma unroll
-        for (int r = 0; r < 4; r++) MR[g][r] = Rn[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
-    bool used = lane >= NP;
-    const int pw = (NW > 1) ? (int)(blockIdx.x % NW) : 0;
+#include "qgd_inverse_cb.h"
 
-    for (int pn = 0; pn < NP / 4; pn++) {
-        const int p0 = pn * 4, gp = p0 >> 3, q0 = p0 & 7, par = pn & 1;
-        double *Gre = Gm + par * 8 * NP, *Gim = Gre + 4 * NP;
-        double *Pw = Prow + par * 4 * PW2;
-        // ---- 1. publish the panel columns
-        {
-            const int s = (c16 & 7) - q0;
-            if (s >= 0 && s < 4) {
-                double *dst = Fm + (c16 < 8 ? 0 : 4 * NP);
-                #pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    if (g == gp) {
-                        #pragma unroll
-                        for (int r = 0; r < 4; r++) dst[(16 * w + kk + 4 * r) * 4 + s] = M[g][r];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 2. one wave: pivoted in-place Gauss-Jordan on the NP x 4 panel, lane = row (as k_inverse_mfma)
-        if (w == pw) {
-            __builtin_amdgcn_s_setprio(1);
-            double xr[4], xi[4];
-            const int lrow = (lane < NP) ? lane : 0;
-            #pragma unroll
-            for (int s = 0; s < 4; s++) { xr[s] = Fm[lrow * 4 + s]; xi[s] = Fm[4 * NP + lrow * 4 + s]; }
-            #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const unsigned mag = (unsigned)__double2hiint(xr[s] * xr[s] + xi[s] * xi[s]);
-                unsigned key = used ? 0u : ((mag & ~63u) | (unsigned)(63 - lane));
-                key = wave_max_u32(key);
-                const int pr = 63 - (int)(key & 63u);
-                if (lane == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; if ((key >> 6) == 0) *status = 1; }
-                used = used || (lane == pr);
-                double yr[4], yi[4];
-                #pragma unroll
-                for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], pr); yi[q] = lane_read(xi[q], pr); }
-                const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
-                const double ir = yr[s] * den, ii = -yi[s] * den;
-                const double fr = xr[s], fi = xi[s];
-                #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const double rr = (q == s) ? ir : yr[q] * ir - yi[q] * ii;      // scaled pivot row
-                    const double ri = (q == s) ? ii : yr[q] * ii + yi[q] * ir;
-                    const double br = (q == s) ? 0.0 : xr[q], bi = (q == s) ? 0.0 : xi[q];
-                    xr[q] = (lane == pr) ? rr : br - (fr * rr - fi * ri);
-                    xi[q] = (lane == pr) ? ri : bi - (fr * ri + fi * rr);
-                }
-            }
-            if (lane < NP) {
-                #pragma unroll
-                for (int s = 0; s < 4; s++) { Gre[lane * 4 + s] = xr[s]; Gim[lane * 4 + s] = xi[s]; }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-        // ---- 3. the owners of the pivot rows publish them (both halves) as the B operand of the block step
-        {
-            const int s0 = rho[p0], s1 = rho[p0 + 1], s2 = rho[p0 + 2], s3 = rho[p0 + 3];
-            #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int x = 16 * w + kk + 4 * r;
-                const int ps = (x == s0) ? 0 : (x == s1) ? 1 : (x == s2) ? 2 : (x == s3) ? 3 : -1;
-                if (ps >= 0) {
-                    #pragma unroll
-                    for (int g = 0; g < NG; g++) { Pw[ps * PW2 + 16 * g + c16] = M[g][r]; Pw[ps * PW2 + PW + 16 * g + c16] = MR[g][r]; }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 4. rank-4 block step on the MFMA over [M | MR], then the pivot columns take the multipliers
-        {
-            const int arow = 16 * w + c16;
-            const double are = Gre[arow * 4 + kk] - ((arow == rho[p0 + kk]) ? 1.0 : 0.0);
-            const double aim = Gim[arow * 4 + kk];
-            #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                double b1, b2;
-                panel_b(Pw + kk * PW2 + 16 * g, c16, b1, b2);
-                M[g] = MFMA(are, b1, M[g]);
-                M[g] = MFMA(aim, b2, M[g]);
-            }
-            #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                double b1, b2;
-                panel_b(Pw + kk * PW2 + PW + 16 * g, c16, b1, b2);
-                MR[g] = MFMA(are, b1, MR[g]);
-                MR[g] = MFMA(aim, b2, MR[g]);
-            }
-            const int s = (c16 & 7) - q0;
-            if (s >= 0 && s < 4) {
-                const double *src = (c16 < 8) ? Gre : Gim;
-                #pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    if (g == gp) {
-                        #pragma unroll
-                        for (int r = 0; r < 4; r++) M[g][r] = src[(16 * w + kk + 4 * r) * 4 + s];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- output.  P[rinv[x]][j] = MR[x][j]: the row-major panel (left operand of the adjoint sweep as P^H) straight
-    // from the registers, the stores in flight under the staging of the other three results
-    int prow[4];
-    #pragma unroll
-    for (int r = 0; r < 4; r++) prow[r] = rinv[16 * w + kk + 4 * r];
-    {
-        double *Prn = Pr + (size_t)(n - 1) * panel;
-        #pragma unroll
-        for (int g = 0; g < NG; g++)
-            #pragma unroll
-            for (int r = 0; r < 4; r++) Prn[(size_t)prow[r] * PW + 16 * g + c16] = MR[g][r];
-    }
-    // A^-1[rinv[x]][rho[j]] = M[x][j] (LinvT, left operand of lambda = L^-H y) and the column-major planes of P (left
-    // operand of the forward sweep) go through LDS one plane at a time
-    double *T = LinvT + (size_t)n * 2 * pl, *Pcn = Pc + (size_t)(n - 1) * 2 * pl;
-    #pragma unroll
-    for (int plane = 0; plane < 4; plane++) {
-        const int pass = plane & 1;
-        if ((c16 >> 3) == pass) {
-            if (plane < 2) {
-                #pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    const int oc = rho[8 * g + (c16 & 7)];
-                    #pragma unroll
-                    for (int r = 0; r < 4; r++) smem[prow[r] * LDP + oc] = M[g][r];
-                }
-            } else {
-                #pragma unroll
-                for (int g = 0; g < NG; g++)
-                    #pragma unroll
-                    for (int r = 0; r < 4; r++) smem[(8 * g + (c16 & 7)) * LDP + prow[r]] = MR[g][r];      // [col][row]
-            }
-        }
-        lds_barrier();
-        {
-            const __amdgpu_buffer_rsrc_t rT = buffer_of((plane < 2 ? T : Pcn) + pass * pl);
-            #pragma unroll
-            for (int q = 0; q < NP * NP / NTH; q++) {
-                const int e = t + q * NTH;
-                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
-            }
-        }
-        lds_barrier();
-    }
+// The last resort of the column-block kernel: the fully pivoted elimination above on the same matrix, as a function that
+// ends the wave.
+__device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
+                                                                int *status, int *fallbacks, double *smem, int *rho, int *rinv)
+{
+    if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1 << 16);           // (high half: matrices both column-block attempts gave up)
+    inverse_mfma_body<64>(cb_uniform(L), cb_uniform(R), cb_uniform(LinvT), cb_uniform(Pr), cb_uniform(Pc), __builtin_amdgcn_readfirstlane(n),
+                          cb_uniform(status), cb_uniform(smem), cb_uniform(rho), cb_uniform(rinv));
+    __builtin_amdgcn_endpgm();
+}
+
+// Np = 64: column-block elimination first; a matrix whose diagonal tiles do not carry the pivots (zero pivot or a multiplier
+// beyond CB_GROWTH inside a tile) is done again by the fully pivoted elimination above, in the same workgroup.
+// fallbacks: optional counter (tests), or null: += 1 per matrix the diagonal attempt gave up, += 65536 per matrix that went on to
+// the fully pivoted elimination.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_inverse_cb(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
+                  double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status, int *__restrict__ fallbacks)
+{
+    constexpr int SM = (INV_SMEM(64) > CB_WORK) ? INV_SMEM(64) : CB_WORK;
+    static_assert(SM >= 4 * 16 * CB_LDP, "staging slabs of the P planes");
+    __shared__ __attribute__((aligned(32))) double smem[SM];
+    __shared__ int rho[64], rinv[64];
+    __shared__ int bad;
+    inverse_cb_body(L, R, LinvT, Pr, Pc, n0 + (int)blockIdx.x, status, fallbacks, smem, rho, rinv, &bad);
 }
 
 // ---------------------------------------------------------------------------
-// K2 (Np = 64, default): the same blocked Gauss-Jordan + fused propagator, NM matrices per workgroup with
-// ALIGNED phases, static pivots first.
-//
-// What k_inverse_mfma loses (profiles/r01_v13: 0.28 of the fp64 MFMA peak, 64 x ~790-cycle pivot steps per matrix):
-// on gfx950 an f64 MFMA holds the SIMD's fp64 pipe for 64 cycles, so a wave that shares its SIMD with another
-// workgroup's burst of rank-4 updates issues about ONE vector instruction per MFMA -- and the serial pivot chain of a
-// matrix is ~200 dependent vector instructions per panel.  Three independent workgroups per CU interleave their
-// phases at random, so most pivot chains run beside somebody's MFMA burst.  Here the NM matrices that share a CU
-// live in ONE workgroup (NM x 4 waves; matrix i's waves on SIMDs 0..3, its panel wave on SIMD i) and every
-// barrier is common: all panel chains run at the same time on different SIMDs with no MFMA in flight, then all
-// waves issue their rank-4 updates together.
-//
-// Static pivots: L(t_n) = sum_j c_j (-dt)^j D_j is strongly diagonally dominant for the reference's physical models
-// (diagonal drift, small couplings: src/ProblemConstructors/multi_qudit_systems.jl), so the first attempt takes the
-// diagonal as pivot -- no DPP max-scan, no readlane of the winner, pivot ROWS known in advance: they are published
-// together with the panel columns (2 barriers per panel instead of 3) and the output permutation is the identity.
-// Every multiplier is checked against a modulus of 8 (partial pivoting guarantees 1); when any matrix of the
-// workgroup exceeds it (or meets a zero pivot) the workgroup reloads its matrices and repeats the elimination with
-// partial pivoting, exactly as k_inverse_mfma does.  Singular matrices raise `status` from the pivoted pass only.
+// The elimination of k_inverse_mfma as a function of a matrix held in registers (used by k_inverse_diag for the diagonal
+// blocks of the N > 64 block inverse, qgd_k_dense.hip).  STATIC = true takes the diagonal as pivots and reports a multiplier
+// beyond a modulus of 8 instead of searching (measured in round 2 as a first attempt for whole matrices: no gain inside the
+// evaluation); the library instantiates the pivoted form only.
 // ---------------------------------------------------------------------------
 #define INV_GROWTH2 64.0
-
-#ifdef QGD_INVM_PROFILE      // scripts/ubench/inverse_multi_bench.hip: cycles of workgroup 0 / thread 0 per phase
-__device__ unsigned long long g_invm_prof[16];
-#define INVM_PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_invm_prof[i] += (unsigned long long)(now_ - prof_last); prof_last = now_; } } while (0)
-#define INVM_PROF_DECL long long &prof_last,
-#define INVM_PROF_ARG prof_last,
-#else
 #define INVM_PROF(i) do { } while (0)
 #define INVM_PROF_DECL
 #define INVM_PROF_ARG
-#endif
 
 template <int NP, bool STATIC>
 __device__ __forceinline__ bool gj_panels(INVM_PROF_DECL d4 (&M)[NP / 8], double *__restrict__ work, int *__restrict__ rho,
@@ -970,153 +741,6 @@ __device__ __forceinline__ bool gj_panels(INVM_PROF_DECL d4 (&M)[NP / 8], double
     return __any(bad);
 }
 
-template <int NP, int NM, int WPE = NM>
-__global__ __launch_bounds__(NP * 4 * NM) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void k_inverse_multi(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
-                     double *__restrict__ Pr, double *__restrict__ Pc, int n0, int n_end, int try_static,
-                     int *__restrict__ status, int *__restrict__ repivoted)
-{
-    constexpr int NG = NP / 8, NW = NP / 16, NTH = 64 * NW, PW = 2 * NP, LDP = NP + 1;
-    constexpr int WORK = 8 * PW + 16 * NP + 8 * NP, SM = (WORK > NP * LDP) ? WORK : NP * LDP;
-    __shared__ double smem_all[NM][SM];
-    __shared__ int rho_all[NM][NP], rinv_all[NM][NP];
-    __shared__ int redo;
-    const int wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // (wave-uniform: addresses stay in SGPRs)
-    const int mat = wg / NW, w = wg % NW, t = threadIdx.x - mat * NTH;       // t: thread index within the matrix
-    const int c16 = lane & 15, kk = lane >> 4;
-    int n = n0 + (int)blockIdx.x * NM + mat;
-    const bool valid = n < n_end;                       // (a workgroup past the end repeats the last matrix, without stores)
-    if (!valid) n = n_end - 1;
-    double *smem = smem_all[mat];
-    int *rho = rho_all[mat], *rinv = rinv_all[mat];
-    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
-    const double *Ln = L + (size_t)n * panel;
-    const int pw = mat % NW;                            // panel waves of the matrices of a workgroup sit on different SIMDs
-
-    d4 M[NG];
-#ifdef QGD_INVM_PROFILE
-    long long prof_last = clock64();
-#endif
-    if (threadIdx.x == 0) redo = 0;
-    // attempt 0: static pivots (skipped when try_static == 0); attempt 1: partial pivoting.  ONE copy of the load in
-    // the code: two copies let the compiler keep the first M alive for the second attempt (64 more registers, spills).
-    for (int attempt = try_static ? 0 : 1; attempt < 2; attempt++) {
-        #pragma unroll
-        for (int g = 0; g < NG; g++)
-            #pragma unroll
-            for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * PW + 16 * g + c16];
-        INVM_PROF(0);
-        if (attempt == 0) {
-            __syncthreads();
-            const bool bad = gj_panels<NP, true>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, pw, status);
-            if (w == pw && bad && lane == 0) redo = 1;
-            __syncthreads();
-            if (!redo) {
-                if (t < NP) { rho[t] = t; rinv[t] = t; }
-                break;
-            }
-            if (threadIdx.x == 0 && repivoted) atomicAdd(repivoted, 1);    // some multiplier was too large: start over
-        } else {
-            (void)gj_panels<NP, false>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, pw, status);
-        }
-    }
-    __syncthreads();
-    INVM_PROF(6);
-    // ---- output (as k_inverse_mfma).  A^-1[rinv[x]][rho[j]] = M[x][j] goes through LDS one plane at a time (real
-    // parts, then imaginary parts): each staged plane is written out as LinvT (left operand of lambda = L^-H y) and is at
-    // once the A operand of one half of the step propagator P_{n-1} = L_n^-1 R_{n-1} = Are [Rre|Rim] + Aim [-Rim|Rre]
-    // (forward_evolution.jl:181-220, the implicit solve done for all right-hand sides).  For the product wave w owns the
-    // column groups 2w, 2w+1 of P over all rows: R is read once.
-    double *T = LinvT + (size_t)n * 2 * pl;
-    const double *Rn = R + (size_t)(n - 1) * panel;
-    int orow[4];
-    #pragma unroll
-    for (int r = 0; r < 4; r++) orow[r] = rinv[16 * w + kk + 4 * r] * LDP;
-    constexpr int NRT = NP / 16, GPW = NG / NW;            // row tiles, column groups per wave
-    d4 acc[NRT][GPW];
-    #pragma unroll
-    for (int rt = 0; rt < NRT; rt++)
-        #pragma unroll
-        for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = (d4){0, 0, 0, 0};
-    #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        if ((c16 >> 3) == pass) {
-            #pragma unroll
-            for (int g = 0; g < NG; g++) {
-                const int oc = rho[8 * g + (c16 & 7)];
-                #pragma unroll
-                for (int r = 0; r < 4; r++) smem[orow[r] + oc] = M[g][r];
-            }
-        }
-        lds_barrier();
-        INVM_PROF(7);
-        if (valid) {   // (buffer-addressed: descriptor and the constant part of the offset in SGPRs, no 64-bit vector adds)
-            const __amdgpu_buffer_rsrc_t rT = buffer_of(T + pass * pl);
-            #pragma unroll
-            for (int q = 0; q < NP * NP / NTH; q++) {
-                const int e = t + q * NTH;
-                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rT, t * 8, q * NTH * 8);
-            }
-        }
-        INVM_PROF(8);
-        #pragma unroll 4
-        for (int ks = 0; ks < NP / 4; ks++) {
-            const int k = 4 * ks + kk;
-            double bf[GPW];
-            #pragma unroll
-            for (int gg = 0; gg < GPW; gg++) {
-                const double *row = Rn + (size_t)k * PW + 16 * (GPW * w + gg);
-                if (pass == 0) bf[gg] = row[c16];
-                else { const double v = row[c16 ^ 8]; bf[gg] = (c16 < 8) ? -v : v; }
-            }
-            #pragma unroll
-            for (int rt = 0; rt < NRT; rt++) {
-                const double af = smem[(16 * rt + c16) * LDP + k];
-                #pragma unroll
-                for (int gg = 0; gg < GPW; gg++) acc[rt][gg] = MFMA(af, bf[gg], acc[rt][gg]);
-            }
-        }
-        INVM_PROF(9);
-        lds_barrier();
-        INVM_PROF(10);
-    }
-    // P: panel (row-major, left operand of the adjoint sweep as P^H) straight from the accumulators,
-    // column-major planes (left operand of the forward sweep) through LDS
-    double *Prn = Pr + (size_t)(n - 1) * panel, *Pcn = Pc + (size_t)(n - 1) * 2 * pl;
-    if (valid) {
-        #pragma unroll
-        for (int rt = 0; rt < NRT; rt++)
-            #pragma unroll
-            for (int gg = 0; gg < GPW; gg++)
-                #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    Prn[(size_t)(16 * rt + kk + 4 * r) * PW + 16 * (GPW * w + gg) + c16] = acc[rt][gg][r];
-    }
-    #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        if ((c16 >> 3) == pass) {
-            #pragma unroll
-            for (int rt = 0; rt < NRT; rt++)
-                #pragma unroll
-                for (int gg = 0; gg < GPW; gg++)
-                    #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        smem[(8 * (GPW * w + gg) + (c16 & 7)) * LDP + 16 * rt + kk + 4 * r] = acc[rt][gg][r];   // [col][row]
-        }
-        lds_barrier();
-        if (valid) {
-            const __amdgpu_buffer_rsrc_t rC = buffer_of(Pcn + pass * pl);
-            #pragma unroll
-            for (int q = 0; q < NP * NP / NTH; q++) {
-                const int e = t + q * NTH;
-                buffer_store_f64(smem[(e / NP) * LDP + (e % NP)], rC, t * 8, q * NTH * 8);
-            }
-        }
-        lds_barrier();
-    }
-    INVM_PROF(11);
-}
-
 // ---------------------------------------------------------------------------
 // Inverse of a diagonal block (bs = NP <= 64 rows) of the N > 64 work matrix, for the block Gauss-Jordan inverse of
 // qgd_k_dense.hip (qgdk_dense_inverse): the elimination of k_inverse_mfma (gj_panels: partial pivoting inside the block,
@@ -1145,9 +769,6 @@ void k_inverse_diag(const double *__restrict__ Win, size_t mstride, int ldw, siz
         for (int r = 0; r < 4; r++) M[g][r] = Ln[(size_t)(16 * w + kk + 4 * r) * ldw + 16 * g + c16];
     if (t == 0) sing = 0;
     __syncthreads();
-#ifdef QGD_INVM_PROFILE
-    long long prof_last = clock64();
-#endif
     (void)gj_panels<NP, false>(INVM_PROF_ARG M, smem, rho, rinv, w, lane, (int)(blockIdx.x % NW), &sing);
     __syncthreads();
     if (t == 0 && sing) flags[n] = 1;
@@ -1726,30 +1347,11 @@ int qgdk_inverse(const qgdk_ctx *c)
     case 16: SET_LDS_ONCE((k_inverse_reg<16, 16>), 2176); hipLaunchKernelGGL((k_inverse_reg<16, 16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 64:   // blocked elimination with MFMA rank-4 updates (the register-blocked VALU kernel measured 0.22 ms)
-        // QGD_INV_STATIC=1: k_inverse_multi (static pivots first, partial pivoting when a multiplier exceeds 8), one matrix
-        // per workgroup and three workgroups per CU; QGD_INV_MULTI=2|3: that many matrices per workgroup with aligned
-        // phases; with QGD_INV_PIVOTED=1 no static attempt.  Comparison paths: in the cnot3 evaluation none of them beats
-        // k_inverse_mfma (347 us per evaluation against 351 static, 354 three aligned matrices, 389 two).
-        if (!getenv("QGD_INVERSE_VALU") && (getenv("QGD_INV_STATIC") || getenv("QGD_INV_MULTI"))) {
-            const char *mm = getenv("QGD_INV_MULTI");
-            const int nm = mm ? atoi(mm) : 1, st = getenv("QGD_INV_PIVOTED") ? 0 : 1;
-#define CALL_IM(NM, WPE) hipLaunchKernelGGL((k_inverse_multi<64, NM, WPE>), dim3((nmat + NM - 1) / NM), dim3(256 * NM), 0, c->stream, c->L, c->R, \
-                                            c->LinvT, c->Pr, c->Pc, 1, nmat + 1, st, c->status, c->status + 1)
-            if (nm == 3) CALL_IM(3, 3); else if (nm == 2) CALL_IM(2, 2); else CALL_IM(1, 3);
-#undef CALL_IM
-            return (int)hipGetLastError();
-        }
-        if (!getenv("QGD_INVERSE_VALU") && getenv("QGD_INV_AUGMENTED")) {    // elimination of [L | R] (comparison path: 117 against 109 us for 550 matrices)
-            hipLaunchKernelGGL((k_inverse_aug<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
-            return (int)hipGetLastError();
-        }
+    case 64:   // column-block elimination of [L | R] (qgd_inverse_cb.h); QGD_INV_PANELS=1: the 4-pivot panel kernel for every matrix
         if (!getenv("QGD_INVERSE_VALU")) {
-            hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status
-#ifdef QGD_INV_PROFILE
-                               , (unsigned long long *)nullptr
-#endif
-                               ); return (int)hipGetLastError();
+            if (getenv("QGD_INV_PANELS")) hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
+            else hipLaunchKernelGGL(k_inverse_cb, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
+            return (int)hipGetLastError();
         }
         SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
     default: break;

@@ -1,15 +1,12 @@
-// Stand-alone timing + phase profile of the Np=64 batched inverse kernel.
+// Stand-alone timing + phase profile of the ROUND-4 Np=64 batched inverse kernel (4-pivot panels; frozen in
+// inverse_r4_kernel.h with its knock-out switches -- the library's kernels are in csrc/qgd_k_inverse.hip and
+// csrc/qgd_inverse_cb.h, their A/B is inverse_cb_bench.hip).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I quantumgatedesign.jl_amd/csrc -I include \
-//         scripts/ubench/inverse_bench.hip -o scripts/ubench/inverse_bench [-DQGD_INV_PROFILE]
+//         scripts/ubench/inverse_bench.hip -o scripts/ubench/bin/inverse_bench [-DQGD_INV_PROFILE] [-DQGD_INV_KO_CHAIN ...]
 // Prints the mean launch time over 50 launches of nmat matrices, the max |Linv*L - I|, and (with
 // -DQGD_INV_PROFILE) the cycles one workgroup spent in each phase of the blocked elimination.
-#include "../../quantumgatedesign.jl_amd/csrc/qgd_k_inverse.hip"
-// (the launcher at the end of that file refers to the N > 64 path, which this stand-alone bench does not link)
-extern "C" int qgdk_dense_inverse(const qgdk_ctx *) { return 0; }
-extern "C" int qgdk_dense_propagator(const qgdk_ctx *) { return 0; }
-#ifndef KERNEL
-#define KERNEL k_inverse_mfma      // -DKERNEL=k_inverse_aug: the augmented elimination
-#endif
+#include "inverse_r4_kernel.h"
+#define KERNEL k_inverse_r4
 #define STR2(x) #x
 #define STR(x) STR2(x)
 #include <cstdio>
@@ -40,7 +37,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
 #ifdef QGD_INV_PROFILE
-        hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS, dprof);
+        hipLaunchKernelGGL((k_inverse_r4<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS, dprof);
 #else
         hipLaunchKernelGGL((KERNEL<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT, dPr, dPc, 1, dS);
 #endif

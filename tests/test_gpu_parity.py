@@ -784,19 +784,18 @@ def test_dahlquist_and_rotating_frame_on_device(qgd):
     qgd.clear_cache()
 
 
-def test_static_pivot_inverse_and_its_fallback(qgd, orc, monkeypatch):
-    """The comparison paths of the N=64 inverse and of the launch order (none is the default: DESIGN.md section 7 has the
-    measurements).  k_inverse_multi (QGD_INV_STATIC=1) tries the diagonal as pivot first (L(t_n) of the dispersive models
-    is strongly diagonally dominant) and redoes a matrix with partial pivoting when a multiplier exceeds 8.  cnot3: no
-    matrix falls back and the result equals the partially-pivoted k_inverse_mfma to rounding, as do the aligned
-    multi-matrix workgroups, the time-chunk pipeline over side streams and the elimination of the augmented [L | R]
-    (k_inverse_aug: the propagator out of the block steps instead of a product phase); a drift that makes the diagonal of L vanish:
-    matrices DO fall back and the result still matches the numpy statement (the fallback is exercised, not just present)."""
+def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
+    """N = 64: the column-block elimination of [L | R] (qgd_inverse_cb.h) and the two stages behind it.  (1) cnot3: every matrix
+    is done by the first attempt (pivots on the diagonal) and gradient, L^-1 and P equal those of the fully pivoted 4-pivot-panel
+    kernel (QGD_INV_PANELS=1) to rounding.  (2) A drift that pairs the levels i <-> i^1 with dt*h at the zero of Re q_3(iy):
+    the diagonal of L vanishes beside off-diagonal entries of modulus ~1 INSIDE the 16 x 16 diagonal tiles -- the diagonal
+    attempt is given up, partial pivoting inside the tiles does every matrix.  (3) The same drift pairing i <-> i^32: the big
+    entries lie outside the diagonal tiles, both column-block attempts are given up and the fully pivoted elimination does
+    every matrix.  (2) and (3) against the numpy statement, itself tied to the oracle: the stages are exercised, not just
+    present.  intermediate("repivoted") = matrices past the first attempt + 65536 * matrices past the second."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
     res = {}
-    for tag, env in (("static", {"QGD_INV_STATIC": "1"}), ("pivoted", {"QGD_INV_STATIC": "1", "QGD_INV_PIVOTED": "1"}),
-                     ("multi3", {"QGD_INV_MULTI": "3"}), ("multi2", {"QGD_INV_MULTI": "2"}), ("old", {}),
-                     ("piped", {"QGD_PIPE_CHUNKS": "2"}), ("augmented", {"QGD_INV_AUGMENTED": "1"})):
+    for tag, env in (("blocks", {}), ("panels", {"QGD_INV_PANELS": "1"})):
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         dp = qgd.DeviceProblem(prob, 8)
@@ -805,29 +804,31 @@ def test_static_pivot_inverse_and_its_fallback(qgd, orc, monkeypatch):
         dp.close()
         for k_ in env:
             monkeypatch.delenv(k_)
-    assert res["static"][2] == 0 and res["multi3"][2] == 0
-    for tag in ("pivoted", "multi3", "multi2", "old", "piped", "augmented"):
-        assert np.abs(res[tag][0] - res["static"][0]).max() <= 1e-12 * np.abs(res["static"][0]).max(), tag
-        assert np.abs(res[tag][3] - res["static"][3]).max() <= 1e-12 * np.abs(res["static"][3]).max(), tag
-        assert np.abs(res[tag][4] - res["static"][4]).max() <= 1e-12, tag
-    # A drift that pairs the levels (zero diagonal, H[i, i^1] = h) with dt*h at the zero of Re q_3(iy) = 1 - y^2/10:
-    # L = q(-dt A) then has a vanishing diagonal beside off-diagonal entries of modulus ~1 -- the diagonal is no pivot.
-    prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=64, c=8, n_ops=2, nsteps=12, tf=0.8, seed=9)
-    order, dt = 6, 0.8 / 12
-    H = np.zeros((64, 64))
-    for i in range(64):
-        H[i, i ^ 1] = np.sqrt(10.0) / dt
-    prob.system_sym = np.asfortranarray(H + 0.1 * prob.system_sym)
-    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
-    ref = pp.evaluate(prob, Gp, Gq, off, 0.1 * pcof, target, order)
-    cases.oracle_pins(orc, prob, ctrl, 0.1 * pcof, target, order, ref)
-    monkeypatch.setenv("QGD_INV_STATIC", "1")
-    dp = qgd.DeviceProblem(prob, order)
-    dp.set_controls(ctrl); dp.set_target(target)
-    grad, _ = dp.discrete_adjoint(0.1 * pcof)
-    assert dp.intermediate("repivoted") > 0
-    assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max()
-    dp.close()
+    assert res["blocks"][2] == 0
+    assert np.abs(res["panels"][0] - res["blocks"][0]).max() <= 1e-12 * np.abs(res["blocks"][0]).max()
+    assert np.abs(res["panels"][3] - res["blocks"][3]).max() <= 1e-12 * np.abs(res["blocks"][3]).max()
+    assert np.abs(res["panels"][4] - res["blocks"][4]).max() <= 1e-12
+    order, nsteps, dt = 6, 12, 0.8 / 12
+    for partner, stage in ((1, 1), (32, 2)):
+        prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=64, c=8, n_ops=2, nsteps=nsteps, tf=0.8, seed=9)
+        H = np.zeros((64, 64))
+        for i in range(64):
+            H[i, i ^ partner] = np.sqrt(10.0) / dt
+        prob.system_sym = np.asfortranarray(H + 0.1 * prob.system_sym)
+        Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+        ref = pp.evaluate(prob, Gp, Gq, off, 0.1 * pcof, target, order)
+        if partner == 1:
+            cases.oracle_pins(orc, prob, ctrl, 0.1 * pcof, target, order, ref)
+        dp = qgd.DeviceProblem(prob, order)
+        dp.set_controls(ctrl); dp.set_target(target)
+        grad, _ = dp.discrete_adjoint(0.1 * pcof)
+        count = int(dp.intermediate("repivoted"))
+        P = dp.intermediate("P")
+        dp.close()
+        assert (count & 0xFFFF) == nsteps, (partner, count)
+        assert (count >> 16) == (nsteps if stage == 2 else 0), (partner, count)
+        assert np.abs(grad - ref["grad"]).max() <= 1e-10 * np.abs(ref["grad"]).max(), partner
+        assert np.abs(P[:nsteps] - ref["P"]).max() <= 1e-11, partner
 
 
 @pytest.mark.parametrize("c", [20, 64])
