@@ -298,7 +298,7 @@ def large_n_case(qgd, np, steps=3):
     gemms_r02 = m * (m - 1) // 2 + m + 4.0 * nsteps / (nsteps + 1) + 3 + m * (m - 1) // 2 + n_ops * m
     tflop = 8.0 * N ** 3 * gemms * (nsteps + 1) / 1e12
     # units on three-product tiles (level recursion, sweep, D-contraction, outer products, chains) issue 6 N^3, the rest 8 N^3
-    units_3m = gemms - 3 if not os.environ.get("QGD_DENSE_4M") else 0.0
+    units_3m = gemms - 3 if "dense_4m" not in os.environ.get("QGD_PATHS", "") else 0.0
     issued = 8.0 * N ** 3 * (0.75 * units_3m + (gemms - units_3m)) * (nsteps + 1) / 1e12
     # `frac` is the HARDWARE fraction: flops the MFMA pipe issues (three real products per complex multiply on most
     # units) / time / peak.  The usual complex-GEMM count (8 N^3 per unit) prices the same time higher and is kept as
@@ -355,7 +355,7 @@ def cnot2_case_gpu(qgd, np, steps=50):
     N_, c_, m_, n_ops_, ns_ = 4, 4, 4, 2, 100
     launches, src = (4, "csrc/qgd_k_tiny.hip (front, scan, gradient, sum)") if small_taken else (12, "DESIGN.md section 7a (launch sequence)")
     ppath = os.path.join(ROOT, "profiles", CNOT2_PROFILE)
-    if os.path.exists(ppath):
+    if small_taken and os.path.exists(ppath):       # (the committed profile is of the small-problem path: its launch count describes no other)
         try:
             d = json.load(open(ppath))
             launches, src = float(d["launches_per_evaluation"]), "profiles/" + CNOT2_PROFILE

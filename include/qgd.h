@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define QGD_ABI_VERSION 1
+/* 2: the last word of qgd_problem_desc, `reserved` in version 1, is the flags word (QGD_CREATE_*): a caller built against
+   version 1 that left garbage there would now be misread, hence the bump (round 4 made the change without one). */
+#define QGD_ABI_VERSION 2
 
 enum {
     QGD_OK = 0,

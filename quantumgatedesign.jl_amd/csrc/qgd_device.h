@@ -1,4 +1,4 @@
-// qgd_device.h -- launch context shared by the kernel translation units (qgd_k_*.hip) and qgd_api.cpp
+// qgd_device.h -- launch context shared by the kernel translation units (qgd_k_*.hip) and the host side (qgd_host_*.cpp)
 #ifndef QGD_DEVICE_H
 #define QGD_DEVICE_H
 #include <hip/hip_runtime.h>
@@ -6,6 +6,24 @@
 #include <stdint.h>
 
 #define QGD_MAX_OPS_DEV 8
+
+/* Path overrides, for tests and A/B timing only: QGD_PATHS="token[=value],token,..." forces a kernel selection the library
+   otherwise makes from the problem's shape (INTEGRATION.md section 5 lists the tokens).  Every token names a path the
+   library takes by itself for some shape -- variants that lost a measurement are not kept behind switches.  Read at every
+   call: tests change it between two handles of one process.  Returns the token's value ("" when it has none) or NULL. */
+#include <stdlib.h>
+#include <string.h>
+static inline const char *qgd_path(const char *key)
+{
+    const char *e = getenv("QGD_PATHS");
+    const size_t n = strlen(key);
+    while (e && *e) {
+        if (strncmp(e, key, n) == 0 && (e[n] == '\0' || e[n] == ',' || e[n] == '=')) return e[n] == '=' ? e + n + 1 : "";
+        e = strchr(e, ',');
+        if (e) e++;
+    }
+    return NULL;
+}
 
 typedef struct qgdk_ctx {
     int N, Np, c, cp, n_ops, n_ess, m, nt, n_pcof, nc_max;
@@ -103,7 +121,7 @@ typedef struct qgdk_ctx {
     int64_t goff_host[QGD_MAX_OPS_DEV];
     // Result mirror (single GPU, resident grid): the last kernel of a gradient evaluation, k_contract_sum, also writes
     // [grad | scal(4) | status] into pinned host memory and then a sequence number the host is polling -- no copy packet
-    // behind the kernel and no wait for the stream's completion signal (qgd_api.cpp: fetch_results).  mirror_dev: the
+    // behind the kernel and no wait for the stream's completion signal (qgd_host_eval.cpp: fetch_results).  mirror_dev: the
     // device-visible address of that host buffer ([n_pcof + 6] doubles, the sequence number in the last one as a 64-bit
     // integer), or null for this launch; mirror_ticket: a zeroed device counter.
     double *mirror_dev;

@@ -457,7 +457,7 @@ __device__ __forceinline__ int cb_attempt(const double *L, const double *R, doub
 __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
                                                              int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
-    if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1);                 // (low half: matrices the diagonal attempt gave up)
+    if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1);                 // (matrices not done by the diagonal attempt)
     if (cb_attempt<false>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
         cb_fallback(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL);
@@ -465,11 +465,14 @@ __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, co
     __builtin_amdgcn_endpgm();
 }
 
-// The workgroup's entry.
+// The workgroup's entry.  fallbacks (or null): [0] += matrices not done by the diagonal attempt, [1] += of these, by the last
+// resort, [2] != 0: skip the diagonal attempt (k_tables sets it when the previous evaluation gave up more than a quarter of
+// its matrices there -- a problem whose step matrices are not diagonally dominant pays for the failed attempt only once).
 __device__ __forceinline__ void inverse_cb_body(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, const int n,
                                                 int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
-    if (cb_attempt<true>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
+    const bool pivot_first = fallbacks && __builtin_amdgcn_readfirstlane(fallbacks[2]) != 0;
+    if (pivot_first || cb_attempt<true>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
         cb_retry(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
     }

@@ -19,7 +19,10 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
     if (!keep) {
         if (gid < 4) scal[gid] = 0.0;        // objective scalars and the singularity flag start at zero
         if (gid == 4) *status = 0;
-        if (gid == 5) status[1] = 0;      // workgroups of the inverse that fell back to partial pivoting
+        if (gid == 5) {                   // counters of the inverse (matrices redone, N = 64: by the last resort), and what the N = 64
+            if (4 * status[1] > nt) status[3] = 1;      // kernel remembers: when more than a quarter of the last evaluation's matrices were
+            status[1] = 0; status[2] = 0;               // given up by the diagonal-pivot attempt it starts with pivoting from now on
+        }
     }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
@@ -53,7 +56,10 @@ __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G
     if (!keep) {
         if (gid < 4) scal[gid] = 0.0;
         if (gid == 4) *status = 0;
-        if (gid == 5) status[1] = 0;      // workgroups of the inverse that fell back to partial pivoting
+        if (gid == 5) {                   // counters of the inverse (matrices redone, N = 64: by the last resort), and what the N = 64
+            if (4 * status[1] > nt) status[3] = 1;      // kernel remembers: when more than a quarter of the last evaluation's matrices were
+            status[1] = 0; status[2] = 0;               // given up by the diagonal-pivot attempt it starts with pivoting from now on
+        }
     }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;

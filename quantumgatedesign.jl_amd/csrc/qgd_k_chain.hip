@@ -1008,7 +1008,7 @@ static int launch_chain_dense_w(const ChainArgs &a, hipStream_t stream)
     const int nwg = (MODE == 0) ? 8 * ngt * ((a.nblocks + 7) / 8) : a.nblocks * ngt;
     const size_t shm = (size_t)a.Np * 16 * NGT * sizeof(double);
     if (nwg <= 0) return 0;
-    const bool m3 = getenv("QGD_DENSE_4M") == nullptr;        // three-product tiles (k_chain_dense3) unless switched off
+    const bool m3 = qgd_path("dense_4m") == nullptr;          // three-product tiles (k_chain_dense3) unless switched off (tests)
 #define CALL_CD(R) do { bool done3_ = false;                                                                                \
         if constexpr (NGT > 1 && !(NGT == 4 && R == 3) && R < 5) {    /* (<.,3,4>, <.,5,2>: spills -- the four-product kernel there) */ \
             if (m3) { SET_LDS_ONCE((k_chain_dense3<MODE, R, NGT>), shm);                                 \
@@ -1030,9 +1030,9 @@ template <int MODE>
 static bool chain_as_steps(const ChainArgs &a)
 {
     if (MODE != 1 && MODE != 3) return false;
-    if (a.nblocks != 1 || a.S < 1 || getenv("QGD_CHAIN_NO_STEPS") || getenv("QGD_DENSE_4M")) return false;
+    if (a.nblocks != 1 || a.S < 1 || qgd_path("dense_4m")) return false;
     if (a.fs_mode || a.guard_diag || a.sub_T || a.npre) return false;                  // plain chains only
-    const char *e = getenv("QGD_CHAIN_STEPS_MIN");                                   // (tests: the step path on small shapes)
+    const char *e = qgd_path("chain_steps_min");                                      // (tests: the step path on small shapes)
     return (long long)a.Np * a.Np * a.cp >= (e ? atoll(e) : 256LL * 256 * 64);
 }
 
@@ -1060,8 +1060,7 @@ static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 {
     if (chain_as_steps<MODE>(a)) return launch_chain_steps<MODE>(a, stream);
     const long long cus = 256;      // (thresholds of 128 .. 1024 tiles give the same times within 2 %)
-    static const long long t1 = getenv("QGD_CHAIN_T1") ? atoll(getenv("QGD_CHAIN_T1")) : cus - 1;     // (tuning; 8-column tiles only while they are fewer than the CUs)
-    static const long long t2 = getenv("QGD_CHAIN_T2") ? atoll(getenv("QGD_CHAIN_T2")) : 2 * cus;
+    const long long t1 = cus - 1, t2 = 2 * cus;     // (8-column tiles only while they are fewer than the CUs)
     if ((long long)a.nblocks * a.ngroups <= t1) return launch_chain_dense_w<MODE, 1>(a, stream);
     if ((long long)a.nblocks * ((a.ngroups + 1) / 2) <= t2 || a.Np > 288) return launch_chain_dense_w<MODE, 2>(a, stream);     // (32-column tiles: Np <= 288, LDS)
     return launch_chain_dense_w<MODE, 4>(a, stream);
@@ -1070,7 +1069,7 @@ static int launch_chain_dense(const ChainArgs &a, hipStream_t stream)
 // the dense chain pays when a tile of 4 groups is (nearly) full and the state tile fits in LDS
 static bool chain_is_dense(const ChainArgs &a)
 {
-    const bool off = getenv("QGD_CHAIN_GENERIC") != nullptr;     // (comparison path; a getenv per launch is noise at these sizes)
+    const bool off = qgd_path("chain_generic") != nullptr;       // (tests: the generic chain, which Np > 640 takes, on a small shape)
     return !off && a.Np > 64 && a.Np <= 640;
 }
 
@@ -1467,7 +1466,7 @@ static inline bool chain_is_fast(const qgdk_ctx *c) { return c->Np == 16 || c->N
 // diagonal guard projector + compiled-size sweeps: k_chain_fast<.,1,.> does the guard work
 static inline bool guard_is_fused(const qgdk_ctx *c)
 {
-    return c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64) && !getenv("QGD_GUARD_KERNEL");
+    return c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64);
 }
 
 // ---------------------------------------------------------------------------
@@ -1484,7 +1483,7 @@ static inline bool guard_is_fused(const qgdk_ctx *c)
 // affine parts, ChainArgs::suf_P): compiled-size chains with a second scan level of more than two blocks per super-block
 static inline bool suffix_on(const qgdk_ctx *c)
 {
-    return c->SufP && c->SufPhi && chain_is_fast(c) && c->scan_blocks2 > 1 && c->scan_g > 2 && !getenv("QGD_NO_SUFFIX");
+    return c->SufP && c->SufPhi && chain_is_fast(c) && c->scan_blocks2 > 1 && c->scan_g > 2 && !qgd_path("no_suffix");
 }
 
 static inline size_t rx_chunk(const qgdk_ctx *c) { return (size_t)4 * c->Np * c->Np; }
@@ -1526,7 +1525,7 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
     return 0;
 }
 
-// forward, part 1 in pieces (time-chunk pipeline of qgd_api.cpp): the block propagators of blocks [b0, b1) on `stream`;
+// forward, part 1 in pieces (ranges of blocks): the block propagators of blocks [b0, b1) on `stream`;
 // then the levels above them (super-blocks, window product) on the context's stream
 int qgdk_forward_blocks_range(const qgdk_ctx *c, int b0, int b1, hipStream_t stream)
 {
@@ -1655,7 +1654,7 @@ int qgdk_guard_parts(const qgdk_ctx *c)
     const int nb = c->sub_hist ? c->scan_blocks * (c->sub_n + 1) : c->scan_blocks;
     return nb * (c->cp / 8);
 }
-int qgdk_terminal_can_fuse(const qgdk_ctx *c) { return chain_is_fast(c) && !getenv("QGD_TERMINAL_KERNEL"); }
+int qgdk_terminal_can_fuse(const qgdk_ctx *c) { return chain_is_fast(c) && !qgd_path("terminal_kernel"); }
 
 int qgdk_guard(const qgdk_ctx *c)
 {
@@ -1685,7 +1684,7 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
 {
     const size_t hstep = (size_t)c->Np * 2 * c->cp;
     double *slot = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;     // y_N for the other ranks
-    if (hstep >= 32768 && !getenv("QGD_TERMINAL_ONE_WG")) {
+    if (hstep >= 32768) {
         // large panels (config 5: 131072 elements): one workgroup took 177 us; many workgroups, two launches
         const int nwg = (int)((hstep + 2047) / 2048);
         const int tchunk = 2048 * ((nwg + 1023) / 1024), twg = (int)((hstep + tchunk - 1) / tchunk);      // (<= 1024 partial sums)

@@ -413,10 +413,11 @@ __device__ __forceinline__ void cgemm3_tile_panelH(d4 (&p1)[DN_RB][DN_NG / 2], d
 }
 
 #define ZERO_ACC3(acc) _Pragma("unroll") for (int r_ = 0; r_ < DN_RB; r_++) _Pragma("unroll") for (int g_ = 0; g_ < DN_NG / 2; g_++) acc[r_][g_] = (d4){0, 0, 0, 0}
-// 3M switch of the N > 64 kernels (QGD_DENSE_4M=1 keeps the four-product tiles: A/B timing and tests)
+// 3M switch of the N > 64 kernels (QGD_PATHS=dense_4m keeps the four-product tiles, which some tile shapes take anyway:
+// tests and A/B timing)
 static bool dense_3m()
 {
-    return getenv("QGD_DENSE_4M") == nullptr;       // (read per call: tests switch it inside one process; noise beside these launches)
+    return qgd_path("dense_4m") == nullptr;          // (read per call: tests switch it inside one process; noise beside these launches)
 }
 
 // ---------------------------------------------------------------------------
@@ -1410,10 +1411,10 @@ __global__ __launch_bounds__(256) void k_yinit(const double *__restrict__ T, con
 // which form the gradient scalars take on the N > 64 path: 0 operator applications (k_ginner_f), 1 outer products with the
 // stage derivatives (k_ginner_m), 2 outer products through the stored D_i (k_gouter + k_ginner_d: no k_derivs_f).
 // 3 the whole reverse sweep on the N x N matrices Y_j (k_youter + k_yinit + k_gsweep_f on Y + k_ginner_d: neither stage
-// derivatives nor a sweep on the state panels).  QGD_GINNER=0|1|2|3 forces one (tests, A/B timing).
+// derivatives nor a sweep on the state panels).  QGD_PATHS=ginner=0|1|2|3 forces one (tests, A/B timing).
 static int dense_sigma_form(const qgdk_ctx *c)
 {
-    if (const char *e = getenv("QGD_GINNER")) { const int f = atoi(e); return (f >= 2 && !c->Xouter) ? 1 : f; }
+    if (const char *e = qgd_path("ginner")) { const int f = atoi(e); return (f >= 2 && !c->Xouter) ? 1 : f; }
     if (c->Np < 128 || c->cp < 64) return 0;
     const int m = c->m;
     if (c->Xouter && c->Tlam && (long long)(m * (m - 1) / 2) * c->Np < (long long)(m * (m + 1) / 2 - 2) * c->cp) return 3;
@@ -1528,12 +1529,12 @@ size_t qgdk_dense_inverse_words(int Np, int nt)
 
 int qgdk_dense_inverse(const qgdk_ctx *c)
 {
-    if (!c->binv || !c->inv_scratch || !dense_3m() || getenv("QGD_BINV_OFF") || c->nt < 2) return 0;
+    if (!c->binv || !c->inv_scratch || !dense_3m() || qgd_path("binv_off") || c->nt < 2) return 0;
     const int Np = c->Np, nt = c->nt, nmat = nt - 1, PW = 2 * Np;
     const size_t panel = (size_t)Np * PW;
     double *PA = c->binv, *PB = PA + (size_t)nt * panel, *DkC = PB + (size_t)nt * panel;
     int *flags = reinterpret_cast<int *>(DkC + (size_t)nt * 2 * BINV_B * BINV_B);
-    const double thresh = getenv("QGD_BINV_THRESH") ? atof(getenv("QGD_BINV_THRESH")) : 2.0;
+    const double thresh = qgd_path("binv_thresh") ? atof(qgd_path("binv_thresh")) : 2.0;
     if (hipMemsetAsync(flags, 0, (size_t)nt * sizeof(int), c->stream) != hipSuccess) return -1;
     const double *Win = c->L;
     double *outs[2] = {PA, PB};
@@ -1619,7 +1620,7 @@ int qgdk_dense_gradient(const qgdk_ctx *c)
     d2 *Xf = reinterpret_cast<d2 *>(c->Xfrag);
     const d2 *Df = reinterpret_cast<const d2 *>(c->Dfrag);
     if (dense_sigma_form(c) == 3) {      // the sweep on the matrices Y_j = g_j psi_0^H (see k_youter)
-        const bool lazy = dense_3m() && c->m >= 2 && !getenv("QGD_YINIT_ALL");      // seeds formed inside the first sweep level
+        const bool lazy = dense_3m() && c->m >= 2;      // seeds formed inside the first sweep level
         const size_t panel = (size_t)c->Np * 2 * c->Np;
         const int ogrid2 = dense_grid(2, 2, c->Np / 16, c->Np / 16, 2, c->nt), ogrid = dense_grid(2, 2, c->Np / 16, c->Np / 16, c->m, c->nt);
         if (dense_3m()) hipLaunchKernelGGL((k_youter<2, 2, true>), dim3(ogrid2), dim3(256), 0, c->stream, c->hist, c->lam, c->Tlam, c->Np, c->cp, c->nt);

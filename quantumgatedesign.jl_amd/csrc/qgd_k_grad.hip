@@ -603,7 +603,7 @@ extern "C" {
 int qgdk_derivs(const qgdk_ctx *c)
 {
     if (c->dense_gemm && !c->use_sparse) return qgdk_dense_derivs(c);
-    if (c->use_sparse && !getenv("QGD_DERIVS_MFMA")) return qgdk_derivs_sparse(c);      // (the comparison path keeps the MFMA kernel)
+    if (c->use_sparse) return qgdk_derivs_sparse(c);
     size_t shm = (size_t)(c->m + 1) * c->Np * 16 * sizeof(double);
     double *gp = nullptr;
     if (c->panel_scratch) { gp = c->panel_scratch; shm = 0; }

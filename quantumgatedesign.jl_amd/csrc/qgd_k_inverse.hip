@@ -126,159 +126,6 @@ __global__ __launch_bounds__(256) void k_inverse(const double *__restrict__ L,
 }
 
 // ---------------------------------------------------------------------------
-// K2 (fast path, Np <= 64): the same Gauss-Jordan inverse with the matrix held in
-// registers: 256 threads as a 16x16 grid, thread (ty,tx) owns the BSxBS block of rows
-// ty*BS.. and columns tx*BS.. (BS = Np/16).  Per pivot only the pivot column, the pivot
-// row and the swapped row travel through LDS (2 barriers); the rank-1 update is local.
-// ---------------------------------------------------------------------------
-template <int NP, int TG>
-__global__ __launch_bounds__(TG * TG) void k_inverse_reg(const double *__restrict__ L,
-                                                     double *__restrict__ LinvA,
-                                                     double *__restrict__ LinvT, int n0,
-                                                     int *__restrict__ status)
-{
-    constexpr int BS = NP / TG, NTH = TG * TG;   // TG x TG threads, BS x BS block each
-    static_assert(BS * TG == NP && BS <= 8, "block");
-    __shared__ double colre[2][NP], colim[2][NP];
-    __shared__ double rowre[2][2][NP], rowim[2][2][NP];
-    __shared__ int perm[NP], outpos[NP], idx[NP];
-    __shared__ double pivinv[2][2];
-    const int n = n0 + blockIdx.x;
-    const int t = threadIdx.x, ty = t / TG, tx = t % TG, lane = t & 63;
-    constexpr int PW = 2 * NP;
-    const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
-    const double *Ln = L + (size_t)n * panel;
-
-    double are[BS][BS], aim[BS][BS];
-    #pragma unroll
-    for (int i = 0; i < BS; i++)
-        #pragma unroll
-        for (int j = 0; j < BS; j++) {
-            const int r = ty * BS + i, c = tx * BS + j;
-            are[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + (c & 7)];
-            aim[i][j] = Ln[(size_t)r * PW + (c >> 3) * 16 + 8 + (c & 7)];
-        }
-
-    // statically indexed access to row / column `ii` of the register block (ii is uniform)
-#define INV_SEL(ii, STMT) switch (ii) { \
-    case 0: { constexpr int I = 0; STMT } break; \
-    case 1: { constexpr int I = (1 < BS) ? 1 : 0; STMT } break; \
-    case 2: { constexpr int I = (2 < BS) ? 2 : 0; STMT } break; \
-    case 3: { constexpr int I = (3 < BS) ? 3 : 0; STMT } break; \
-    case 4: { constexpr int I = (4 < BS) ? 4 : 0; STMT } break; \
-    case 5: { constexpr int I = (5 < BS) ? 5 : 0; STMT } break; \
-    case 6: { constexpr int I = (6 < BS) ? 6 : 0; STMT } break; \
-    default: { constexpr int I = (7 < BS) ? 7 : 0; STMT } break; }
-    for (int p = 0; p < NP; p++) {
-        const int buf = p & 1;
-        const int pblk = p / BS, poff = p % BS;        // uniform
-        if (tx == pblk) {                               // publish column p
-            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
-                colre[buf][ty * BS + i] = are[i][I]; colim[buf][ty * BS + i] = aim[i][I]; })
-        }
-        if (ty == pblk) {                               // publish row p (before any swap)
-            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
-                rowre[buf][0][tx * BS + j] = are[I][j]; rowim[buf][0][tx * BS + j] = aim[I][j]; })
-        }
-        __syncthreads();
-        // pivot search, redundantly in every wave.  One 64-bit key per lane: the bit pattern of
-        // |a|^2 (non-negative doubles order like unsigned integers) with the low 6 mantissa bits
-        // replaced by 63-row, so that one max-reduction yields the arg-max (ties -> lowest row).
-        unsigned long long key = 0;
-        if (lane < NP && lane >= p) {
-            const double a = colre[buf][lane], b = colim[buf][lane];
-            key = ((unsigned long long)__double_as_longlong(a * a + b * b) & ~63ull) | (unsigned long long)(63 - lane);
-        }
-        #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long ok = __shfl_xor(key, off);
-            key = ok > key ? ok : key;
-        }
-        const int pr = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63ull));
-        if (t == 0) { perm[p] = pr; if (!((key >> 6) != 0)) *status = 1; }
-        const int rblk = pr / BS, roff = pr % BS;
-        if (ty == rblk) {                               // owners of row pr publish it scaled by 1/pivot
-            const double pa = colre[buf][pr], pb = colim[buf][pr];
-            const double den = 1.0 / (pa * pa + pb * pb);
-            const double ir = pa * den, ii = -pb * den;
-            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
-                const double x = are[I][j]; const double y = aim[I][j];
-                rowre[buf][1][tx * BS + j] = x * ir - y * ii; rowim[buf][1][tx * BS + j] = x * ii + y * ir; })
-            if (tx == 0) { pivinv[buf][0] = ir; pivinv[buf][1] = ii; }
-        }
-        const double cpr = colre[buf][p], cpi = colim[buf][p];   // old a_pp: multiplier of the swapped row
-        __syncthreads();
-        const double ir = pivinv[buf][0], ii = pivinv[buf][1];  // 1/pivot
-        if (ty == rblk && pr != p) {                    // row swap: row pr takes the old row p
-            INV_SEL(roff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
-                are[I][j] = rowre[buf][0][tx * BS + j]; aim[I][j] = rowim[buf][0][tx * BS + j]; })
-        }
-        double rpr[BS], rpi[BS], ur[BS], ui[BS];        // scaled pivot row; the same with column p zeroed
-        #pragma unroll
-        for (int j = 0; j < BS; j++) {
-            const int c = tx * BS + j;
-            rpr[j] = rowre[buf][1][c];
-            rpi[j] = rowim[buf][1][c];
-            ur[j] = (c == p) ? 0.0 : rpr[j];
-            ui[j] = (c == p) ? 0.0 : rpi[j];
-        }
-        double fr[BS], fi[BS];                          // multipliers of my rows (0 for the pivot row)
-        #pragma unroll
-        for (int i = 0; i < BS; i++) {
-            const int r = ty * BS + i;
-            const double cr = colre[buf][r], ci = colim[buf][r];
-            fr[i] = (r == p) ? 0.0 : ((r == pr) ? cpr : cr);
-            fi[i] = (r == p) ? 0.0 : ((r == pr) ? cpi : ci);
-        }
-        #pragma unroll
-        for (int i = 0; i < BS; i++)
-            #pragma unroll
-            for (int j = 0; j < BS; j++) {
-                are[i][j] -= fr[i] * ur[j] - fi[i] * ui[j];
-                aim[i][j] -= fr[i] * ui[j] + fi[i] * ur[j];
-            }
-        if (tx == pblk) {                               // column p: -f/pivot (pivot row fixed next)
-            INV_SEL(poff, _Pragma("unroll") for (int i = 0; i < BS; i++) {
-                are[i][I] = -(fr[i] * ir - fi[i] * ii); aim[i][I] = -(fr[i] * ii + fi[i] * ir); })
-        }
-        if (ty == pblk) {                               // pivot row: scaled row, 1/pivot in column p
-            INV_SEL(poff, _Pragma("unroll") for (int j = 0; j < BS; j++) {
-                const bool dg = (tx * BS + j == p);
-                are[I][j] = dg ? ir : rpr[j]; aim[I][j] = dg ? ii : rpi[j]; })
-        }
-    }
-#undef INV_SEL
-    __syncthreads();
-    if (t == 0) {   // compose the column swaps that undo the row interchanges
-        for (int x = 0; x < NP; x++) idx[x] = x;
-        for (int p = NP - 1; p >= 0; p--) { const int q = perm[p]; const int tmp = idx[p]; idx[p] = idx[q]; idx[q] = tmp; }
-        for (int x = 0; x < NP; x++) outpos[idx[x]] = x;
-    }
-    __syncthreads();
-    // stage the (column-permuted) inverse through LDS so that both output layouts are
-    // written with coalesced stores; rows padded by one double against bank conflicts
-    extern __shared__ double stage[];          // one plane at a time: NP x (NP+1)
-    constexpr int LDP = NP + 1;
-    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
-    #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        #pragma unroll
-        for (int j = 0; j < BS; j++) {
-            const int oc = outpos[tx * BS + j];
-            #pragma unroll
-            for (int i = 0; i < BS; i++) stage[(ty * BS + i) * LDP + oc] = pass ? aim[i][j] : are[i][j];
-        }
-        __syncthreads();
-        for (int e = t; e < NP * NP; e += NTH) {
-            const int hi = e / NP, lo = e % NP;       // NP is a compile-time constant
-            T[pass * pl + e] = stage[hi * LDP + lo];  // row-major: (r=hi, c=lo)
-            A[pass * pl + e] = stage[lo * LDP + hi];  // column-major: (r=lo, c=hi)
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------
 // K2 (fast path, Np <= 64): blocked Gauss-Jordan inverse, 4 pivots per panel, rank-4 updates on
 // the fp64 MFMA.  The matrix lives in registers in accumulator layout (wave w owns rows
 // 16w..16w+15 of all columns: d4 M[Np/8]) and rows are never moved: pivoting is implicit (the
@@ -572,7 +419,7 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
                                                                 int *status, int *fallbacks, double *smem, int *rho, int *rinv)
 {
-    if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1 << 16);           // (high half: matrices both column-block attempts gave up)
+    if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks + 1, 1);             // (matrices both column-block attempts gave up)
     inverse_mfma_body<64>(cb_uniform(L), cb_uniform(R), cb_uniform(LinvT), cb_uniform(Pr), cb_uniform(Pc), __builtin_amdgcn_readfirstlane(n),
                           cb_uniform(status), cb_uniform(smem), cb_uniform(rho), cb_uniform(rinv));
     __builtin_amdgcn_endpgm();
@@ -580,8 +427,7 @@ __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L,
 
 // Np = 64: column-block elimination first; a matrix whose diagonal tiles do not carry the pivots (zero pivot or a multiplier
 // beyond CB_GROWTH inside a tile) is done again by the fully pivoted elimination above, in the same workgroup.
-// fallbacks: optional counter (tests), or null: += 1 per matrix the diagonal attempt gave up, += 65536 per matrix that went on to
-// the fully pivoted elimination.
+// fallbacks: three words or null (inverse_cb_body).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_inverse_cb(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
                   double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status, int *__restrict__ fallbacks)
@@ -798,151 +644,6 @@ void k_inverse_diag(const double *__restrict__ Win, size_t mstride, int ldw, siz
 }
 
 // ---------------------------------------------------------------------------
-// K2 (any Np > 64 whose panels fit in LDS, Np <= 288): blocked Gauss-Jordan with the matrix in an
-// HBM/L2 work slab (panel layout) and 16 pivots per panel.  The same scheme as k_inverse_mfma --
-// implicit pivoting, the pivoted in-place elimination of the Np x 16 panel yields the multipliers,
-// rank-16 trailing updates on the fp64 MFMA -- but the panel is factored by the whole workgroup in
-// LDS and the matrix streams through the accumulators tile by tile: the slab is read and written
-// once per 16 pivots instead of once per pivot (the unblocked k_inverse moves 2 N^3 * 16 bytes).
-// ---------------------------------------------------------------------------
-#define INVB_NB 16
-__global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restrict__ L,
-                                                         double *__restrict__ LinvA,
-                                                         double *__restrict__ LinvT,
-                                                         double *__restrict__ scratch, int Np, int n0,
-                                                         int *__restrict__ status)
-{
-    constexpr int NB = INVB_NB;
-    extern __shared__ double smem[];
-    const int PW = 2 * Np;
-    double *Fre = smem, *Fim = Fre + (size_t)Np * NB;          // panel columns -> multipliers
-    double *Bp = Fim + (size_t)Np * NB;                         // [NB][PW] pivot rows (B operand)
-    double *fre = Bp + (size_t)NB * PW, *fim = fre + Np;        // column s of the panel before the step
-    double *yrow = fim + Np;                                    // [2*NB] scaled pivot row
-    double *redv = yrow + 2 * NB;                               // [8]
-    int *redi = reinterpret_cast<int *>(redv + 8);              // [8]
-    int *rho = redi + 8, *rinv = rho + Np, *used = rinv + Np;
-    const int n = n0 + blockIdx.x;
-    const int t = threadIdx.x, nth = blockDim.x, wave = t >> 6, lane = t & 63, nw = nth >> 6;
-    const int c16 = lane & 15, kk = lane >> 4;
-    const size_t panel = (size_t)Np * PW, pl = (size_t)Np * Np;
-    double *W = scratch + (size_t)blockIdx.x * panel;
-    const double *Ln = L + (size_t)n * panel;
-#ifdef QGD_INVB_PROFILE
-    long long pt[8] = {0,0,0,0,0,0,0,0}, pl_ = clock64();
-#define IBP(i) do { const long long n_ = clock64(); pt[i] += n_ - pl_; pl_ = n_; } while (0)
-#else
-#define IBP(i) do { } while (0)
-#endif
-    for (size_t e = t; e < panel; e += nth) W[e] = Ln[e];
-    for (int r = t; r < Np; r += nth) used[r] = 0;
-    __syncthreads();
-
-    IBP(0);
-    for (int p0 = 0; p0 < Np; p0 += NB) {
-        // ---- 1. the 16 panel columns into LDS
-        for (int e = t; e < Np * NB; e += nth) {
-            const int r = e / NB, col = p0 + (e % NB);
-            const size_t o = (size_t)r * PW + (col >> 3) * 16 + (col & 7);
-            Fre[e] = W[o]; Fim[e] = W[o + 8];
-        }
-        __syncthreads();
-        IBP(1);
-        // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
-        for (int s = 0; s < NB; s++) {
-            double best = -1.0; int bi = 0;
-            for (int r = t; r < Np; r += nth) {
-                const double a = Fre[r * NB + s], b = Fim[r * NB + s];
-                fre[r] = a; fim[r] = b;
-                const double v = a * a + b * b;
-                if (!used[r] && v > best) { best = v; bi = r; }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_down(best, off);
-                const int oi = __shfl_down(bi, off);
-                if (ob > best) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
-            __syncthreads();
-            int pr = redi[0]; double pb = redv[0];
-            for (int w = 1; w < nw; w++) if (redv[w] > pb) { pb = redv[w]; pr = redi[w]; }
-            if (t < NB) {                                    // scaled pivot row (the pivot entry becomes 1/pivot)
-                const double a = fre[pr], b = fim[pr];
-                const double den = 1.0 / (a * a + b * b), ir = a * den, ii = -b * den;
-                const double x = Fre[pr * NB + t], y = Fim[pr * NB + t];
-                yrow[t] = (t == s) ? ir : x * ir - y * ii;
-                yrow[NB + t] = (t == s) ? ii : x * ii + y * ir;
-            }
-            if (t == 0) { rho[p0 + s] = pr; rinv[pr] = p0 + s; used[pr] = 1; if (!(pb > 0.0)) *status = 1; }
-            __syncthreads();
-            for (int e = t; e < Np * NB; e += nth) {
-                const int r = e / NB, q = e % NB;
-                const double rr = yrow[q], ri = yrow[NB + q];
-                if (r == pr) { Fre[e] = rr; Fim[e] = ri; }
-                else {
-                    const double f1 = fre[r], f2 = fim[r];
-                    const double br = (q == s) ? 0.0 : Fre[e], bi2 = (q == s) ? 0.0 : Fim[e];
-                    Fre[e] = br - (f1 * rr - f2 * ri);
-                    Fim[e] = bi2 - (f1 * ri + f2 * rr);
-                }
-            }
-            __syncthreads();
-        }
-        IBP(2);
-        // ---- 3. the 16 pivot rows (their values before the block step) as B operand
-        for (int e = t; e < NB * PW; e += nth) Bp[e] = W[(size_t)rho[p0 + e / PW] * PW + (e % PW)];
-        __syncthreads();
-        IBP(3);
-        // ---- 4. rank-16 block step, tile by tile: M += A M[P,:], A = multipliers (minus identity on the
-        //         pivot rows); the pivot columns then take the multipliers (the in-place inverse entries)
-        const int ngroups = Np / 8, gp = p0 >> 3;
-        for (int ti = wave; ti < (Np / 16) * ngroups; ti += nw) {
-            const int rb = ti / ngroups, g = ti % ngroups;
-            const int arow = 16 * rb + c16;
-            d4 acc;
-            #pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16];
-            #pragma unroll
-            for (int ks = 0; ks < NB / 4; ks++) {
-                const int sidx = 4 * ks + kk;
-                const double are = Fre[arow * NB + sidx] - ((arow == rho[p0 + sidx]) ? 1.0 : 0.0);
-                const double aim = Fim[arow * NB + sidx];
-                double b1, b2;
-                panel_b(Bp + (size_t)sidx * PW + 16 * g, c16, b1, b2);
-                acc = MFMA(are, b1, acc);
-                acc = MFMA(aim, b2, acc);
-            }
-            if (g == gp || g == gp + 1) {
-                const int sidx = 8 * (g - gp) + (c16 & 7);
-                #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = 16 * rb + kk + 4 * r;
-                    acc[r] = (c16 < 8) ? Fre[row * NB + sidx] : Fim[row * NB + sidx];
-                }
-            }
-            #pragma unroll
-            for (int r = 0; r < 4; r++) W[(size_t)(16 * rb + kk + 4 * r) * PW + 16 * g + c16] = acc[r];
-        }
-        __syncthreads();
-        IBP(4);
-    }
-    // A^-1[rinv[x]][rho[j]] = M[x][j]
-    double *A = LinvA + (size_t)n * 2 * pl, *T = LinvT + (size_t)n * 2 * pl;
-    for (size_t e = t; e < pl; e += nth) {
-        const int x = e / Np, j = e % Np;
-        const size_t o = (size_t)x * PW + (j >> 3) * 16 + (j & 7);
-        const double re = W[o], im = W[o + 8];
-        const size_t i = rinv[x], c = rho[j];
-        T[i * Np + c] = re; T[pl + i * Np + c] = im;
-        A[i + Np * c] = re; A[pl + i + Np * c] = im;
-    }
-    IBP(5);
-#ifdef QGD_INVB_PROFILE
-    if (blockIdx.x == 0 && t == 0) printf("invb cycles: load %lld, panel cols %lld, pivots %lld, pivot rows %lld, update %lld, output %lld\n", pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
-#endif
-}
-
-// ---------------------------------------------------------------------------
 // K2 (64 < Np <= 288, default): the same blocked Gauss-Jordan with TWO block levels.  k_inverse_blocked streams the whole
 // work slab (2 Np^2 doubles, 1 MB at Np = 256) through the accumulators once per 16 pivots: 6.4 GB per launch at config
 // 5 against 0.6 GB algorithmic (PMC, profiles/r01_v8_pmc_c5.json), and it is HBM-bound there.  Block Gauss-Jordan has the
@@ -953,6 +654,7 @@ __global__ __launch_bounds__(512) void k_inverse_blocked(const double *__restric
 // column groups; its B operand, the 64 pivot rows as they were before the super-step, is copied to a scratch area
 // behind the slab first (the rows are overwritten in place by their own tiles).
 // ---------------------------------------------------------------------------
+#define INVB_NB 16
 #define INVB_SB 64
 // [-Bim | Bre] from [Bre | Bim]: rotate the 16-lane row by 8 and negate lanes 0..7 (as swap8_signed of qgd_k_dense.hip)
 __device__ __forceinline__ double swap8_signed_inv(double b1, int sign_hi)
@@ -988,17 +690,10 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
     double *W = scratch + (size_t)blockIdx.x * (panel + (size_t)SB * PW);
     double *Bg = W + panel;                                      // [SB][PW] pivot rows of the super-step (old values)
     const double *Ln = L + (size_t)n * panel;
-#ifdef QGD_INVB_PROFILE
-    long long pt[8] = {0,0,0,0,0,0,0,0}, pl_ = clock64();
-#define IB2(i) do { const long long n_ = clock64(); pt[i] += n_ - pl_; pl_ = n_; } while (0)
-#else
-#define IB2(i) do { } while (0)
-#endif
     // (no copy of L into the slab: every element is READ from L until the step that first writes it -- the columns of
     //  super-panel 0 until its first inner update, the other columns until the first rank-64 update -- and from the slab after)
     for (int r = t; r < Np; r += nth) used[r] = 0;
     __syncthreads();
-    IB2(0);
 
     for (int q0 = 0; q0 < Np; q0 += SB) {
         const int sbw = (Np - q0 < SB) ? Np - q0 : SB;          // pivots of this super-panel (a multiple of 16)
@@ -1018,7 +713,6 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
                 const size_t o = (size_t)(ok ? r : 0) * PW + (col >> 3) * 16 + (col & 7);
                 xr[k] = ok ? Ws[o] : 0.0; xi[k] = ok ? Ws[o + 8] : 0.0;
             }
-            IB2(1);
             // ---- 2. pivoted in-place Gauss-Jordan on the Np x 16 panel (rows stay where they are)
             for (int s = 0; s < NB; s++) {
                 if (q == s) {                                    // column s of the panel, for everybody
@@ -1075,14 +769,12 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
                 if (r < Np) { Fre[r * NB + q] = xr[k]; Fim[r * NB + q] = xi[k]; }
             }
             __syncthreads();
-            IB2(2);
             // ---- 3. the 16 pivot rows (their values before the step), super-panel columns only, as B operand
             for (int e = t; e < NB * 2 * sbw; e += nth) {
                 const int k = e / (2 * sbw), c = e % (2 * sbw);
                 Bp[k * 2 * SB + c] = Ws[(size_t)rho[p0 + k] * PW + 16 * g_lo + c];
             }
             __syncthreads();
-            IB2(3);
             // ---- 4. rank-16 step on the columns of the super-panel; the pivot columns then take the multipliers
             const int gp = p0 >> 3;
             // (four column groups of a row block at a time: independent accumulators, one A operand, 16 loads in flight)
@@ -1130,7 +822,6 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
                 }
             }
             __syncthreads();
-            IB2(4);
         }
         if (sbw == Np) break;                                   // one super-panel covers the matrix: nothing outside it
         const double *Wo = (q0 == 0) ? Ln : W;                  // the outside columns have not been written before the first rank-64 update
@@ -1141,7 +832,6 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
             if ((c >> 4) < g_lo || (c >> 4) >= g_lo + sg) Bg[(size_t)k * PW + c] = Wo[(size_t)rho[q0 + k] * PW + c];
         }
         __syncthreads();
-        IB2(5);
         // ---- 6. rank-sbw update of the outside columns: M += (G - E_P) M_old[P,:], G = the super-panel's columns
         const int nks = sbw >> 2;
         for (int rb = wave; rb < Np / 16; rb += nw) {
@@ -1201,7 +891,6 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
             }
         }
         __syncthreads();
-        IB2(6);
     }
     // A^-1[i][c] = M[rho[i]][rinv[c]].  Tiles of 32 x 64 go through LDS: the slab is gathered (rows rho[i], columns
     // rinv[c]: scattered inside a row, L1-friendly) and BOTH outputs are written in runs of consecutive doubles --
@@ -1236,11 +925,6 @@ __global__ __launch_bounds__(512) void k_inverse_blocked2(const double *__restri
             }
             __syncthreads();
         }
-    IB2(7);
-#ifdef QGD_INVB_PROFILE
-    if (blockIdx.x == 0 && t == 0) printf("invb2 cycles: load %lld, panel cols %lld, pivots %lld, pivot rows %lld, inner update %lld, outer rows %lld, outer update %lld, output %lld\n", pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6], pt[7]);
-#endif
-#undef IB2
 }
 
 static inline size_t inverse_blocked2_lds(int Np)
@@ -1334,49 +1018,29 @@ extern "C" {
 int qgdk_inverse(const qgdk_ctx *c)
 {
     const int nmat = c->nt - 1;
-    // Np = 16, 32, 48: the same fused MFMA kernel as Np = 64 (one wave per 16 rows; inverse and propagator in one launch:
-    // cnot2 17.7 + 6.5 us for k_inverse_reg + k_propagator -> see DESIGN.md section 7); QGD_INVERSE_VALU=1 keeps the older pair
-    if (!getenv("QGD_INVERSE_VALU") && nmat > 0) switch (c->Np) {
+    if (nmat <= 0) return 0;
+    switch (c->Np) {     // Np <= 64: inverse and propagator in one launch, the matrix in registers
 #define CALL_IMF(N) case N: hipLaunchKernelGGL((k_inverse_mfma<N>), dim3(nmat), dim3(N * 4), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status); \
                             return (int)hipGetLastError()
         CALL_IMF(16); CALL_IMF(32); CALL_IMF(48);
 #undef CALL_IMF
-        default: break;
-    }
-    switch (c->Np) {
-    case 16: SET_LDS_ONCE((k_inverse_reg<16, 16>), 2176); hipLaunchKernelGGL((k_inverse_reg<16, 16>), dim3(nmat), dim3(256), 2176, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 32: SET_LDS_ONCE((k_inverse_reg<32, 16>), 8448); hipLaunchKernelGGL((k_inverse_reg<32, 16>), dim3(nmat), dim3(256), 8448, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 48: SET_LDS_ONCE((k_inverse_reg<48, 16>), 18816); hipLaunchKernelGGL((k_inverse_reg<48, 16>), dim3(nmat), dim3(256), 18816, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
-    case 64:   // column-block elimination of [L | R] (qgd_inverse_cb.h); QGD_INV_PANELS=1: the 4-pivot panel kernel for every matrix
-        if (!getenv("QGD_INVERSE_VALU")) {
-            if (getenv("QGD_INV_PANELS")) hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
-            else hipLaunchKernelGGL(k_inverse_cb, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
-            return (int)hipGetLastError();
-        }
-        SET_LDS_ONCE((k_inverse_reg<64, 16>), 33280); hipLaunchKernelGGL((k_inverse_reg<64, 16>), dim3(nmat), dim3(256), 33280, c->stream, c->L, c->LinvA, c->LinvT, 1, c->status); return (int)hipGetLastError();
+    case 64:   // column-block elimination of [L | R] (qgd_inverse_cb.h); QGD_PATHS=inv_panels: its last resort, the 4-pivot panel kernel, for every matrix
+        if (qgd_path("inv_panels")) hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
+        else hipLaunchKernelGGL(k_inverse_cb, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
+        return (int)hipGetLastError();
     default: break;
     }
-    if (c->Np > 64 && c->dense_gemm && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {    // (any size: no LDS limit)
+    if (c->Np > 64 && c->dense_gemm) {    // (any size: no LDS limit)
         const int took = qgdk_dense_inverse(c);              // block Gauss-Jordan as batched GEMM launches (qgd_k_dense.hip)
         if (took) return took < 0 ? (int)hipErrorUnknown : (int)hipGetLastError();
     }
-    if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED") && !getenv("QGD_INVB_ONE_LEVEL")) {
+    if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024) {
         const size_t shm = inverse_blocked2_lds(c->Np);      // two block levels: 64-column super-panels
         HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
             const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
             hipLaunchKernelGGL(k_inverse_blocked2, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch,
                                c->Np, n0, c->status, (const int *)nullptr);
-        }
-        return (int)hipGetLastError();
-    }
-    if (c->inv_scratch && inverse_blocked_lds(c->Np) <= 150 * 1024 && !getenv("QGD_INVERSE_UNBLOCKED")) {
-        const size_t shm = inverse_blocked_lds(c->Np);
-        HIPCHK(hipFuncSetAttribute((const void *)k_inverse_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        for (int n0 = 1; n0 < c->nt; n0 += c->inv_batch) {
-            const int nb = (c->nt - n0 < c->inv_batch) ? c->nt - n0 : c->inv_batch;
-            hipLaunchKernelGGL(k_inverse_blocked, dim3(nb), dim3(512), shm, c->stream, c->L, c->LinvA, c->LinvT, c->inv_scratch,
-                               c->Np, n0, c->status);
         }
         return (int)hipGetLastError();
     }
@@ -1434,7 +1098,7 @@ int qgdk_inverse_redo(const qgdk_ctx *c, const int *flags)
     return (int)hipGetLastError();
 }
 
-int qgdk_propagator_is_fused(const qgdk_ctx *c) { return (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64) && !getenv("QGD_INVERSE_VALU"); }
+int qgdk_propagator_is_fused(const qgdk_ctx *c) { return c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64; }
 
 int qgdk_propagator(const qgdk_ctx *c)
 {

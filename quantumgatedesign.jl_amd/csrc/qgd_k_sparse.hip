@@ -5,7 +5,7 @@
 // controls a_k +/- a_k^dagger lifted by Kronecker products) have a handful of non-zeros per row;
 // the dense MFMA kernels (qgd_k_build.hip, qgd_k_grad.hip) spend N/nnz times the necessary
 // flops on them.  Here A_d(t_n) = sum_o coef * op_o is kept in ELL form over the UNION sparsity
-// pattern of all operators (built once on the host, qgd_api.cpp): lane = matrix row, each
+// pattern of all operators (built once on the host, qgd_host_alloc.cpp): lane = matrix row, each
 // thread owns a few complex columns, the neighbour rows of the current source are fetched from
 // LDS (row stride padded so that 16 consecutive rows cover all 64 banks).  fp64 VALU, no MFMA:
 // the flops left after exploiting the sparsity are below the cost of writing L and R.
@@ -473,8 +473,8 @@ static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 }
 
 // Workgroup = (time point, 4*NW columns), NW waves.  NW = 8 (32 columns, 64 KB of LDS, two workgroups per CU) is the
-// default: 46.5 us on the 551-point benchmark grid against 49.8 us for NW = 4 (16 columns, 48 KB, three per CU,
-// QGD_BUILD_ELL_NARROW=1) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.
+// only instantiation: 46.5 us on the 551-point benchmark grid against 49.8 us for NW = 4 (16 columns, 48 KB, three per CU,
+// measured in round 2) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.
 // (Before the LDS accesses were 16-byte aligned both took 63 us, bound by bank conflicts.)
 template <int M, int NW, int NOPS>
 static int launch_build_ell_nw(const qgdk_ctx *c)
@@ -489,8 +489,6 @@ static int launch_build_ell_nw(const qgdk_ctx *c)
 template <int M>
 static int launch_build_ell(const qgdk_ctx *c)
 {
-    const bool narrow = getenv("QGD_BUILD_ELL_NARROW") != nullptr;      // (comparison path; not static so that tests can switch it)
-    if (narrow) return launch_build_ell_nw<M, 4, -1>(c);
 #define CALL_BE(N) return launch_build_ell_nw<M, 8, N>(c)
     DISPATCH_NOPS(c->n_ops, CALL_BE)
 #undef CALL_BE

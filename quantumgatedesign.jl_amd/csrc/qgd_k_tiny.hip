@@ -24,7 +24,7 @@
 // All sums have a fixed order: the same bits on every run.  A first version did ALL of this in one workgroup: correct, and
 // 107 us -- one compute unit can neither stream the control basis (300 KB) nor do the per-time-point work of 101 points
 // fast enough ("Round 4" (4)).  The general path's device buffers hold this path's compact arrays
-// afterwards, not its own intermediates: the host side marks the handle's stored history stale (qgd_api.cpp).
+// afterwards, not its own intermediates: the host side marks the handle's stored history stale (qgd_host_eval.cpp: tiny_evaluate).
 #include "qgd_kernels_common.h"
 #include <string.h>
 #include <algorithm>
@@ -832,6 +832,7 @@ int qgdk_tiny_supported(const qgdk_ctx *c, int n_pcof)
     if (c->N > 4 || c->c > 4 || c->n_ops < 1 || c->n_ops > 4 || c->m < 1 || c->m > 6 || n_pcof < 1 || n_pcof > QGD_TINY_PCOF_MAX) return 0;
     if (c->have_guard == 1 || c->nt < 3 || 4 * c->nt > 512) return 0;
     if (c->part_world != 1 || c->g_nt != 0) return 0;
+    for (int o = 0; o < c->n_ops; o++) if (c->ncoef_host[o] < 1) return 0;      // (k_tiny_front indexes coefficient nc - 1 of every control)
     TinyArgs a; size_t d; int th;
     tiny_layout(c, a, d, th);
     return d * sizeof(double) <= (size_t)150 * 1024 && th <= 512;

@@ -15,7 +15,9 @@ for k in qgd_k_build qgd_k_inverse qgd_k_chain qgd_k_grad qgd_k_sparse qgd_k_for
   F="$FLAGS"; if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $k "; then F=""; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $F -I$SRC -I$ROOT/include -c $SRC/$k.hip -o $B/$k.o &
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I$SRC -I$ROOT/include -c $SRC/qgd_api.cpp -o $B/qgd_api.o &
+for k in qgd_host_alloc qgd_host_eval qgd_host_windows qgd_host_comm; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I$SRC -I$ROOT/include -c $SRC/$k.cpp -o $B/$k.o &
+done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libqgd_$NAME.so $B/*.o
 rm -rf $B

@@ -1,7 +1,7 @@
 """Randomised check of the paths added in round 3 against the plain resident evaluation of the same handle type:
   * the bounded-memory time grid (random budgets -> 2..12 windows): gradient, scalars, the three reference-layout arrays;
   * the in-library RCCL route with one rank, both shard kinds;
-  * the stepping adjoint history pass (QGD_NO_SUFFIX=1) against the suffix-product pass;
+  * the stepping adjoint history pass (QGD_PATHS=no_suffix) against the suffix-product pass;
 on dispersive (sparse kernels, guard levels) and random dense problems, N = 2..300, orders 2..12, 20..900 steps.
 Usage: python scripts/fuzz_windows.py [n_cases] [seed]"""
 import os, sys
@@ -68,11 +68,11 @@ for it in range(ncases):
         errs["rccl-" + shard] = max(np.abs(g - g_ref).max() / sc, np.abs(np.asarray(o) - np.asarray(o_ref)).max() / max(1.0, np.abs(o_ref).max()))
         ev.close()
     # stepping adjoint history pass
-    os.environ["QGD_NO_SUFFIX"] = "1"
+    os.environ["QGD_PATHS"] = "no_suffix"
     dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
     g, o = dp.discrete_adjoint(pcof)
     errs["no-suffix"] = np.abs(g - g_ref).max() / sc
-    dp.close(); del os.environ["QGD_NO_SUFFIX"]
+    dp.close(); del os.environ["QGD_PATHS"]
     w = max(errs.values()); worst = max(worst, w)
     print(f"[{it}] {kind} c={c} order={order} nsteps={nsteps}: " + "  ".join(f"{k} {v:.1e}" for k, v in errs.items()) + ("" if w < 1e-10 else "   <-- FAIL"), flush=True)
     qgd.clear_cache()

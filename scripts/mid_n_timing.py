@@ -1,5 +1,5 @@
 """Mid-size dense problems (64 < N <= 128): per-phase device time of one gradient evaluation.
-QGD_DENSE_OLD=1 selects the older LDS-panel kernels instead of the GEMM-style kernels of qgd_k_dense.hip."""
+(Round 2 used it to compare the older LDS-panel kernels, which N > 64 no longer takes, with the GEMM-style kernels of qgd_k_dense.hip.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,6 @@
 """Does a large problem evaluated earlier IN THE SAME PROCESS slow the pinned downloads of the reference-shaped cnot3 call?
 (bench.py with C5 in front of `with_history`: 3.3-3.9 ms instead of 0.87.)  Prints ms per evaluation with the three arrays
-(a) in a fresh process, (b) after a C5 evaluation whose handle was closed, (c) the same with QGD_COPY_BLIT=1 (plain 1-D copies)."""
+(a) in a fresh process, (b) after a C5 evaluation whose handle was closed, (the plain 1-D copy variant it once compared, QGD_COPY_BLIT, is gone)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

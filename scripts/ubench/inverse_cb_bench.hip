@@ -3,7 +3,7 @@
 //   k_inverse_cb   (column blocks, 16-pivot block steps, [L | R] eliminated together; qgd_inverse_cb.h)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I quantumgatedesign.jl_amd/csrc -I include \
 //         scripts/ubench/inverse_cb_bench.hip -o scripts/ubench/bin/inverse_cb_bench
-//   inverse_cb_bench [nmat] [data]     data 0: I + 0.1 N(0,1) (the conditioning of the cnot3 step matrices)
+//   inverse_cb_bench [nmat] [data] [pivot_first]     data 0: I + 0.1 N(0,1) (the conditioning of the cnot3 step matrices)
 //                                      data 1: the same with the rows of every 16-row block permuted (in-tile pivoting)
 //                                      data 2: unit entries on a permuted diagonal, noise 0.3 (the pivoted attempt finds pivots in the tiles)
 //                                      data 3: noise 0.1 (the diagonal attempt is given up for some matrices)
@@ -49,7 +49,8 @@ int main(int argc, char **argv)
     hipMalloc(&dL, L.size() * 8); hipMalloc(&dR, L.size() * 8);
     for (int v = 0; v < 2; v++) { hipMalloc(&dT[v], (nmat + 1) * 2 * pl * 8); hipMalloc(&dPr[v], L.size() * 8); hipMalloc(&dPc[v], L.size() * 8);
         hipMemset(dT[v], 0, (nmat + 1) * 2 * pl * 8); hipMemset(dPr[v], 0, L.size() * 8); hipMemset(dPc[v], 0, L.size() * 8); }
-    hipMalloc(&dS, 16); hipMemset(dS, 0, 16);
+    hipMalloc(&dS, 32); hipMemset(dS, 0, 32);      // [status mfma | status cb | cb: not by the diagonal attempt | cb: by the last resort | cb: pivot first]
+    if (argc > 3 && atoi(argv[3])) { const int one = 1; hipMemcpy(dS + 4, &one, 4, hipMemcpyHostToDevice); }
     hipMemcpy(dL, L.data(), L.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dR, Rm.data(), L.size() * 8, hipMemcpyHostToDevice);
     auto launch = [&](int v) {
@@ -90,8 +91,8 @@ int main(int argc, char **argv)
         }
     }
 #endif
-    int st[4]; hipMemcpy(st, dS, 16, hipMemcpyDeviceToHost);
-    printf("status: mfma %d, cb %d, cb fallbacks %d\n", st[0], st[1], st[2]);
+    int st[5]; hipMemcpy(st, dS, 20, hipMemcpyDeviceToHost);
+    printf("status: mfma %d, cb %d; cb over all launches: %d matrices not done by the diagonal attempt, %d by the last resort; pivot first: %d\n", st[0], st[1], st[2], st[3], st[4]);
     // check a few matrices of each kernel
     const int picks[4] = {1, 2, nmat / 2 + 1, nmat};
     for (int v = 0; v < 2; v++) {

@@ -1,6 +1,6 @@
 """The reference-shaped call discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, ...) on the cnot3 headline
-problem with the three output arrays registered: ms per evaluation (QGD_ZEROCOPY_WGS selects the writer: 0 = device
-staging + copies, n = n persistent workgroups writing into the registered host memory)."""
+problem with the three output arrays registered: ms per evaluation (device staging + copies; the
+zero-copy writer it once compared with was slower and is gone)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -18,8 +18,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): g, _ = dp.discrete_adjoint(pcof, False, hist, lam, forc)
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 20
 h2 = np.zeros((128, 5, 551, 8), order="F"); dp.eval_forward(pcof, h2)
-print("QGD_ZEROCOPY_WGS=%s: %.3f ms per evaluation with history; grad diff %.1e, history diff %.1e" %
-      (os.environ.get("QGD_ZEROCOPY_WGS", "default"), el * 1e3, np.abs(g - g0).max(), np.abs(h2 - hist).max()))
+print("%.3f ms per evaluation with history; grad diff %.1e, history diff %.1e" %
+      (el * 1e3, np.abs(g - g0).max(), np.abs(h2 - hist).max()))
 # where the time of one call goes: the bare C entry point against the Python wrapper around it
 import ctypes as C
 vp = lambda a: a.ctypes.data_as(C.c_void_p)

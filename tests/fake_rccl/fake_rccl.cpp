@@ -1,6 +1,6 @@
 // fake_rccl.cpp -- TEST INFRASTRUCTURE: a stand-in for librccl that carries the collectives of the library's multi-GPU path
 // between PROCESSES THAT SHARE ONE GPU (RCCL itself refuses two ranks on one device, and the test boxes have one GPU).
-// Loaded through QGD_RCCL_LIB (csrc/qgd_api.cpp: load_rccl), it exports the seven entry points the library binds.  Data
+// Loaded through QGD_RCCL_LIB (csrc/qgd_host_comm.cpp: load_rccl), it exports the seven entry points the library binds.  Data
 // travel through a POSIX shared-memory segment named after the unique id: every collective synchronises the caller's
 // stream, copies the rank's contribution to its slot, meets the other ranks at a barrier, assembles the result on the
 // device and meets them again.  Synchronous and slow on purpose; what it exercises is the PRODUCT's side of the protocol in

@@ -11,7 +11,7 @@ import proto_propagator as pp
 
 
 def partition(S, world, rank):
-    """Same rule as alloc_grid() in csrc/qgd_api.cpp."""
+    """Same rule as alloc_grid() in csrc/qgd_host_alloc.cpp."""
     B0 = int(round(S ** (2.0 / 3.0)))
     if S < 24:
         B0 = 1

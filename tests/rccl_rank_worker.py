@@ -1,9 +1,12 @@
 """One rank of a multi-process evaluation through the library's own communicator path (tests/test_gpu_rccl.py):
-    python tests/rccl_rank_worker.py <case> <shard> <rank> <world> <dir> [fail_at]
+    python tests/rccl_rank_worker.py <case> <shard> <rank | threads> <world> <dir> [fail_at]
 The transport is whatever QGD_RCCL_LIB names (tests/fake_rccl: shared memory between processes on one GPU).  Rank 0 draws the
 unique id and leaves it in <dir>/uid; every rank compares its results with <dir>/ref.npz (the single-GPU evaluation) and
 writes <dir>/rank<r>.npz.  With fail_at, rank `world-1` injects a local failure in front of that exchange
-(qgd_comm_debug_fail_at) and every rank must come back with QGD_ERR_COMM instead of hanging: exit code 7 then."""
+(qgd_comm_debug_fail_at) and every rank must come back with QGD_ERR_COMM instead of hanging: exit code 7 then.
+`threads` instead of a rank: all `world` ranks as THREADS of this one process, each with its own handle and communicator (a GPU
+box admits six processes on its card, so eight ranks cannot be eight processes there; ctypes releases the interpreter lock
+inside the library, so the ranks do meet in the collectives).  The exit code is the ranks' common code, 9 when they differ."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +19,8 @@ import cases
 def problem(qgd, case):
     if case == "cnot3":
         return cases.cnot3_case(qgd, nsteps=120, tf=120.0) + (8,)
+    if case == "cnot3_headline":         # the benchmark grid: 550 steps, 69-step windows on 8 ranks
+        return cases.cnot3_case(qgd, nsteps=550, tf=550.0) + (8,)
     if case == "guarded":
         return cases.guarded_case(qgd, nsteps=60, tf=30.0) + (6,)
     if case == "dense":
@@ -23,10 +28,12 @@ def problem(qgd, case):
     raise ValueError(case)
 
 
-def main():
-    case, shard, rank, world, d = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    fail_at = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-    qgd = import_package()
+class RankExit(Exception):
+    def __init__(self, code):
+        self.code = code
+
+
+def run_rank(qgd, case, shard, rank, world, d, fail_at):
     prob, ctrl, pcof, target, order = problem(qgd, case)
     uid_path = os.path.join(d, "uid")
     if rank == 0:
@@ -38,7 +45,7 @@ def main():
         t0 = time.time()
         while not os.path.exists(uid_path):
             if time.time() - t0 > 60:
-                sys.exit("no unique id from rank 0")
+                raise RuntimeError("no unique id from rank 0")
             time.sleep(0.01)
         uid = open(uid_path, "rb").read()
     ev = qgd.RcclEvaluation(prob, order, ctrl, target, rank, world, uid, shard=shard)
@@ -51,8 +58,8 @@ def main():
             ev.discrete_adjoint(pcof)
         except qgd._lib.QGDError as e:
             print(f"rank {rank}: {e}", flush=True)
-            sys.exit(7 if e.code == qgd._lib.QGD_ERR_COMM else 3)
-        sys.exit(4)      # (no error at all: the failure was lost)
+            raise RankExit(7 if e.code == qgd._lib.QGD_ERR_COMM else 3)
+        raise RankExit(4)      # (no error at all: the failure was lost)
     ref = np.load(os.path.join(d, "ref.npz"))
     g_ref, o_ref, f_ref = ref["g"], ref["o"], ref["f"]
     scale = max(1.0, np.abs(o_ref).max())
@@ -89,6 +96,37 @@ def main():
     np.savez(os.path.join(d, f"rank{rank}.npz"), **out)
     ev.close()
     print(f"rank {rank} of {world} ({case}, {shard}): ok", flush=True)
+
+
+def main():
+    case, shard, who, world, d = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    fail_at = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    qgd = import_package()
+    if who != "threads":
+        try:
+            run_rank(qgd, case, shard, int(who), world, d, fail_at)
+        except RankExit as e:
+            sys.exit(e.code)
+        return
+    import threading, traceback
+    codes = [None] * world
+
+    def body(r):
+        try:
+            run_rank(qgd, case, shard, r, world, d, fail_at)
+            codes[r] = 0
+        except RankExit as e:
+            codes[r] = e.code
+        except BaseException:
+            traceback.print_exc()
+            codes[r] = 5
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    print("rank codes:", codes, flush=True)
+    sys.exit(codes[0] if all(c == codes[0] for c in codes) else 9)
 
 
 if __name__ == "__main__":

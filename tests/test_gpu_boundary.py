@@ -91,14 +91,11 @@ def test_gradient_is_bitwise_reproducible(qgd, which, order, cols):
     assert np.abs(fwd[0] - scalars[0]).max() <= 1e-13 * max(1.0, np.abs(scalars[0]).max())
 
 
-@pytest.mark.parametrize("zerocopy", [None, "16"])
-def test_registered_outputs_match_pageable(qgd, orc, zerocopy, monkeypatch):
+def test_registered_outputs_match_pageable(qgd, orc):
     """The reference-shaped call discrete_adjoint!(grad, history, lambda_history, adjoint_forcing, ...) as optimize_gate
     makes it (ipopt_optimal_control.jl:304-330), with the three output arrays registered (pinned: device re-layout +
     asynchronous copies beside the adjoint sweep, strided copy of the j = 0 columns of lambda_history) and not
     registered: identical arrays, and both equal to the oracle's."""
-    if zerocopy:        # the comparison path: persistent workgroups write the registered (mapped) arrays in place
-        monkeypatch.setenv("QGD_ZEROCOPY_WGS", zerocopy)
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=24, tf=24.0)
     order = 8
     orc.set_converged_terminal(True)

@@ -231,7 +231,7 @@ def test_sigma_forms_agree(qgd, N, c, n_ops, order, monkeypatch):
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
     grads = {}
     for f in ("0", "1", "2", "3"):
-        monkeypatch.setenv("QGD_GINNER", f)
+        monkeypatch.setenv("QGD_PATHS", "ginner=" + f)
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         grads[f], _ = dp.discrete_adjoint(pcof)
         dp.close()
@@ -244,19 +244,15 @@ def test_sigma_forms_agree(qgd, N, c, n_ops, order, monkeypatch):
                                                   (100, 32, 2, 8, "0"), (80, 24, 1, 4, "0")])
 def test_three_product_tiles_against_four(qgd, N, c, n_ops, order, form, monkeypatch):
     """Since round 3 the N > 64 kernels form a complex product from THREE real ones (cgemm3_tile, outer_tile3, outer_frag3,
-    k_chain_dense3: Re = P1 - P2, Im = P3 - P1 - P2).  The four-product kernels stay in the library (QGD_DENSE_4M=1): both
+    k_chain_dense3: Re = P1 - P2, Im = P3 - P1 - P2).  The four-product kernels stay in the library (QGD_PATHS=dense_4m): both
     against the numpy statement (1e-10) and against each other (history 1e-12, gradient 1e-11 -- 3M is exact to
     eps |A||B| norm-wise, not component-wise), on shapes with an odd number of column groups (c = 24) and partial tiles."""
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=12, tf=0.12, seed=N + c)
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
-    monkeypatch.setenv("QGD_GINNER", form)
     out = {}
     for four in (False, True):
-        if four:
-            monkeypatch.setenv("QGD_DENSE_4M", "1")
-        else:
-            monkeypatch.delenv("QGD_DENSE_4M", raising=False)
+        monkeypatch.setenv("QGD_PATHS", "ginner=" + form + (",dense_4m" if four else ""))
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         hist = np.zeros(dp._hist_shape(), order="F")
         g, o = dp.discrete_adjoint(pcof, False, hist)
@@ -274,15 +270,12 @@ def test_block_gauss_jordan_inverse_and_its_fallback(qgd, N, c, order, monkeypat
     the diagonal blocks only, the block operations as batched GEMM tiles (qgdk_dense_inverse) -- and a matrix whose block
     multipliers exceed a threshold (or whose diagonal block meets a zero pivot) is redone by k_inverse_blocked2 with
     partial pivoting over whole columns.  Three routes must agree: the default (nothing redone on these matrices), every
-    matrix forced through the fallback (QGD_BINV_THRESH=0), and the round-2 kernel alone (QGD_BINV_OFF=1, a new handle);
+    matrix forced through the fallback (QGD_PATHS=binv_thresh=0), and the round-2 kernel alone (QGD_PATHS=binv_off, a new handle);
     N = 80, 144, 272: last blocks of 16 columns."""
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=6, tf=0.06, seed=3 * N)
     out = {}
-    for tag, env in (("default", {}), ("forced_fallback", {"QGD_BINV_THRESH": "0"}), ("off", {"QGD_BINV_OFF": "1"})):
-        for k in ("QGD_BINV_THRESH", "QGD_BINV_OFF"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for tag, paths in (("default", ""), ("forced_fallback", "binv_thresh=0"), ("off", "binv_off")):
+        monkeypatch.setenv("QGD_PATHS", paths)
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         g, o = dp.discrete_adjoint(pcof)
         out[tag] = (g, np.asarray(o), dp.intermediate("Linv"), dp.intermediate("L"), int(dp.intermediate("repivoted")))
@@ -319,9 +312,9 @@ def test_sequential_chains_as_full_chip_steps(qgd, N, c, world, monkeypatch):
     """The single sequential chains of the scan on big problems (states at the super-block starts, the prefix over the
     lower ranks' windows, and their adjoint counterparts) run one full-chip GEMM launch per step (k_chain_step: 16 x 16
     output tiles, the four waves of a workgroup split the contraction) instead of one chain kernel on c/8 workgroups.
-    The switch depends on the size (N^2 c >= 256^2 64); here the step path is forced on small shapes (QGD_CHAIN_STEPS_MIN=1)
+    The switch depends on the size (N^2 c >= 256^2 64); here the step path is forced on small shapes (QGD_PATHS=chain_steps_min=1)
     -- partial column pairs (c = 24, 40: 3 and 5 groups), N not a multiple of 64, a time partition of 2 and 3 ranks --
-    against the chain kernels (QGD_CHAIN_NO_STEPS=1) and the numpy statement."""
+    against the chain kernels (chain_steps_min out of reach) and the numpy statement."""
     import torch
     order = 8
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=2, nsteps=40, tf=0.4, seed=N + world)
@@ -329,11 +322,8 @@ def test_sequential_chains_as_full_chip_steps(qgd, N, c, world, monkeypatch):
     ref = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
-    for tag, env in (("steps", {"QGD_CHAIN_STEPS_MIN": "1"}), ("chains", {"QGD_CHAIN_NO_STEPS": "1"})):
-        for k in ("QGD_CHAIN_STEPS_MIN", "QGD_CHAIN_NO_STEPS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for tag, paths in (("steps", "chain_steps_min=1"), ("chains", "chain_steps_min=1000000000000000")):
+        monkeypatch.setenv("QGD_PATHS", paths)
         if world == 1:
             dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
             dp.set_timing(1)
@@ -356,7 +346,7 @@ def test_gradient_is_bitwise_reproducible_large_n(qgd, N, c, n_ops, order, form,
     """The N > 64 gradient kernels add their scalars in a fixed order too (round 3: per-wave LDS slots, one plane of sigma per
     contributing tile, planes added in order by k_contract -- no atomicAdd left on the gradient path): the same inputs give the
     same bits, for every form of the gradient scalars, from one handle five times and from a fresh handle."""
-    monkeypatch.setenv("QGD_GINNER", form)
+    monkeypatch.setenv("QGD_PATHS", "ginner=" + form)
     prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=N, c=c, n_ops=n_ops, nsteps=10, tf=0.1, seed=N)
     rng = np.random.default_rng(N)
     prob.guard_subspace_projector = np.asfortranarray(np.diag(rng.random(2 * N)))      # (a guard penalty to add up as well)

@@ -22,7 +22,7 @@ def close(a, ref, tol=HIST_ATOL):
 
 def _loaded(qgd):
     lib = qgd._lib.lib()
-    assert lib.qgd_abi_version() == 1
+    assert lib.qgd_abi_version() == 2
 
 
 def test_library_loaded(qgd):
@@ -237,12 +237,11 @@ def test_graph_replay_matches_plain_launches(qgd, which, monkeypatch):
     qgd.clear_cache()
 
 
-@pytest.mark.parametrize("switch", ["QGD_ELL_ROW_PACKED", "QGD_BUILD_ELL_NARROW"])
-def test_sparse_kernel_comparison_paths(qgd, orc, switch, monkeypatch):
-    """The alternatives kept beside the default sparse kernels -- row-packed ELL slots instead of diagonal-ordered
-    ones, 16-column build workgroups instead of 32-column ones -- give the same gradient (cnot3 order 8, guarded
+def test_row_packed_ell_slots(qgd, orc, monkeypatch):
+    """Row-packed ELL slots -- what an operator pattern that is not banded gets -- instead of the diagonal-ordered ones of
+    the banded a +- a^dagger patterns (QGD_PATHS=ell_row_packed forces them here): the same gradient (cnot3 order 8, guarded
     two-qutrit problem order 6) as the numpy statement of the algorithm."""
-    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv("QGD_PATHS", "ell_row_packed")
     qgd.clear_cache()
     for which, order in (("cnot3", 8), ("guarded", 6)):
         prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
@@ -260,9 +259,9 @@ def test_sparse_kernel_comparison_paths(qgd, orc, switch, monkeypatch):
 @pytest.mark.parametrize("n_basis,force_copy", [(10, True), (300, False)])
 def test_pcof_upload_paths(qgd, orc, n_basis, force_copy, monkeypatch):
     """pcof travels in the kernel arguments of k_tables when it fits (<= 448 coefficients) and through a device
-    copy otherwise (here 2 x 600) or with QGD_PCOF_COPY=1: both against the numpy statement of the algorithm."""
+    copy otherwise (here 2 x 600) or with QGD_PATHS=pcof_copy: both against the numpy statement of the algorithm."""
     if force_copy:
-        monkeypatch.setenv("QGD_PCOF_COPY", "1")
+        monkeypatch.setenv("QGD_PATHS", "pcof_copy")
     prob, target = qgd.cnot2_problem(nsteps=24, tf=24.0)
     ctrl = [qgd.GeneralBSplineControl(2, n_basis, prob.tf) for _ in range(prob.N_operators)]
     npar = qgd.get_number_of_control_parameters(ctrl)
@@ -424,14 +423,12 @@ def test_lambda_history_derivative_columns_cnot3(qgd, orc):
     dp.close()
 
 
-@pytest.mark.parametrize("older_kernels", [False, True])
-def test_large_n_fallback_paths(qgd, orc, older_kernels, monkeypatch):
+@pytest.mark.parametrize("generic_chain", [False, True])
+def test_large_n_fallback_paths(qgd, orc, generic_chain, monkeypatch):
     """N=100 (padded to 112), 20 columns (3 groups), 4 control operators, order 12 -- vs the numpy statement
-    of the algorithm.  older_kernels: QGD_DENSE_OLD=1 keeps the pre-GEMM large-N kernels (assembled-at-use
-    recursion, panel slabs in HBM, generic chain) alive as a comparison path."""
-    if older_kernels:
-        monkeypatch.setenv("QGD_DENSE_OLD", "1")
-        monkeypatch.setenv("QGD_CHAIN_GENERIC", "1")
+    of the algorithm.  generic_chain: the chain kernel that sizes beyond Np = 640 take (QGD_PATHS=chain_generic) on this shape."""
+    if generic_chain:
+        monkeypatch.setenv("QGD_PATHS", "chain_generic")
     qgd.clear_cache()
     prob, ctrl, pcof, target = cases.synthetic_case(qgd)
     order = 12
@@ -586,8 +583,8 @@ def test_operator_path_selection(qgd):
     """cnot3 (drift diagonal + a_k +/- a_k^dagger on three subsystems) has 7 entries per row and 2 per
     control operator -> sparse; a random dense problem stays on the MFMA kernels and refuses 'sparse'."""
     import os
-    if os.environ.get("QGD_DENSE_OPS"):
-        pytest.skip("QGD_DENSE_OPS overrides the automatic choice")
+    if "dense_ops" in os.environ.get("QGD_PATHS", ""):
+        pytest.skip("QGD_PATHS=dense_ops overrides the automatic choice")
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=4, tf=4.0)
     dp = qgd.DeviceProblem(prob, 8)
     assert dp.operator_path() == ("sparse", 7, 2)
@@ -787,7 +784,7 @@ def test_dahlquist_and_rotating_frame_on_device(qgd):
 def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
     """N = 64: the column-block elimination of [L | R] (qgd_inverse_cb.h) and the two stages behind it.  (1) cnot3: every matrix
     is done by the first attempt (pivots on the diagonal) and gradient, L^-1 and P equal those of the fully pivoted 4-pivot-panel
-    kernel (QGD_INV_PANELS=1) to rounding.  (2) A drift that pairs the levels i <-> i^1 with dt*h at the zero of Re q_3(iy):
+    kernel (QGD_PATHS=inv_panels) to rounding.  (2) A drift that pairs the levels i <-> i^1 with dt*h at the zero of Re q_3(iy):
     the diagonal of L vanishes beside off-diagonal entries of modulus ~1 INSIDE the 16 x 16 diagonal tiles -- the diagonal
     attempt is given up, partial pivoting inside the tiles does every matrix.  (3) The same drift pairing i <-> i^32: the big
     entries lie outside the diagonal tiles, both column-block attempts are given up and the fully pivoted elimination does
@@ -795,7 +792,7 @@ def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
     present.  intermediate("repivoted") = matrices past the first attempt + 65536 * matrices past the second."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
     res = {}
-    for tag, env in (("blocks", {}), ("panels", {"QGD_INV_PANELS": "1"})):
+    for tag, env in (("blocks", {}), ("panels", {"QGD_PATHS": "inv_panels"})):
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         dp = qgd.DeviceProblem(prob, 8)
@@ -824,6 +821,10 @@ def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
         grad, _ = dp.discrete_adjoint(0.1 * pcof)
         count = int(dp.intermediate("repivoted"))
         P = dp.intermediate("P")
+        # the handle remembers that the diagonal attempt failed for (more than a quarter of) its matrices: the next evaluation
+        # starts with pivoting -- same counts, same result
+        grad2, _ = dp.discrete_adjoint(0.1 * pcof)
+        assert int(dp.intermediate("repivoted")) == count and np.abs(grad2 - grad).max() <= 1e-13 * np.abs(grad).max()
         dp.close()
         assert (count & 0xFFFF) == nsteps, (partner, count)
         assert (count >> 16) == (nsteps if stage == 2 else 0), (partner, count)
@@ -911,9 +912,9 @@ def test_cost_types_vs_oracle(qgd, orc, cost_type):
 
 
 def test_cost_type_stand_alone_terminal_kernel(qgd, orc, monkeypatch):
-    """The same through k_terminal as its own launch (QGD_TERMINAL_KERNEL=1) instead of the extra workgroup of the first
+    """The same through k_terminal as its own launch (QGD_PATHS=terminal_kernel) instead of the extra workgroup of the first
     adjoint launch."""
-    monkeypatch.setenv("QGD_TERMINAL_KERNEL", "1")
+    monkeypatch.setenv("QGD_PATHS", "terminal_kernel")
     prob, ctrl, pcof, target = cases.guarded_case(qgd, nsteps=20, tf=10.0)
     orc.set_converged_terminal(True); orc.set_cost_type("Tracking")
     try:
@@ -1023,7 +1024,7 @@ def test_long_grid_vs_statement(qgd, orc):
 def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeypatch):
     """The adjoint history pass reaches the end of its block through the stored suffix product and affine part of the
     blocks behind it in the super-block (k_chain_fast MODE 6 beside the level-2 products, running values of the MODE 2
-    level-2 chain) instead of stepping over them: same lambda and gradient as with QGD_NO_SUFFIX=1 (the stepping pass),
+    level-2 chain) instead of stepping over them: same lambda and gradient as with QGD_PATHS=no_suffix (the stepping pass),
     on grids whose last super-block is full and not, and under a time partition."""
     import torch
     prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd, nsteps=nsteps, tf=float(nsteps) / 2)
@@ -1031,7 +1032,7 @@ def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeyp
     out = {}
     for off in (False, True):
         if off:
-            monkeypatch.setenv("QGD_NO_SUFFIX", "1")
+            monkeypatch.setenv("QGD_PATHS", "no_suffix")
         dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
         lam = np.zeros(shape, order="F")
         g, o = dp.discrete_adjoint(pcof, False, None, lam, None)
@@ -1039,7 +1040,7 @@ def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeyp
         dp.close()
     assert np.abs(out[False][2] - out[True][2]).max() <= 1e-13 * max(1.0, np.abs(out[True][2]).max())
     assert np.abs(out[False][0] - out[True][0]).max() <= 1e-13 * np.abs(out[True][0]).max()
-    monkeypatch.delenv("QGD_NO_SUFFIX")
+    monkeypatch.delenv("QGD_PATHS")
     stream = torch.cuda.current_stream().cuda_stream
     backs = [qgd.DeviceBackend(prob, order, ctrl, target, r, 2, device=0, stream=stream) for r in range(2)]
     for g, o in qgd.LocalGroup(backs).discrete_adjoint(pcof):

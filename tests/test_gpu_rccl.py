@@ -165,12 +165,14 @@ def _fake_transport(tmp_path):
     return out
 
 
-def _run_ranks(tmp_path, lib, case, shard, world, fail_at=0):
+def _run_ranks(tmp_path, lib, case, shard, world, fail_at=0, threads=False):
+    """One process per rank; threads=True: all ranks as threads of ONE process (a GPU box admits six processes on its card)."""
     import os, subprocess, sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_rank_worker.py")
     env = dict(os.environ, QGD_RCCL_LIB=lib, FAKE_RCCL_TIMEOUT_MS="60000" if not fail_at else "15000")
-    procs = [subprocess.Popen([sys.executable, worker, case, shard, str(r), str(world), str(tmp_path)] + ([str(fail_at)] if fail_at else []),
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, case, shard, who, str(world), str(tmp_path)] + ([str(fail_at)] if fail_at else []),
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for who in (["threads"] if threads else [str(r) for r in range(world)])]
     outs = []
     for p in procs:
         try:
@@ -183,15 +185,7 @@ def _run_ranks(tmp_path, lib, case, shard, world, fail_at=0):
     return [p.returncode for p in procs], outs
 
 
-@pytest.mark.parametrize("case,shard,world", [("cnot3", "time", 2), ("cnot3", "columns", 2), ("cnot3", "time", 3), ("guarded", "columns", 3),
-                                              ("dense", "time", 2), ("dense", "columns", 2)])
-def test_library_protocol_between_processes(qgd, tmp_path, case, shard, world):
-    """World sizes above one through the library's OWN communicator path (comm_discrete_adjoint / comm_eval_forward in
-    csrc/qgd_api.cpp: the in-place all-gathers at the rank's offset, the out-of-place reduction of [grad | scalars], the
-    terminal condition deferred into the last rank's first adjoint launch, the zeroed scalars of column ranks other than 0,
-    history_precomputed across ranks, the rank's share of the three output arrays), one PROCESS per rank on the one GPU of
-    the box, with the transport replaced by tests/fake_rccl (shared memory; QGD_RCCL_LIB): every rank must return the
-    single-GPU gradient and scalars to 1e-12, and all ranks the same bits."""
+def _single_gpu_reference(qgd, tmp_path, case):
     import rccl_rank_worker as w
     prob, ctrl, pcof, target, order = w.problem(qgd, case)
     dp = qgd.DeviceProblem(prob, order); dp.set_controls(ctrl); dp.set_target(target)
@@ -202,25 +196,59 @@ def test_library_protocol_between_processes(qgd, tmp_path, case, shard, world):
     g_half, o_half = dp.discrete_adjoint(0.5 * pcof)
     dp.close()
     np.savez(tmp_path / "ref.npz", g=g, o=np.asarray(o), f=np.asarray(f), hist=arrays[0], lam=arrays[1], forc=arrays[2])
-    lib = _fake_transport(tmp_path)
-    codes, outs = _run_ranks(tmp_path, lib, case, shard, world)
-    assert codes == [0] * world, "\n".join(x[-1500:] for x in outs)
+    return g_half, np.asarray(o_half)
+
+
+def _check_ranks(tmp_path, world, g_half, o_half):
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for r in range(1, world):
         for key in res[0].files:
             assert np.array_equal(res[r][key], res[0][key]), (r, key)
     assert np.abs(res[0]["g_half"] - g_half).max() <= 1e-12 * np.abs(g_half).max()
-    assert np.abs(res[0]["o_half"] - np.asarray(o_half)).max() <= 1e-12 * max(1.0, np.abs(np.asarray(o_half)).max())
+    assert np.abs(res[0]["o_half"] - o_half).max() <= 1e-12 * max(1.0, np.abs(o_half).max())
 
 
-@pytest.mark.parametrize("shard,fail_at", [("time", 1), ("time", 2), ("time", 3), ("columns", 4), ("columns", 3)])
-def test_failure_on_one_rank_ends_every_rank(qgd, tmp_path, shard, fail_at):
-    """The failure mode between processes: the last of two ranks fails locally in front of one of the exchanges
-    (qgd_comm_debug_fail_at).  It aborts its communicator and returns QGD_ERR_COMM; the other rank, already waiting in the
-    collective, is released by the abort and returns QGD_ERR_COMM as well -- nobody hangs (exit code 7 from both)."""
+@pytest.mark.parametrize("case,shard,world", [("cnot3", "time", 2), ("cnot3", "columns", 2), ("cnot3", "time", 3), ("guarded", "columns", 3),
+                                              ("dense", "time", 2), ("dense", "columns", 2), ("cnot3", "time", 4), ("cnot3", "columns", 4)])
+def test_library_protocol_between_processes(qgd, tmp_path, case, shard, world):
+    """World sizes above one through the library's OWN communicator path (comm_discrete_adjoint / comm_eval_forward in
+    csrc/qgd_host_comm.cpp: the in-place all-gathers at the rank's offset, the out-of-place reduction of [grad | scalars], the
+    terminal condition deferred into the last rank's first adjoint launch, the zeroed scalars of column ranks other than 0,
+    history_precomputed across ranks, the rank's share of the three output arrays), one PROCESS per rank on the one GPU of
+    the box, with the transport replaced by tests/fake_rccl (shared memory; QGD_RCCL_LIB): every rank must return the
+    single-GPU gradient and scalars to 1e-12, and all ranks the same bits."""
+    g_half, o_half = _single_gpu_reference(qgd, tmp_path, case)
     lib = _fake_transport(tmp_path)
-    codes, outs = _run_ranks(tmp_path, lib, "cnot3", shard, 2, fail_at=fail_at)
-    assert codes == [7, 7], "\n".join(x[-1500:] for x in outs)
+    codes, outs = _run_ranks(tmp_path, lib, case, shard, world)
+    assert codes == [0] * world, "\n".join(x[-1500:] for x in outs)
+    _check_ranks(tmp_path, world, g_half, o_half)
+
+
+@pytest.mark.parametrize("case,shard", [("cnot3", "time"), ("cnot3_headline", "time"), ("cnot3", "columns")])
+def test_library_protocol_with_eight_ranks(qgd, tmp_path, case, shard):
+    """The world size of the driver's scaling run, EIGHT, through the library's own communicator path before its first
+    execution over real RCCL: the ranks as eight threads of one process (a GPU box admits six processes on its card), each with
+    its own handle, stream and communicator over tests/fake_rccl.  cnot3 with 120 steps: 15-step windows, ONE scan block per
+    rank; the headline grid of 550 steps: 69-step windows (the last one 67); column blocks: one initial condition per rank.
+    Every rank returns the single-GPU gradient and scalars to 1e-12, all ranks the same bits, the reference-shaped arrays
+    its share."""
+    g_half, o_half = _single_gpu_reference(qgd, tmp_path, case)
+    lib = _fake_transport(tmp_path)
+    codes, outs = _run_ranks(tmp_path, lib, case, shard, 8, threads=True)
+    assert codes == [0], "\n".join(x[-3000:] for x in outs)
+    _check_ranks(tmp_path, 8, g_half, o_half)
+
+
+@pytest.mark.parametrize("shard,fail_at,world", [("time", 1, 2), ("time", 2, 2), ("time", 3, 2), ("columns", 4, 2), ("columns", 3, 2),
+                                                 ("time", 2, 4), ("columns", 3, 4), ("time", 1, 8), ("columns", 4, 8)])
+def test_failure_on_one_rank_ends_every_rank(qgd, tmp_path, shard, fail_at, world):
+    """The failure mode between ranks: the last rank fails locally in front of one of the exchanges
+    (qgd_comm_debug_fail_at).  It aborts its communicator and returns QGD_ERR_COMM; the other ranks, already waiting in the
+    collective, are released by the abort and return QGD_ERR_COMM as well -- nobody hangs (exit code 7 from all).  Two and four
+    ranks as processes, eight as threads of one process."""
+    lib = _fake_transport(tmp_path)
+    codes, outs = _run_ranks(tmp_path, lib, "cnot3", shard, world, fail_at=fail_at, threads=world > 4)
+    assert codes == ([7] if world > 4 else [7] * world), "\n".join(x[-1500:] for x in outs)
 
 
 def test_bench_default_multi_gpu_flow_between_processes(tmp_path):
@@ -249,3 +277,24 @@ def test_bench_default_multi_gpu_flow_between_processes(tmp_path):
     assert set(other["collectives_ms"]) >= {"comm_reduce_scal", "comm_reduce"}
     assert j2["weak_in_time"] and "error" not in j2["weak_in_time"], j2["weak_in_time"]
     assert "error" not in j2["large_n"] and j2["large_n"]["grad_norm_rel_diff_vs_1gpu"] <= 1e-10, j2["large_n"]
+
+
+def test_bench_multi_gpu_flow_with_four_ranks(tmp_path):
+    """The same flow with FOUR ranks (the most a one-GPU box admits beside the test process; the driver's scaling run goes on to
+    eight): the line must carry `value`, the north star's column split and both splits' collective times, and finish well
+    inside the driver's 600 s."""
+    import json, os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _fake_transport(tmp_path)
+    env = dict(os.environ, QGD_RCCL_LIB=lib, MASTER_PORT="29671", QGD_TINY="1")
+    t0 = time.time()
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--oversubscribe", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-large-n"], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert time.time() - t0 < 400
+    j = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["value"] > 0 and j["config"]["workload"]
+    assert set(j["collectives_ms"]) >= {"comm_gather_fwd", "comm_gather_adj", "comm_reduce"}, j["collectives_ms"]
+    other = j["north_star_split"]
+    assert other and "error" not in other and other["shard"] == "columns" and other["grad_rel_diff_vs_headline_split"] <= 1e-10, other
+    assert set(other["collectives_ms"]) >= {"comm_reduce_scal", "comm_reduce"}

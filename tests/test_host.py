@@ -176,7 +176,7 @@ def test_c_abi_exports_match_header(qgd):
     lib = qgd._lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qgd_abi_version() == 1
+    assert lib.qgd_abi_version() == 2
 
 
 def test_no_silent_cpu_fallback(qgd):
