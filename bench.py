@@ -67,11 +67,11 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
     return model
 
 
-KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_mfma", "propagator": "k_propagator",
+KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_cb", "propagator": "k_propagator",
                    "lambda": "k_lambda", "guard": "k_guard_diag"}
-CNOT2_PROFILE = "r04_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
-PMC_PROFILE = "r04_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
-PMC_MFMA_PROFILE = "r04_pmc_mfma_cnot3.json"
+CNOT2_PROFILE = "r05_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
+PMC_PROFILE = "r05_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
+PMC_MFMA_PROFILE = "r05_pmc_mfma_cnot3.json"
 
 
 def _lookup_kernel(table, kern):

@@ -6,7 +6,7 @@ CNOT problem of the benchmark (subsystems (4,4,4), 8 essential states, order 8 b
 
 The reference's run of this script (cnot3_optimize_gate.sb: one CPU core, order 8, stepsize 1.0) is the
 workload BASELINE.json quotes its metric on; here one optimiser iteration is one forward+adjoint
-evaluation on the GPU (~0.5 ms) plus scipy's bookkeeping.
+evaluation on the GPU (~0.31 ms) plus scipy's bookkeeping.
 """
 import argparse
 import os

@@ -276,22 +276,26 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
         double b2[4];
         #pragma unroll
         for (int s = 0; s < 4; s++) b2[s] = cb_swapneg(T[K][ct][s], smask);
+        const d4 b1 = T[K][ct];
+        // eight groups of four MFMAs (row block, k-step pair); the left operands of group g + 1 are read before the MFMAs of group g
+        d2 a[2], an[2];
         #pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int i = (K + 1 + ii) & 3;
-            const d4 b1 = T[K][ct];
-            #pragma unroll
-            for (int sh = 0; sh < 2; sh++) {
-                d2 a[2];
+        for (int u = 0; u < 2; u++) a[u] = *(const d2 *)(G + abase + u * 512 + ((K + 1) & 3) * 64);
+        #pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int i = (K + 1 + (g >> 1)) & 3, sh = g & 1;
+            if (g < 7) {
+                const int i2 = (K + 1 + ((g + 1) >> 1)) & 3, sh2 = (g + 1) & 1;
                 #pragma unroll
-                for (int u = 0; u < 2; u++) a[u] = *(const d2 *)(G + abase + (2 * sh + u) * 512 + i * 64);
-                #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    T[i][ct] = MFMA(a[u][0], b1[2 * sh + u], T[i][ct]);
-                    T[i][ct] = MFMA(a[u][1], b2[2 * sh + u], T[i][ct]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 2; u++) an[u] = *(const d2 *)(G + abase + (2 * sh2 + u) * 512 + i2 * 64);
             }
+            #pragma unroll
+            for (int u = 0; u < 2; u++) {
+                T[i][ct] = MFMA(a[u][0], b1[2 * sh + u], T[i][ct]);
+                T[i][ct] = MFMA(a[u][1], b2[2 * sh + u], T[i][ct]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a[0] = an[0]; a[1] = an[1];
         }
     }
 }

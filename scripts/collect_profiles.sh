@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r04
+#   bash scripts/collect_profiles.sh r05
 # -> gpurun_out/prof_<tag>/{kernel_stats_cnot3.csv, kernel_stats_c5.csv, bench_under_rocprof.json, pmc_*.json};
 # copy what is to be judged into profiles/.  Counters are collected in their own passes (--pmc with --kernel-trace only;
 # FETCH_SIZE and WRITE_SIZE cannot share a pass), exactly as MI355X_MICROARCH.md 'HBM' / 'rocprofv3 PMC slots' prescribe.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1047,3 +1047,35 @@ def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeyp
         assert np.abs(g - out[True][0]).max() <= 1e-12 * np.abs(out[True][0]).max()
     for b in backs:
         b.close()
+
+
+@pytest.mark.parametrize("data,first,later", [(0, 0, 0), (1, 1, 0), (3, None, 0), (4, 1, 1)])
+def test_inverse_kernels_side_by_side(tmp_path, data, first, later):
+    """Kernel level, outside the library's launch sequence: scripts/ubench/inverse_cb_bench.hip compiled here and run on 300
+    random step matrices -- k_inverse_cb beside k_inverse_mfma<64> on the same L and R, `Linv L = I` and `L P = R` (both copies of
+    P) checked on the host.  data 0: diagonally dominant (every matrix by the diagonal attempt); 1: rows permuted inside the
+    16-row blocks (every matrix by the pivoted attempt); 3: noise 0.1 (some matrices leave the diagonal attempt); 4: entries of
+    1000 outside the diagonal tiles (every matrix by the last resort).  first / later: the share of matrices past the first / second stage (None: some)."""
+    import os, re, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "inverse_cb_bench")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(root, "quantumgatedesign.jl_amd", "csrc"),
+                        "-I", os.path.join(root, "include"), os.path.join(root, "scripts", "ubench", "inverse_cb_bench.hip"), "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([exe, "300", str(data)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    errs = re.findall(r"(k_inverse_\w+)\S*\s+max \|Linv L - I\| = (\S+), max \|L P - R\| = (\S+) \(panel\) (\S+) \(planes\)", run.stdout)
+    assert len(errs) == 2, run.stdout
+    for name, e_inv, e_pp, e_pq in errs:
+        assert float(e_inv) <= 1e-12 and float(e_pp) <= 2e-11 and float(e_pq) <= 2e-11, (name, e_inv, e_pp, e_pq)
+    m = re.search(r"cb over all launches: (\d+) matrices not done by the diagonal attempt, (\d+) by the last resort", run.stdout)
+    launches = 3 + 12 * 10      # warm-up + timed launches of the bench
+    n_first, n_later = int(m.group(1)), int(m.group(2))
+    if first is None:
+        assert 0 < n_first < 300 * launches
+    else:
+        assert n_first == first * 300 * launches
+    assert n_later == later * 300 * launches
+    assert "status: mfma 0, cb 0" in run.stdout
