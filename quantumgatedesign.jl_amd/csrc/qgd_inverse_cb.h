@@ -30,6 +30,10 @@
 //     pivot chain and the updates (134 us instead of 98 for 550 matrices).
 #pragma once
 
+// wave priorities: the panel of the current owner, and the next owner from its L update to the end of its publish (the critical
+// path of a matrix).  550 matrices: 86.0 us without, 83.4 with 1 / 0, 82.2 with 2 / 1, 82.5-83.4 with 3 / 2.
+#define CB_PRIO_PANEL 2
+#define CB_PRIO_CRIT 1
 #define CB_GROWTH_STATIC 8.0
 #define CB_GROWTH 256.0
 
@@ -310,19 +314,20 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
         CB_STAMP(K, 0); \
         if (W == (K)) { \
             cb_park<true>(MR, Gk_, lane0); \
-            __builtin_amdgcn_s_setprio(1); \
+            __builtin_amdgcn_s_setprio(CB_PRIO_PANEL); \
             const int f_ = cb_panel<K, STATIC>(ML, smem, rhoL, rinvL, lane0); \
-            __builtin_amdgcn_s_setprio(0); \
+            __builtin_amdgcn_s_setprio(CB_PRIO_CRIT); \
             if (f_ && (lane0 & 63) == 0) bad = f_; \
             cb_park<false>(MR, Gk_, lane0); \
         } \
         CB_STAMP(K, 1); \
         lds_barrier(); \
-        if (W == (K)) cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); \
+        if (W == (K)) { cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); __builtin_amdgcn_s_setprio(0); } \
         lds_barrier(); \
         CB_STAMP(K, 2); \
         failed = __builtin_amdgcn_readfirstlane(bad); \
         if (!failed) { \
+            if (W == (K) + 1) __builtin_amdgcn_s_setprio(CB_PRIO_CRIT);      /* (the next owner: its L update and its panel are the critical path) */ \
             if (W != (K)) cb_update<K>(ML, Gk_, lane0); \
             if ((K) > 0 && W == (K)) cb_update<((K) > 0 ? (K) - 1 : 0)>(MR, smem + (((K) + 1) & 1) * CB_G, lane0); \
             CB_STAMP(K, 3); \
