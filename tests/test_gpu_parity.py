@@ -1049,21 +1049,30 @@ def test_adjoint_history_pass_suffix_products(qgd, which, nsteps, order, monkeyp
         b.close()
 
 
-@pytest.mark.parametrize("data,first,later", [(0, 0, 0), (1, 1, 0), (3, None, 0), (4, 1, 1)])
-def test_inverse_kernels_side_by_side(tmp_path, data, first, later):
-    """Kernel level, outside the library's launch sequence: scripts/ubench/inverse_cb_bench.hip compiled here and run on 300
-    random step matrices -- k_inverse_cb beside k_inverse_mfma<64> on the same L and R, `Linv L = I` and `L P = R` (both copies of
-    P) checked on the host.  data 0: diagonally dominant (every matrix by the diagonal attempt); 1: rows permuted inside the
-    16-row blocks (every matrix by the pivoted attempt); 3: noise 0.1 (some matrices leave the diagonal attempt); 4: entries of
-    1000 outside the diagonal tiles (every matrix by the last resort).  first / later: the share of matrices past the first / second stage (None: some)."""
-    import os, re, shutil, subprocess
+@pytest.fixture(scope="module")
+def inverse_bench_exe(tmp_path_factory):
+    """scripts/ubench/inverse_cb_bench.hip compiled once for the module (hipcc is on the GPU box)."""
+    import os, shutil, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "inverse_cb_bench")
+    exe = str(tmp_path_factory.mktemp("ubench") / "inverse_cb_bench")
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(root, "quantumgatedesign.jl_amd", "csrc"),
                         "-I", os.path.join(root, "include"), os.path.join(root, "scripts", "ubench", "inverse_cb_bench.hip"), "-o", exe],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+@pytest.mark.parametrize("data,first,later", [(0, 0, 0), (1, 1, 0), (3, None, 0), (4, 1, 1)])
+def test_inverse_kernels_side_by_side(inverse_bench_exe, data, first, later):
+    """Kernel level, outside the library's launch sequence: scripts/ubench/inverse_cb_bench.hip run on 300 random step
+    matrices -- k_inverse_cb beside k_inverse_mfma<64> on the same L and R, `Linv L = I` and `L P = R` (both copies of
+    P) checked on the host.  data 0: diagonally dominant (every matrix by the diagonal attempt); 1: rows permuted inside the
+    16-row blocks (every matrix by the pivoted attempt); 3: noise 0.1 (some matrices leave the diagonal attempt); 4: entries of
+    1000 outside the diagonal tiles (every matrix by the last resort).  first / later: the share of matrices past the first /
+    second stage (None: some)."""
+    import re, subprocess
+    exe = inverse_bench_exe
     run = subprocess.run([exe, "300", str(data)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     errs = re.findall(r"(k_inverse_\w+)\S*\s+max \|Linv L - I\| = (\S+), max \|L P - R\| = (\S+) \(panel\) (\S+) \(planes\)", run.stdout)
