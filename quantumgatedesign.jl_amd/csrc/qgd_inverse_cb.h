@@ -48,7 +48,17 @@
 #ifdef CB_PROFILE       // scripts/ubench/inverse_cb_bench.hip -DCB_PROFILE: s_memtime stamps of workgroup 0 (timing only, same results)
 __device__ unsigned long long g_cb_prof[4][8][8];
 #define CB_STAMP(K, i) do { if (blockIdx.x == 0 && (lane0 & 63) == 0) g_cb_prof[w][K][i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_cb_place[4096][4][4];      // per workgroup and wave: HW_ID, XCC_ID, first and last stamp
+#ifndef CB_PK
+#define CB_PK 0
+#endif
+#define CB_PSTAMP(i) do { if (K == CB_PK && sp < 2 && blockIdx.x == 0 && lane == 0) g_cb_prof[0][5 + sp][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CB_PLACE(i) do { if (blockIdx.x < 4096 && (lane0 & 63) == 0) { unsigned long long *q_ = g_cb_place[blockIdx.x][lane0 >> 6]; \
+        if ((i) == 0) { q_[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q_[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } \
+        q_[2 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
+#define CB_PLACE(i) do { } while (0)
+#define CB_PSTAMP(i) do { } while (0)
 #define CB_STAMP(K, i) do { } while (0)
 #endif
 
@@ -97,6 +107,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
         const int s_ = (c16 & 7) - q0;
         const bool mine = s_ >= 0 && s_ < 4;
         const int cofs = ((s_ >> 1) & 1) * 256 + kk * 4 + (s_ & 1) * 2 + (c16 >> 3);
+        CB_PSTAMP(0);
         // ---- the sub-panel's columns (and, pivoted attempt, row block K of the panel) go to LDS
         if (mine) {
             #pragma unroll
@@ -118,6 +129,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
             const d4 v = *(const d4 *)(Fm + (h * 64 + lane) * 4);
             xr[2 * h] = v[0]; xi[2 * h] = v[1]; xr[2 * h + 1] = v[2]; xi[2 * h + 1] = v[3];
         }
+        CB_PSTAMP(1);
         int pr[4];
         #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -154,6 +166,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
             // growth: the multipliers of THIS pivot (a pair of tiny pivots can undo each other's blow-up within a sub-panel)
             gmax = __builtin_fmax(gmax, __builtin_fmax(__builtin_fabs(gr), __builtin_fabs(gi)));
         }
+        CB_PSTAMP(2);
         #pragma unroll
         for (int h = 0; h < 2; h++) {
             d4 v; v[0] = xr[2 * h]; v[1] = xi[2 * h]; v[2] = xr[2 * h + 1]; v[3] = xi[2 * h + 1];
@@ -164,6 +177,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
             for (int s = 0; s < 4; s++) { rhoL[4 * sp + s] = pr[s] - 16 * K; rinvL[pr[s] - 16 * K] = 4 * sp + s; }
         }
         wave_lds_fence();
+        CB_PSTAMP(3);
         // ---- rank-4 update of the panel: M += A M[P, :], A = multipliers (minus the identity on the pivot rows)
         {
             const int prm = STATIC ? 16 * K + 4 * sp + kk : (kk == 0) ? pr[0] : (kk == 1) ? pr[1] : (kk == 2) ? pr[2] : pr[3];
@@ -192,6 +206,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
                     M[i][c2] = MFMA(a[1], b2[c2], M[i][c2]);
                 }
             }
+            CB_PSTAMP(4);
             if (mine) {
                 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -200,6 +215,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
             }
         }
         wave_lds_fence();       // (the next sub-panel rewrites Fm and Prow)
+        CB_PSTAMP(5);
     }
     const int grow = !(gmax <= (STATIC ? CB_GROWTH_STATIC : CB_GROWTH));      // (also true for a NaN)
     return sing | (__builtin_amdgcn_ballot_w64(grow) != 0 ? 2 : 0);
@@ -375,6 +391,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     const int lane0 = threadIdx.x;
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
     d4 ML[4][2], MR[4][2];
+    CB_PLACE(0);
     {
         const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
         const __amdgpu_buffer_rsrc_t rl = buffer_of(L + (size_t)n * panel + 32 * w), rr = buffer_of(R + (size_t)(n - 1) * panel + 32 * w);
@@ -446,6 +463,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
         }
     }
     CB_STAMP(4, 3);
+    CB_PLACE(1);
     return 0;
 }
 

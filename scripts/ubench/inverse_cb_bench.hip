@@ -81,7 +81,7 @@ int main(int argc, char **argv)
         unsigned long long pr[4][8][8];
         hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_cb_prof), sizeof pr);
         const unsigned long long t0 = pr[0][4][0];
-        printf("stamps of workgroup 0 (s_memtime ticks since the kernel's first stamp; 100 MHz clock => x24 for shader cycles at 2.4 GHz?)\n");
+        printf("stamps of workgroup 0 (s_memtime ticks since the kernel's first stamp; about one per shader cycle: an update of 64 MFMAs takes 4500-4700)\n");
         for (int w = 0; w < 4; w++) {
             printf(" wave %d: loaded %6lld start %6lld |", w, (long long)(pr[w][4][0] - t0), (long long)(pr[w][4][1] - t0));
             for (int k = 0; k < 4; k++)
@@ -89,6 +89,35 @@ int main(int argc, char **argv)
                        (long long)(pr[w][k][2] - t0), (long long)(pr[w][k][3] - t0), (long long)(pr[w][k][4] - t0));
             printf(" elim-end %6lld out-end %6lld\n", (long long)(pr[w][4][2] - t0), (long long)(pr[w][4][3] - t0));
         }
+        for (int sp = 0; sp < 2; sp++)
+            printf(" panel %d sub-panel %d: to-LDS+rows %lld | chain %lld | write-back %lld | reads+MFMA %lld | read-back %lld\n", CB_PK, sp, (long long)(pr[0][5 + sp][1] - pr[0][5 + sp][0]),
+                   (long long)(pr[0][5 + sp][2] - pr[0][5 + sp][1]), (long long)(pr[0][5 + sp][3] - pr[0][5 + sp][2]), (long long)(pr[0][5 + sp][4] - pr[0][5 + sp][3]), (long long)(pr[0][5 + sp][5] - pr[0][5 + sp][4]));
+        // placement of the LAST launch: workgroups per CU, and the waves' SIMDs
+        static unsigned long long place[4096][4][4];
+        hipMemcpyFromSymbol(place, HIP_SYMBOL(g_cb_place), sizeof place);
+        std::vector<int> per_cu(8 * 64, 0);
+        unsigned long long tmin = ~0ull;
+        for (int b = 0; b < nmat && b < 4096; b++) tmin = std::min(tmin, place[b][0][2]);
+        for (int b = 0; b < nmat && b < 4096; b++) {
+            const unsigned hw = (unsigned)place[b][0][0], xcc = (unsigned)place[b][0][1] & 15;
+            const int cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+            per_cu[xcc * 64 + se * 16 + cu]++;      // (SH folded: one SH per SE here)
+            if (b < 24 || b % 64 == 0 || b >= nmat - 8) {
+                printf(" wg %4d: xcc %u se %d sh %d cu %2d | simd/slot", b, xcc, se, sh, cu);
+                for (int w = 0; w < 4; w++) printf(" %u/%u", ((unsigned)place[b][w][0] >> 4) & 3, (unsigned)place[b][w][0] & 15);
+                printf(" | start %6lld end %6lld\n", (long long)(place[b][0][2] - tmin), (long long)(place[b][0][3] - tmin));
+            }
+        }
+        int hist[8] = {0}; for (int c : per_cu) hist[std::min(c, 7)]++;
+        printf(" CUs with 0..5 workgroups: %d %d %d %d %d %d\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+        // completion time by the number of workgroups on the CU
+        double sum[8] = {0}; int cnt[8] = {0};
+        for (int b = 0; b < nmat && b < 4096; b++) {
+            const unsigned hw = (unsigned)place[b][0][0], xcc = (unsigned)place[b][0][1] & 15;
+            const int c = per_cu[xcc * 64 + ((hw >> 13) & 7) * 16 + ((hw >> 8) & 15)];
+            sum[std::min(c, 7)] += (double)(place[b][0][3] - place[b][0][2]); cnt[std::min(c, 7)]++;
+        }
+        for (int c = 1; c < 6; c++) if (cnt[c]) printf(" workgroups on a CU with %d: %d, mean in-kernel time %.0f ticks\n", c, cnt[c], sum[c] / cnt[c]);
     }
 #endif
     int st[5]; hipMemcpy(st, dS, 20, hipMemcpyDeviceToHost);
