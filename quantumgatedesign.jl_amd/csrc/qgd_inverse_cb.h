@@ -36,6 +36,9 @@
 #define CB_PRIO_CRIT 1
 #define CB_GROWTH_STATIC 8.0
 #define CB_GROWTH 256.0
+// waves 1-3 hold their loads back by this many 64-cycle units (550 matrices, kernel alone: 80.8 us with 0, 79.9 with 8, 81.5 with 32,
+// 82.1 with 64; 83.5 with wave 0 loading its R block up front and L^-1 stored with the rest at the end)
+#define CB_FRONT_SLEEP 8
 
 // LDS map (doubles).  G: a multiplier block, [column pair][row][column & 1][re, im] = 2048 (A-operand order: the 32 lanes
 // (row c16, k = 0..1) of a 16-byte read are 32 consecutive slots); two of them, by block-step parity.
@@ -324,21 +327,22 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
 // time the conditional updates of 64-register tile blocks cost several hundred spilled registers).  The next owner (W == K + 1) applies step K to its L tiles only and goes on to its panel; its R
 // tiles take steps K and K + 1 after it has published.  Barrier A: the panel of step K is done and every wave has finished
 // with the multiplier block of step K - 2 (same slot); B: block K is published; C: the owner of step K has caught up with
-// step K - 1, whose slot the next owner now takes as its parking slab.
+// step K - 1, whose slot the next owner now takes as its parking slab.  The first owner has nothing to park (its R block is
+// loaded after its panel); L^-1 is final after a wave's update of step 3 and leaves before the wave's last R update.
 #define CB_STEP(K) if (!failed) { \
         double *Gk_ = smem + ((K) & 1) * CB_G; \
         CB_STAMP(K, 0); \
         if (W == (K)) { \
-            cb_park<true>(MR, Gk_, lane0); \
+            if ((K) > 0) cb_park<true>(MR, Gk_, lane0); \
             __builtin_amdgcn_s_setprio(CB_PRIO_PANEL); \
             const int f_ = cb_panel<K, STATIC>(ML, smem, rhoL, rinvL, lane0); \
             __builtin_amdgcn_s_setprio(CB_PRIO_CRIT); \
             if (f_ && (lane0 & 63) == 0) bad = f_; \
-            cb_park<false>(MR, Gk_, lane0); \
+            if ((K) > 0) cb_park<false>(MR, Gk_, lane0); \
         } \
         CB_STAMP(K, 1); \
         lds_barrier(); \
-        if (W == (K)) { cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); __builtin_amdgcn_s_setprio(0); } \
+        if (W == (K)) { cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); __builtin_amdgcn_s_setprio(0); if ((K) == 0) load_R(); } \
         lds_barrier(); \
         CB_STAMP(K, 2); \
         failed = __builtin_amdgcn_readfirstlane(bad); \
@@ -346,6 +350,7 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
             if (W == (K) + 1) __builtin_amdgcn_s_setprio(CB_PRIO_CRIT);      /* (the next owner: its L update and its panel are the critical path) */ \
             if (W != (K)) cb_update<K>(ML, Gk_, lane0); \
             if ((K) > 0 && W == (K)) cb_update<((K) > 0 ? (K) - 1 : 0)>(MR, smem + (((K) + 1) & 1) * CB_G, lane0); \
+            if ((K) == 3) store_Linv(); \
             CB_STAMP(K, 3); \
             lds_barrier(); \
             if (W != (K) + 1) cb_update<K>(MR, Gk_, lane0); \
@@ -392,23 +397,46 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
     d4 ML[4][2], MR[4][2];
     CB_PLACE(0);
-    {
+    // Loads: every wave its L block first.  The first owner (wave 0) starts its panel as soon as that has arrived -- its R block
+    // is loaded after the panel (no parking in step 0) -- and the other waves hold their loads back a little: all workgroups of
+    // the launch start together, and the panels of step 0 wait for whatever stands in the queue in front of their 16 KB.
+    auto load_R = [&]() {
         const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
-        const __amdgpu_buffer_rsrc_t rl = buffer_of(L + (size_t)n * panel + 32 * w), rr = buffer_of(R + (size_t)(n - 1) * panel + 32 * w);
+        const __amdgpu_buffer_rsrc_t rr = buffer_of(R + (size_t)(n - 1) * panel + 32 * w);
         const int voff = (kk * PW + c16) * 8;
         #pragma unroll
         for (int i = 0; i < 4; i++)
             #pragma unroll
             for (int ct = 0; ct < 2; ct++)
                 #pragma unroll
-                for (int r = 0; r < 4; r++) ML[i][ct][r] = buffer_load_f64(rl, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
+                for (int r = 0; r < 4; r++) MR[i][ct][r] = buffer_load_f64(rr, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
+    };
+    {
+        const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rl = buffer_of(L + (size_t)n * panel + 32 * w);
+        const int voff = (kk * PW + c16) * 8;
+        if (W != 0) __builtin_amdgcn_s_sleep(CB_FRONT_SLEEP);
         #pragma unroll
         for (int i = 0; i < 4; i++)
             #pragma unroll
             for (int ct = 0; ct < 2; ct++)
                 #pragma unroll
-                for (int r = 0; r < 4; r++) MR[i][ct][r] = buffer_load_f64(rr, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
+                for (int r = 0; r < 4; r++) ML[i][ct][r] = buffer_load_f64(rl, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
     }
+    if (W != 0) load_R();
+    // L^-1, row-major planes (left operand of lambda = L^-H y): columns 16w..16w+15 of every row, straight from the registers
+    // (issued after the wave's last L update, in front of its last R update)
+    auto store_Linv = [&]() {
+        const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
+        const __amdgpu_buffer_rsrc_t rT = buffer_of(LinvT + (size_t)n * 2 * pl + 16 * w);
+        const int voff = ((c16 >> 3) * (int)pl + kk * NP + (c16 & 7)) * 8;
+        #pragma unroll
+        for (int i = 0; i < 4; i++)
+            #pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++) buffer_store_f64(ML[i][ct][r], rT, voff, ((16 * i + 4 * r) * NP + 8 * ct) * 8);
+    };
     CB_STAMP(4, 0);
     if (lane0 == 0) bad = 0;
     __syncthreads();
@@ -422,16 +450,6 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     CB_STAMP(4, 2);
     lds_barrier();              // the multiplier blocks are dead: their space stages the column-major planes of P
     const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
-    {   // L^-1, row-major planes (left operand of lambda = L^-H y): columns 16w..16w+15 of every row, straight from the registers
-        const __amdgpu_buffer_rsrc_t rT = buffer_of(LinvT + (size_t)n * 2 * pl + 16 * w);
-        const int voff = ((c16 >> 3) * (int)pl + kk * NP + (c16 & 7)) * 8;
-        #pragma unroll
-        for (int i = 0; i < 4; i++)
-            #pragma unroll
-            for (int ct = 0; ct < 2; ct++)
-                #pragma unroll
-                for (int r = 0; r < 4; r++) buffer_store_f64(ML[i][ct][r], rT, voff, ((16 * i + 4 * r) * NP + 8 * ct) * 8);
-    }
     {   // P, row-major panel (left operand of the adjoint sweep as P^H)
         const __amdgpu_buffer_rsrc_t rP = buffer_of(Pr + (size_t)(n - 1) * panel + 32 * w);
         const int voff = (kk * PW + c16) * 8;
