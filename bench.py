@@ -72,6 +72,7 @@ KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_cb", "pro
 CNOT2_PROFILE = "r05_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
 PMC_PROFILE = "r05_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
 PMC_MFMA_PROFILE = "r05_pmc_mfma_cnot3.json"
+STATS_PROFILE = "r05_kernel_stats_cnot3.csv"         # rocprofv3 --kernel-trace --stats of this command (scripts/collect_profiles.sh)
 
 
 def _lookup_kernel(table, kern):
@@ -99,6 +100,20 @@ def measured_traffic(phase):
     if f is None or w is None:
         return None, None
     return (2.0 * f + w) * 1024.0, "profiles/" + PMC_PROFILE
+
+
+def profiled_launch_ms(phase):
+    """Average duration of the phase's kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this same command
+    (profiles/STATS_PROFILE: first wave to last wave), in ms, and the file; (None, None) without one."""
+    import csv
+    path = os.path.join(ROOT, "profiles", STATS_PROFILE)
+    kern = KERNEL_OF_PHASE.get(phase)
+    if not kern or not os.path.exists(path):
+        return None, None
+    for row in csv.DictReader(open(path)):
+        if kern in row["Name"]:
+            return float(row["AverageNs"]) * 1e-6, "profiles/" + STATS_PROFILE
+    return None, None
 
 
 def measured_mfma_util(phase):
@@ -791,6 +806,10 @@ def main():
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work,
+                         "launch_ms_profile": profiled_launch_ms(dom)[0], "launch_ms_profile_source": profiled_launch_ms(dom)[1],
+                         "launch_ms_note": "launch_ms: HIP event pair on the library's stream around the launch, inside the timed region -- it also covers "
+                                           "the dispatch of the grid behind the drained queue and the end-of-kernel signal (5-8 us); the rocprofv3 "
+                                           "figure is first wave to last wave.  frac uses launch_ms",
                          # (single-launch phases only: the sweeps are several launches each)
                          "dominant_confirmed": bool(max((k for k in breakdown if k in model and not k.startswith("sweep")), key=breakdown.get, default=dom) == dom),
                          "history_stream": {"bound": "hbm", "bytes_per_timestep": b_step, "achieved": hs, "peak": PEAK_HBM_GBS, "unit": "GB/s",

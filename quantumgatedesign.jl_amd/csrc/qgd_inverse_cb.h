@@ -39,6 +39,8 @@
 // waves 1-3 hold their loads back by this many 64-cycle units (550 matrices, kernel alone: 80.8 us with 0, 79.9 with 8, 81.5 with 32,
 // 82.1 with 64; 83.5 with wave 0 loading its R block up front and L^-1 stored with the rest at the end)
 #define CB_FRONT_SLEEP 8
+#define CB_ONE_ROUND 768       // 256 CUs x 3 workgroups
+#define CB_ONE_ALONE 256       // (one workgroup per CU: nothing to queue behind -- 46.6 us without the measures, 47.3 with)
 
 // LDS map (doubles).  G: a multiplier block, [column pair][row][column & 1][re, im] = 2048 (A-operand order: the 32 lanes
 // (row c16, k = 0..1) of a 16-byte read are 32 consecutive slots); two of them, by block-step parity.
@@ -333,16 +335,16 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
         double *Gk_ = smem + ((K) & 1) * CB_G; \
         CB_STAMP(K, 0); \
         if (W == (K)) { \
-            if ((K) > 0) cb_park<true>(MR, Gk_, lane0); \
+            if ((K) > 0 || !ONE) cb_park<true>(MR, Gk_, lane0); \
             __builtin_amdgcn_s_setprio(CB_PRIO_PANEL); \
             const int f_ = cb_panel<K, STATIC>(ML, smem, rhoL, rinvL, lane0); \
             __builtin_amdgcn_s_setprio(CB_PRIO_CRIT); \
             if (f_ && (lane0 & 63) == 0) bad = f_; \
-            if ((K) > 0) cb_park<false>(MR, Gk_, lane0); \
+            if ((K) > 0 || !ONE) cb_park<false>(MR, Gk_, lane0); \
         } \
         CB_STAMP(K, 1); \
         lds_barrier(); \
-        if (W == (K)) { cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); __builtin_amdgcn_s_setprio(0); if ((K) == 0) load_R(); } \
+        if (W == (K)) { cb_publish<K, STATIC>(ML, Gk_, rhoL, rinvL, lane0); __builtin_amdgcn_s_setprio(0); if ((K) == 0 && ONE) load_R(); } \
         lds_barrier(); \
         CB_STAMP(K, 2); \
         failed = __builtin_amdgcn_readfirstlane(bad); \
@@ -350,7 +352,7 @@ __device__ __forceinline__ void cb_update(d4 (&T)[4][2], const double *G, const 
             if (W == (K) + 1) __builtin_amdgcn_s_setprio(CB_PRIO_CRIT);      /* (the next owner: its L update and its panel are the critical path) */ \
             if (W != (K)) cb_update<K>(ML, Gk_, lane0); \
             if ((K) > 0 && W == (K)) cb_update<((K) > 0 ? (K) - 1 : 0)>(MR, smem + (((K) + 1) & 1) * CB_G, lane0); \
-            if ((K) == 3) store_Linv(); \
+            if ((K) == 3 && ONE) store_Linv(); \
             CB_STAMP(K, 3); \
             lds_barrier(); \
             if (W != (K) + 1) cb_update<K>(MR, Gk_, lane0); \
@@ -368,6 +370,15 @@ struct CbArgs {
     int *rho, *rinv, *bad;
     int n;
 };
+// A pointer into LDS, said to be one: cb_retry is a real function with two callers (the two kernels), so nothing tells the compiler
+// where its pointer arguments point -- left generic, every LDS access in it became a flat_load / flat_store (2800 of them, and the
+// pivoted attempt went from 124 to 151 us for 550 matrices).  The low word of a generic LDS address is the LDS offset.
+template <typename T> __device__ __forceinline__ T *cb_lds(T *p)
+{
+    typedef __attribute__((address_space(3))) T lds_T;
+    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
+    return (T *)(lds_T *)(unsigned long long)off;
+}
 template <typename T> __device__ __forceinline__ T *cb_uniform(T *p)
 {
     const unsigned long long v = (unsigned long long)p;
@@ -381,22 +392,26 @@ __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L,
 // are written and hands a matrix it has to give up to the next attempt (diagonal pivots -> pivots inside the diagonal tile
 // -> k_inverse_mfma's elimination).  Inlined into one kernel the three bodies cost the first one several hundred spilled
 // registers; as functions that return they would save and restore 64 callee-saved registers per call.
-template <int W, bool STATIC>
+template <int W, bool STATIC, bool ONE>
 __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, double *LinvT_, double *Pr_, double *Pc_, int n_,
                                        int *status_, int *fallbacks_, double *smem_, int *rhoL_, int *rinvL_, int *bad_)
 {
     const double *__restrict__ L = cb_uniform(L_), *__restrict__ R = cb_uniform(R_);
     double *__restrict__ LinvT = cb_uniform(LinvT_), *__restrict__ Pr = cb_uniform(Pr_), *__restrict__ Pc = cb_uniform(Pc_);
-    double *smem = cb_uniform(smem_);
-    int *rhoL = cb_uniform(rhoL_), *rinvL = cb_uniform(rinvL_);
+    double *smem = cb_lds(smem_);
+    int *rhoL = cb_lds(rhoL_), *rinvL = cb_lds(rinvL_);
     (void)status_; (void)fallbacks_;
-    int &bad = *cb_uniform(bad_);
+    int &bad = *cb_lds(bad_);
     const int n = __builtin_amdgcn_readfirstlane(n_);
     constexpr int NP = 64, PW = 128, w = W;
     const int lane0 = threadIdx.x;
     const size_t panel = (size_t)NP * PW, pl = (size_t)NP * NP;
     d4 ML[4][2], MR[4][2];
     CB_PLACE(0);
+    // ONE: a launch whose workgroups are all resident at once (three per CU, CB_ONE_ROUND) runs them in step -- the loads of all of
+    // them stand in one queue at the start, their stores at the end.  There the measures below pay (83.5 -> 80.5 us for the 550
+    // matrices of the headline); in a longer launch, where workgroups start as others finish, they cost 4-6 % (1100 matrices: 148
+    // -> 157 us, 2200: 248 -> 258) and are compiled out.  (As a run-time switch: 200 spilled registers, 86 us.)
     // Loads: every wave its L block first.  The first owner (wave 0) starts its panel as soon as that has arrived -- its R block
     // is loaded after the panel (no parking in step 0) -- and the other waves hold their loads back a little: all workgroups of
     // the launch start together, and the panels of step 0 wait for whatever stands in the queue in front of their 16 KB.
@@ -415,7 +430,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
         const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
         const __amdgpu_buffer_rsrc_t rl = buffer_of(L + (size_t)n * panel + 32 * w);
         const int voff = (kk * PW + c16) * 8;
-        if (W != 0) __builtin_amdgcn_s_sleep(CB_FRONT_SLEEP);
+        if (W != 0 && ONE) __builtin_amdgcn_s_sleep(CB_FRONT_SLEEP);
         #pragma unroll
         for (int i = 0; i < 4; i++)
             #pragma unroll
@@ -423,7 +438,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
                 #pragma unroll
                 for (int r = 0; r < 4; r++) ML[i][ct][r] = buffer_load_f64(rl, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
     }
-    if (W != 0) load_R();
+    if (W != 0 || !ONE) load_R();
     // L^-1, row-major planes (left operand of lambda = L^-H y): columns 16w..16w+15 of every row, straight from the registers
     // (issued after the wave's last L update, in front of its last R update)
     auto store_Linv = [&]() {
@@ -450,6 +465,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     CB_STAMP(4, 2);
     lds_barrier();              // the multiplier blocks are dead: their space stages the column-major planes of P
     const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
+    if (!ONE) store_Linv();
     {   // P, row-major panel (left operand of the adjoint sweep as P^H)
         const __amdgpu_buffer_rsrc_t rP = buffer_of(Pr + (size_t)(n - 1) * panel + 32 * w);
         const int voff = (kk * PW + c16) * 8;
@@ -485,15 +501,15 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     return 0;
 }
 
-template <bool STATIC>
+template <bool STATIC, bool ONE>
 __device__ __forceinline__ int cb_attempt(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
                                           int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: return cb_wave<0, STATIC>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    case 1: return cb_wave<1, STATIC>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    case 2: return cb_wave<2, STATIC>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    default: return cb_wave<3, STATIC>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 0: return cb_wave<0, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 1: return cb_wave<1, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 2: return cb_wave<2, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    default: return cb_wave<3, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
     }
 }
 
@@ -503,7 +519,7 @@ __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, co
                                                              int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
     if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1);                 // (matrices not done by the diagonal attempt)
-    if (cb_attempt<false>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
+    if (cb_attempt<false, true>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
         cb_fallback(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL);
     }
@@ -513,11 +529,12 @@ __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, co
 // The workgroup's entry.  fallbacks (or null): [0] += matrices not done by the diagonal attempt, [1] += of these, by the last
 // resort, [2] != 0: skip the diagonal attempt (k_tables sets it when the previous evaluation gave up more than a quarter of
 // its matrices there -- a problem whose step matrices are not diagonally dominant pays for the failed attempt only once).
+template <bool ONE>
 __device__ __forceinline__ void inverse_cb_body(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, const int n,
                                                 int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
     const bool pivot_first = fallbacks && __builtin_amdgcn_readfirstlane(fallbacks[2]) != 0;
-    if (pivot_first || cb_attempt<true>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
+    if (pivot_first || cb_attempt<true, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
         cb_retry(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
     }

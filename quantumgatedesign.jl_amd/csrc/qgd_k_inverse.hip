@@ -421,13 +421,14 @@ __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L,
 {
     if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks + 1, 1);             // (matrices both column-block attempts gave up)
     inverse_mfma_body<64>(cb_uniform(L), cb_uniform(R), cb_uniform(LinvT), cb_uniform(Pr), cb_uniform(Pc), __builtin_amdgcn_readfirstlane(n),
-                          cb_uniform(status), cb_uniform(smem), cb_uniform(rho), cb_uniform(rinv));
+                          cb_uniform(status), cb_lds(smem), cb_lds(rho), cb_lds(rinv));
     __builtin_amdgcn_endpgm();
 }
 
 // Np = 64: column-block elimination first; a matrix whose diagonal tiles do not carry the pivots (zero pivot or a multiplier
 // beyond CB_GROWTH inside a tile) is done again by the fully pivoted elimination above, in the same workgroup.
-// fallbacks: three words or null (inverse_cb_body).
+// fallbacks: three words or null (inverse_cb_body).  ONE: every workgroup of the launch is resident at once (qgd_inverse_cb.h).
+template <bool ONE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_inverse_cb(const double *__restrict__ L, const double *__restrict__ R, double *__restrict__ LinvT,
                   double *__restrict__ Pr, double *__restrict__ Pc, int n0, int *__restrict__ status, int *__restrict__ fallbacks)
@@ -437,7 +438,7 @@ void k_inverse_cb(const double *__restrict__ L, const double *__restrict__ R, do
     __shared__ __attribute__((aligned(32))) double smem[SM];
     __shared__ int rho[64], rinv[64];
     __shared__ int bad;
-    inverse_cb_body(L, R, LinvT, Pr, Pc, n0 + (int)blockIdx.x, status, fallbacks, smem, rho, rinv, &bad);
+    inverse_cb_body<ONE>(L, R, LinvT, Pr, Pc, n0 + (int)blockIdx.x, status, fallbacks, smem, rho, rinv, &bad);
 }
 
 // ---------------------------------------------------------------------------
@@ -1026,7 +1027,8 @@ int qgdk_inverse(const qgdk_ctx *c)
 #undef CALL_IMF
     case 64:   // column-block elimination of [L | R] (qgd_inverse_cb.h); QGD_PATHS=inv_panels: its last resort, the 4-pivot panel kernel, for every matrix
         if (qgd_path("inv_panels")) hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status);
-        else hipLaunchKernelGGL(k_inverse_cb, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
+        else if (nmat > CB_ONE_ALONE && nmat <= CB_ONE_ROUND) hipLaunchKernelGGL(k_inverse_cb<true>, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
+        else hipLaunchKernelGGL(k_inverse_cb<false>, dim3(nmat), dim3(256), 0, c->stream, c->L, c->R, c->LinvT, c->Pr, c->Pc, 1, c->status, c->status + 1);
         return (int)hipGetLastError();
     default: break;
     }

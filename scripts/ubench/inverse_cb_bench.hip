@@ -3,7 +3,7 @@
 //   k_inverse_cb   (column blocks, 16-pivot block steps, [L | R] eliminated together; qgd_inverse_cb.h)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I quantumgatedesign.jl_amd/csrc -I include \
 //         scripts/ubench/inverse_cb_bench.hip -o scripts/ubench/bin/inverse_cb_bench
-//   inverse_cb_bench [nmat] [data] [pivot_first]     data 0: I + 0.1 N(0,1) (the conditioning of the cnot3 step matrices)
+//   inverse_cb_bench [nmat] [data] [pivot_first] [one_round: 0 / 1 forces k_inverse_cb<false / true>]     data 0: I + 0.1 N(0,1) (the conditioning of the cnot3 step matrices)
 //                                      data 1: the same with the rows of every 16-row block permuted (in-tile pivoting)
 //                                      data 2: unit entries on a permuted diagonal, noise 0.3 (the pivoted attempt finds pivots in the tiles)
 //                                      data 3: noise 0.1 (the diagonal attempt is given up for some matrices)
@@ -53,9 +53,11 @@ int main(int argc, char **argv)
     if (argc > 3 && atoi(argv[3])) { const int one = 1; hipMemcpy(dS + 4, &one, 4, hipMemcpyHostToDevice); }
     hipMemcpy(dL, L.data(), L.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dR, Rm.data(), L.size() * 8, hipMemcpyHostToDevice);
+    const bool one_round = argc > 4 ? atoi(argv[4]) != 0 : nmat > CB_ONE_ALONE && nmat <= CB_ONE_ROUND;      // (the library's choice, or forced)
     auto launch = [&](int v) {
         if (v == 0) hipLaunchKernelGGL((k_inverse_mfma<64>), dim3(nmat), dim3(256), 0, 0, dL, dR, dT[0], dPr[0], dPc[0], 1, dS);
-        else hipLaunchKernelGGL(k_inverse_cb, dim3(nmat), dim3(256), 0, 0, dL, dR, dT[1], dPr[1], dPc[1], 1, dS + 1, dS + 2);
+        else if (one_round) hipLaunchKernelGGL(k_inverse_cb<true>, dim3(nmat), dim3(256), 0, 0, dL, dR, dT[1], dPr[1], dPc[1], 1, dS + 1, dS + 2);
+        else hipLaunchKernelGGL(k_inverse_cb<false>, dim3(nmat), dim3(256), 0, 0, dL, dR, dT[1], dPr[1], dPc[1], 1, dS + 1, dS + 2);
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int v = 0; v < 2; v++) { for (int i = 0; i < 3; i++) launch(v); }
