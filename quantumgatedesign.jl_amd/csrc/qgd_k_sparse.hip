@@ -91,12 +91,27 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     const bool active = (r < Np) && (cl < vc);
     SP_PROF_BEGIN
 
-    for (int item = tid; item < Z * 64; item += NTH) {
-        const int rr = item & 63, e = item >> 6;
-        Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
+    // (every global load of the prologue is issued before the first wait: the neighbour lists travel to registers while A_d(t_n)
+    //  is assembled -- as loops of their own, load / wait / ds_write, they were a second round trip in each of the kernel's three
+    //  rounds of workgroups)
+    constexpr int EIT = 2;                              // Z <= 16: Z * 64 <= EIT * NTH
+    int ecv[EIT];
+    #pragma unroll
+    for (int it = 0; it < EIT; it++) {
+        const int item = tid + it * NTH, rr = item & 63, e = item >> 6;
+        ecv[it] = (item < Z * 64 && rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
     const uint32_t slots = active ? *reinterpret_cast<const uint32_t *>(ell_inv + (size_t)r * Np + c0) : 0xffffffffu;
     assemble_ell<NOPS>(As, ell_val, tab, n, M, M, n_ops, Z, Np, tid, NTH);
+    #pragma unroll
+    for (int it = 0; it < EIT; it++) {
+        const int item = tid + it * NTH;
+        if (item < Z * 64) Ecol[item] = ecv[it];
+    }
+    for (int item = tid + EIT * NTH; item < Z * 64; item += NTH) {      // (not reached for Z <= 16)
+        const int rr = item & 63, e = item >> 6;
+        Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
+    }
     SP_PROF(0);
     c2 T[M][4], Lacc[4], Racc[4];
     #pragma unroll
@@ -251,13 +266,40 @@ void k_gradpoint_ell(const int32_t *__restrict__ ell_col,
         for (int j = 1; j <= M; j++)
             g[j - 1][c] = (c2){cw[2 * j] * lx.re - cw[2 * j + 1] * ln.re, cw[2 * j] * lx.im - cw[2 * j + 1] * ln.im};
     }
+    // the neighbour lists and the operator values: loaded to registers here, written to LDS behind the assembly (one round trip
+    // for the whole prologue instead of one per list)
+    constexpr int EIT = 4, OIT = 2;                     // Z <= 16: Z * 64 <= EIT * 256; the first OIT * 256 operator entries
+    int ecv[EIT], ocv[OIT];
+    c2 ovv[OIT];
+    #pragma unroll
+    for (int it = 0; it < EIT; it++) {
+        const int item = tid + it * 256, rr = item & 63, e = item >> 6;
+        ecv[it] = (item < Z * 64 && rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
+    }
+    #pragma unroll
+    for (int it = 0; it < OIT; it++) {
+        const int item = tid + it * 256, rr = item & 63, oe = item >> 6, o = oe / Zo, e = oe % Zo;
+        const bool ok = item < n_ops * Zo * 64 && rr < Np;
+        ocv[it] = ok ? op_col[(size_t)oe * Np + rr] : 0;
+        ovv[it] = ok ? (c2){op_val[((size_t)(2 * o) * Zo + e) * Np + rr], op_val[((size_t)(2 * o + 1) * Zo + e) * Np + rr]} : (c2){0.0, 0.0};
+    }
     if (M > 1) assemble_ell<NOPS>(As, ell_val, tab, n, M, ND, n_ops, Z, Np, tid, 256);
     SP_PROF(16);
-    for (int item = tid; item < Z * 64; item += 256) {
+    #pragma unroll
+    for (int it = 0; it < EIT; it++) {
+        const int item = tid + it * 256;
+        if (item < Z * 64) Ecol[item] = ecv[it];
+    }
+    for (int item = tid + EIT * 256; item < Z * 64; item += 256) {      // (not reached for Z <= 16)
         const int rr = item & 63, e = item >> 6;
         Ecol[item] = (rr < Np) ? ell_col[(size_t)e * Np + rr] : 0;
     }
-    for (int item = tid; item < n_ops * Zo * 64; item += 256) {
+    #pragma unroll
+    for (int it = 0; it < OIT; it++) {
+        const int item = tid + it * 256;
+        if (item < n_ops * Zo * 64) { Ocol[item] = ocv[it]; Ov[item] = ovv[it]; }
+    }
+    for (int item = tid + OIT * 256; item < n_ops * Zo * 64; item += 256) {
         const int rr = item & 63, oe = item >> 6, o = oe / Zo, e = oe % Zo;
         const bool ok = rr < Np;
         Ocol[item] = ok ? op_col[(size_t)oe * Np + rr] : 0;
