@@ -790,21 +790,24 @@ def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
     entries lie outside the diagonal tiles, both column-block attempts are given up and the fully pivoted elimination does
     every matrix.  (2) and (3) against the numpy statement, itself tied to the oracle: the stages are exercised, not just
     present.  intermediate("repivoted") = matrices past the first attempt + 65536 * matrices past the second."""
-    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
-    res = {}
-    for tag, env in (("blocks", {}), ("panels", {"QGD_PATHS": "inv_panels"})):
-        for k_, v in env.items():
-            monkeypatch.setenv(k_, v)
-        dp = qgd.DeviceProblem(prob, 8)
-        dp.set_controls(ctrl); dp.set_target(target)
-        res[tag] = dp.discrete_adjoint(pcof) + (dp.intermediate("repivoted"), dp.intermediate("Linv"), dp.intermediate("P"))
-        dp.close()
-        for k_ in env:
-            monkeypatch.delenv(k_)
-    assert res["blocks"][2] == 0
-    assert np.abs(res["panels"][0] - res["blocks"][0]).max() <= 1e-12 * np.abs(res["blocks"][0]).max()
-    assert np.abs(res["panels"][3] - res["blocks"][3]).max() <= 1e-12 * np.abs(res["blocks"][3]).max()
-    assert np.abs(res["panels"][4] - res["blocks"][4]).max() <= 1e-12
+    # the kernel has two instantiations (qgd_inverse_cb.h, ONE): 256 < matrices <= 768, where every workgroup of the launch is
+    # resident at once, and the rest -- 40 and 800 steps run the second, 300 the first
+    for nsteps in (40, 300, 800):
+        prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
+        res = {}
+        for tag, env in (("blocks", {}), ("panels", {"QGD_PATHS": "inv_panels"})):
+            for k_, v in env.items():
+                monkeypatch.setenv(k_, v)
+            dp = qgd.DeviceProblem(prob, 8)
+            dp.set_controls(ctrl); dp.set_target(target)
+            res[tag] = dp.discrete_adjoint(pcof) + (dp.intermediate("repivoted"), dp.intermediate("Linv"), dp.intermediate("P"))
+            dp.close()
+            for k_ in env:
+                monkeypatch.delenv(k_)
+        assert res["blocks"][2] == 0, nsteps
+        assert np.abs(res["panels"][0] - res["blocks"][0]).max() <= 1e-12 * np.abs(res["blocks"][0]).max(), nsteps
+        assert np.abs(res["panels"][3] - res["blocks"][3]).max() <= 1e-12 * np.abs(res["blocks"][3]).max(), nsteps
+        assert np.abs(res["panels"][4] - res["blocks"][4]).max() <= 1e-12, nsteps
     order, nsteps, dt = 6, 12, 0.8 / 12
     for partner, stage in ((1, 1), (32, 2)):
         prob, ctrl, pcof, target = cases.synthetic_case(qgd, N=64, c=8, n_ops=2, nsteps=nsteps, tf=0.8, seed=9)
@@ -1063,17 +1066,17 @@ def inverse_bench_exe(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("data,first,later", [(0, 0, 0), (1, 1, 0), (3, None, 0), (4, 1, 1)])
-def test_inverse_kernels_side_by_side(inverse_bench_exe, data, first, later):
-    """Kernel level, outside the library's launch sequence: scripts/ubench/inverse_cb_bench.hip run on 300 random step
-    matrices -- k_inverse_cb beside k_inverse_mfma<64> on the same L and R, `Linv L = I` and `L P = R` (both copies of
+@pytest.mark.parametrize("nmat,data,first,later", [(300, 0, 0, 0), (300, 1, 1, 0), (300, 3, None, 0), (300, 4, 1, 1), (800, 0, 0, 0), (800, 1, 1, 0), (800, 4, 1, 1)])
+def test_inverse_kernels_side_by_side(inverse_bench_exe, nmat, data, first, later):
+    """Kernel level, outside the library's launch sequence: scripts/ubench/inverse_cb_bench.hip run on 300 (k_inverse_cb<true>:
+    one round of workgroups) or 800 (k_inverse_cb<false>) random step matrices -- k_inverse_cb beside k_inverse_mfma<64> on the same L and R, `Linv L = I` and `L P = R` (both copies of
     P) checked on the host.  data 0: diagonally dominant (every matrix by the diagonal attempt); 1: rows permuted inside the
     16-row blocks (every matrix by the pivoted attempt); 3: noise 0.1 (some matrices leave the diagonal attempt); 4: entries of
     1000 outside the diagonal tiles (every matrix by the last resort).  first / later: the share of matrices past the first /
     second stage (None: some)."""
     import re, subprocess
     exe = inverse_bench_exe
-    run = subprocess.run([exe, "300", str(data)], capture_output=True, text=True, timeout=120)
+    run = subprocess.run([exe, str(nmat), str(data)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     errs = re.findall(r"(k_inverse_\w+)\S*\s+max \|Linv L - I\| = (\S+), max \|L P - R\| = (\S+) \(panel\) (\S+) \(planes\)", run.stdout)
     assert len(errs) == 2, run.stdout
@@ -1083,8 +1086,8 @@ def test_inverse_kernels_side_by_side(inverse_bench_exe, data, first, later):
     launches = 3 + 12 * 10      # warm-up + timed launches of the bench
     n_first, n_later = int(m.group(1)), int(m.group(2))
     if first is None:
-        assert 0 < n_first < 300 * launches
+        assert 0 < n_first < nmat * launches
     else:
-        assert n_first == first * 300 * launches
-    assert n_later == later * 300 * launches
+        assert n_first == first * nmat * launches
+    assert n_later == later * nmat * launches
     assert "status: mfma 0, cb 0" in run.stdout
