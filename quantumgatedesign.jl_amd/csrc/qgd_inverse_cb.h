@@ -12,7 +12,7 @@
 //     Gauss-Jordan chain on the 64 x 4 sub-panel, rank-4 MFMA update of the panel; exchanges through LDS inside the
 //     wave, no workgroup barrier).  It publishes the multiplier block G (rows of block k: D^-1, other rows: -F D^-1) in
 //     natural order; then every wave applies M[:, J] += (G - I_K) M[K, J] to its other tiles: 128 MFMAs per wave and block
-//     step, left operands read from LDS (one ds_read_b128 per (re, im) pair, constant offsets).  Two barriers per block
+//     step, left operands read from LDS (one ds_read_b128 per (re, im) pair, constant offsets).  Three barriers per block
 //     step instead of twelve.
 //   * R rides through the elimination as four more column blocks, so P = L^-1 R needs no product phase, no staging of the
 //     inverse and no loads inside a loop; the MFMA count is the same (2048 per matrix).
@@ -24,6 +24,9 @@
 //     rows never move, the permutation is resolved when the multiplier block is published).  A pivot confined to a
 //     16 x 16 tile can still be small although the matrix is well conditioned: beyond CB_GROWTH (or on a zero pivot) the
 //     matrix is reported to the caller, which runs the fully pivoted elimination of k_inverse_mfma on it.
+//   * two instantiations: ONE = every workgroup of the launch is resident at once (256 < matrices <= 768) and all of them
+//     run in step -- there the first owner loads its R block after its panel, the other waves hold their loads back and L^-1
+//     leaves before the last R update (cb_wave); in longer launches the same measures cost time and are compiled out.
 //   * registers: 128 accumulators of 168 (three workgroups per CU).  While a wave eliminates its panel half of its R tiles
 //     wait in LDS, and every phase derives its lane constants from an opaque copy of the lane id, so that nothing but the
 //     accumulators is alive across phases -- left to itself the compiler spilled several hundred registers into the
