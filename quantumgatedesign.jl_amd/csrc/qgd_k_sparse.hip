@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     // (every global load of the prologue is issued before the first wait: the neighbour lists travel to registers while A_d(t_n)
     //  is assembled -- as loops of their own, load / wait / ds_write, they were a second round trip in each of the kernel's three
     //  rounds of workgroups)
-    constexpr int EIT = 2;                              // Z <= 16: Z * 64 <= EIT * NTH
+    constexpr int EIT = 1024 / NTH;                     // Z <= 16: Z * 64 <= EIT * NTH
     int ecv[EIT];
     #pragma unroll
     for (int it = 0; it < EIT; it++) {
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
     const int PW = 2 * Np, SW = 2 * vc;                 // panel width, width of this slab's part of a row
     constexpr int SS = 2 * CW + 1;
     double *st = reinterpret_cast<double *>(Ds);        // [64][SS]
+    const int row0 = tid / SW, k0 = tid % SW, rstep = NTH / SW, kstep = NTH % SW, nit = (Np * SW + NTH - 1) / NTH;
     #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         lds_barrier();                                  // (LDS-only: the stores of L stay in flight while R is staged)
@@ -202,9 +203,22 @@ __global__ __launch_bounds__(64 * NW) void k_build_LR_ell(const int32_t *__restr
         }
         lds_barrier();
         double *dst = (pass ? R : L) + (size_t)n * Np * PW + slab * 2 * CW;
-        for (int item = tid; item < Np * SW; item += NTH) {
-            const int row = item / SW, k = item % SW;
-            dst[(size_t)row * PW + k] = st[row * SS + k];
+        // item = tid, tid + NTH, ...: (row, k) = (item / SW, item % SW) advanced by (NTH / SW, NTH % SW) -- the division per item
+        // was a third of the kernel's vector instructions -- and four LDS reads in flight ahead of their stores
+        int row = row0, k = k0;
+        for (int it0 = 0; it0 < nit; it0 += 4) {
+            double v[4]; int at[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool on = it0 + u < nit && row < Np;
+                at[u] = on ? row * PW + k : -1;
+                v[u] = on ? st[row * SS + k] : 0.0;
+                k += kstep; row += rstep;
+                if (k >= SW) { k -= SW; row++; }
+            }
+            #pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (at[u] >= 0) dst[at[u]] = v[u];
         }
     }
     SP_PROF(4);
@@ -516,7 +530,8 @@ static size_t lds_grad_ell(int M, int Z, int n_ops, int Zo)
 
 // Workgroup = (time point, 4*NW columns), NW waves.  NW = 8 (32 columns, 64 KB of LDS, two workgroups per CU) is the
 // only instantiation: 46.5 us on the 551-point benchmark grid against 49.8 us for NW = 4 (16 columns, 48 KB, three per CU,
-// measured in round 2) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.
+// measured in round 2) -- the narrow unit packs the CUs better but assembles A_d(t_n) four times per time point.  (Round 5, with
+// today's kernel: 40.2-40.4 us for NW = 4 against 39.4-40.3.)
 // (Before the LDS accesses were 16-byte aligned both took 63 us, bound by bank conflicts.)
 template <int M, int NW, int NOPS>
 static int launch_build_ell_nw(const qgdk_ctx *c)
