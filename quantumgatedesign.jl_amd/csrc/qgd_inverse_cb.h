@@ -375,7 +375,8 @@ struct CbArgs {
 };
 // A pointer into LDS, said to be one: cb_retry is a real function with two callers (the two kernels), so nothing tells the compiler
 // where its pointer arguments point -- left generic, every LDS access in it became a flat_load / flat_store (2800 of them, and the
-// pivoted attempt went from 124 to 151 us for 550 matrices).  The low word of a generic LDS address is the LDS offset.
+// pivoted attempt went from 124 to 151 us for 550 matrices).  The low word of a generic LDS address is the LDS offset (what the
+// compiler's own generic -> local cast computes, behind a null check that brought the flat instructions back when it was used here).
 template <typename T> __device__ __forceinline__ T *cb_lds(T *p)
 {
     typedef __attribute__((address_space(3))) T lds_T;
