@@ -77,8 +77,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        alt = os.environ.get("QGD_ORACLE_LIB")        # another build of the same source (scripts/oracle_sanitizers.sh: ASan + UBSan)
+        if not alt:
+            build()
+        _lib = C.CDLL(alt or _LIB_PATH)
         _lib.qo_coefficient.restype = C.c_double
         _lib.qo_coefficient.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib.qo_eval_p_derivative.restype = C.c_double
