@@ -104,7 +104,7 @@ int comm_wait(qgd_handle h)
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (ms > h->comm_timeout_ms)
                 return comm_failed(h, "rank " + std::to_string(rank) + ": a collective evaluation did not complete within " + std::to_string((long long)h->comm_timeout_ms) +
-                                      " ms (qgd_set_comm_timeout / QGD_COMM_TIMEOUT_MS): another rank failed or never made the call");
+                                      " ms (qgd_set_comm_timeout): another rank failed or never made the call");
             if (ms > 2.0) sched_yield();      // (an evaluation takes well under a millisecond: past that, stop burning the core)
         }
     }
