@@ -318,7 +318,7 @@ int qgd_comm_info(qgd_handle h, int32_t *out3);
 /* Failure mode of the collective calls.  A collective that one rank never enters would block the others inside an RCCL
  * kernel for good (the reference's thread loop has no such state: a failing column throws out of Threads.@threads,
  * src/forward_evolution.jl:48).  Therefore: the one host wait of a collective qgd_discrete_adjoint / qgd_eval_forward is
- * bounded (default 30 000 ms; QGD_COMM_TIMEOUT_MS in the environment, or this setter); when it expires, when RCCL
+ * bounded (default 30 000 ms, or this setter); when it expires, when RCCL
  * reports an asynchronous error, or when THIS rank fails between two collectives (HIP / launch / memory / RCCL error),
  * the library aborts the handle's communicator (ncclCommAbort -- RCCL's kernels leave the stream), and the call returns
  * QGD_ERR_COMM with the cause in qgd_last_error.  The handle then has no communicator (qgd_comm_info: rank -1): the host
