@@ -225,7 +225,7 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
         wave_lds_fence();       // (the next sub-panel rewrites Fm and Prow)
         CB_PSTAMP(5);
     }
-    const int grow = !(gmax <= (STATIC ? CB_GROWTH_STATIC : CB_GROWTH));      // (also true for a NaN)
+    const int grow = !(gmax <= (STATIC ? CB_GROWTH_STATIC : CB_GROWTH));      // (non-finite multipliers do not count: fmax drops a NaN, the matrix goes through with non-finite results)
     return sing | (__builtin_amdgcn_ballot_w64(grow) != 0 ? 2 : 0);
 }
 
@@ -531,8 +531,8 @@ __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, co
 }
 
 // The workgroup's entry.  fallbacks (or null): [0] += matrices not done by the diagonal attempt, [1] += of these, by the last
-// resort, [2] != 0: skip the diagonal attempt (k_tables sets it when the previous evaluation gave up more than a quarter of
-// its matrices there -- a problem whose step matrices are not diagonally dominant pays for the failed attempt only once).
+// resort, [2] != 0: skip the diagonal attempt (k_tables: for the 32 evaluations after one that gave up more than a quarter of
+// its matrices there -- a problem whose step matrices are not diagonally dominant pays for the failed attempt once in 33).
 template <bool ONE>
 __device__ __forceinline__ void inverse_cb_body(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, const int n,
                                                 int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)

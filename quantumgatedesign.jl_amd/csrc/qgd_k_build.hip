@@ -3,6 +3,20 @@
 #include "qgd_kernels_common.h"
 #include <string.h>
 
+// The counters of the inverse (status[1]: matrices redone, status[2], N = 64: by the last resort) start at zero, and what the
+// N = 64 kernel remembers between evaluations (status[3]: evaluations left that START with pivoting): when the diagonal-pivot
+// attempt of the last evaluation was given up for more than a quarter of its matrices, the next QGD_PIVOT_FIRST_EVALS evaluations
+// skip it; then it is tried again -- one evaluation with non-finite coefficients (a line search that overshoots) must not slow
+// the handle down for good, and a problem whose matrices are not diagonally dominant pays for the failed attempt once in 33.
+#define QGD_PIVOT_FIRST_EVALS 32
+__device__ __forceinline__ void inverse_memory(int *status, int nt)
+{
+    const int left = status[3];
+    if (left > 0) status[3] = left - 1;                       // (the last evaluation did not try the diagonal: nothing to learn from its count)
+    else if (4 * status[1] > nt) status[3] = QGD_PIVOT_FIRST_EVALS;
+    status[1] = 0; status[2] = 0;
+}
+
 // ---------------------------------------------------------------------------
 // K0: control tables  tab[n][d][k][pq] = sum_l G[k][n][d][l] * pcof[off_k + l]
 // (fill_p_mat!/fill_q_mat!, Control.jl:125-149, for the whole grid at once)
@@ -19,10 +33,7 @@ __global__ __launch_bounds__(256) void k_tables(const double *__restrict__ G, co
     if (!keep) {
         if (gid < 4) scal[gid] = 0.0;        // objective scalars and the singularity flag start at zero
         if (gid == 4) *status = 0;
-        if (gid == 5) {                   // counters of the inverse (matrices redone, N = 64: by the last resort), and what the N = 64
-            if (4 * status[1] > nt) status[3] = 1;      // kernel remembers: when more than a quarter of the last evaluation's matrices were
-            status[1] = 0; status[2] = 0;               // given up by the diagonal-pivot attempt it starts with pivoting from now on
-        }
+        if (gid == 5) inverse_memory(status, nt);
     }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;
@@ -56,10 +67,7 @@ __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G
     if (!keep) {
         if (gid < 4) scal[gid] = 0.0;
         if (gid == 4) *status = 0;
-        if (gid == 5) {                   // counters of the inverse (matrices redone, N = 64: by the last resort), and what the N = 64
-            if (4 * status[1] > nt) status[3] = 1;      // kernel remembers: when more than a quarter of the last evaluation's matrices were
-            status[1] = 0; status[2] = 0;               // given up by the diagonal-pivot attempt it starts with pivoting from now on
-        }
+        if (gid == 5) inverse_memory(status, nt);
     }
     const int idx = gid >> 4, sub = gid & 15;
     const int total = nt * (m + 1) * n_ops * 2;

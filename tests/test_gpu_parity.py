@@ -835,6 +835,52 @@ def test_column_block_inverse_and_its_fallbacks(qgd, orc, monkeypatch):
         assert np.abs(P[:nsteps] - ref["P"]).max() <= 1e-11, partner
 
 
+def test_non_finite_coefficients_end_and_leave_the_handle_usable(qgd):
+    """A coefficient vector with a NaN / an infinity / 1e200 in it (a line search that overshoots): the evaluation ENDS, its
+    results are non-finite, as the reference's would be, and the next evaluation of the same handle is bit for bit what it was
+    before.  (Non-finite step matrices go through the diagonal attempt of the N = 64 inverse: `repivoted` stays 0.)"""
+    nsteps = 40
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
+    dp = qgd.DeviceProblem(prob, 8)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g0, o0 = dp.discrete_adjoint(pcof)
+    assert int(dp.intermediate("repivoted")) == 0
+    for bad in (np.nan, np.inf, 1e200):
+        p2 = pcof.copy(); p2[3] = bad
+        g, o = dp.discrete_adjoint(p2)
+        assert not np.isfinite(g).all() and not np.isfinite(o[0])
+        g1, o1 = dp.discrete_adjoint(pcof)
+        assert np.array_equal(g1, g0) and np.array_equal(np.asarray(o1), np.asarray(o0)), bad
+        assert int(dp.intermediate("repivoted")) == 0
+    dp.close()
+
+
+def test_inverse_returns_to_the_diagonal_attempt(qgd):
+    """One evaluation whose step matrices are finite but far from diagonally dominant (coefficients a thousand times too large: the
+    diagonal attempt of the N = 64 inverse is given up for more than a quarter of them) makes the next 32 evaluations of the handle
+    START with pivoting (qgd_k_build.hip: inverse_memory; `repivoted` counts every matrix while they do); then the diagonal attempt
+    is tried again and, the matrices being what they were, stays.  Results are the same bits throughout."""
+    nsteps = 40
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
+    dp = qgd.DeviceProblem(prob, 8)
+    dp.set_controls(ctrl); dp.set_target(target)
+    g0, _ = dp.discrete_adjoint(pcof)
+    scale = None
+    for s_ in (30.0, 100.0, 300.0, 1000.0):
+        dp.discrete_adjoint(s_ * pcof)
+        if 4 * (int(dp.intermediate("repivoted")) & 0xFFFF) > nsteps + 1:
+            scale = s_
+            break
+    assert scale is not None
+    counts = []
+    for _ in range(36):
+        g1, _ = dp.discrete_adjoint(pcof)
+        counts.append(int(dp.intermediate("repivoted")) & 0xFFFF)
+        assert np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
+    assert counts[:32] == [nsteps] * 32 and counts[32:] == [0] * 4, (scale, counts)
+    dp.close()
+
+
 @pytest.mark.parametrize("c", [20, 64])
 def test_cnot3_many_columns(qgd, orc, c):
     """The sparse N=64 path with more initial conditions than one MFMA tile (the whole 64-dimensional basis, and a
