@@ -1,5 +1,5 @@
 """A/B of an environment switch on the cnot3 headline evaluation, both variants in ONE process on the same box, interleaved:
-    python3 scripts/ab_env.py QGD_AS_GLOBAL          (or VAR=value, e.g. QGD_LIB_PATH=scripts/ubench/bin/libqgd_x.so)
+    python3 scripts/ab_env.py QGD_PATHS=inv_panels   (or any VAR=value, e.g. QGD_LIB_PATH=scripts/ubench/bin/libqgd_x.so from scripts/build_variant.sh)
 Each variant: its own handle (the switch is read when the library first needs it, so the variants run in child processes),
 60 untimed evaluations, then the median of 300 timed ones; the gradient of the two variants is compared bit for bit."""
 import os, subprocess, sys, json
