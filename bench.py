@@ -777,7 +777,10 @@ def main():
         # N > 1: ONE evaluation is spread over the ranks (strong scaling)
         total_timesteps = args.nsteps * args.steps
         sec_eval = elapsed / args.steps
-        traffic, traffic_source = measured_traffic(dom)
+        # what the committed profiles say about the dominant kernel belongs to the profiled workload only (550 steps on one GPU)
+        profiled = (args.nsteps == 550 and not use_dist)
+        traffic, traffic_source = measured_traffic(dom) if profiled else (None, None)
+        prof_ms, prof_src = profiled_launch_ms(dom) if profiled else (None, None)
         N_, c_, m_ = prob.N_tot_levels, prob.N_initial_conditions, order // 2
         # the only HBM-proportional term of the ALGORITHM is the history stream, written once and read
         # once: B_step = 2*16*N*(1+m)*c + 2*16*N*c bytes per timestep
@@ -804,9 +807,9 @@ def main():
                                       ((f"time windows over {n_gpus} GPUs, 2 all-gathers + 1 all-reduce per evaluation" if args.shard == "time"
                                         else f"column blocks over {n_gpus} GPUs, 2 all-reduces per evaluation") + "; " + how)},
             "roofline": {"kernel": KERNEL_OF_PHASE.get(dom, dom), "phase": dom, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom),
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "mfma_pipe_busy_pmc": measured_mfma_util(dom) if profiled else None,
                          "launch_ms": timed[dom], "launches_timed": nsamp, "algorithmic_work_per_launch": work,
-                         "launch_ms_profile": profiled_launch_ms(dom)[0], "launch_ms_profile_source": profiled_launch_ms(dom)[1],
+                         "launch_ms_profile": prof_ms, "launch_ms_profile_source": prof_src,
                          "launch_ms_note": "launch_ms: HIP event pair on the library's stream around the launch, inside the timed region -- it also covers "
                                            "the dispatch of the grid behind the drained queue and the end-of-kernel signal (5-8 us); the rocprofv3 "
                                            "figure is first wave to last wave.  frac uses launch_ms",

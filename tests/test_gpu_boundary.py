@@ -225,6 +225,14 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert j1["cnot2"]["path"].startswith("small-problem") and j1["cnot2"]["general_path"]["max_rel_gradient_difference"] <= 1e-12
     # the roofline object is about the dominant kernel of the evaluation (the inverse), whatever the first call's one-time costs were
     assert j1["roofline"]["phase"] == "inverse" and j1["roofline"]["kernel"].startswith("k_inverse") and j1["roofline"]["dominant_confirmed"], j1["roofline"]
+    # ... timed live (event pair) and, beside it, the average duration of that kernel in the committed rocprofv3 summary: they
+    # agree up to what the event pair adds (dispatch of the grid behind a drained queue, end-of-kernel signal)
+    # (only for the profiled workload, 550 steps on one GPU: this run is shorter, the fields are there and empty)
+    r = j1["roofline"]
+    assert r["launch_ms"] > 0 and "launch_ms_profile" in r and "traffic" in r
+    if r["launch_ms_profile"] is not None:
+        assert r["launch_ms_profile_source"].startswith("profiles/")
+        assert 0.8 * r["launch_ms"] <= r["launch_ms_profile"] <= 1.05 * r["launch_ms"], (r["launch_ms"], r["launch_ms_profile"])
 
 
 @pytest.mark.parametrize("shard", ["time", "columns"])
