@@ -128,6 +128,93 @@ def evaluate(prob, Gp, Gq, offsets, pcof, target, order, overlap=None):
                 overlap=(a, b), f=fc, y=y, lam=lam, g=g, sigP=sigP, sigQ=sigQ, grad=grad)
 
 
+def evaluate_local(prob, Gp, Gq, offsets, pcof, target, order, overlap=None):
+    """The same evaluation with every per-time-point quantity LOCAL to its time point (round 6, the fused front kernel
+    csrc/qgd_k_front.hip): the step propagator is the same-point product S_n = R_n L_n^-1 instead of P_n = L_{n+1}^-1 R_n.
+      forward in phi_n = L_n psi_n:   phi_0 = L_0 psi_0,  phi_{n+1} = S_n phi_n,  psi_n = L_n^-1 phi_n   (forward_evolution.jl:181-220)
+      adjoint directly in lambda:     lambda_N = L_N^-H rhs_N,  lambda_n = S_n^H lambda_{n+1} + L_n^-H f_n  (forward_evolution.jl:421-461)
+    The device eliminates [L_n^H | R_n^H] -> [L_n^-H | S_n^H]: X = L^-H and Y = S^H are what it stores; they are formed that way
+    here too.  Gradient part unchanged.  Returns the dict of evaluate() plus S, X, Y, phi, h."""
+    m = order // 2
+    N, c, nsteps = prob.N_tot_levels, prob.N_initial_conditions, prob.nsteps
+    dt = prob.tf / nsteps
+    nt = nsteps + 1
+    tp, tq = tables(Gp, Gq, offsets, pcof, m)
+    Ac = assemble(prob, tp, tq, m)
+    L, R, _ = build_LR(Ac, m, dt)
+    LH = np.conj(np.transpose(L, (0, 2, 1)))
+    RH = np.conj(np.transpose(R, (0, 2, 1)))
+    X = np.linalg.inv(LH)                                    # L_n^-H
+    Y = X @ RH                                               # S_n^H
+    XH = np.conj(np.transpose(X, (0, 2, 1)))                 # L_n^-1
+    YH = np.conj(np.transpose(Y, (0, 2, 1)))                 # S_n
+    phi = np.zeros((nt, N, c), dtype=complex)
+    phi[0] = L[0] @ (prob.u0 + 1j * prob.v0)
+    for n in range(nsteps):
+        phi[n + 1] = YH[n] @ phi[n]
+    psi = XH @ phi
+    psi[0] = prob.u0 + 1j * prob.v0                          # (the device keeps the given initial state, not L_0^-1 L_0 psi_0)
+    W = prob.guard_subspace_projector
+    wreal = np.concatenate([psi.real, psi.imag], axis=1)
+    Ww = np.einsum("ij,njc->nic", W, wreal)
+    trap = np.ones(nt); trap[0] = trap[-1] = 0.5
+    guard = (dt / prob.tf) * np.einsum("n,nic,nic->", trap, wreal, Ww)
+    f = -(2 * dt / prob.tf) * trap[:, None, None] * Ww
+    fc = f[:, :N] + 1j * f[:, N:]
+    h = X @ fc                                               # L_n^-H f_n
+    T = np.asarray(target)
+    ovl = np.sum(np.conj(T) * psi[-1])
+    a, b = ovl.real, ovl.imag
+    infid = 1 - (a * a + b * b) / prob.N_ess_levels ** 2
+    ga, gb = (a, b) if overlap is None else overlap
+    lam = np.zeros((nt, N, c), dtype=complex)
+    lam[-1] = X[-1] @ ((2 / prob.N_ess_levels ** 2) * (ga + 1j * gb) * T) + h[-1]
+    for n in range(nsteps - 1, 0, -1):
+        lam[n] = Y[n] @ lam[n + 1] + h[n]
+    out = gradient_from(prob, Gp, Gq, offsets, pcof, Ac, psi, lam, m, dt)
+    out.update(tp=tp, tq=tq, Ac=Ac, L=L, R=R, X=X, Y=Y, S=YH, phi=phi, psi=psi, h=h, f=fc, lam=lam, guard=guard,
+               infidelity=infid, overlap=(a, b))
+    return out
+
+
+def gradient_from(prob, Gp, Gq, offsets, pcof, Ac, psi, lam, m, dt):
+    """Stage derivatives, reverse sweep and contraction with the control basis (the tail of evaluate())."""
+    nt = psi.shape[0]
+    ws = [psi]
+    for j in range(m):
+        acc = np.zeros_like(psi)
+        for i in range(j + 1):
+            acc += Ac[:, j - i] @ ws[i]
+        ws.append(acc / (j + 1))
+    g = [None] * (m + 1)
+    lam_next = np.zeros_like(lam); lam_next[:-1] = lam[1:]
+    lam_here = lam.copy(); lam_here[0] = 0
+    for j in range(m + 1):
+        cj = coefficient(j, m, m)
+        g[j] = cj * dt ** j * lam_next - cj * (-dt) ** j * lam_here
+    AcH = np.conj(np.transpose(Ac, (0, 1, 3, 2)))
+    for j in range(m, 1, -1):
+        for i in range(1, j):
+            g[i] = g[i] + (1.0 / j) * (AcH[:, j - 1 - i] @ g[j])
+    nops = prob.N_operators
+    sigP = np.zeros((nt, nops, m))
+    sigQ = np.zeros((nt, nops, m))
+    for k in range(nops):
+        Sk, Ak = prob.sym_operators[k], prob.asym_operators[k]
+        for j in range(1, m + 1):
+            for i in range(j):
+                d = j - 1 - i
+                Pw = -1j * (Sk @ ws[i])
+                Qw = Ak @ ws[i]
+                sigP[:, k, d] += (1.0 / j) * np.einsum("nic,nic->n", np.conj(Pw), g[j]).real
+                sigQ[:, k, d] += (1.0 / j) * np.einsum("nic,nic->n", np.conj(Qw), g[j]).real
+    grad = np.zeros(len(pcof))
+    for k, (gp, gq, off) in enumerate(zip(Gp, Gq, offsets)):
+        nl = gp.shape[2]
+        grad[off:off + nl] -= np.einsum("ndl,nd->l", gp[:, :m], sigP[:, k]) + np.einsum("ndl,nd->l", gq[:, :m], sigQ[:, k])
+    return dict(ws=ws, g=g, sigP=sigP, sigQ=sigQ, grad=grad)
+
+
 def history_real(ws):
     """[2N, 1+m, nt, c] Julia-layout history from the list of complex derivatives."""
     arr = np.stack(ws, axis=0)                       # [1+m, nt, N, c]

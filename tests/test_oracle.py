@@ -347,3 +347,35 @@ def test_parallel_gradient_columns_are_bit_identical(qgd, orc):
         orc.set_parallel_gradient(False)
         orc.set_num_threads(0)
     assert np.array_equal(g_serial, g_par) and np.abs(g_serial).max() > 0
+
+
+@pytest.mark.parametrize("which,order", [("cnot2", 2), ("cnot2", 8), ("guarded", 6), ("cnot3", 8), ("dense_guard", 4)])
+def test_local_front_form_equals_propagator_form(qgd, orc, which, order):
+    """Round 6: the same-point propagator S_n = R_n L_n^-1 (forward sweep in phi = L psi, adjoint sweep directly in lambda:
+    proto_propagator.evaluate_local, the statement of csrc/qgd_k_front.hip's evaluation order) gives the state history, lambda,
+    guard and gradient of the two-point form P_n = L_{n+1}^-1 R_n to rounding, and those of the reference-structured oracle."""
+    prob, ctrl, pcof, target = getattr(cases, which + "_case")(qgd)
+    m = order // 2
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, m)
+    r = pp.evaluate(prob, Gp, Gq, off, pcof, target, order)
+    q = pp.evaluate_local(prob, Gp, Gq, off, pcof, target, order)
+    gs = np.abs(r["grad"]).max()
+    assert np.abs(q["psi"] - r["psi"]).max() < 1e-13
+    assert np.abs(q["lam"] - r["lam"]).max() <= 1e-12 * max(1e-30, np.abs(r["lam"]).max())
+    assert np.abs(q["grad"] - r["grad"]).max() <= 1e-12 * gs
+    assert abs(q["guard"] - r["guard"]) < 1e-14 and abs(q["infidelity"] - r["infidelity"]) < 1e-13
+    assert cases.oracle_pins(orc, prob, ctrl, pcof, target, order, q)
+
+
+def test_local_front_form_cnot3_headline_grid(qgd, orc):
+    """Gate (i) of the round-6 plan: on the headline grid (cnot3, order 8, 550 steps of dt = 1) the local form agrees with the
+    two-point form to 1e-12 and with the oracle (GMRES per step at 1e-15, converged terminal solve) to 1e-10 on the gradient."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=550, tf=550.0)
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, 4)
+    r = pp.evaluate(prob, Gp, Gq, off, pcof, target, 8)
+    q = pp.evaluate_local(prob, Gp, Gq, off, pcof, target, 8)
+    gs = np.abs(r["grad"]).max()
+    assert np.abs(q["grad"] - r["grad"]).max() <= 1e-12 * gs
+    assert np.abs(q["psi"] - r["psi"]).max() < 1e-12
+    assert np.abs(q["lam"] - r["lam"]).max() <= 1e-12 * np.abs(r["lam"]).max()
+    assert cases.oracle_pins(orc, prob, ctrl, pcof, target, 8, q, budget=1e12)
