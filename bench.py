@@ -58,6 +58,10 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
         "inverse": ("mfma", (nt - 1) * cgemm * (2 if fused_propagator else 1)),
         "propagator": ("mfma", (nt - 1) * cgemm),
         "lambda": ("hbm", (nt - 1) * (mat_b + 2 * hist_b)),
+        # fused front (csrc/qgd_front.h): per time point the Gauss-Jordan inverse of L^H and S^H = L^-H R^H (the build of L, R rides
+        # in the same workgroup on the vector ALU and is not counted); psi: L^-H once, phi in, psi / f / h out
+        "front": ("mfma", nt * cgemm * 2),
+        "psi": ("hbm", nt * (mat_b + 4 * hist_b)),
         "guard": ("hbm", nt * (3 * hist_b)),
     }
     if sparse_ops:   # ELL kernels: flops are negligible, the kernel exists to write L_n and R_n
@@ -68,7 +72,7 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
 
 
 KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_cb", "propagator": "k_propagator",
-                   "lambda": "k_lambda", "guard": "k_guard_diag"}
+                   "lambda": "k_lambda", "guard": "k_guard_diag", "front": "k_front", "psi": "k_psi"}
 CNOT2_PROFILE = "r05_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
 PMC_PROFILE = "r05_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
 PMC_MFMA_PROFILE = "r05_pmc_mfma_cnot3.json"
@@ -550,7 +554,7 @@ def main():
     path = inner.operator_path() if hasattr(inner, "operator_path") else ("sparse", 0, 0)
     model = phase_model(prob.N_tot_levels, prob.N_initial_conditions, order // 2, prob.N_operators, args.nsteps + 1,
                         sparse_ops=(path[0] == "sparse"), fused_propagator=("propagator" not in first))
-    dom_raw = "inverse" if ("inverse" in first and "inverse" in model) else max((k for k in first if k in model), key=first.get)
+    dom_raw = next((k for k in ("front", "inverse") if k in first and k in model), None) or max((k for k in first if k in model), key=first.get)
     for _ in range(max(args.warmup, 1) - nbr + args.run_in):
         dp.discrete_adjoint(pcof)
     phase_ms = {}

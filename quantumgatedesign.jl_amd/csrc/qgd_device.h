@@ -127,6 +127,15 @@ typedef struct qgdk_ctx {
     double *mirror_dev;
     unsigned long long mirror_seq;
     unsigned int *mirror_ticket;
+    // Fused front (qgd_front.h; Np = 64, sparse operators, one rank, resident grid): front = 1 for the evaluation in flight --
+    // the step propagators are the same-point products S_n = R_n L_n^-1 (Pc / Pr hold S_n, LinvT holds L_n^-H, L / R hold
+    // L_n^H / R_n^H), the forward scan runs in phi_n = L_n psi_n from phi0 into phist, k_psi turns it into the state history,
+    // the guard forcing f_n and h_n = L_n^-H f_n (hforc), and the adjoint scan runs directly in lambda with the forcing h.
+    int front;
+    double *phi0;       // [Np][2cp]   L_0 psi_0
+    double *phist;      // [nt][Np][2cp] (the buffer of yhist: the front path has no y)
+    double *hforc;      // [nt][Np][2cp]
+    double *termU;      // [Np][2cp]   L_N^-H target: lambda_N = (2/N_ess^2)(a + ib) termU + h_N
 } qgdk_ctx;
 
 #ifdef __cplusplus
@@ -136,6 +145,10 @@ int qgdk_tables(const qgdk_ctx *c, const double *pcof_dev);
 int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double *qt_dev);
 #define QGD_PCOF_KERNARG 448      /* doubles of pcof that fit beside the other kernel arguments (4 KB) */
 int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof);
+int qgdk_front_supported(const qgdk_ctx *c);   /* Np = 64, sparse operators, order <= 8, the build's LDS beside the elimination's */
+int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof);   /* tables + the pre-built step matrices + phi_0 */
+int qgdk_front(const qgdk_ctx *c);             /* L_n^-H, S_n for every time point: build + elimination in one workgroup */
+int qgdk_psi(const qgdk_ctx *c);               /* psi_n = L_n^-1 phi_n, guard forcing and penalty, h_n = L_n^-H f_n, termU */
 int qgdk_build_LR(const qgdk_ctx *c);
 int qgdk_inverse(const qgdk_ctx *c);
 int qgdk_propagator(const qgdk_ctx *c);

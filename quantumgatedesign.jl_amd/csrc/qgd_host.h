@@ -77,6 +77,11 @@ struct qgd_handle_s {
     // redo the evaluation on the general path first.  QGD_TINY=0 / qgd_set_small_path(h, 0): off.
     bool small_path = !(getenv("QGD_TINY") && atoi(getenv("QGD_TINY")) == 0);
     bool history_stale = false;
+    // The fused front (qgd_device.h: qgdk_ctx::front) takes full evaluations of qgd_eval_forward / qgd_discrete_adjoint on problems
+    // qgdk_front_supported admits.  front_last: the device buffers hold such an evaluation -- state history, lambda and forcing
+    // are the same quantities as ever, but L / R / Linv / P are the same-point form's: an entry point that wants the two-point
+    // form's (qgd_get_intermediate) redoes the forward evaluation on the general path first.
+    bool front_last = false;
     std::vector<double> tiny_pcof;      // pcof of the last small-path evaluation
     bool tiny_was_gradient = false;
     bool mirror_off = (getenv("QGD_RESULT_MIRROR") && atoi(getenv("QGD_RESULT_MIRROR")) == 0);
@@ -271,7 +276,7 @@ int copy_history_out(qgd_handle h, double *uv_history, int save = 1);
 int copy_panels_out(qgd_handle h, const double *panels, double **stage, double *out, size_t J, int n_first);
 int copy_lambda_full_out(qgd_handle h, double *out);
 int upload_pcof(qgd_handle h, const double *pcof, int n_pcof);
-int forward_begin(qgd_handle h, const double *pcof, int n_pcof);
+int forward_begin(qgd_handle h, const double *pcof, int n_pcof, bool allow_front = false);
 int forward_end(qgd_handle h);
 int adjoint_begin(qgd_handle h);
 int adjoint_end(qgd_handle h);
@@ -290,7 +295,7 @@ int upload_forcing(qgd_handle h, const double *forcing, size_t nt, size_t n_off)
 int chunked_forward_forced(qgd_handle h, const double *pcof, int n_pcof, const double *forcing, double *uv_history, double *out3);
 
 // qgd_host_eval.cpp
-int run_forward(qgd_handle h, const double *pcof, int n_pcof);
+int run_forward(qgd_handle h, const double *pcof, int n_pcof, bool allow_front = false);
 bool tiny_applies(qgd_handle h, const double *pcof, int n_pcof);
 int tiny_evaluate(qgd_handle h, const double *pcof, int n_pcof, bool gradient, double *grad, double *out3);
 int check_status(qgd_handle h);

@@ -161,10 +161,24 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 }
 
 
+// Does this evaluation take the fused front (qgd_front.h)?  A full evaluation on one rank with the grid resident, the control
+// basis on the device and pcof small enough for the kernel arguments, a diagonal guard projector or none, :Infidelity.
+static bool front_applies(qgd_handle h, const double *pcof, int n_pcof)
+{
+    const qgdk_ctx &k = h->k;
+    return pcof && h->have_basis && n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy") &&
+           !qgd_path("no_front") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
+           !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) && k.cost_type == 0 &&
+           (size_t)k.Np * 2 * k.cp < 32768 && k.phi0 && k.hforc && k.termU && k.n_ops > 0 && qgdk_front_supported(&k) != 0;
+}
+
+
 // forward, part 1: everything that needs no other rank (tables .. block propagators)
-int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
+int forward_begin(qgd_handle h, const double *pcof, int n_pcof, bool allow_front)
 {
     qgdk_ctx &k = h->k;
+    k.front = (allow_front && front_applies(h, pcof, n_pcof)) ? 1 : 0;
+    h->front_last = k.front != 0;
     // guard penalty: the guard stage stores its workgroups' partial sums and a later stage adds them in a fixed order (the
     // same bits on every run)
     k.gpart_on = k.gpart ? 1 : 0;
@@ -175,7 +189,9 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
     if (pcof) {
         if (!h->have_basis) return fail(h, QGD_ERR_STATE, "qgd_set_control_basis must be called before passing pcof");
         PhaseTimer t(h, "tables");
-        if (n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy")) {   // (a captured graph would freeze the values)
+        if (k.front) {
+            K_TRY(h, qgdk_tables_front(&k, pcof, n_pcof));      // tables + the step matrices k_front's workgroups past two per CU start from + phi_0
+        } else if (n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy")) {   // (a captured graph would freeze the values)
             K_TRY(h, qgdk_tables_kernarg(&k, pcof, n_pcof));      // pcof rides in the kernel arguments: no copy packet
         } else {
             int rc = upload_pcof(h, pcof, n_pcof);
@@ -189,7 +205,10 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof)
         if (!k.keep_scal) HIP_TRY(h, hipMemsetAsync(k.scal, 0, 4 * sizeof(double), k.stream));      // (a later window of a long grid keeps the running guard sum)
         HIP_TRY(h, hipMemsetAsync(k.status, 0, 3 * sizeof(int), k.stream));      // (flag and the two counters; the fourth word is the inverse's memory of the last evaluation)
     }
-    {
+    if (k.front) {
+        { PhaseTimer t(h, "front"); K_TRY(h, qgdk_front(&k)); }      // L_n^-H and S_n = R_n L_n^-1 of every time point, one workgroup each
+        { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
+    } else {
         { PhaseTimer t(h, "build_LR"); K_TRY(h, qgdk_build_LR(&k)); }
         { PhaseTimer t(h, "inverse"); K_TRY(h, qgdk_inverse(&k)); }
         if (qgdk_propagator_is_fused(&k)) { K_TRY(h, qgdk_propagator(&k)); }   // k_inverse_mfma formed P_n already
@@ -209,7 +228,15 @@ int forward_end(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_forward2"); K_TRY(h, qgdk_forward_finish(&k)); }
-    if (k.have_guard == 0 && h->forcing_zero) {
+    if (k.front) {
+        // the sweep ran in phi = L psi: state history, guard forcing and penalty, the adjoint sweep's forcing L^-H f
+        if (k.have_guard == 0 && !h->forcing_zero) {
+            HIP_TRY(h, hipMemsetAsync(k.forcing, 0, (size_t)k.nt * k.Np * 2 * k.cp * sizeof(double), k.stream));
+            h->forcing_zero = true;
+        }
+        if (k.have_guard) h->forcing_zero = false;
+        PhaseTimer t(h, "psi"); K_TRY(h, qgdk_psi(&k));
+    } else if (k.have_guard == 0 && h->forcing_zero) {
         // nothing to do: without a guard projector the kernel only re-clears the forcing (6 us of the 100 us of a cnot2 evaluation)
     } else if (!qgdk_guard_is_fused(&k)) {
         PhaseTimer t(h, "guard"); K_TRY(h, qgdk_guard(&k));      // else: done by the history pass
@@ -239,7 +266,7 @@ int adjoint_end(qgd_handle h)
 {
     qgdk_ctx &k = h->k;
     { PhaseTimer t(h, "sweep_adjoint2"); K_TRY(h, qgdk_adjoint_finish(&k)); }
-    { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }
+    if (!k.front) { PhaseTimer t(h, "lambda"); K_TRY(h, qgdk_lambda(&k)); }      // (fused front: the sweep ran in lambda itself)
     if (h->lambda_out) {      // its download runs beside the gradient kernels
         double *out = h->lambda_out; h->lambda_out = nullptr;
         int rc = h->lambda_derivs ? copy_lambda_full_out(h, out) : copy_panels_out(h, k.lam, &h->stage_lam, out, (size_t)k.m + 1, 1);
@@ -251,11 +278,11 @@ int adjoint_end(qgd_handle h)
 }
 
 
-int run_forward(qgd_handle h, const double *pcof, int n_pcof)
+int run_forward(qgd_handle h, const double *pcof, int n_pcof, bool allow_front)
 {
     if (h->chunks_eff > 1) return chunked_forward(h, pcof, n_pcof);
     if (h->part_world != 1) return fail(h, QGD_ERR_STATE, "partitioned handle: use the qgd_dist_* entry points");
-    int rc = forward_begin(h, pcof, n_pcof);
+    int rc = forward_begin(h, pcof, n_pcof, allow_front);
     if (rc) return rc;
     if ((rc = forward_end(h))) return rc;
     if (pcof) h->fwd_pcof.assign(pcof, pcof + n_pcof); else h->fwd_pcof.clear();
@@ -397,7 +424,7 @@ int qgd_eval_forward(qgd_handle h, const double *pcof, int32_t n_pcof, double *u
         return rcw ? rcw : fetch_results(h, nullptr, out3);
     }
     if (!uv_history && tiny_applies(h, pcof, n_pcof)) return tiny_evaluate(h, pcof, n_pcof, false, nullptr, out3);
-    int rc = run_forward(h, pcof, n_pcof);
+    int rc = run_forward(h, pcof, n_pcof, true);
     if (rc) return rc;
     if (uv_history) {
         { PhaseTimer t(h, "derivs"); K_TRY(h, qgdk_derivs(&k)); }
@@ -485,7 +512,7 @@ int qgd_discrete_adjoint(qgd_handle h, const double *pcof, int32_t n_pcof, int32
         { PhaseTimer t(h, "terminal"); K_TRY(h, qgdk_terminal(&k, 1)); }
     } else {
         h->defer_terminal = k.have_target && qgdk_terminal_can_fuse(&k) != 0;
-        rc = run_forward(h, pcof, n_pcof);
+        rc = run_forward(h, pcof, n_pcof, true);
         if (rc) { h->defer_terminal = false; return rc; }
     }
     // The downloads run on the copy stream beside the adjoint sweep and are what bounds this form of the call (PCIe):
@@ -763,11 +790,13 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
     else if (s == "repivoted") need = 1;
     else if (s == "selection") need = 4;
     else if (s == "small_path") need = 1;
+    else if (s == "front_path") need = 1;
     else return fail(h, QGD_ERR_ARGUMENT, "unknown intermediate '" + s + "'");
     if (needed) *needed = need;
     if (!out) return QGD_OK;
     if (capacity < need) return fail(h, QGD_ERR_ARGUMENT, "buffer too small");
-    if (s == "small_path") { out[0] = h->history_stale ? 1.0 : 0.0; return QGD_OK; }      // did the LAST evaluation run on the small-problem path
+    if (s == "small_path") { out[0] = h->history_stale ? 1.0 : 0.0; return QGD_OK; }
+    if (s == "front_path") { out[0] = h->front_last ? 1.0 : 0.0; return QGD_OK; }         // did the LAST forward evaluation take the fused front      // did the LAST evaluation run on the small-problem path
     if (s == "selection") {      // which kernel families this problem runs on (tests assert that a shape selects what it is meant to)
         out[0] = k.use_sparse ? 2.0 : (k.dense_gemm ? 1.0 : 0.0);      // 2 sparse (ELL), 1 N > 64 GEMM-style kernels, 0 dense N <= 64
         out[1] = (k.dense_gemm && !k.use_sparse) ? (double)qgdk_dense_sigma_form(&k) : -1.0;
@@ -782,6 +811,13 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         const std::vector<double> pc = h->tiny_pcof;
         int rcs = run_forward(h, pc.data(), (int)pc.size());
         if (!rcs && h->tiny_was_gradient && k.have_target) { rcs = adjoint_begin(h); if (!rcs) rcs = adjoint_end(h); }
+        if (rcs) return rcs;
+    }
+    if (h->front_last && (s == "L" || s == "R" || s == "Linv" || s == "P") && !h->fwd_pcof.empty()) {
+        // the last evaluation took the fused front, whose step matrices are the same-point form's (L^H, R^H, L^-H, S): the
+        // forward evaluation once more on the general path (diagnostics only)
+        const std::vector<double> pc = h->fwd_pcof;
+        const int rcs = run_forward(h, pc.data(), (int)pc.size(), false);
         if (rcs) return rcs;
     }
     HIP_TRY(h, hipStreamSynchronize(k.stream));

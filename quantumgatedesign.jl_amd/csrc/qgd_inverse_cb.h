@@ -390,13 +390,14 @@ template <typename T> __device__ __forceinline__ T *cb_uniform(T *p)
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
-                                                                int *status, int *fallbacks, double *smem, int *rho, int *rinv);
+                                                                int *status, int *fallbacks, double *smem, int *rho, int *rinv, int front);
+__device__ __attribute__((noinline)) void front_relayout(const double *L, const double *R, double *Pr, double *Pc, int n);
 
 // The program of wave W: a real function, one per wave and attempt, that never returns -- it ends the wave when its outputs
 // are written and hands a matrix it has to give up to the next attempt (diagonal pivots -> pivots inside the diagonal tile
 // -> k_inverse_mfma's elimination).  Inlined into one kernel the three bodies cost the first one several hundred spilled
 // registers; as functions that return they would save and restore 64 callee-saved registers per call.
-template <int W, bool STATIC, bool ONE>
+template <int W, bool STATIC, bool ONE, bool FRONT>
 __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, double *LinvT_, double *Pr_, double *Pc_, int n_,
                                        int *status_, int *fallbacks_, double *smem_, int *rhoL_, int *rinvL_, int *bad_)
 {
@@ -470,7 +471,7 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     lds_barrier();              // the multiplier blocks are dead: their space stages the column-major planes of P
     const int lane = cb_opaque(lane0) & 63, c16 = lane & 15, kk = lane >> 4;
     if (!ONE) store_Linv();
-    {   // P, row-major panel (left operand of the adjoint sweep as P^H)
+    if (!FRONT) {   // P, row-major panel (left operand of the adjoint sweep as P^H)
         const __amdgpu_buffer_rsrc_t rP = buffer_of(Pr + (size_t)(n - 1) * panel + 32 * w);
         const int voff = (kk * PW + c16) * 8;
         #pragma unroll
@@ -479,9 +480,25 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
             for (int ct = 0; ct < 2; ct++)
                 #pragma unroll
                 for (int r = 0; r < 4; r++) buffer_store_f64(MR[i][ct][r], rP, voff, ((16 * i + 4 * r) * PW + 16 * ct) * 8);
+    } else {
+        // the fused front (qgd_front.h): the elimination ran on [L^H | R^H], MR = Y = S^H.  The forward sweep's left operand, S in
+        // column-major planes, is conj(Y) in ROW-major planes -- straight from the registers like L^-1 above, the sign of the
+        // imaginary plane flipped in the lanes that hold it
+        const __amdgpu_buffer_rsrc_t rS = buffer_of(Pc + (size_t)(n - 1) * 2 * pl + 16 * w);
+        const int voff = ((c16 >> 3) * (int)pl + kk * NP + (c16 & 7)) * 8, nmask = (c16 >= 8) ? (int)0x80000000 : 0;
+        #pragma unroll
+        for (int i = 0; i < 4; i++)
+            #pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double v = MR[i][ct][r];
+                    buffer_store_f64(__hiloint2double(__double2hiint(v) ^ nmask, __double2loint(v)), rS, voff, ((16 * i + 4 * r) * NP + 8 * ct) * 8);
+                }
     }
     {   // P, column-major planes (left operand of the forward sweep): the wave's 16 columns are contiguous there; one plane
-        // at a time through the wave's own LDS slab
+        // at a time through the wave's own LDS slab.  FRONT: the adjoint sweep's left operand, S as a row-major panel, is
+        // conj(Y) as a COLUMN-major panel -- the same staging, the rows of 64 written as eight runs of (8 re | 8 im)
         double *stage = smem + w * (16 * CB_LDP);
         #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -494,9 +511,16 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
                         for (int r = 0; r < 4; r++) stage[(8 * ct + (c16 & 7)) * CB_LDP + 16 * i + kk + 4 * r] = MR[i][ct][r];
             }
             wave_lds_fence();
-            const __amdgpu_buffer_rsrc_t rC = buffer_of(Pc + (size_t)(n - 1) * 2 * pl + p * pl + (size_t)16 * NP * w);
-            #pragma unroll
-            for (int q = 0; q < 16; q++) buffer_store_f64(stage[q * CB_LDP + lane], rC, lane * 8, q * 64 * 8);
+            if (!FRONT) {
+                const __amdgpu_buffer_rsrc_t rC = buffer_of(Pc + (size_t)(n - 1) * 2 * pl + p * pl + (size_t)16 * NP * w);
+                #pragma unroll
+                for (int q = 0; q < 16; q++) buffer_store_f64(stage[q * CB_LDP + lane], rC, lane * 8, q * 64 * 8);
+            } else {
+                const __amdgpu_buffer_rsrc_t rC = buffer_of(Pr + (size_t)(n - 1) * panel + (size_t)16 * PW * w + 8 * p);
+                const int voff = ((lane >> 3) * 16 + (lane & 7)) * 8;
+                #pragma unroll
+                for (int q = 0; q < 16; q++) { const double v = stage[q * CB_LDP + lane]; buffer_store_f64(p ? -v : v, rC, voff, q * PW * 8); }
+            }
             wave_lds_fence();
         }
     }
@@ -505,41 +529,44 @@ __device__ __forceinline__ int cb_wave(const double *L_, const double *R_, doubl
     return 0;
 }
 
-template <bool STATIC, bool ONE>
+template <bool STATIC, bool ONE, bool FRONT>
 __device__ __forceinline__ int cb_attempt(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
                                           int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: return cb_wave<0, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    case 1: return cb_wave<1, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    case 2: return cb_wave<2, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
-    default: return cb_wave<3, STATIC, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 0: return cb_wave<0, STATIC, ONE, FRONT>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 1: return cb_wave<1, STATIC, ONE, FRONT>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    case 2: return cb_wave<2, STATIC, ONE, FRONT>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+    default: return cb_wave<3, STATIC, ONE, FRONT>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
     }
 }
 
 // Second attempt and last resort, as ONE real function that ends the wave (a call in the kernel's cold tail; nothing is alive
 // across it).
 __device__ __attribute__((noinline, noreturn)) void cb_retry(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
-                                                             int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
+                                                             int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad, int front)
 {
     if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1);                 // (matrices not done by the diagonal attempt)
-    if (cb_attempt<false, true>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
+    if (cb_attempt<false, true, false>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
-        cb_fallback(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL);
+        cb_fallback(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, front);
     }
+    // (the pivoted stages write P in the layouts of the two-point form; the fused front's consumers read conj(P^T): re-laid out here,
+    //  through the panels of L^H and R^H the elimination is done with -- a cold path)
+    if (front) front_relayout(L, R, Pr, Pc, n);
     __builtin_amdgcn_endpgm();
 }
 
 // The workgroup's entry.  fallbacks (or null): [0] += matrices not done by the diagonal attempt, [1] += of these, by the last
 // resort, [2] != 0: skip the diagonal attempt (k_tables: for the 32 evaluations after one that gave up more than a quarter of
 // its matrices there -- a problem whose step matrices are not diagonally dominant pays for the failed attempt once in 33).
-template <bool ONE>
+template <bool ONE, bool FRONT = false>
 __device__ __forceinline__ void inverse_cb_body(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, const int n,
                                                 int *status, int *fallbacks, double *smem, int *rhoL, int *rinvL, int *bad)
 {
     const bool pivot_first = fallbacks && __builtin_amdgcn_readfirstlane(fallbacks[2]) != 0;
-    if (pivot_first || cb_attempt<true, ONE>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
+    if (pivot_first || cb_attempt<true, ONE, FRONT>(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad)) {
         __syncthreads();
-        cb_retry(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad);
+        cb_retry(L, R, LinvT, Pr, Pc, n, status, fallbacks, smem, rhoL, rinvL, bad, FRONT ? 1 : 0);
     }
 }

@@ -1,6 +1,7 @@
 // qgd_k_build.hip -- control tables and the step matrices L_n, R_n
 // (conventions and layouts: qgd_kernels_common.h; algorithm: DESIGN.md)
 #include "qgd_kernels_common.h"
+#include "qgd_front.h"
 #include <string.h>
 
 // The counters of the inverse (status[1]: matrices redone, status[2], N = 64: by the last resort) start at zero, and what the
@@ -84,6 +85,77 @@ __global__ __launch_bounds__(256) void k_tables_arg(const double *__restrict__ G
     }
     s = row16_sum(s);
     if (idx < total && sub == 15) tab[idx] = s;
+}
+
+// The first launch of an evaluation on the fused-front path (qgd_front.h; Np = 64, sparse operators, pcof in the kernel
+// arguments): the control tables as in k_tables_arg, and -- in the FIRST npre workgroups of the grid -- the step matrices
+// L_n^H, R_n^H of the time points whose k_front workgroup should start with its elimination (front_pre_point).  A pre-building workgroup forms the (m+1) n_ops 2 table entries of its time point itself, with the
+// arithmetic of the table workgroups (same bits: both store them).  1024 threads: a pre-building workgroup is alone on its CU,
+// its four 16-column slabs go side by side (front_build<., ., 1024>); every workgroup carries the build's LDS (one per CU), so
+// the table part is at most 256 - npre workgroups that stride over the entries.
+#ifdef QGD_STAMPS      // scripts/build_variant.sh stamps -DQGD_STAMPS: device wall clock (10 ns) at the marks of the first 512 workgroups
+__device__ unsigned long long g_stamps_build[512][8];
+extern "C" int qgdk_stamps_build(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_build), sizeof(g_stamps_build)); }
+#define TF_STAMP(i) do { if (blockIdx.x < 512 && threadIdx.x == 0) g_stamps_build[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define TF_STAMP(i) do { } while (0)
+#endif
+template <int NMAX, int M, int NOPS>
+__global__ __launch_bounds__(1024) void k_tables_front(const double *__restrict__ G, const int64_t *__restrict__ goff,
+                         const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
+                         const PcofArg<NMAX> pcof, double *__restrict__ tab, const int nt, const int n_ops,
+                         double *__restrict__ scal, int *__restrict__ status,
+                         const int npre, const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv,
+                         const double *__restrict__ ell_val, const double *__restrict__ cw, const int Z,
+                         double *__restrict__ Eh, double *__restrict__ Fh)
+{
+    extern __shared__ __attribute__((aligned(32))) double front_smem[];
+    const int per = (M + 1) * n_ops * 2, total = nt * per, sub = threadIdx.x & 15;
+    auto entry = [&](const int idx) -> double {
+        const int pq = idx & 1;
+        const int k = (idx >> 1) % n_ops;
+        const int d = ((idx >> 1) / n_ops) % (M + 1);
+        const int n = ((idx >> 1) / n_ops) / (M + 1);
+        const int nc = ncoef[k];
+        const double *g = G + goff[k] + (((size_t)pq * nt + n) * (M + 1) + d) * nc;
+        const double *pc = pcof.v + poff[k];
+        double s = 0.0;
+        // (the loads of four steps in flight together: the rolled loop waited for a memory round trip per 16 coefficients --
+        //  at the head of a pre-building workgroup that is the head of the evaluation.  Same sums in the same order.)
+        for (int l0 = sub; l0 < nc; l0 += 64) {
+            double gv[4], pv[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) { const int l = l0 + 16 * u; gv[u] = (l < nc) ? g[l] : 0.0; pv[u] = (l < nc) ? pc[l] : 0.0; }
+            #pragma unroll
+            for (int u = 0; u < 4; u++) if (l0 + 16 * u < nc) s = __builtin_fma(gv[u], pv[u], s);
+        }
+        return row16_sum(s);
+    };
+    TF_STAMP(0);
+    if ((int)blockIdx.x < npre) {
+        const int n = front_pre_point(blockIdx.x, nt);
+        for (int e = threadIdx.x >> 4; e < per; e += 64) {
+            const double s = entry(n * per + e);
+            if (sub == 15) tab[n * per + e] = s;
+        }
+        __syncthreads();
+        TF_STAMP(1);
+        constexpr size_t panel = 64 * 128;
+        front_build<M, NOPS, 1024>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
+        TF_STAMP(2);
+        return;
+    }
+    const int tb = blockIdx.x - npre, ntb = gridDim.x - npre;
+    if (tb == 0) {
+        if (threadIdx.x < 4) scal[threadIdx.x] = 0.0;
+        if (threadIdx.x == 4) *status = 0;
+        if (threadIdx.x == 5) inverse_memory(status, nt);
+    }
+    for (int idx = tb * 64 + (threadIdx.x >> 4); idx < total; idx += ntb * 64) {
+        const double s = entry(idx);
+        if (sub == 15) tab[idx] = s;
+    }
+    TF_STAMP(1);
 }
 
 // general path: tables given by the host in Julia layout [(1+m), n_ops, nt]
@@ -375,6 +447,34 @@ static int launch_tables_arg(const qgdk_ctx *c, const double *pcof_host, int n_p
     return (int)hipGetLastError();
 }
 
+template <int NMAX, int M, int NOPS>
+static int launch_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    PcofArg<NMAX> arg;
+    memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
+    const size_t shm = front_build_lds(M, c->ell_z, 4);
+    SET_LDS_ONCE((k_tables_front<NMAX, M, NOPS>), shm);
+    const int total = c->nt * (c->m + 1) * c->n_ops * 2, npre = front_pre_count(c->nt);
+    int ntb = (total + 63) / 64; if (ntb > 256 - npre) ntb = (npre < 192) ? 256 - npre : 64;
+    hipLaunchKernelGGL((k_tables_front<NMAX, M, NOPS>), dim3(npre + ntb), dim3(1024), shm, c->stream, c->G, c->goff, c->ncoef, c->poff, arg,
+                       c->tab, c->nt, c->n_ops, c->scal, c->status, npre, c->ell_col, c->ell_inv, c->ell_val, c->cw, c->ell_z,
+                       c->L, c->R);
+    return (int)hipGetLastError();
+}
+
+template <int NMAX>
+static int launch_tables_front_m(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    if (c->m == 4 && c->n_ops == 3) return launch_tables_front<NMAX, 4, 3>(c, pcof_host, n_pcof);
+    switch (c->m) {
+    case 1: return launch_tables_front<NMAX, 1, -1>(c, pcof_host, n_pcof);
+    case 2: return launch_tables_front<NMAX, 2, -1>(c, pcof_host, n_pcof);
+    case 3: return launch_tables_front<NMAX, 3, -1>(c, pcof_host, n_pcof);
+    case 4: return launch_tables_front<NMAX, 4, -1>(c, pcof_host, n_pcof);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
 extern "C" {
 
 int qgdk_tables(const qgdk_ctx *c, const double *pcof)
@@ -390,6 +490,16 @@ int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
     if (n_pcof <= 64) return launch_tables_arg<64>(c, pcof_host, n_pcof);
     if (n_pcof <= 192) return launch_tables_arg<192>(c, pcof_host, n_pcof);
     if (n_pcof <= QGD_PCOF_KERNARG) return launch_tables_arg<QGD_PCOF_KERNARG>(c, pcof_host, n_pcof);
+    return (int)hipErrorInvalidValue;
+}
+
+// the fused-front path's first launch (qgdk_front_supported; pcof in the kernel arguments, the basis covering exactly the grid)
+int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    if (front_pre_count(c->nt) == 0 || qgd_path("front_nopre")) return qgdk_tables_kernarg(c, pcof_host, n_pcof);      // (no tail to balance: the plain tables kernel)
+    if (n_pcof <= 64) return launch_tables_front_m<64>(c, pcof_host, n_pcof);
+    if (n_pcof <= 192) return launch_tables_front_m<192>(c, pcof_host, n_pcof);
+    if (n_pcof <= QGD_PCOF_KERNARG) return launch_tables_front_m<QGD_PCOF_KERNARG>(c, pcof_host, n_pcof);
     return (int)hipErrorInvalidValue;
 }
 

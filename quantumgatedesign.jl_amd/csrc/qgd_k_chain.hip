@@ -81,7 +81,12 @@ struct ChainArgs {
     // MODE 2, t_on: ONE extra workgroup (the last of the grid) does the work of k_terminal -- overlaps <w_N,R>, <w_N,T>
     // and y_N -- beside the affine parts of the blocks, which do not need it: the adjoint sweep starts one launch earlier
     int t_on, t_nt, t_ness, t_have_target;
-    const double *t_hist, *t_target, *t_forcing;
+    const double *t_hist, *t_target, *t_forcing, *t_ytarget;
+    // MODE 0, p0_on (fused front, qgd_front.h): ONE extra workgroup (the last of the grid) forms phi_0 = L_0 psi_0 from the panel
+    // of L_0^H beside the block products, which do not need it (the history pass, two launches later, starts from it)
+    int p0_on;
+    const double *p0_E, *p0_psi0;
+    double *p0_out;
     double *t_yhist, *t_scal, *t_y2, *t_y3, *t_y4;
 };
 
@@ -89,7 +94,41 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                const double *__restrict__ forcing, double *__restrict__ yhist,
                                                double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
                                                int write_y, double *__restrict__ y2, double *__restrict__ y3,
-                                               double *__restrict__ y4, int given_ab, const double *gpart = nullptr, int gpart_n = 0);
+                                               double *__restrict__ y4, int given_ab, const double *gpart = nullptr, int gpart_n = 0,
+                                               const double *ytarget = nullptr);
+
+// phi_0 = L_0 psi_0 = E^H psi_0 (E = L_0^H, panel layout) as one MFMA product: the left operand is read the way the adjoint
+// sweep reads a step matrix (P^H from the panel of P), all 32 fragment loads of a wave in flight at once; waves 0-3 of the
+// workgroup take the four row blocks.  (A loop over k with one thread per output element took 15 us inside a 25 us launch.)
+__device__ __forceinline__ void phi0_block(const double *__restrict__ E, const double *__restrict__ psi0, double *__restrict__ phi0, const int cp)
+{
+    __shared__ double ps[64 * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, kk = lane >> 4, PWc = 2 * cp;
+    const int arow = (wave & 3) * 16 + c16;
+    double are[16], aim[16];
+    #pragma unroll
+    for (int i = 0; i < 16; i++) {      // (E^H)(row, k) = conj(E(k, row))
+        const double *P = E + (size_t)(4 * i + kk) * 128 + (arow >> 3) * 16 + (arow & 7);
+        are[i] = P[0]; aim[i] = P[8];
+    }
+    for (int g = 0; g < cp / 8; g++) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 16; e += blockDim.x) ps[e] = psi0[(size_t)(e >> 4) * PWc + 16 * g + (e & 15)];
+        __syncthreads();
+        if (wave < 4) {
+            d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double b1, b2;
+                panel_b(ps + (size_t)(4 * i + kk) * 16, c16, b1, b2);
+                acc0 = MFMA(are[i], b1, acc0);
+                acc1 = MFMA(-aim[i], b2, acc1);
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) phi0[(size_t)(wave * 16 + kk + 4 * r) * PWc + 16 * g + c16] = acc0[r] + acc1[r];
+        }
+    }
+}
 
 __host__ __device__ __forceinline__ const double *chain_matrix(const ChainArgs &a, int n)
 {
@@ -185,9 +224,10 @@ __device__ __forceinline__ void chain_fast_body(const ChainArgs &a, const int bi
     constexpr int NRB = NP / 16, NT = CHAIN_NT(MODE), KST = NP / 4, NTH = NP * 4 * NT;
     __shared__ __attribute__((aligned(16))) double part[2][NG][NP * 16];
 
+    if (MODE == 0 && a.p0_on && bid == nbid - 1) { phi0_block(a.p0_E, a.p0_psi0, a.p0_out, a.cp); return; }
     if (MODE == 2 && a.t_on && bid == nbid - 1) {      // the extra workgroup: k_terminal's work
         terminal_block(a.t_hist, a.t_target, a.t_forcing, a.t_yhist, a.t_scal, NP, a.cp, a.t_nt, a.t_ness, a.t_have_target, 1,
-                       a.t_y2, a.t_y3, a.t_y4, 0, a.t_gpart, a.t_gpart_n);
+                       a.t_y2, a.t_y3, a.t_y4, 0, a.t_gpart, a.t_gpart_n, a.t_ytarget);
         return;
     }
     int b, grp0;
@@ -1078,7 +1118,8 @@ static int launch_chain_ng(const ChainArgs &a, hipStream_t stream)
 {
     const bool fast = (a.Np == 16 || a.Np == 32 || a.Np == 48 || a.Np == 64) && a.ngroups % NG == 0;
     const int ng = fast ? a.ngroups / NG : a.ngroups;
-    const int nwg = ((MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng) + ((MODE == 2 && fast && a.t_on) ? 1 : 0);
+    const int nwg = ((MODE == 0) ? 8 * ng * ((a.nblocks + 7) / 8) : a.nblocks * ng) + ((MODE == 2 && fast && a.t_on) ? 1 : 0) +
+                    ((MODE == 0 && fast && a.p0_on) ? 1 : 0);
     if (nwg <= 0) return 0;
     switch (fast ? a.Np : 0) {
     case 16: hipLaunchKernelGGL((k_chain_fast<16, MODE, NG>), dim3(nwg), dim3(16 * 4 * CHAIN_NT(MODE)), 0, stream, a); break;
@@ -1116,7 +1157,7 @@ static int launch_chain_level2(const ChainArgs &a0, const ChainArgs &a6, bool wi
 {
     const bool fast = (a0.Np == 16 || a0.Np == 32 || a0.Np == 48 || a0.Np == 64);
     if (!with_suffix || !fast || (long long)a0.nblocks * a0.ngroups > 256) return launch_chain<0>(a0, stream);
-    const int nA = 8 * a0.ngroups * ((a0.nblocks + 7) / 8), nB = 8 * a6.ngroups * ((a6.nblocks + 7) / 8);
+    const int nA = 8 * a0.ngroups * ((a0.nblocks + 7) / 8) + (a0.p0_on ? 1 : 0), nB = 8 * a6.ngroups * ((a6.nblocks + 7) / 8);
     switch (a0.Np) {
     case 16: hipLaunchKernelGGL((k_chain_fast2<16, 0, 6, 1>), dim3(nA + nB), dim3(16 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
     case 32: hipLaunchKernelGGL((k_chain_fast2<32, 0, 6, 1>), dim3(nA + nB), dim3(32 * 4 * CHAIN_NT(0)), 0, stream, a0, a6, nA); break;
@@ -1223,8 +1264,11 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                const double *__restrict__ forcing, double *__restrict__ yhist,
                                                double *__restrict__ scal, int Np, int cp, int nt, int n_ess, int have_target,
                                                int write_y, double *__restrict__ y2, double *__restrict__ y3,
-                                               double *__restrict__ y4, int given_ab, const double *gpart, int gpart_n)
+                                               double *__restrict__ y4, int given_ab, const double *gpart, int gpart_n,
+                                               const double *ytarget)
 {
+    // ytarget (fused front, qgd_front.h): the terminal value is lambda_N = L_N^-H rhs_N itself -- the overlaps are taken with
+    // `target`, the state is formed from ytarget = L_N^-H target and `forcing` = h = L^-H f (:Infidelity only)
     __shared__ double red[32];
     __shared__ double gred[16];
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
@@ -1278,6 +1322,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
     const double sc = 2.0 / ((double)n_ess * (double)n_ess);
     double *y = yhist + (size_t)(nt - 1) * hstep;
     const double *f = forcing + (size_t)(nt - 1) * hstep;
+    if (ytarget) target = ytarget;
     for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
         const int c16 = (e % PWc) & 15;
         const double tv = target[e], tp = target[e ^ 8];
@@ -1379,6 +1424,147 @@ __global__ __launch_bounds__(256) void k_lambda_c(const double *__restrict__ Lin
 }
 
 
+// ---------------------------------------------------------------------------
+// Fused front (qgd_front.h), between the two sweeps: per (column group, time point)
+//   psi_n = L_n^-1 phi_n = X_n^H phi_n                      (the state history; psi_0 is the given initial state)
+//   f_n = -(2 dt/tf) trap_n W psi_n, the guard penalty        (eval_grad_discrete_adjoint.jl:732-752, infidelity.jl:56-96; W diagonal)
+//   h_n = L_n^-H f_n = X_n f_n                               (the forcing of the adjoint sweep in lambda)
+//   n = nt-1: termU = X_N target                            (terminal_block forms lambda_N from it)
+// X_n = L_n^-H: row-major planes in LinvT, read once and staged through LDS plane by plane (below).
+// ---------------------------------------------------------------------------
+typedef double psi_d2 __attribute__((ext_vector_type(2)));
+#ifdef QGD_STAMPS
+__device__ unsigned long long g_stamps_chain[1024][8];
+extern "C" int qgdk_stamps_chain(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_chain), sizeof(g_stamps_chain)); }
+#define PSI_STAMP(i) do { if (blockIdx.x < 1024 && threadIdx.x == 0) g_stamps_chain[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define PSI_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_psi(const double *__restrict__ LinvT, const double *__restrict__ phist, const double *__restrict__ psi0,
+                                             double *__restrict__ hist, double *__restrict__ forcing, double *__restrict__ hforc,
+                                             const double *__restrict__ guard_diag, double *__restrict__ gpart,
+                                             const double *__restrict__ target, double *__restrict__ termU,
+                                             const int cp, const int nt, const int gN, const double dt, const double tf)
+{
+    constexpr int NPC = 64, XS = 68;
+    __shared__ double xs[NPC * XS];                      // one plane of X_n at a time, then the right operands
+    double *bs = xs;
+    __shared__ double red[16];
+    const int n = blockIdx.x, grp = blockIdx.y;      // (time point fastest: the workgroups of a CU are then three different time points)
+    const int PWc = 2 * cp;
+    const size_t hstep = (size_t)NPC * PWc, pl = (size_t)NPC * NPC;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c16 = lane & 15, kk = lane >> 4, arow = wave * 16 + c16;
+    const double *Tre = LinvT + (size_t)n * 2 * pl, *Tim = Tre + pl;
+    const bool guard = guard_diag != nullptr, last = (n == nt - 1) && target != nullptr;
+    // X_n is read from memory ONCE, in runs of 128 bytes per thread (both left operands read straight from global memory --
+    // the second one with the lanes of a row block 512 bytes apart -- took 26 us for the 551 time points of the headline
+    // against 11.6 for k_lambda_c's single pass: 4.4 MB of L^-H per XCD do not stay in its 4 MB of L2 between the two).
+    // Each plane goes through LDS, where X^H (16 consecutive rows of one k) and X (16 consecutive k of one row) are both
+    // fragment reads.
+    const int srow = threadIdx.x >> 2, sq = (threadIdx.x & 3) * 16;
+    PSI_STAMP(0);
+    double xr[16], xi[16];
+    #pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const psi_d2 vr = *reinterpret_cast<const psi_d2 *>(Tre + (size_t)srow * NPC + sq + j), vi = *reinterpret_cast<const psi_d2 *>(Tim + (size_t)srow * NPC + sq + j);
+        xr[j] = vr[0]; xr[j + 1] = vr[1]; xi[j] = vi[0]; xi[j + 1] = vi[1];
+    }
+    const double *src = (n > 0) ? phist + (size_t)n * hstep : psi0;
+    double bv[4];
+    #pragma unroll
+    for (int q = 0; q < 4; q++) { const int e = threadIdx.x + 256 * q; bv[q] = src[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)]; }
+    double are[NPC / 4], aim[NPC / 4], are2[NPC / 4], aim2[NPC / 4];
+    #pragma unroll
+    for (int j = 0; j < 16; j++) xs[srow * XS + sq + j] = xr[j];
+    __syncthreads();
+    #pragma unroll
+    for (int i = 0; i < NPC / 4; i++) { are[i] = xs[(4 * i + kk) * XS + arow]; are2[i] = xs[arow * XS + 4 * i + kk]; }
+    __syncthreads();
+    #pragma unroll
+    for (int j = 0; j < 16; j++) xs[srow * XS + sq + j] = xi[j];
+    __syncthreads();
+    #pragma unroll
+    for (int i = 0; i < NPC / 4; i++) { aim[i] = xs[(4 * i + kk) * XS + arow]; aim2[i] = xs[arow * XS + 4 * i + kk]; }
+    __syncthreads();                                     // the planes are in registers: their space takes the right operand
+    #pragma unroll
+    for (int q = 0; q < 4; q++) bs[threadIdx.x + 256 * q] = bv[q];
+    __syncthreads();
+    PSI_STAMP(1);
+    double res[4];
+    if (n > 0) {
+        d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+        #pragma unroll
+        for (int i = 0; i < NPC / 4; i++) {
+            double b1, b2;
+            panel_b(bs + (size_t)(4 * i + kk) * 16, c16, b1, b2);
+            acc0 = MFMA(are[i], b1, acc0);
+            acc1 = MFMA(-aim[i], b2, acc1);          // (X^H)(row,k) = conj(X(k,row))
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            res[r] = acc0[r] + acc1[r];
+            hist[(size_t)n * hstep + (size_t)(wave * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = res[r];
+        }
+    } else {
+        #pragma unroll
+        for (int r = 0; r < 4; r++) res[r] = bs[(wave * 16 + kk + 4 * r) * 16 + c16];
+    }
+    PSI_STAMP(2);
+    if (!guard && !last) return;
+    if (guard) {
+        const double trap = (n == 0 || n == nt - 1) ? 0.5 : 1.0, sc = -(2.0 * dt / tf) * trap;
+        double pen = 0.0, fv[4];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = wave * 16 + kk + 4 * r;
+            const double gw = (row < gN) ? guard_diag[row + ((c16 >= 8) ? gN : 0)] : 0.0;
+            fv[r] = sc * gw * res[r];
+            pen += gw * res[r] * res[r];
+            forcing[(size_t)n * hstep + (size_t)row * PWc + grp * 16 + c16] = fv[r];
+        }
+        __syncthreads();                                 // every wave has read the first right operand
+        #pragma unroll
+        for (int r = 0; r < 4; r++) bs[(wave * 16 + kk + 4 * r) * 16 + c16] = fv[r];
+        pen = row16_sum(pen);
+        if (c16 == 15) red[threadIdx.x >> 4] = pen;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            #pragma unroll
+            for (int q = 0; q < 16; q++) tot += red[q];
+            gpart[(size_t)n * gridDim.y + grp] = tot * trap * dt / tf;      // added in index order by the terminal stage
+        }
+        d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+        #pragma unroll
+        for (int i = 0; i < NPC / 4; i++) {
+            double b1, b2;
+            panel_b(bs + (size_t)(4 * i + kk) * 16, c16, b1, b2);
+            acc0 = MFMA(are2[i], b1, acc0);
+            acc1 = MFMA(aim2[i], b2, acc1);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+            hforc[(size_t)n * hstep + (size_t)(wave * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = acc0[r] + acc1[r];
+        PSI_STAMP(3);
+    }
+    if (last) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPC * 16; e += 256) bs[e] = target[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+        __syncthreads();
+        d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
+        #pragma unroll
+        for (int i = 0; i < NPC / 4; i++) {
+            double b1, b2;
+            panel_b(bs + (size_t)(4 * i + kk) * 16, c16, b1, b2);
+            acc0 = MFMA(are2[i], b1, acc0);
+            acc1 = MFMA(aim2[i], b2, acc1);
+        }
+        #pragma unroll
+        for (int r = 0; r < 4; r++) termU[(size_t)(wave * 16 + kk + 4 * r) * PWc + grp * 16 + c16] = acc0[r] + acc1[r];
+    }
+}
+
 // the same in two launches of many workgroups, for panels of >= 32768 elements: partial overlaps per workgroup, then y_N.
 // The partial sums are STORED (part[2 b], part[2 b + 1]); the workgroup that draws the last ticket adds them in index order
 // and writes scal[0..1] -- the same bits whichever workgroup that is (the gradient depends on these two numbers through
@@ -1440,9 +1626,10 @@ __global__ __launch_bounds__(1024) void k_terminal(const double *__restrict__ hi
                                                   double *__restrict__ scal, int Np, int cp, int nt,
                                                   int n_ess, int have_target, int write_y,
                                                   double *__restrict__ y2, double *__restrict__ y3,
-                                                  double *__restrict__ y4, int given_ab, const double *__restrict__ gpart, int gpart_n)
+                                                  double *__restrict__ y4, int given_ab, const double *__restrict__ gpart, int gpart_n,
+                                                  const double *__restrict__ ytarget)
 {
-    terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab, gpart, gpart_n);
+    terminal_block(hist, target, forcing, yhist, scal, Np, cp, nt, n_ess, have_target, write_y, y2, y3, y4, given_ab, gpart, gpart_n, ytarget);
 }
 
 // scal[2] += the guard partials in a fixed order (thread-strided ascending sums, shuffle tree, waves in order): where no
@@ -1466,7 +1653,7 @@ static inline bool chain_is_fast(const qgdk_ctx *c) { return c->Np == 16 || c->N
 // diagonal guard projector + compiled-size sweeps: k_chain_fast<.,1,.> does the guard work
 static inline bool guard_is_fused(const qgdk_ctx *c)
 {
-    return c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64);
+    return !c->front && c->have_guard == 2 && (c->Np == 16 || c->Np == 32 || c->Np == 48 || c->Np == 64);
 }
 
 // ---------------------------------------------------------------------------
@@ -1500,11 +1687,15 @@ int qgdk_forward_blocks(const qgdk_ctx *c)
     a.PiC = c->PiX; a.PiR = c->PiX + (size_t)B * pl2;
     a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->Np / 8;
     if (c->sub_hist) { a.mid_out = c->Hmid; a.mid_every = QGD_SUB_LEN; a.mid_first = QGD_SUB_LEN; a.mid_n = c->sub_n; }
+    // fused front: phi_0 = L_0 psi_0 rides along -- in the level-2 launch where there is one (most of the chip is idle there;
+    // beside the block products, one workgroup per CU, the extra workgroup cost the launch 2.4 us), else here
+    if (c->front && B2 <= 1) { a.p0_on = 1; a.p0_E = c->L; a.p0_psi0 = c->psi0; a.p0_out = c->phi0; }
     if ((rc = launch_chain<0>(a, c->stream))) return rc;
     if (B2 > 1) {      // super-block propagators from the block propagators
         ChainArgs a2{};
         a2.Np = c->Np; a2.cp = c->cp; a2.S = B; a2.Pmat = c->PiX;
         a2.PiC = c->PiC2; a2.PiR = c->PiR2; a2.nblocks = B2; a2.blen = g; a2.ngroups = c->Np / 8;
+        if (c->front) { a2.p0_on = 1; a2.p0_E = c->L; a2.p0_psi0 = c->psi0; a2.p0_out = c->phi0; }
         if (c->sub_hist && g > 2) { a2.mid_out = c->Qmid; a2.mid_every = 1; a2.mid_first = 2; a2.mid_n = g - 2; }
         // beside them (same grid, idle CUs): the suffix products of the blocks of every super-block for the adjoint history pass
         ChainArgs a6{};
@@ -1583,6 +1774,7 @@ int qgdk_forward_finish(const qgdk_ctx *c)
         ChainArgs s3{};
         s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->psi0; s3.start_stride = 0;
         s3.out = c->hist; s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
+        if (c->front) { s3.start = c->phi0; s3.out = c->phist; }      // fused front: the sweep runs in phi = L psi (k_psi follows)
         int q = 0;
         if (c->part_rank > 0) {
             s3.pre_kind[q] = 0; s3.pre_P[q] = c->RX; s3.pre_pm_bpr[q] = 1; s3.pre_pm_chunk[q] = (long long)rx_chunk(c);
@@ -1650,6 +1842,7 @@ int qgdk_guard_fold(const qgdk_ctx *c)
 // (chain_is_fast sizes: one per (block or sub-block, column group)), else one per time point (k_guard_diag / k_guard)
 int qgdk_guard_parts(const qgdk_ctx *c)
 {
+    if (c->front) return c->nt * (c->cp / 8);        // k_psi: one per (time point, column group)
     if (!guard_is_fused(c)) return c->nt;
     const int nb = c->sub_hist ? c->scan_blocks * (c->sub_n + 1) : c->scan_blocks;
     return nb * (c->cp / 8);
@@ -1695,7 +1888,7 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
                                                    (c->gpart_on && c->gpart_terminal && c->have_guard) ? c->gpart : nullptr, c->gpart_n);
             else if (c->gpart_on && c->gpart_terminal && c->have_guard)      // no target: only the guard penalty is to be added up
                 hipLaunchKernelGGL(k_terminal, dim3(1), dim3(256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist, c->scal, c->Np, c->cp, c->nt,
-                                   c->n_ess, 0, 0, slot, slot, slot, 0, c->gpart, c->gpart_n);
+                                   c->n_ess, 0, 0, slot, slot, slot, 0, c->gpart, c->gpart_n, (const double *)nullptr);
         }
         if (write_y)
             hipLaunchKernelGGL(k_terminal_y, dim3(nwg), dim3(256), 0, c->stream, c->target, c->forcing + (size_t)(c->nt - 1) * hstep,
@@ -1703,10 +1896,13 @@ static int launch_terminal(const qgdk_ctx *c, int write_y, int given_ab)
                                c->bndY2 + (size_t)c->scan_blocks2 * hstep, (int)hstep, 2 * c->cp, c->n_ess, c->cost_type, w);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->forcing, c->yhist,
+    // (fused front: the terminal value is lambda_N, formed from termU = L_N^-H target and h_N, into lambda's history)
+    hipLaunchKernelGGL(k_terminal, dim3(1), dim3(hstep >= 32768 ? 1024 : 256), 0, c->stream, c->hist, c->target, c->front ? c->hforc : c->forcing,
+                       c->front ? c->lam : c->yhist,
                        c->scal, c->Np, c->cp, c->nt, c->n_ess, c->have_target * (1 + c->cost_type), write_y, slot,
                        c->bndY + (size_t)c->scan_blocks * hstep, c->bndY2 + (size_t)c->scan_blocks2 * hstep, given_ab,
-                       (c->gpart_on && c->gpart_terminal && c->have_guard && !given_ab) ? c->gpart : nullptr, c->gpart_n);
+                       (c->gpart_on && c->gpart_terminal && c->have_guard && !given_ab) ? c->gpart : nullptr, c->gpart_n,
+                       c->front ? c->termU : (const double *)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1718,12 +1914,13 @@ int qgdk_adjoint_blocks(const qgdk_ctx *c)
     const double *PiRx = c->PiX + (size_t)B * pl2;       // panel copies of the block propagators
     int rc;
     ChainArgs a{};
-    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->forcing; a.phi = c->phiX;
+    a.Np = c->Np; a.cp = c->cp; a.S = c->nt - 1; a.Pmat = c->Pr; a.forcing = c->front ? c->hforc : c->forcing; a.phi = c->phiX;
     a.nblocks = B; a.blen = c->scan_blen; a.ngroups = c->cp / 8;
     if (c->fuse_terminal && chain_is_fast(c)) {          // y_N and the overlaps by an extra workgroup of this launch
         const size_t hstep = (size_t)c->Np * 2 * c->cp;
         a.t_on = 1; a.t_nt = c->nt; a.t_ness = c->n_ess; a.t_have_target = c->have_target * (1 + c->cost_type);
         a.t_hist = c->hist; a.t_target = c->target; a.t_forcing = c->forcing; a.t_yhist = c->yhist; a.t_scal = c->scal;
+        if (c->front) { a.t_forcing = c->hforc; a.t_yhist = c->lam; a.t_ytarget = c->termU; }      // fused front: lambda_N itself, into lambda's history
         a.t_gpart = (c->gpart_on && c->gpart_terminal && c->have_guard) ? c->gpart : nullptr; a.t_gpart_n = c->gpart_n;
         a.t_y2 = c->phiRX + (size_t)c->part_rank * phirx_chunk(c) + hstep;
         a.t_y3 = c->bndY + (size_t)c->scan_blocks * hstep; a.t_y4 = c->bndY2 + (size_t)c->scan_blocks2 * hstep;
@@ -1781,6 +1978,7 @@ int qgdk_adjoint_finish(const qgdk_ctx *c)
         s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pr; s3.forcing = c->forcing; s3.out = c->yhist;
         s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8; s3.start_stride = 0;
         s3.start = (r == W - 1) ? c->yhist + (size_t)(c->nt - 1) * hstep : c->phiRX + (size_t)(W - 1) * phirx_chunk(c) + hstep;
+        if (c->front) { s3.forcing = c->hforc; s3.out = c->lam; s3.start = c->lam + (size_t)(c->nt - 1) * hstep; }      // fused front: the sweep is in lambda
         int q = 0;
         if (r < W - 1) {
             s3.pre_kind[q] = 0; s3.pre_P[q] = c->RX + (size_t)(r + 1) * rx_chunk(c) + pl2; s3.pre_pm_bpr[q] = 1;
@@ -1879,6 +2077,15 @@ int qgdk_forcing_sweep(const qgdk_ctx *c)
     s3.Np = c->Np; s3.cp = c->cp; s3.S = c->nt - 1; s3.Pmat = c->Pc; s3.start = c->ff_bnd; s3.start_stride = (long long)hstep;
     s3.out = c->hist; s3.forcing = c->ff_Q; s3.nblocks = B; s3.blen = c->scan_blen; s3.ngroups = c->cp / 8;
     return launch_chain<5>(s3, c->stream);
+}
+
+int qgdk_psi(const qgdk_ctx *c)
+{
+    const bool guard = c->have_guard == 2;
+    hipLaunchKernelGGL(k_psi, dim3(c->nt, c->cp / 8), dim3(256), 0, c->stream, c->LinvT, c->phist, c->psi0, c->hist, c->forcing, c->hforc,
+                       guard ? c->guard_diag : (const double *)nullptr, guard ? c->gpart : (double *)nullptr,
+                       (c->have_target && c->cost_type == 0) ? c->target : (const double *)nullptr, c->termU, c->cp, c->nt, c->N, c->dt, c->tf);
+    return (int)hipGetLastError();
 }
 
 int qgdk_lambda(const qgdk_ctx *c)

@@ -417,12 +417,41 @@ void k_inverse_mfma(const double *__restrict__ L, const double *__restrict__ R, 
 // The last resort of the column-block kernel: the fully pivoted elimination above on the same matrix, as a function that
 // ends the wave.
 __device__ __attribute__((noinline, noreturn)) void cb_fallback(const double *L, const double *R, double *LinvT, double *Pr, double *Pc, int n,
-                                                                int *status, int *fallbacks, double *smem, int *rho, int *rinv)
+                                                                int *status, int *fallbacks, double *smem, int *rho, int *rinv, int front)
 {
     if (fallbacks && threadIdx.x == 0) atomicAdd(fallbacks + 1, 1);             // (matrices both column-block attempts gave up)
     inverse_mfma_body<64>(cb_uniform(L), cb_uniform(R), cb_uniform(LinvT), cb_uniform(Pr), cb_uniform(Pc), __builtin_amdgcn_readfirstlane(n),
                           cb_uniform(status), cb_lds(smem), cb_lds(rho), cb_lds(rinv));
+    if (front) front_relayout(L, R, Pr, Pc, n);
     __builtin_amdgcn_endpgm();
+}
+
+// The pivoted stages leave Y = L^-1 R as a row-major panel (Pr[n-1]) and as column-major planes (Pc[n-1]); the fused front's
+// sweeps read S = Y^H as column-major planes from Pc and as a row-major panel from Pr (qgd_front.h).  Both are row-local
+// re-interleavings: planes[p][a][b] = +-panel[a][b]_p and panel[a][b]_p = +-planes[p][a][b].  The first goes through the panel
+// of R[n-1] (an input, dead by now; L[n] stays as it is: phi_0 is formed from L_0^H later), the second straight across.
+// 256 threads, the whole workgroup.
+__device__ __attribute__((noinline)) void front_relayout(const double *L, const double *R, double *Pr, double *Pc, int n)
+{
+    constexpr int NP = 64, PW = 128;
+    const size_t panel = (size_t)NP * PW;
+    (void)L;
+    double *F = const_cast<double *>(R) + (size_t)(n - 1) * panel;
+    double *pr = Pr + (size_t)(n - 1) * panel, *pc = Pc + (size_t)(n - 1) * panel;
+    __syncthreads();                                    // (the stages' own stores have reached memory)
+    for (int idx = threadIdx.x; idx < NP * PW; idx += 256) {
+        const int p = idx >> 12, a = (idx >> 6) & 63, b = idx & 63, pan = a * PW + (b >> 3) * 16 + (b & 7) + 8 * p;
+        const double v = __builtin_nontemporal_load(pr + pan);
+        F[idx] = p ? -v : v;                            // conj(Y) in row-major planes (to become Pc)
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NP * PW; idx += 256) {
+        const int p = idx >> 12, a = (idx >> 6) & 63, b = idx & 63, pan = a * PW + (b >> 3) * 16 + (b & 7) + 8 * p;
+        const double v = __builtin_nontemporal_load(pc + idx);
+        pr[pan] = p ? -v : v;                           // conj(Y) as a column-major panel
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NP * PW; idx += 256) pc[idx] = F[idx];
 }
 
 // Np = 64: column-block elimination first; a matrix whose diagonal tiles do not carry the pivots (zero pivot or a multiplier
@@ -439,6 +468,68 @@ void k_inverse_cb(const double *__restrict__ L, const double *__restrict__ R, do
     __shared__ int rho[64], rinv[64];
     __shared__ int bad;
     inverse_cb_body<ONE>(L, R, LinvT, Pr, Pc, n0 + (int)blockIdx.x, status, fallbacks, smem, rho, rinv, &bad);
+}
+
+#include "qgd_front.h"
+#ifndef FRONT_PRIO_BUILD
+#define FRONT_PRIO_BUILD 3
+#endif
+#ifdef CB_PROFILE       // scripts/ubench/front_bench.hip -DCB_PROFILE: s_memtime at the start and end of the build phase of every workgroup
+__device__ unsigned long long g_front_prof[4096][4];      // wall clock (100 MHz, one counter for the whole device): start, build end, elimination start, end
+#define FRONT_STAMP(i) do { if (blockIdx.x < 4096 && threadIdx.x == 0) g_front_prof[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define FRONT_STAMP(i) do { } while (0)
+#endif
+
+// The fused front (qgd_front.h): workgroup n builds L_n^H, R_n^H into Eh[n], Fh[n] and eliminates [L_n^H | R_n^H] in place of
+// k_build_LR_ell + k_inverse_cb.  LinvT[n] = L_n^-H (row-major planes); Pc[n] / Pr[n] = S_n = R_n L_n^-1 as column-major planes /
+// row-major panel -- what the sweeps read where the two-point form has P_n -- for n = 0 .. nt-1.  pre_nt = nt: the time points
+// front_is_prebuilt(n, nt) were built by the launch in front (k_tables_front / k_front_pre); 0: every workgroup builds its own.
+// Dynamic LDS: max(front_build_lds, the column-block kernel's work space).
+template <int M, int NOPS, bool ONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv, const double *__restrict__ ell_val,
+             const double *__restrict__ tab, const double *__restrict__ cw, int n_ops, int Z,
+             double *__restrict__ Eh, double *__restrict__ Fh, double *__restrict__ LinvT, double *__restrict__ Pr,
+             double *__restrict__ Pc, int *__restrict__ status, int *__restrict__ fallbacks, const int pre_nt)
+{
+    extern __shared__ __attribute__((aligned(32))) double front_smem[];
+    __shared__ int rho[64], rinv[64];
+    __shared__ int bad;
+    constexpr size_t panel = 64 * 128, pl = 64 * 64;
+    const int n = blockIdx.x;
+    FRONT_STAMP(0);
+    if (!(pre_nt && front_is_prebuilt(n, pre_nt))) {
+        // (the build ahead of everything else on the CU: a workgroup that is still building while its neighbours eliminate at
+        //  raised priority crawls -- 113 -> 109 us for the 551 time points of the headline)
+        __builtin_amdgcn_s_setprio(FRONT_PRIO_BUILD);
+        front_build<M, NOPS>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    FRONT_STAMP(1);
+    __syncthreads();        // (s_waitcnt vmcnt(0) + s_barrier: the panels are in the L2 every wave of this workgroup reads through)
+    FRONT_STAMP(2);
+    // the column-block kernel pairs L[n] with R[n-1], Pr[n-1], Pc[n-1]: shifted by one matrix they are this time point's
+    inverse_cb_body<ONE, true>(Eh, Fh + panel, LinvT, Pr + panel, Pc + 2 * pl, n, status, fallbacks, front_smem, rho, rinv, &bad);
+    FRONT_STAMP(3);
+}
+
+// The pre-built step matrices as a launch of their own (scripts/ubench/front_bench.hip; the library builds them in k_tables_front).
+template <int M, int NOPS>
+__global__ __launch_bounds__(256) void k_front_pre(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv, const double *__restrict__ ell_val,
+                                                   const double *__restrict__ tab, const double *__restrict__ cw, int n_ops, int Z,
+                                                   double *__restrict__ Eh, double *__restrict__ Fh, const int nt)
+{
+    extern __shared__ __attribute__((aligned(32))) double front_smem[];
+    constexpr size_t panel = 64 * 128;
+    const int n = front_pre_point(blockIdx.x, nt);
+    front_build<M, NOPS>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
+}
+static inline size_t front_lds(int M, int Z)
+{
+    constexpr size_t SM = ((INV_SMEM(64) > CB_WORK) ? INV_SMEM(64) : CB_WORK) * sizeof(double);
+    const size_t b = front_build_lds(M, Z);
+    return b > SM ? b : SM;
 }
 
 // ---------------------------------------------------------------------------
@@ -1014,7 +1105,43 @@ __global__ __launch_bounds__(256) void k_propagator(const double *__restrict__ L
     }
 }
 
+template <int M, int NOPS>
+static int launch_front(const qgdk_ctx *c)
+{
+    const size_t shm = front_lds(M, c->ell_z);
+    const int nt = c->nt, pre_nt = qgd_path("front_nopre") ? 0 : nt;      // (A/B: no pre-built step matrices)
+    if (nt > CB_ONE_ALONE && nt <= CB_ONE_ROUND) {
+        SET_LDS_ONCE((k_front<M, NOPS, true>), shm);
+        hipLaunchKernelGGL((k_front<M, NOPS, true>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
+    } else {
+        SET_LDS_ONCE((k_front<M, NOPS, false>), shm);
+        hipLaunchKernelGGL((k_front<M, NOPS, false>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" {
+
+// Fused front: which problems take it (the host asks before it plans an evaluation), and its launch
+int qgdk_front_supported(const qgdk_ctx *c)
+{
+    if (c->Np != 64 || !c->use_sparse || c->m < 1 || c->m > 4 || c->ell_z < 1 || c->ell_z > 16) return 0;
+    return front_lds(c->m, c->ell_z) <= 53 * 1024 ? 1 : 0;      // three workgroups per CU
+}
+
+int qgdk_front(const qgdk_ctx *c)
+{
+    if (c->m == 4 && c->n_ops == 3) return launch_front<4, 3>(c);
+    switch (c->m) {
+    case 1: return launch_front<1, -1>(c);
+    case 2: return launch_front<2, -1>(c);
+    case 3: return launch_front<3, -1>(c);
+    case 4: return launch_front<4, -1>(c);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
 
 int qgdk_inverse(const qgdk_ctx *c)
 {

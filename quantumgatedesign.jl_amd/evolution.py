@@ -351,6 +351,10 @@ class DeviceProblem:
         """Whether the last evaluation of this handle ran on the small-problem path."""
         return bool(self.intermediate("small_path")[0])
 
+    def front_path_taken(self):
+        """Did the last forward evaluation take the fused front (csrc/qgd_front.h: same-point step propagators)?"""
+        return bool(self.intermediate("front_path")[0])
+
     def set_lambda_derivatives(self, on=True):
         """Fill ``lambda_history[:, 1:, :, :]`` as the reference leaves it (forward_evolution.jl:427-433, :471-480):
         the adjoint derivatives of lambda_n with the controls at t_{n-1} (t_1 for n = 1).  Off by default -- nothing
@@ -375,7 +379,7 @@ class DeviceProblem:
             return z[..., 0] + 1j * z[..., 1]
         if name == "repivoted":
             return int(out[0])
-        if name in ("selection", "small_path"):
+        if name in ("selection", "small_path", "front_path"):
             return out
         if name == "sigma":
             return out.reshape(nt, self.n_ops, self.m, 2)
