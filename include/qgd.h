@@ -237,11 +237,25 @@ int qgd_set_small_path(qgd_handle h, int32_t on);
  * Names: "L", "R", "Linv", "P" (complex, returned as [nt][N][N][2] C-order),
  * "sigma" ([nt][n_ops][m][2]), "tables" ([nt][m][n_ops][2]), "repivoted" (1 value: how many step matrices of the last
  * evaluation were redone with full partial pivoting -- N > 64: after the block Gauss-Jordan inverse, which pivots inside its
- * 64-column diagonal blocks only, found a block multiplier above its threshold; N = 64: after the optional static-pivot
- * attempt), "selection" (4 values: operator path -- 2 sparse ELL kernels, 1 the N > 64 GEMM-style kernels, 0 dense N <= 64 --,
+ * 64-column diagonal blocks only, found a block multiplier above its threshold; N = 64: matrices not done by the diagonal-pivot
+ * attempt + 65536 * (of these, done by the fully pivoted last resort): the low field wraps beyond 65535 such matrices),
+ * "selection" (4 values: operator path -- 2 sparse ELL kernels, 1 the N > 64 GEMM-style kernels, 0 dense N <= 64 --,
  * form of the gradient scalars on the N > 64 path 0..3 or -1, block Gauss-Jordan inverse in use 0/1, windows of the time
- * grid), "small_path" (1 value: whether the last evaluation ran on the small-problem path of qgd_set_small_path).  Returns the number
- * of doubles the buffer needs through *needed when out == NULL. */
+ * grid), "small_path" (1 value: whether the last evaluation ran on the small-problem path of qgd_set_small_path), "front_path"
+ * (1 value: whether the last forward evaluation took the fused front, below).  Returns the number of doubles the buffer needs
+ * through *needed when out == NULL.
+ *
+ * The fused front (N = 64 with sparse operators, Hermite order <= 8, one rank, the grid resident, :Infidelity, a diagonal guard
+ * projector or none, pcof through the control basis): full evaluations of qgd_eval_forward / qgd_discrete_adjoint use the
+ * same-point step propagators S_n = R_n L_n^-1 (csrc/qgd_front.h); state history, lambda, forcing, scalars and gradient are the
+ * same quantities as ever.  "L", "R", "Linv", "P" are always the two-point form's: asked for after such an evaluation they
+ * make the library redo the forward evaluation on the general path first.
+ *
+ * Pivoting history of the N = 64 inverse (both paths): an evaluation in which the diagonal-pivot attempt was given up for more
+ * than a quarter of the step matrices makes the next 32 evaluations of the handle START with pivoting inside the diagonal tiles;
+ * then the diagonal is tried again.  In-tile pivoting rounds differently from diagonal pivots, so the same pcof can return
+ * results that differ in the last bits (1e-13 relative) before, during and after those 32 evaluations; within one regime the
+ * results are the same bits from call to call. */
 int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t capacity,
                          size_t *needed);
 
@@ -325,16 +339,15 @@ int qgd_comm_info(qgd_handle h, int32_t *out3);
  * ends the job or calls qgd_comm_init_rccl again with a fresh id on every rank.  Argument and call-order errors are
  * raised before anything is launched, and a singular step matrix is summed into the reductions: those fail on every
  * rank alike, with their own codes, and leave the communicator intact.
- * qgd_comm_debug_fail_at(h, n) is a TEST HOOK: the next collective call fails locally in front of its exchange n-1
- * (n = 1..4: window products, affine parts, [grad | scalars], scalars); 0 = off. */
+ * (The tests inject a local failure in front of each exchange with a hook that is NOT part of this library:
+ * tests/hooks/qgd_test_hooks.cpp.) */
 int qgd_set_comm_timeout(qgd_handle h, double milliseconds);
-int qgd_comm_debug_fail_at(qgd_handle h, int32_t collective);
 
 /* Per-phase device time of the last evaluation (HIP events), milliseconds.
  * names/ms hold up to cap entries; returns the number of phases through *n. */
 int qgd_get_timings(qgd_handle h, const char **names, float *ms, int32_t cap, int32_t *n);
 /* Event bracketing costs ~0.17 ms per evaluation on cnot3 (26 event records): mode 0 = off,
- * (default; QGD_PHASE_TIMING=1 in the environment turns it on), 1 = every phase, 2 = only the named phase.
+ * (default), 1 = every phase, 2 = only the named phase.
  * Switching off keeps the times of the last bracketed evaluation readable (qgd_get_timings). */
 int qgd_set_timing(qgd_handle h, int32_t mode, const char *phase);
 

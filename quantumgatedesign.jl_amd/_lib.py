@@ -28,7 +28,7 @@ EXPORTS = [
     "qgd_register_host_buffer", "qgd_unregister_host_buffer", "qgd_create_csc", "qgd_cols_forward", "qgd_cols_adjoint",
     "qgd_set_lambda_derivatives", "qgd_set_cost_type",
     "qgd_comm_unique_id", "qgd_comm_init_rccl", "qgd_comm_destroy", "qgd_comm_info", "qgd_set_save_every",
-    "qgd_set_memory_budget", "qgd_get_memory_plan", "qgd_set_comm_timeout", "qgd_comm_debug_fail_at", "qgd_set_small_path",
+    "qgd_set_memory_budget", "qgd_get_memory_plan", "qgd_set_comm_timeout", "qgd_set_small_path",
 ]
 QGD_CREATE_DEFER_GRID = 1
 
@@ -124,7 +124,6 @@ def lib():
     L.qgd_comm_destroy.argtypes = [C.c_void_p]
     L.qgd_comm_info.argtypes = [C.c_void_p, C.c_void_p]
     L.qgd_set_comm_timeout.argtypes = [C.c_void_p, C.c_double]
-    L.qgd_comm_debug_fail_at.argtypes = [C.c_void_p, C.c_int32]
     L.qgd_set_small_path.argtypes = [C.c_void_p, C.c_int32]
     _lib = L
     return L

@@ -102,7 +102,7 @@ struct qgd_handle_s {
     bool lambda_derivs = false;
     double *dlam = nullptr, *dlam_scratch = nullptr, *stage_lam_full = nullptr;
     hipStream_t copy_stream = nullptr;
-    hipStream_t copy_stream2 = nullptr;   // the second half of a large pinned download goes to a second DMA engine (QGD_COPY_SPLIT=0: off)
+    hipStream_t copy_stream2 = nullptr;   // the second half of a large pinned download goes to a second DMA engine 
     hipEvent_t ev_ready = nullptr;
     std::vector<double> fwd_pcof;       // the pcof of the forward sweep that is on the device (history_precomputed)
     std::vector<double> scatter_tmp;    // unregistered lambda_history: compact copy, scattered on the host
@@ -125,7 +125,9 @@ struct qgd_handle_s {
     // the communicator is ABORTED (ncclCommAbort: its kernels leave the stream) and the call returns QGD_ERR_COMM --
     // the other ranks then run into their own bound instead of waiting for this one forever.
     double comm_timeout_ms = 30000.0;
-    int comm_fail_at = 0;               // qgd_comm_debug_fail_at (test hook): pretend a local failure in front of collective #n
+    bool stream_dead = false;           // a communicator had to be leaked with a collective stuck on the stream (no ncclCommAbort in this librccl):
+                                        // every later compute entry point fails fast with QGD_ERR_COMM, qgd_destroy does not wait for the stream
+    int comm_fail_at = 0;               // != 0: pretend a local failure in front of collective #n (set only by the tests' fault injector, tests/hooks/qgd_test_hooks.cpp -- no entry point of the library writes it)
     bool grid_ready = false;            // QGD_CREATE_DEFER_GRID: the time grid is allocated by the first entry point that needs it
     bool comm_pending = false;          // qgd_comm_init_rccl is re-allocating the grid for the communicator it is about to
                                         // create: the grid stays resident (comm_discrete_adjoint does not walk windows)
@@ -303,7 +305,7 @@ int fetch_results(qgd_handle h, double *grad, double *out3, const double *src = 
 
 // qgd_host_comm.cpp
 RcclApi load_rccl();
-void comm_abort(qgd_handle h);
+bool comm_abort(qgd_handle h);
 int comm_failed(qgd_handle h, const std::string &why);
 int comm_local_error(qgd_handle h, int rc);
 int comm_wait(qgd_handle h);

@@ -322,7 +322,7 @@ int qgd_create(const qgd_problem_desc *d, qgd_handle *out)
     CREATE_TRY(hipMemcpy(k.ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
     // sparse-operator path: ELL over the union pattern of all planes + one ELL list per control.
     // Used when a row of A has at most 16 and at most Np/2 entries (the drift + a_k +/- a_k^dagger
-    // operators of multi_qudit_systems.jl have 1 + 2*subsystems); QGD_DENSE_OPS=1 keeps the MFMA path.
+    // operators of multi_qudit_systems.jl have 1 + 2*subsystems); QGD_PATHS=dense_ops keeps the MFMA path.
     {
         const size_t planes = 2 + 2 * (size_t)n_ops;
         std::vector<std::vector<int>> cols(Np);
@@ -506,6 +506,13 @@ void qgd_destroy(qgd_handle h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->stream_dead) {
+        // a leaked communicator's collective is stuck on the stream (qgd_host_comm.cpp: comm_abort without ncclCommAbort): waiting
+        // for the stream, or freeing device memory (which waits for the device), would never return -- the device side of the
+        // handle is leaked with the communicator; the host is expected to end the process
+        delete h;
+        return;
+    }
     if (h->k.stream) (void)hipStreamSynchronize(h->k.stream);
     drop_graph(h);
     if (h->comm) (void)qgd_comm_destroy(h);

@@ -43,9 +43,11 @@ RcclApi &rccl() { static RcclApi a = load_rccl(); return a; }
 // reports QGD_ERR_COMM.  The handle is left without a communicator: the host tears the job down (bench.py: the rank
 // process exits non-zero) or builds a fresh communicator.  There is no retry inside the library.
 // ---------------------------------------------------------------------------
-void comm_abort(qgd_handle h)
+// Returns false when the communicator could only be LEAKED (a librccl without ncclCommAbort): the stuck collective is then
+// still on the handle's stream, and the handle must not wait for that stream again.
+bool comm_abort(qgd_handle h)
 {
-    if (!h->comm) return;
+    if (!h->comm) return true;
     RcclApi &R = rccl();
     ncclComm_t c = h->comm;
     h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
@@ -54,18 +56,21 @@ void comm_abort(qgd_handle h)
         // blocks, and so does a wait for the stream -- the bounded-wait promise of qgd.h would not hold.  The communicator
         // is leaked instead and the handle's stream is left alone; the call returns QGD_ERR_COMM.
         (void)hipGetLastError();
-        return;
+        h->stream_dead = true;
+        return false;
     }
     (void)R.CommAbort(c);
     (void)hipStreamSynchronize(h->k.stream);      // the library's own kernels behind the aborted collective drain normally
     (void)hipGetLastError();
+    return true;
 }
 
 
 int comm_failed(qgd_handle h, const std::string &why)
 {
-    comm_abort(h);
-    return fail(h, QGD_ERR_COMM, why + "; the communicator of this handle was aborted (ncclCommAbort)");
+    if (comm_abort(h)) return fail(h, QGD_ERR_COMM, why + "; the communicator of this handle was aborted (ncclCommAbort)");
+    return fail(h, QGD_ERR_COMM, why + "; this librccl has no ncclCommAbort: the communicator was leaked with its collective still on the handle's "
+                                       "stream -- the handle accepts no further evaluation (destroy it; its stream is not waited for)");
 }
 
 
@@ -119,7 +124,7 @@ int comm_collective(qgd_handle h, int which)
     RcclApi &R = rccl();
     if (h->comm_fail_at && h->comm_fail_at == which + 1) {      // (test hook: a local failure in front of this collective)
         h->comm_fail_at = 0;
-        return fail(h, QGD_ERR_NO_DEVICE, "injected failure in front of collective " + std::to_string(which) + " (qgd_comm_debug_fail_at)");
+        return fail(h, QGD_ERR_NO_DEVICE, "injected failure in front of collective " + std::to_string(which) + " (tests/hooks/qgd_test_hooks.cpp)");
     }
     const size_t pl = (size_t)k.Np * k.Np, hstep = (size_t)k.Np * 2 * k.cp;
     static const char *names[4] = {"comm_gather_fwd", "comm_gather_adj", "comm_reduce", "comm_reduce_scal"};
@@ -337,15 +342,6 @@ int qgd_set_comm_timeout(qgd_handle h, double milliseconds)
     if (!h) return QGD_ERR_ARGUMENT;
     if (!(milliseconds > 0)) return fail(h, QGD_ERR_ARGUMENT, "the time limit of a collective evaluation must be positive (milliseconds)");
     h->comm_timeout_ms = milliseconds;
-    return QGD_OK;
-}
-
-
-int qgd_comm_debug_fail_at(qgd_handle h, int32_t collective)
-{
-    if (!h) return QGD_ERR_ARGUMENT;
-    if (collective < 0 || collective > 4) return fail(h, QGD_ERR_ARGUMENT, "collective: 0 off, 1..4 = in front of exchange 0..3");
-    h->comm_fail_at = collective;
     return QGD_OK;
 }
 

@@ -167,7 +167,7 @@ static bool front_applies(qgd_handle h, const double *pcof, int n_pcof)
 {
     const qgdk_ctx &k = h->k;
     return pcof && h->have_basis && n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy") &&
-           !qgd_path("no_front") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
+           !qgd_path("no_front") && !qgd_path("inv_panels") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
            !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) && k.cost_type == 0 &&
            (size_t)k.Np * 2 * k.cp < 32768 && k.phi0 && k.hforc && k.termU && k.n_ops > 0 && qgdk_front_supported(&k) != 0;
 }
@@ -177,6 +177,7 @@ static bool front_applies(qgd_handle h, const double *pcof, int n_pcof)
 int forward_begin(qgd_handle h, const double *pcof, int n_pcof, bool allow_front)
 {
     qgdk_ctx &k = h->k;
+    if (h->stream_dead) return fail(h, QGD_ERR_COMM, "a communicator of this handle was leaked with a collective stuck on its stream: the handle accepts no further evaluation");
     k.front = (allow_front && front_applies(h, pcof, n_pcof)) ? 1 : 0;
     h->front_last = k.front != 0;
     // guard penalty: the guard stage stores its workgroups' partial sums and a later stage adds them in a fixed order (the
@@ -805,6 +806,7 @@ int qgd_get_intermediate(qgd_handle h, const char *name, double *out, size_t cap
         return QGD_OK;
     }
     NEEDS_RESIDENT_GRID(h, "qgd_get_intermediate");
+    if (h->stream_dead) return fail(h, QGD_ERR_COMM, "a communicator of this handle was leaked with a collective stuck on its stream");
     if (h->history_stale && s != "repivoted" && !h->tiny_pcof.empty()) {
         // the last evaluation ran on the small-problem path, which keeps no intermediates: the same evaluation once more on
         // the general path (diagnostics only)

@@ -160,6 +160,11 @@ __device__ __forceinline__ int cb_panel(d4 (&M)[4][2], double *smem, int *rhoL, 
             #pragma unroll
             for (int q = 0; q < 4; q++) { yr[q] = lane_read(xr[q], p); yi[q] = lane_read(xi[q], p); }
             const double den = fast_rcp(yr[s] * yr[s] + yi[s] * yi[s]);
+            // A pivot that is exactly zero (or whose |p|^2 leaves the range of a double) gives den = inf and NaN multipliers,
+            // which the growth check below cannot see (fmax drops a NaN): the matrix is regular, only this pivot ORDER fails.
+            // Finite pivot, non-finite reciprocal => give the attempt up.  (A pivot that is itself non-finite -- coefficients
+            // that overflowed -- goes through: the results are then non-finite, as the reference's would be.)
+            if (STATIC) sing |= (!(den * 0.0 == 0.0) && (yr[s] * 0.0 + yi[s] * 0.0 == 0.0)) ? 1 : 0;
             const double ir = yr[s] * den, ii = -yi[s] * den;
             const double delta = isp ? 1.0 : 0.0;
             const double fr = xr[s] - delta, fi = xi[s];

@@ -25,7 +25,7 @@
 //
 // Round 3:
 //   * three real products per complex multiply (cgemm3_tile, cgemm3_tile_planes, cgemm3_tile_panelH, outer_tile3, outer_frag3;
-//     kernels *_f3, k_propagator3, k_chain_step; QGD_DENSE_4M=1 keeps the four-product kernels beside them),
+//     kernels *_f3, k_propagator3, k_chain_step; QGD_PATHS=dense_4m keeps the four-product kernels beside them),
 //   * the gradient scalars from outer products (k_youter, k_yinit, k_gouter, k_ginner_m, k_ginner_d) with fixed-order sums,
 //   * the inverse as block Gauss-Jordan over 64-column blocks (k_binv_row, k_binv_rest, k_binv_planes + k_inverse_diag),
 //   * one chain step as a full-chip GEMM (k_chain_step) for the sequential top-level chains of the scan.

@@ -223,10 +223,6 @@ class DeviceProblem:
         aborted and the call raises QGDError(QGD_ERR_COMM)."""
         _lib.check(self.h, self.lib.qgd_set_comm_timeout(self.h, float(milliseconds)))
 
-    def comm_debug_fail_at(self, collective):
-        """Test hook (qgd_comm_debug_fail_at): the next collective call fails locally in front of its exchange."""
-        _lib.check(self.h, self.lib.qgd_comm_debug_fail_at(self.h, int(collective)))
-
     def comm_info(self):
         out = (C.c_int32 * 3)()
         _lib.check(self.h, self.lib.qgd_comm_info(self.h, out))

@@ -161,16 +161,16 @@ int main(void)
         return 1;
     }
     if (qgd_set_memory_budget(h, 64) != QGD_ERR_MEMORY) { fprintf(stderr, "a 64-byte budget must be QGD_ERR_MEMORY\n"); return 1; }
-    /* 7. the failure mode of a collective call: a rank that fails locally in front of an exchange aborts its communicator and
-     *    reports QGD_ERR_COMM (it does not leave the call half-entered); so does a collective call that outlives its time
-     *    limit.  Afterwards the handle has no communicator (rank -1) and takes a fresh one. */
-    for (int trial = 0; trial < 2; trial++) {
+    /* 7. the failure mode of a collective call: a collective call that outlives its time limit aborts its communicator and
+     *    reports QGD_ERR_COMM (it does not leave the call half-entered).  Afterwards the handle has no communicator (rank -1)
+     *    and takes a fresh one.  (A rank that fails locally in front of an exchange does the same: the Python tests inject
+     *    that with a hook outside the library, tests/hooks/qgd_test_hooks.cpp -- this consumer uses include/qgd.h only.) */
+    for (int trial = 1; trial < 2; trial++) {
         if ((rc = qgd_comm_unique_id(id))) return die("qgd_comm_unique_id", NULL, rc);
         if ((rc = qgd_comm_init_rccl(hc, id, 0, 1, QGD_SHARD_TIME))) return die("qgd_comm_init_rccl(7)", hc, rc);
         if ((rc = qgd_set_control_basis(hc, ncoef, gp, gq))) return die("qgd_set_control_basis(7)", hc, rc);
         if ((rc = qgd_set_target(hc, target))) return die("qgd_set_target(7)", hc, rc);
-        if (trial == 0) { if ((rc = qgd_comm_debug_fail_at(hc, 2))) return die("qgd_comm_debug_fail_at", hc, rc); }
-        else if ((rc = qgd_set_comm_timeout(hc, 1e-6))) return die("qgd_set_comm_timeout", hc, rc);
+        if ((rc = qgd_set_comm_timeout(hc, 1e-6))) return die("qgd_set_comm_timeout", hc, rc);
         double gm[2], om3[3];
         rc = qgd_discrete_adjoint(hc, theta, 2, 0, gm, NULL, NULL, NULL, om3);
         if (rc != QGD_ERR_COMM || !strstr(qgd_last_error(hc), "aborted")) {

@@ -3,7 +3,7 @@
 The transport is whatever QGD_RCCL_LIB names (tests/fake_rccl: shared memory between processes on one GPU).  Rank 0 draws the
 unique id and leaves it in <dir>/uid; every rank compares its results with <dir>/ref.npz (the single-GPU evaluation) and
 writes <dir>/rank<r>.npz.  With fail_at, rank `world-1` injects a local failure in front of that exchange
-(qgd_comm_debug_fail_at) and every rank must come back with QGD_ERR_COMM instead of hanging: exit code 7 then.
+(tests/qgd_hooks.py: qgd_comm_debug_fail_at, a test-only hook outside the library) and every rank must come back with QGD_ERR_COMM instead of hanging: exit code 7 then.
 `threads` instead of a rank: all `world` ranks as THREADS of this one process, each with its own handle and communicator (a GPU
 box admits six processes on its card, so eight ranks cannot be eight processes there; ctypes releases the interpreter lock
 inside the library, so the ranks do meet in the collectives).  The exit code is the ranks' common code, 9 when they differ."""
@@ -14,6 +14,7 @@ import numpy as np
 import torch  # noqa: F401  (first: one HIP runtime in the process)
 from __graft_entry__ import import_package
 import cases
+import qgd_hooks
 
 
 def problem(qgd, case):
@@ -53,7 +54,7 @@ def run_rank(qgd, case, shard, rank, world, d, fail_at):
     if fail_at:
         ev.dp.set_comm_timeout(15000.0)
         if rank == world - 1:
-            ev.dp.comm_debug_fail_at(fail_at)
+            qgd_hooks.comm_debug_fail_at(ev.dp, fail_at)
         try:
             ev.discrete_adjoint(pcof)
         except qgd._lib.QGDError as e:

@@ -859,7 +859,8 @@ def test_inverse_returns_to_the_diagonal_attempt(qgd):
     """One evaluation whose step matrices are finite but far from diagonally dominant (coefficients a thousand times too large: the
     diagonal attempt of the N = 64 inverse is given up for more than a quarter of them) makes the next 32 evaluations of the handle
     START with pivoting (qgd_k_build.hip: inverse_memory; `repivoted` counts every matrix while they do); then the diagonal attempt
-    is tried again and, the matrices being what they were, stays.  Results are the same bits throughout."""
+    is tried again and, the matrices being what they were, stays.  The results agree to 1e-12 throughout (in-tile pivoting rounds
+    differently from diagonal pivots: include/qgd.h documents the history dependence; within one regime the bits repeat)."""
     nsteps = 40
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
     dp = qgd.DeviceProblem(prob, 8)
@@ -877,7 +878,8 @@ def test_inverse_returns_to_the_diagonal_attempt(qgd):
         g1, _ = dp.discrete_adjoint(pcof)
         counts.append(int(dp.intermediate("repivoted")) & 0xFFFF)
         assert np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
-    assert counts[:32] == [nsteps] * 32 and counts[32:] == [0] * 4, (scale, counts)
+    nmat = nsteps + 1 if dp.front_path_taken() else nsteps      # (the fused front inverts L at every time point, the general path at all but the first)
+    assert counts[:32] == [nmat] * 32 and counts[32:] == [0] * 4, (scale, counts)
     dp.close()
 
 

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import cases
+import qgd_hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -95,7 +96,7 @@ def test_rccl_errors(qgd):
 def test_rccl_failure_mode(qgd, shard, where):
     """A collective call that cannot complete must END, with QGD_ERR_COMM and the communicator aborted (ncclCommAbort) --
     not leave this rank's stream, or the other ranks, waiting inside a collective: (a) a local failure injected in front
-    of each exchange of both protocols (qgd_comm_debug_fail_at), (b) a time limit that expires (qgd_set_comm_timeout).
+    of each exchange of both protocols (tests/qgd_hooks.py: qgd_comm_debug_fail_at, a test-only hook outside the library), (b) a time limit that expires (qgd_set_comm_timeout).
     Afterwards the handle has no communicator and accepts a fresh one, with which the evaluation is right again.
     (The reference's thread loop has no such state: an exception leaves Threads.@threads, src/forward_evolution.jl:48.)"""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=60, tf=60.0)
@@ -107,7 +108,7 @@ def test_rccl_failure_mode(qgd, shard, where):
     if where == "timeout":
         ev.dp.set_comm_timeout(1e-6)
     else:
-        ev.dp.comm_debug_fail_at(where)
+        qgd_hooks.comm_debug_fail_at(ev.dp, where)
     with pytest.raises(qgd._lib.QGDError) as e:
         ev.discrete_adjoint(pcof)
     assert e.value.code == qgd._lib.QGD_ERR_COMM and "aborted" in str(e.value), str(e.value)
@@ -243,7 +244,7 @@ def test_library_protocol_with_eight_ranks(qgd, tmp_path, case, shard):
                                                  ("time", 2, 4), ("columns", 3, 4), ("time", 1, 8), ("columns", 4, 8)])
 def test_failure_on_one_rank_ends_every_rank(qgd, tmp_path, shard, fail_at, world):
     """The failure mode between ranks: the last rank fails locally in front of one of the exchanges
-    (qgd_comm_debug_fail_at).  It aborts its communicator and returns QGD_ERR_COMM; the other ranks, already waiting in the
+    (tests/qgd_hooks.py: qgd_comm_debug_fail_at, a test-only hook outside the library).  It aborts its communicator and returns QGD_ERR_COMM; the other ranks, already waiting in the
     collective, are released by the abort and return QGD_ERR_COMM as well -- nobody hangs (exit code 7 from all).  Two and four
     ranks as processes, eight as threads of one process."""
     lib = _fake_transport(tmp_path)
