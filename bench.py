@@ -400,7 +400,7 @@ def cnot2_case_gpu(qgd, np, steps=50):
             "infidelity": float(1 - (out3[0] ** 2 + out3[1] ** 2) / prob.N_ess_levels ** 2), "grad_norm": float(np.linalg.norm(grad))}
 
 
-def executed_gflop(N, c, m, n_ops, nsteps, blocks, blen, sparse_ops):
+def executed_gflop(N, c, m, n_ops, nsteps, blocks, blen, sparse_ops, front=False):
     """Real flops one cnot3-shaped evaluation EXECUTES on the N <= 64 path: Gauss-Jordan inverse +
     L^-1 R (2 complex N^3 products per step), the matrix-matrix products of the two scan levels, the matrix-panel
     products of the history passes with their prefixes, the affine parts, lambda, and the step-matrix build and
@@ -409,12 +409,12 @@ def executed_gflop(N, c, m, n_ops, nsteps, blocks, blen, sparse_ops):
     B = max(1, blocks)
     B2 = max(1, int(round((2.0 * B) ** 0.5))) if B > 8 else 1
     g = (B + B2 - 1) // B2
-    inv = nsteps * 2 * cg
+    inv = (nsteps + 1 if front else nsteps) * 2 * cg          # (fused front: every time point, same-point products)
     scan_mm = (nsteps - B) * cg + (B - B2 if B2 > 1 else 0) * cg
     hist_fwd = (nsteps + 3 * B * (B2 + 2)) * ap                   # own steps + prefixes of the 3-step sub-block workgroups
     hist_adj = (nsteps + B * (B2 + g)) * ap
     affine = (nsteps + B) * ap
-    lam = nsteps * ap
+    lam = 2 * (nsteps + 1) * ap if front else nsteps * ap       # (fused front: k_psi -- psi = L^-1 phi and h = L^-H f per time point)
     if sparse_ops:
         build, grad = 0.76e9 * nsteps / 550.0, 0.35e9 * nsteps / 550.0
     else:
@@ -792,7 +792,7 @@ def main():
         hs = b_step * args.nsteps / sec_eval / 1e9
         blocks = part_info["blocks"] if part_info else min(64, int(round(args.nsteps ** (2.0 / 3.0))))
         blen = part_info["block_len"] if part_info else -(-args.nsteps // max(blocks, 1))
-        gflop = executed_gflop(N_, c_, m_, prob.N_operators, args.nsteps, -(-args.nsteps // blen), blen, path[0] == "sparse")
+        gflop = executed_gflop(N_, c_, m_, prob.N_operators, args.nsteps, -(-args.nsteps // blen), blen, path[0] == "sparse", front=("front" in first))
         if args.comm == "lib":
             how = "RCCL collectives issued inside libqgd_hip.so (qgd_comm_init_rccl)"
         else:

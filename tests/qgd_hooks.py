@@ -11,9 +11,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            csrc = os.path.join(os.path.dirname(_HERE), "quantumgatedesign.jl_amd", "csrc")
-            subprocess.check_call(["make", "-C", csrc, "testhooks"], stdout=subprocess.DEVNULL)
+        # always through make: the hook writes a field of the library's handle, so it must be compiled against the very headers
+        # the library was built from (the Makefile knows the dependency; a stale copy pokes the wrong field)
+        csrc = os.path.join(os.path.dirname(_HERE), "quantumgatedesign.jl_amd", "csrc")
+        subprocess.check_call(["make", "-C", csrc, "libqgd_hip.so", "testhooks"], stdout=subprocess.DEVNULL)
         _lib = C.CDLL(_SO)
         _lib.qgd_comm_debug_fail_at.argtypes = [C.c_void_p, C.c_int32]
         _lib.qgd_comm_debug_fail_at.restype = C.c_int
