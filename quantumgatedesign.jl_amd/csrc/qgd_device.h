@@ -136,8 +136,6 @@ typedef struct qgdk_ctx {
     double *phist;      // [nt][Np][2cp] (the buffer of yhist: the front path has no y)
     double *hforc;      // [nt][Np][2cp]
     double *termU;      // [Np][2cp]   L_N^-H target: lambda_N = (2/N_ess^2)(a + ib) termU + h_N
-    int *coop_flags;    // [nt] slabs delivered per time point, 4 more per evaluation (cooperative build, qgd_front.h); coop_epoch: evaluations so far
-    int coop_epoch;
 } qgdk_ctx;
 
 #ifdef __cplusplus
@@ -150,7 +148,6 @@ int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof);
 int qgdk_front_supported(const qgdk_ctx *c);   /* Np = 64, sparse operators, order <= 8, the build's LDS beside the elimination's */
 int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof);   /* tables + the pre-built step matrices + phi_0 */
 int qgdk_front(const qgdk_ctx *c);             /* L_n^-H, S_n for every time point: build + elimination in one workgroup */
-int qgdk_front_cooperative(const qgdk_ctx *c); /* 1: this launch of k_front builds the tail workgroups' matrices itself (no pre-building tables launch) */
 int qgdk_psi(const qgdk_ctx *c);               /* psi_n = L_n^-1 phi_n, guard forcing and penalty, h_n = L_n^-H f_n, termU */
 int qgdk_build_LR(const qgdk_ctx *c);
 int qgdk_inverse(const qgdk_ctx *c);

@@ -30,7 +30,7 @@ template <int M, int NOPS, int NTH = 256>
 __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv,
                                             const double *__restrict__ ell_val, const double *__restrict__ tab,
                                             const double *__restrict__ cw, const int n, const int n_ops, const int Z,
-                                            double *__restrict__ Eh, double *__restrict__ Fh, const int slab_first = 0, const int slab_end = 4)
+                                            double *__restrict__ Eh, double *__restrict__ Fh)
 {
     constexpr int NP = 64, CW = 16, DS = CW + 1, PW = 2 * NP, SPAR = NTH / 256;      // SPAR slabs side by side
     static_assert(NTH == 256 || NTH == 1024, "four waves per slab");
@@ -61,7 +61,7 @@ __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__r
     __syncthreads();
     // this lane's element of a panel row: column r of L^H / R^H
     const int ocol = (r >> 3) * 16 + (r & 7);
-    _Pragma("unroll 1") for (int s = (SPAR > 1 ? (tid >> 8) : slab_first); s < (SPAR > 1 ? (tid >> 8) + 1 : slab_end); s++) {
+    _Pragma("unroll 1") for (int s = (SPAR > 1 ? (tid >> 8) : 0); s < (SPAR > 1 ? (tid >> 8) + 1 : 4); s++) {
         const int c0 = CW * s + cl;                     // first of this thread's four columns of L, R
         const uint32_t slots = (s == 0) ? slot4[0] : (s == 1) ? slot4[1] : (s == 2) ? slot4[2] : slot4[3];
         c2 T[M][4], Lacc[4], Racc[4];
@@ -138,17 +138,3 @@ __host__ __device__ static inline bool front_is_prebuilt(int n, int nt)
 {
     return n >= 256 && (n & 255) < front_extra(nt);
 }
-
-// Cooperative build (k_front, 512 < nt <= 768): the step matrices of the time points 512 .. nt-1 -- whose workgroups are the
-// THIRD on their CUs -- are built, one 16-column slab each, by workgroups of the CUs that hold only two, ahead of their own
-// build; a third workgroup waits for its four slabs (a counter per time point, bumped by 4 per evaluation) and starts with the
-// elimination.  The CUs that hold three then run two builds and three eliminations like everyone else runs two and two,
-// and no launch in front of k_front has to carry the pre-built matrices (k_tables_front: +10 us on the tables launch).
-//   producers: workgroups b in [extra, 256) (first slot of a CU that holds two), task t = b - extra, b - extra + nprod, ...
-//   task t -> time point 512 + t / 4, slab t % 4.
-// The wait is bounded: a consumer that runs out of patience reports it through the status word (the evaluation fails loudly,
-// QGD_ERR_NUMERIC "cooperative build timed out") -- it cannot happen while the producers, which wait for nobody and are
-// dispatched before any consumer, make progress.
-__host__ __device__ static inline int front_coop_extra(int nt) { return (nt > 512 && nt <= 768) ? nt - 512 : 0; }
-__host__ __device__ static inline bool front_coop_consumer(int n, int nt) { return front_coop_extra(nt) > 0 && n >= 512; }
-#define FRONT_COOP_SPINS (1 << 12)      /* x s_sleep 32 (2048 cycles): about 4 ms */

@@ -128,12 +128,9 @@ static int alloc_window(qgd_handle h, bool dry, size_t *bytes)
               A(&k.PiR2, nb2 * 2 * pl) && A(&k.phi2, nb2 * hstep) && A(&k.bnd2, (nb2 + 1) * hstep) && A(&k.bndY2, (nb2 + 1) * hstep);
     if (!ok) return rc;
     // fused front (qgd_front.h): phi_0, the adjoint sweep's forcing L^-H f, L_N^-H target; the history of phi takes y's buffer
-    if (!dry) { k.front = 0; k.phi0 = k.hforc = k.termU = nullptr; k.phist = k.yhist; k.coop_flags = nullptr; k.coop_epoch = 0; }
-    if (Np == 64 && h->sparse_available && m <= 4 && h->part_world == 1) {
-        double *flags = nullptr;
-        if (!A(&k.phi0, hstep) || !A(&k.hforc, nt * hstep) || !A(&k.termU, hstep) || !A(&flags, (nt + 1) / 2 + 1)) return rc;
-        if (!dry) k.coop_flags = reinterpret_cast<int *>(flags);
-    }
+    if (!dry) { k.front = 0; k.phi0 = k.hforc = k.termU = nullptr; k.phist = k.yhist; }
+    if (Np == 64 && h->sparse_available && m <= 4 && h->part_world == 1 &&
+        (!A(&k.phi0, hstep) || !A(&k.hforc, nt * hstep) || !A(&k.termU, hstep))) return rc;
     // sub-block history pass (qgd_k_chain.hip): only with compiled-size chains, blocks of at least 6 steps
     k.sub_hist = 0; k.sub_n = 0; if (!dry) k.Hmid = k.Qmid = k.SufP = k.SufPhi = nullptr;
     if ((k.Np == 16 || k.Np == 32 || k.Np == 48 || k.Np == 64) && k.scan_blocks2 > 1 && k.scan_g > 2 &&
@@ -237,7 +234,6 @@ int alloc_grid(qgd_handle h)
     HIP_TRY(h, hipMemsetAsync(k.lam, 0, nt * hstep * sizeof(double), k.stream));
     HIP_TRY(h, hipMemsetAsync(k.forcing, 0, nt * hstep * sizeof(double), k.stream));
     if (k.hforc) HIP_TRY(h, hipMemsetAsync(k.hforc, 0, nt * hstep * sizeof(double), k.stream));      // (written only under a guard projector)
-    if (k.coop_flags) HIP_TRY(h, hipMemsetAsync(k.coop_flags, 0, (nt + 2) * sizeof(int), k.stream));
     h->forcing_zero = true;
     if (k.blk_lo == 0)   // the first window starts at the (constant) initial state
         HIP_TRY(h, hipMemcpyAsync(k.hist, h->u0v0_panel.data(), hstep * sizeof(double), hipMemcpyHostToDevice, k.stream));

@@ -207,7 +207,6 @@ int forward_begin(qgd_handle h, const double *pcof, int n_pcof, bool allow_front
         HIP_TRY(h, hipMemsetAsync(k.status, 0, 3 * sizeof(int), k.stream));      // (flag and the two counters; the fourth word is the inverse's memory of the last evaluation)
     }
     if (k.front) {
-        if (qgdk_front_cooperative(&k)) k.coop_epoch++;      // (the slab counters of this launch: 4 more per tail time point)
         { PhaseTimer t(h, "front"); K_TRY(h, qgdk_front(&k)); }      // L_n^-H and S_n = R_n L_n^-1 of every time point, one workgroup each
         { PhaseTimer t(h, "sweep_forward"); K_TRY(h, qgdk_forward_blocks(&k)); }
     } else {
@@ -329,7 +328,6 @@ int check_status(qgd_handle h)
     int st = 0;
     HIP_TRY(h, hipMemcpyAsync(&st, h->k.status, sizeof(int), hipMemcpyDeviceToHost, h->k.stream));
     HIP_TRY(h, hipStreamSynchronize(h->k.stream));
-    if (st == 2) return fail(h, QGD_ERR_NUMERIC, "internal: the cooperative build of the front kernel timed out (csrc/qgd_front.h)");
     if (st) return fail(h, QGD_ERR_NUMERIC, "singular implicit step matrix L(t_n)");
     return QGD_OK;
 }

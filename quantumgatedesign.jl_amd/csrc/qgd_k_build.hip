@@ -496,7 +496,7 @@ int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
 // the fused-front path's first launch (qgdk_front_supported; pcof in the kernel arguments, the basis covering exactly the grid)
 int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
 {
-    if (front_pre_count(c->nt) == 0 || qgd_path("front_nopre") || qgdk_front_cooperative(c)) return qgdk_tables_kernarg(c, pcof_host, n_pcof);      // (no tail to balance, or k_front balances it itself: the plain tables kernel)
+    if (front_pre_count(c->nt) == 0 || qgd_path("front_nopre")) return qgdk_tables_kernarg(c, pcof_host, n_pcof);      // (no tail to balance: the plain tables kernel)
     if (n_pcof <= 64) return launch_tables_front_m<64>(c, pcof_host, n_pcof);
     if (n_pcof <= 192) return launch_tables_front_m<192>(c, pcof_host, n_pcof);
     if (n_pcof <= QGD_PCOF_KERNARG) return launch_tables_front_m<QGD_PCOF_KERNARG>(c, pcof_host, n_pcof);

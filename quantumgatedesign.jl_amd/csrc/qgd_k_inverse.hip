@@ -491,8 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv, const double *__restrict__ ell_val,
              const double *__restrict__ tab, const double *__restrict__ cw, int n_ops, int Z,
              double *__restrict__ Eh, double *__restrict__ Fh, double *__restrict__ LinvT, double *__restrict__ Pr,
-             double *__restrict__ Pc, int *__restrict__ status, int *__restrict__ fallbacks, const int pre_nt,
-             int *__restrict__ coop_flags, const int coop_target, const int nt)
+             double *__restrict__ Pc, int *__restrict__ status, int *__restrict__ fallbacks, const int pre_nt)
 {
     extern __shared__ __attribute__((aligned(32))) double front_smem[];
     __shared__ int rho[64], rinv[64];
@@ -500,28 +499,10 @@ void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ el
     constexpr size_t panel = 64 * 128, pl = 64 * 64;
     const int n = blockIdx.x;
     FRONT_STAMP(0);
-    const int cx = coop_flags ? front_coop_extra(nt) : 0;
-    if (cx && n >= 512) {
-        // a third workgroup of its CU: its step matrices come from four producers (qgd_front.h)
-        if (threadIdx.x == 0) {
-            int it = 0;
-            while (__hip_atomic_load(coop_flags + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < coop_target && it < FRONT_COOP_SPINS) { __builtin_amdgcn_s_sleep(32); it++; }
-            if (it >= FRONT_COOP_SPINS) atomicMax(status, 2);      // (never, while the producers run: the evaluation fails loudly)
-            __threadfence();                              // acquire: the producers' panels, written on other XCDs
-        }
-    } else if (!(pre_nt && front_is_prebuilt(n, pre_nt))) {
+    if (!(pre_nt && front_is_prebuilt(n, pre_nt))) {
         // (the build ahead of everything else on the CU: a workgroup that is still building while its neighbours eliminate at
         //  raised priority crawls -- 113 -> 109 us for the 551 time points of the headline)
         __builtin_amdgcn_s_setprio(FRONT_PRIO_BUILD);
-        if (cx && n >= cx && n < 256) {
-            const int nprod = 256 - cx;
-            for (int t = n - cx; t < 4 * cx; t += nprod) {
-                const int nc = 512 + (t >> 2), sl = t & 3;
-                front_build<M, NOPS>(front_smem, ell_col, ell_inv, ell_val, tab, cw, nc, n_ops, Z, Eh + (size_t)nc * panel, Fh + (size_t)nc * panel, sl, sl + 1);
-                __syncthreads();                          // (vmcnt(0): the slab has left this CU; and the work space is free for the next prologue)
-                if (threadIdx.x == 0) { __threadfence(); atomicAdd(coop_flags + nc, 1); }      // release, then the count
-            }
-        }
         front_build<M, NOPS>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
         __builtin_amdgcn_s_setprio(0);
     }
@@ -1128,21 +1109,15 @@ template <int M, int NOPS>
 static int launch_front(const qgdk_ctx *c)
 {
     const size_t shm = front_lds(M, c->ell_z);
-    const int nt = c->nt;
-    // how the workgroups past two per CU get their step matrices: cooperative build inside this launch (default), pre-built by
-    // the tables launch (QGD_PATHS=front_prebuild), or by themselves (front_nopre) -- A/B tokens
-    const bool coop = c->coop_flags && front_coop_extra(nt) > 0 && !qgd_path("front_prebuild") && !qgd_path("front_nopre");
-    const int pre_nt = (coop || qgd_path("front_nopre")) ? 0 : nt;
-    int *flags = coop ? c->coop_flags : nullptr;
-    const int target = 4 * c->coop_epoch;
+    const int nt = c->nt, pre_nt = qgd_path("front_nopre") ? 0 : nt;      // (A/B: no pre-built step matrices)
     if (nt > CB_ONE_ALONE && nt <= CB_ONE_ROUND) {
         SET_LDS_ONCE((k_front<M, NOPS, true>), shm);
         hipLaunchKernelGGL((k_front<M, NOPS, true>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
-                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt, flags, target, nt);
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
     } else {
         SET_LDS_ONCE((k_front<M, NOPS, false>), shm);
         hipLaunchKernelGGL((k_front<M, NOPS, false>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
-                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt, flags, target, nt);
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
     }
     return (int)hipGetLastError();
 }
@@ -1154,11 +1129,6 @@ int qgdk_front_supported(const qgdk_ctx *c)
 {
     if (c->Np != 64 || !c->use_sparse || c->m < 1 || c->m > 4 || c->ell_z < 1 || c->ell_z > 16) return 0;
     return front_lds(c->m, c->ell_z) <= 53 * 1024 ? 1 : 0;      // three workgroups per CU
-}
-
-int qgdk_front_cooperative(const qgdk_ctx *c)
-{
-    return (c->coop_flags && front_coop_extra(c->nt) > 0 && !qgd_path("front_prebuild") && !qgd_path("front_nopre")) ? 1 : 0;
 }
 
 int qgdk_front(const qgdk_ctx *c)
