@@ -74,9 +74,9 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
 KERNEL_OF_PHASE = {"build_LR": "k_build_LR_ell", "inverse": "k_inverse_cb", "propagator": "k_propagator",
                    "lambda": "k_lambda", "guard": "k_guard_diag", "front": "k_front", "psi": "k_psi"}
 CNOT2_PROFILE = "r05_cnot2_launches.json"           # scripts/cnot2_profile.sh: launches per evaluation from rocprofv3 kernel statistics
-PMC_PROFILE = "r05_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
-PMC_MFMA_PROFILE = "r05_pmc_mfma_cnot3.json"
-STATS_PROFILE = "r05_kernel_stats_cnot3.csv"         # rocprofv3 --kernel-trace --stats of this command (scripts/collect_profiles.sh)
+PMC_PROFILE = "r06_pmc_fetch_write_cnot3.json"      # regenerated for this round's kernels (profiles/README.md)
+PMC_MFMA_PROFILE = "r06_pmc_mfma_cnot3.json"
+STATS_PROFILE = "r06_kernel_stats_cnot3.csv"         # rocprofv3 --kernel-trace --stats of this command (scripts/collect_profiles.sh)
 
 
 def _lookup_kernel(table, kern):

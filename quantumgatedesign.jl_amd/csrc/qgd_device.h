@@ -145,6 +145,7 @@ int qgdk_tables(const qgdk_ctx *c, const double *pcof_dev);
 int qgdk_tables_from_host(const qgdk_ctx *c, const double *pt_dev, const double *qt_dev);
 #define QGD_PCOF_KERNARG 448      /* doubles of pcof that fit beside the other kernel arguments (4 KB) */
 int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof);
+int qgdk_front_pre_plan(const qgdk_ctx *c, int *q2, int *q1);   /* how many second / first workgroups of k_front start from pre-built step matrices; returns extra */
 int qgdk_front_supported(const qgdk_ctx *c);   /* Np = 64, sparse operators, order <= 8, the build's LDS beside the elimination's */
 int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof);   /* tables + the pre-built step matrices + phi_0 */
 int qgdk_front(const qgdk_ctx *c);             /* L_n^-H, S_n for every time point: build + elimination in one workgroup */

@@ -61,7 +61,7 @@ __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__r
     __syncthreads();
     // this lane's element of a panel row: column r of L^H / R^H
     const int ocol = (r >> 3) * 16 + (r & 7);
-    _Pragma("unroll 1") for (int s = (SPAR > 1 ? (tid >> 8) : 0); s < (SPAR > 1 ? (tid >> 8) + 1 : 4); s++) {
+    _Pragma("unroll 1") for (int s = (SPAR > 1 ? (tid >> 8) : 0); s < 4; s += SPAR) {
         const int c0 = CW * s + cl;                     // first of this thread's four columns of L, R
         const uint32_t slots = (s == 0) ? slot4[0] : (s == 1) ? slot4[1] : (s == 2) ? slot4[2] : slot4[3];
         c2 T[M][4], Lacc[4], Racc[4];
@@ -123,18 +123,19 @@ __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__r
     }
 }
 
-// Which workgroups of k_front find their L_n^H, R_n^H built by the launch in front of it (k_tables_front).  The launch is one
-// round of up to three workgroups per CU, workgroups b, b + 256, b + 512 on one CU: with nt = 512 + extra time points the CUs
-// 0 .. extra-1 hold three, and the launch ends with them.  Their second and third workgroups start with the elimination
-// while the first one builds.
+// Which workgroups of k_front find their L_n^H, R_n^H built by the launch in front of it (k_tables_front).  k_front is one round
+// of up to three workgroups per CU, workgroups b, b + 256, b + 512 on one CU: with nt = 512 + extra time points the CUs
+// 0 .. extra-1 hold three, and the launch ends with them.  Pre-built: every third workgroup (b >= 512), the second workgroups
+// b = 256 .. 256 + q2 - 1 and the first workgroups b = 0 .. q1 - 1 (q1 <= extra) -- they start with the elimination while the
+// rest of their CU builds.  (q2, q1) is the library's choice (qgdk_front_pre_plan: q2 = extra, q1 = 0), measured in EXPERIMENTS.md "Round 6".
+struct FrontPre { int extra, q2, q1; };
 __host__ __device__ static inline int front_extra(int nt) { const int e = nt - 512; return e < 0 ? 0 : (e > 256 ? 0 : e); }      // (beyond one round: no tail to balance)
-__host__ __device__ static inline int front_pre_count(int nt) { return 2 * front_extra(nt); }
-__host__ __device__ static inline int front_pre_point(int j, int nt)      // the time point of pre-built workgroup j
+__host__ __device__ static inline int front_pre_count(const FrontPre p) { return p.extra + p.q2 + p.q1; }
+__host__ __device__ static inline int front_pre_point(int j, const FrontPre p)      // the time point of pre-built workgroup j
 {
-    const int e = front_extra(nt);
-    return j < e ? 256 + j : 512 + (j - e);
+    return j < p.extra ? 512 + j : (j < p.extra + p.q2 ? 256 + (j - p.extra) : j - p.extra - p.q2);
 }
-__host__ __device__ static inline bool front_is_prebuilt(int n, int nt)
+__host__ __device__ static inline bool front_is_prebuilt(int n, const FrontPre p)
 {
-    return n >= 256 && (n & 255) < front_extra(nt);
+    return n >= 512 ? p.extra > 0 : (n >= 256 ? n - 256 < p.q2 : n < p.q1);
 }

@@ -559,6 +559,9 @@ int qgd_set_target(qgd_handle h, const double *target_real)
     HIP_TRY(h, hipMemcpy(k.target, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
     h->target_host.assign(target_real, target_real + (size_t)2 * k.N * k.c);
     k.have_target = 1;
+    // (a stored forward sweep of the fused front carries L_N^-H target with it: a history_precomputed call after a new target
+    //  redoes the sweep instead of reusing it)
+    if (h->front_last) h->fwd_pcof.clear();
     return QGD_OK;
 }
 
@@ -571,6 +574,7 @@ int qgd_set_cost_type(qgd_handle h, int32_t cost_type)
     if (h->k.cost_type == cost_type) return QGD_OK;      // (a shim that sets it on every call must not cost a captured graph)
     drop_graph(h);
     h->k.cost_type = cost_type;     // (a stored forward sweep stays valid: history_precomputed re-forms the terminal condition)
+    if (h->front_last) h->fwd_pcof.clear();      // (... unless it is the fused front's, which forms :Infidelity terminal values only: the sweep is redone)
     return QGD_OK;
 }
 

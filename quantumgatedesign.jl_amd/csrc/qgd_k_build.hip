@@ -100,12 +100,12 @@ extern "C" int qgdk_stamps_build(unsigned long long *out) { return (int)hipMemcp
 #else
 #define TF_STAMP(i) do { } while (0)
 #endif
-template <int NMAX, int M, int NOPS>
-__global__ __launch_bounds__(1024) void k_tables_front(const double *__restrict__ G, const int64_t *__restrict__ goff,
+template <int NMAX, int M, int NOPS, int NTH>
+__global__ __launch_bounds__(NTH) void k_tables_front(const double *__restrict__ G, const int64_t *__restrict__ goff,
                          const int32_t *__restrict__ ncoef, const int32_t *__restrict__ poff,
                          const PcofArg<NMAX> pcof, double *__restrict__ tab, const int nt, const int n_ops,
                          double *__restrict__ scal, int *__restrict__ status,
-                         const int npre, const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv,
+                         const FrontPre pre, const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv,
                          const double *__restrict__ ell_val, const double *__restrict__ cw, const int Z,
                          double *__restrict__ Eh, double *__restrict__ Fh)
 {
@@ -132,16 +132,17 @@ __global__ __launch_bounds__(1024) void k_tables_front(const double *__restrict_
         return row16_sum(s);
     };
     TF_STAMP(0);
+    const int npre = front_pre_count(pre);
     if ((int)blockIdx.x < npre) {
-        const int n = front_pre_point(blockIdx.x, nt);
-        for (int e = threadIdx.x >> 4; e < per; e += 64) {
+        const int n = front_pre_point(blockIdx.x, pre);
+        for (int e = threadIdx.x >> 4; e < per; e += NTH / 16) {
             const double s = entry(n * per + e);
             if (sub == 15) tab[n * per + e] = s;
         }
         __syncthreads();
         TF_STAMP(1);
         constexpr size_t panel = 64 * 128;
-        front_build<M, NOPS, 1024>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
+        front_build<M, NOPS, NTH>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
         TF_STAMP(2);
         return;
     }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(1024) void k_tables_front(const double *__restrict_
         if (threadIdx.x == 4) *status = 0;
         if (threadIdx.x == 5) inverse_memory(status, nt);
     }
-    for (int idx = tb * 64 + (threadIdx.x >> 4); idx < total; idx += ntb * 64) {
+    for (int idx = tb * (NTH / 16) + (threadIdx.x >> 4); idx < total; idx += ntb * (NTH / 16)) {
         const double s = entry(idx);
         if (sub == 15) tab[idx] = s;
     }
@@ -447,19 +448,29 @@ static int launch_tables_arg(const qgdk_ctx *c, const double *pcof_host, int n_p
     return (int)hipGetLastError();
 }
 
-template <int NMAX, int M, int NOPS>
-static int launch_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+template <int NMAX, int M, int NOPS, int NTH>
+static int launch_tables_front_n(const qgdk_ctx *c, const double *pcof_host, int n_pcof, const FrontPre pre, int ntb)
 {
     PcofArg<NMAX> arg;
     memcpy(arg.v, pcof_host, sizeof(double) * n_pcof);
-    const size_t shm = front_build_lds(M, c->ell_z, 4);
-    SET_LDS_ONCE((k_tables_front<NMAX, M, NOPS>), shm);
-    const int total = c->nt * (c->m + 1) * c->n_ops * 2, npre = front_pre_count(c->nt);
-    int ntb = (total + 63) / 64; if (ntb > 256 - npre) ntb = (npre < 192) ? 256 - npre : 64;
-    hipLaunchKernelGGL((k_tables_front<NMAX, M, NOPS>), dim3(npre + ntb), dim3(1024), shm, c->stream, c->G, c->goff, c->ncoef, c->poff, arg,
-                       c->tab, c->nt, c->n_ops, c->scal, c->status, npre, c->ell_col, c->ell_inv, c->ell_val, c->cw, c->ell_z,
+    const size_t shm = front_build_lds(M, c->ell_z, NTH / 256);
+    SET_LDS_ONCE((k_tables_front<NMAX, M, NOPS, NTH>), shm);
+    hipLaunchKernelGGL((k_tables_front<NMAX, M, NOPS, NTH>), dim3(front_pre_count(pre) + ntb), dim3(NTH), shm, c->stream, c->G, c->goff, c->ncoef, c->poff, arg,
+                       c->tab, c->nt, c->n_ops, c->scal, c->status, pre, c->ell_col, c->ell_inv, c->ell_val, c->cw, c->ell_z,
                        c->L, c->R);
     return (int)hipGetLastError();
+}
+
+// One round of workgroups: the pre-building workgroups (at most 192, qgdk_front_pre_plan) go one per CU with 1024 threads (the
+// four slabs side by side) beside at least 64 table workgroups.
+template <int NMAX, int M, int NOPS>
+static int launch_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
+{
+    FrontPre pre{0, 0, 0};
+    pre.extra = qgdk_front_pre_plan(c, &pre.q2, &pre.q1);
+    const int npre = front_pre_count(pre), total = c->nt * (c->m + 1) * c->n_ops * 2;
+    int ntb = (total + 63) / 64; if (ntb > 256 - npre) ntb = 256 - npre;
+    return launch_tables_front_n<NMAX, M, NOPS, 1024>(c, pcof_host, n_pcof, pre, ntb);
 }
 
 template <int NMAX>
@@ -496,7 +507,7 @@ int qgdk_tables_kernarg(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
 // the fused-front path's first launch (qgdk_front_supported; pcof in the kernel arguments, the basis covering exactly the grid)
 int qgdk_tables_front(const qgdk_ctx *c, const double *pcof_host, int n_pcof)
 {
-    if (front_pre_count(c->nt) == 0 || qgd_path("front_nopre")) return qgdk_tables_kernarg(c, pcof_host, n_pcof);      // (no tail to balance: the plain tables kernel)
+    { int q2, q1; if (qgdk_front_pre_plan(c, &q2, &q1) == 0) return qgdk_tables_kernarg(c, pcof_host, n_pcof); }      // (no tail to balance: the plain tables kernel)
     if (n_pcof <= 64) return launch_tables_front_m<64>(c, pcof_host, n_pcof);
     if (n_pcof <= 192) return launch_tables_front_m<192>(c, pcof_host, n_pcof);
     if (n_pcof <= QGD_PCOF_KERNARG) return launch_tables_front_m<QGD_PCOF_KERNARG>(c, pcof_host, n_pcof);

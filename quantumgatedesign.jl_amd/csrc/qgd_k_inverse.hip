@@ -483,15 +483,15 @@ __device__ unsigned long long g_front_prof[4096][4];      // wall clock (100 MHz
 
 // The fused front (qgd_front.h): workgroup n builds L_n^H, R_n^H into Eh[n], Fh[n] and eliminates [L_n^H | R_n^H] in place of
 // k_build_LR_ell + k_inverse_cb.  LinvT[n] = L_n^-H (row-major planes); Pc[n] / Pr[n] = S_n = R_n L_n^-1 as column-major planes /
-// row-major panel -- what the sweeps read where the two-point form has P_n -- for n = 0 .. nt-1.  pre_nt = nt: the time points
-// front_is_prebuilt(n, nt) were built by the launch in front (k_tables_front / k_front_pre); 0: every workgroup builds its own.
+// row-major panel -- what the sweeps read where the two-point form has P_n -- for n = 0 .. nt-1.  pre: the time points
+// front_is_prebuilt(n, pre) were built by the launch in front (k_tables_front / k_front_pre); all zero: every workgroup builds its own.
 // Dynamic LDS: max(front_build_lds, the column-block kernel's work space).
 template <int M, int NOPS, bool ONE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv, const double *__restrict__ ell_val,
              const double *__restrict__ tab, const double *__restrict__ cw, int n_ops, int Z,
              double *__restrict__ Eh, double *__restrict__ Fh, double *__restrict__ LinvT, double *__restrict__ Pr,
-             double *__restrict__ Pc, int *__restrict__ status, int *__restrict__ fallbacks, const int pre_nt)
+             double *__restrict__ Pc, int *__restrict__ status, int *__restrict__ fallbacks, const FrontPre pre)
 {
     extern __shared__ __attribute__((aligned(32))) double front_smem[];
     __shared__ int rho[64], rinv[64];
@@ -499,7 +499,7 @@ void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ el
     constexpr size_t panel = 64 * 128, pl = 64 * 64;
     const int n = blockIdx.x;
     FRONT_STAMP(0);
-    if (!(pre_nt && front_is_prebuilt(n, pre_nt))) {
+    if (!front_is_prebuilt(n, pre)) {
         // (the build ahead of everything else on the CU: a workgroup that is still building while its neighbours eliminate at
         //  raised priority crawls -- 113 -> 109 us for the 551 time points of the headline)
         __builtin_amdgcn_s_setprio(FRONT_PRIO_BUILD);
@@ -518,11 +518,11 @@ void k_front(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ el
 template <int M, int NOPS>
 __global__ __launch_bounds__(256) void k_front_pre(const int32_t *__restrict__ ell_col, const uint8_t *__restrict__ ell_inv, const double *__restrict__ ell_val,
                                                    const double *__restrict__ tab, const double *__restrict__ cw, int n_ops, int Z,
-                                                   double *__restrict__ Eh, double *__restrict__ Fh, const int nt)
+                                                   double *__restrict__ Eh, double *__restrict__ Fh, const FrontPre pre)
 {
     extern __shared__ __attribute__((aligned(32))) double front_smem[];
     constexpr size_t panel = 64 * 128;
-    const int n = front_pre_point(blockIdx.x, nt);
+    const int n = front_pre_point(blockIdx.x, pre);
     front_build<M, NOPS>(front_smem, ell_col, ell_inv, ell_val, tab, cw, n, n_ops, Z, Eh + (size_t)n * panel, Fh + (size_t)n * panel);
 }
 static inline size_t front_lds(int M, int Z)
@@ -1109,15 +1109,17 @@ template <int M, int NOPS>
 static int launch_front(const qgdk_ctx *c)
 {
     const size_t shm = front_lds(M, c->ell_z);
-    const int nt = c->nt, pre_nt = qgd_path("front_nopre") ? 0 : nt;      // (A/B: no pre-built step matrices)
+    const int nt = c->nt;
+    FrontPre pre{0, 0, 0};
+    pre.extra = qgdk_front_pre_plan(c, &pre.q2, &pre.q1);
     if (nt > CB_ONE_ALONE && nt <= CB_ONE_ROUND) {
         SET_LDS_ONCE((k_front<M, NOPS, true>), shm);
         hipLaunchKernelGGL((k_front<M, NOPS, true>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
-                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre);
     } else {
         SET_LDS_ONCE((k_front<M, NOPS, false>), shm);
         hipLaunchKernelGGL((k_front<M, NOPS, false>), dim3(nt), dim3(256), shm, c->stream, c->ell_col, c->ell_inv, c->ell_val, c->tab, c->cw, c->n_ops, c->ell_z,
-                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre_nt);
+                           c->L, c->R, c->LinvT, c->Pr, c->Pc, c->status, c->status + 1, pre);
     }
     return (int)hipGetLastError();
 }
@@ -1129,6 +1131,19 @@ int qgdk_front_supported(const qgdk_ctx *c)
 {
     if (c->Np != 64 || !c->use_sparse || c->m < 1 || c->m > 4 || c->ell_z < 1 || c->ell_z > 16) return 0;
     return front_lds(c->m, c->ell_z) <= 53 * 1024 ? 1 : 0;      // three workgroups per CU
+}
+
+// Which workgroups of k_front start from step matrices the tables launch built (qgd_front.h: FrontPre): the third workgroup
+// and the second of every CU that holds three -- as long as they fit, one per CU, beside 64 table workgroups.  (More was
+// measured, up to every second and third workgroup and the first ones of the CUs that hold three -- scripts/front_pre_sweep.py,
+// EXPERIMENTS.md "Round 6": the tables launch grows by what the front kernel gains.)  QGD_PATHS=front_nopre: none (A/B).
+int qgdk_front_pre_plan(const qgdk_ctx *c, int *q2, int *q1)
+{
+    const int extra = qgd_path("front_nopre") ? 0 : front_extra(c->nt);
+    int a = extra;
+    if (extra + a > 192) a = 192 - extra;
+    *q2 = a > 0 ? a : 0; *q1 = 0;
+    return extra <= 192 ? extra : 0;
 }
 
 int qgdk_front(const qgdk_ctx *c)

@@ -84,6 +84,8 @@ int main(int argc, char **argv)
     if (argc > 4 && atoi(argv[4])) { const int onei = 1; hipMemcpy(dS + 11, &onei, 4, hipMemcpyHostToDevice); }      // fused kernel: skip the diagonal attempt (fallbacks[2])
 
     const int n_pre = argc > 3 ? atoi(argv[3]) : 0;       // 1: the time points front_is_prebuilt() are built by a launch in front of k_front (the library: by k_tables_front)
+    FrontPre pre{0, 0, 0};
+    if (n_pre) { pre.extra = front_extra(nt); pre.q2 = pre.extra; }
     const bool one = argc > 2 ? atoi(argv[2]) != 0 : (nt > CB_ONE_ALONE && nt <= CB_ONE_ROUND);
     const size_t shm_b = lds_build_ell(M, Z, 8), shm_f = front_lds(M, Z);
     hipFuncSetAttribute((const void *)k_build_LR_ell<M, 8, NOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_b);
@@ -97,9 +99,9 @@ int main(int argc, char **argv)
             if (one) hipLaunchKernelGGL(k_inverse_cb<true>, dim3(nt - 1), dim3(256), 0, 0, dL, dR, dT[0], dPr[0], dPc[0], 1, dS, dS + 1);
             else hipLaunchKernelGGL(k_inverse_cb<false>, dim3(nt - 1), dim3(256), 0, 0, dL, dR, dT[0], dPr[0], dPc[0], 1, dS, dS + 1);
         } else {
-            if (n_pre) hipLaunchKernelGGL((k_front_pre<M, NOPS>), dim3(front_pre_count(nt)), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, nt);
-            if (one) hipLaunchKernelGGL((k_front<M, NOPS, true>), dim3(nt), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, dT[1], dPr[1], dPc[1], dS + 8, dS + 9, n_pre ? nt : 0);
-            else hipLaunchKernelGGL((k_front<M, NOPS, false>), dim3(nt), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, dT[1], dPr[1], dPc[1], dS + 8, dS + 9, n_pre ? nt : 0);
+            if (n_pre) hipLaunchKernelGGL((k_front_pre<M, NOPS>), dim3(front_pre_count(pre)), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, pre);
+            if (one) hipLaunchKernelGGL((k_front<M, NOPS, true>), dim3(nt), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, dT[1], dPr[1], dPc[1], dS + 8, dS + 9, pre);
+            else hipLaunchKernelGGL((k_front<M, NOPS, false>), dim3(nt), dim3(256), shm_f, 0, d_col, d_inv, d_val, d_tab, d_cw, NOPS, Z, dE, dF, dT[1], dPr[1], dPc[1], dS + 8, dS + 9, pre);
         }
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -158,10 +158,21 @@ def test_front_eligibility_and_reuse(qgd, monkeypatch):
     assert not dp.front_path_taken() and np.abs(gf - g).max() <= 1e-11 * gs
     g3, _ = dp.discrete_adjoint(pcof)
     assert dp.front_path_taken() and np.array_equal(g3, g2)
+    # a stored front sweep is not reused across a change of cost type or target (its terminal value is :Infidelity's, with the
+    # target it was computed for): history_precomputed then redoes the sweep on the path that applies
     dp.set_cost_type("Tracking")
-    dp.discrete_adjoint(pcof)
+    gt, _ = dp.discrete_adjoint(pcof, history_precomputed=True)
     assert not dp.front_path_taken()
+    gt2, _ = dp.discrete_adjoint(pcof)
+    assert np.abs(gt - gt2).max() <= 1e-13 * np.abs(gt2).max()
     dp.set_cost_type("Infidelity")
+    dp.eval_forward(pcof)
+    t2 = target[:, ::-1].copy()
+    dp.set_target(t2)
+    gn, _ = dp.discrete_adjoint(pcof, history_precomputed=True)
+    refn = pp.evaluate(prob, Gp, Gq, off, pcof, t2, order)
+    assert np.abs(gn - refn["grad"]).max() <= 1e-11 * np.abs(refn["grad"]).max()
+    dp.set_target(target)
     dp.set_memory_budget(40 << 20)
     if dp.memory_plan()["windows"] > 1:
         g4, _ = dp.discrete_adjoint(pcof)
