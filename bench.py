@@ -58,9 +58,11 @@ def phase_model(N, c, m, n_ops, nt, sparse_ops=False, fused_propagator=True):
         "inverse": ("mfma", (nt - 1) * cgemm * (2 if fused_propagator else 1)),
         "propagator": ("mfma", (nt - 1) * cgemm),
         "lambda": ("hbm", (nt - 1) * (mat_b + 2 * hist_b)),
-        # fused front (csrc/qgd_front.h): per time point the Gauss-Jordan inverse of L^H and S^H = L^-H R^H (the build of L, R rides
-        # in the same workgroup on the vector ALU and is not counted); psi: L^-H once, phi in, psi / f / h out
-        "front": ("mfma", nt * cgemm * 2),
+        # fused front (csrc/qgd_front.h): per time point the Gauss-Jordan inverse of L^H and S^H = L^-H R^H on the MFMA (2 cgemm) and
+        # the build of L, R from the ELL operators on the fp64 vector ALU (0.76 GFLOP per 551 time points, DESIGN.md section 4:
+        # k_build_LR_ell's count) -- on gfx950 the two share one fp64 arithmetic pipe, so one peak prices both;
+        # psi: L^-H once, phi in, psi / f / h out
+        "front": ("mfma", nt * cgemm * 2 + (0.76e9 * nt / 551.0 if sparse_ops else 0.0)),
         "psi": ("hbm", nt * (mat_b + 4 * hist_b)),
         "guard": ("hbm", nt * (3 * hist_b)),
     }

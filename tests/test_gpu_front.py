@@ -199,3 +199,29 @@ def test_front_non_finite_coefficients(qgd):
         g1, o1 = dp.discrete_adjoint(pcof)
         assert np.array_equal(g1, g0) and np.array_equal(np.asarray(o1), np.asarray(o0)), bad
     dp.close()
+
+
+def test_front_padded_problem(qgd, orc, monkeypatch):
+    """N = 60 = (5, 4, 3) levels in 64 x 64 tiles (rows and columns 60..63 are padding: identity in L and R, zero in the states),
+    two of three controls' worth of guard levels, order 6: the front against the general path and the oracle."""
+    freqs = 2 * np.pi * np.array([4.10595, 4.81526, 7.8447])
+    kerr = 2 * np.pi * np.array([[0.2198, 1e-6, 0.0025], [1e-6, 0.2252, 0.0025], [0.0025, 0.0025, 3e-5]])
+    nsteps = 10
+    prob = qgd.DispersiveProblem((5, 4, 3), (2, 2, 2), freqs, freqs, kerr, float(nsteps), nsteps, sparse_rep=False,
+                                 gmres_abstol=1e-15, gmres_reltol=1e-15)
+    assert prob.N_tot_levels == 60
+    ctrl = cases.cnot3_controls(qgd, prob)
+    rng = np.random.default_rng(5)
+    pcof = (rng.random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
+    target = cases.rand_target(prob, 7)
+    order = 6
+    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "", monkeypatch)
+    g = _evaluate(qgd, prob, ctrl, pcof, target, order, "no_front", monkeypatch)
+    assert f["front"] and not g["front"]
+    gs = np.abs(g["g"]).max()
+    assert np.abs(f["g"] - g["g"]).max() <= 1e-12 * gs and np.abs(f["o3"] - g["o3"]).max() <= 1e-12
+    assert np.abs(f["hist"] - g["hist"]).max() <= 1e-12 and np.abs(f["lam"] - g["lam"]).max() <= 1e-12 * np.abs(g["lam"]).max()
+    Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
+    r = pp.evaluate_local(prob, Gp, Gq, off, pcof, target, order)
+    assert np.abs(f["g"] - r["grad"]).max() <= 1e-11 * gs
+    assert cases.oracle_pins(orc, prob, ctrl, pcof, target, order, r)
