@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                              const int cp, const int nt, const int gN, const double dt, const double tf)
 {
     constexpr int NPC = 64, XS = 68;
-    __shared__ double xs[NPC * XS];                      // one plane of X_n at a time, then the right operands
+    __shared__ __attribute__((aligned(16))) double xs[NPC * XS];      // one plane of X_n at a time, then the right operands
     double *bs = xs;
     __shared__ double red[16];
     const int n = blockIdx.x, grp = blockIdx.y;      // (time point fastest: the workgroups of a CU are then three different time points)
@@ -1457,18 +1457,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int c16 = lane & 15, kk = lane >> 4, arow = wave * 16 + c16;
     const double *Tre = LinvT + (size_t)n * 2 * pl, *Tim = Tre + pl;
     const bool guard = guard_diag != nullptr, last = (n == nt - 1) && target != nullptr;
-    // X_n is read from memory ONCE, in runs of 128 bytes per thread (both left operands read straight from global memory --
+    // X_n is read from memory ONCE (both left operands read straight from global memory --
     // the second one with the lanes of a row block 512 bytes apart -- took 26 us for the 551 time points of the headline
     // against 11.6 for k_lambda_c's single pass: 4.4 MB of L^-H per XCD do not stay in its 4 MB of L2 between the two).
     // Each plane goes through LDS, where X^H (16 consecutive rows of one k) and X (16 consecutive k of one row) are both
     // fragment reads.
-    const int srow = threadIdx.x >> 2, sq = (threadIdx.x & 3) * 16;
+    // (every load instruction of a wave reads 1 KB contiguous: thread t takes the 16-byte pieces t, t + 256, ... of a plane)
     PSI_STAMP(0);
     double xr[16], xi[16];
     #pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const psi_d2 vr = *reinterpret_cast<const psi_d2 *>(Tre + (size_t)srow * NPC + sq + j), vi = *reinterpret_cast<const psi_d2 *>(Tim + (size_t)srow * NPC + sq + j);
-        xr[j] = vr[0]; xr[j + 1] = vr[1]; xi[j] = vi[0]; xi[j + 1] = vi[1];
+    for (int q = 0; q < 8; q++) {
+        const int e2 = 2 * (q * 256 + (int)threadIdx.x);
+        const psi_d2 vr = *reinterpret_cast<const psi_d2 *>(Tre + e2), vi = *reinterpret_cast<const psi_d2 *>(Tim + e2);
+        xr[2 * q] = vr[0]; xr[2 * q + 1] = vr[1]; xi[2 * q] = vi[0]; xi[2 * q + 1] = vi[1];
     }
     const double *src = (n > 0) ? phist + (size_t)n * hstep : psi0;
     double bv[4];
@@ -1476,13 +1477,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int q = 0; q < 4; q++) { const int e = threadIdx.x + 256 * q; bv[q] = src[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)]; }
     double are[NPC / 4], aim[NPC / 4], are2[NPC / 4], aim2[NPC / 4];
     #pragma unroll
-    for (int j = 0; j < 16; j++) xs[srow * XS + sq + j] = xr[j];
+    for (int q = 0; q < 8; q++) {
+        const int e2 = 2 * (q * 256 + (int)threadIdx.x);
+        *reinterpret_cast<psi_d2 *>(xs + (e2 >> 6) * XS + (e2 & 63)) = (psi_d2){xr[2 * q], xr[2 * q + 1]};
+    }
     __syncthreads();
     #pragma unroll
     for (int i = 0; i < NPC / 4; i++) { are[i] = xs[(4 * i + kk) * XS + arow]; are2[i] = xs[arow * XS + 4 * i + kk]; }
     __syncthreads();
     #pragma unroll
-    for (int j = 0; j < 16; j++) xs[srow * XS + sq + j] = xi[j];
+    for (int q = 0; q < 8; q++) {
+        const int e2 = 2 * (q * 256 + (int)threadIdx.x);
+        *reinterpret_cast<psi_d2 *>(xs + (e2 >> 6) * XS + (e2 & 63)) = (psi_d2){xi[2 * q], xi[2 * q + 1]};
+    }
     __syncthreads();
     #pragma unroll
     for (int i = 0; i < NPC / 4; i++) { aim[i] = xs[(4 * i + kk) * XS + arow]; aim2[i] = xs[arow * XS + 4 * i + kk]; }
