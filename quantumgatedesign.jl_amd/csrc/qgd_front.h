@@ -12,11 +12,14 @@
 //      transposition is in the store addresses and the stores are runs of 64 bytes; no staging through LDS;
 //   B. eliminate [E | F] -> [E^-1 | E^-1 F] = [L_n^-H | S_n^H] with the column-block Gauss-Jordan of qgd_inverse_cb.h as it
 //      stands, pivot stages and all (its loads find E and F in the L2 of the XCD that has just written them).
-// What leaves the kernel: X = L_n^-H as row-major planes (left operand of psi_n = L_n^-1 phi_n = X^H phi_n, read the way
-// k_lambda_c reads L^-1 for L^-H y), Y = S_n^H as a row-major panel (left operand Y^H = S_n of the forward sweep, read the
-// way the adjoint sweep reads P for P^H) and as column-major planes (left operand Y = S_n^H of the adjoint sweep, read the
-// way the forward sweep reads P).  No launch boundary between build and elimination, and the build's latency-bound phases
-// (lists and operator values from global memory, LDS gathers) run beside the MFMA stretches of the CU's other workgroups.
+// What leaves the kernel: X = L_n^-H as row-major planes in LinvT (left operand of psi_n = L_n^-1 phi_n = X^H phi_n and of
+// h_n = X f_n: k_psi), and S_n exactly where and how the two-point form keeps P_n -- column-major planes in Pc (left operand of
+// the forward scan), row-major panel in Pr (left operand S_n^H of the adjoint scan) -- so the scan kernels did not change.
+// With Y = S_n^H in the accumulators, S in column-major planes is conj(Y) in row-major planes (straight from the registers, the
+// sign of the imaginary plane flipped) and S as a row-major panel is conj(Y) as a column-major panel (through the wave's LDS
+// slab): qgd_inverse_cb.h, cb_wave<.., FRONT>.  No launch boundary between build and elimination, and the build's
+// latency-bound phases run beside the MFMA stretches of the CU's other workgroups; the panels of L^H and R^H still pass
+// through memory (three workgroups per CU leave no room for 128 KB).  Measured: EXPERIMENTS.md "Round 6".
 #pragma once
 #include "qgd_ell.h"
 
