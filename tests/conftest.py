@@ -29,6 +29,8 @@ def _works_on_a_small_problem(metafunc):
         text = inspect.getsource(metafunc.function)
     except (OSError, TypeError):
         text = ""
+    if "subprocess" in text:        # (the work happens in child processes, which run on the library's defaults whatever this process does)
+        return False
     text += " ".join(str(m.args) for m in metafunc.definition.iter_markers("parametrize"))
     return any(w in text for w in _SMALL_WORDS)
 
