@@ -574,7 +574,7 @@ int qgd_set_cost_type(qgd_handle h, int32_t cost_type)
     if (h->k.cost_type == cost_type) return QGD_OK;      // (a shim that sets it on every call must not cost a captured graph)
     drop_graph(h);
     h->k.cost_type = cost_type;     // (a stored forward sweep stays valid: history_precomputed re-forms the terminal condition)
-    if (h->front_last) h->fwd_pcof.clear();      // (... unless it is the fused front's, which forms :Infidelity terminal values only: the sweep is redone)
+    if (h->front_last) h->fwd_pcof.clear();      // (... unless it is the fused front's, whose k_psi formed the terminal value of the OLD cost type: the sweep is redone)
     return QGD_OK;
 }
 

@@ -162,13 +162,13 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 
 
 // Does this evaluation take the fused front (qgd_front.h)?  A full evaluation on one rank with the grid resident, the control
-// basis on the device and pcof small enough for the kernel arguments, a diagonal guard projector or none, :Infidelity.
+// basis on the device and pcof small enough for the kernel arguments, a diagonal guard projector or none.
 static bool front_applies(qgd_handle h, const double *pcof, int n_pcof)
 {
     const qgdk_ctx &k = h->k;
     return pcof && h->have_basis && n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy") &&
            !qgd_path("no_front") && !qgd_path("inv_panels") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
-           !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) && k.cost_type == 0 &&
+           !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) &&
            (size_t)k.Np * 2 * k.cp < 32768 && k.phi0 && k.hforc && k.termU && k.n_ops > 0 && qgdk_front_supported(&k) != 0;
 }
 

@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
                                                const double *ytarget)
 {
     // ytarget (fused front, qgd_front.h): the terminal value is lambda_N = L_N^-H rhs_N itself -- the overlaps are taken with
-    // `target`, the state is formed from ytarget = L_N^-H target and `forcing` = h = L^-H f (:Infidelity only)
+    // `target`, the state is formed from ytarget = L_N^-H target (:Tracking / :Norm: L_N^-H rhs) and `forcing` = h = L^-H f
     __shared__ double red[32];
     __shared__ double gred[16];
     const int PWc = 2 * cp, nw = blockDim.x >> 6;          // 4 waves, or 16 for large panels
@@ -1314,7 +1314,7 @@ __device__ __forceinline__ void terminal_block(const double *__restrict__ hist, 
         double *yc = yhist + (size_t)(nt - 1) * hstep;
         const double *fc = forcing + (size_t)(nt - 1) * hstep;
         for (int e = threadIdx.x; e < (int)hstep; e += blockDim.x) {
-            const double v = ((cost == 1) ? target[e] - w[e] : -w[e]) + fc[e];
+            const double v = (ytarget ? ytarget[e] : ((cost == 1) ? target[e] - w[e] : -w[e])) + fc[e];      // (fused front: ytarget = L_N^-H rhs, k_psi)
             yc[e] = v; y2[e] = v; y3[e] = v; y4[e] = v;
         }
         return;
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                              double *__restrict__ hist, double *__restrict__ forcing, double *__restrict__ hforc,
                                              const double *__restrict__ guard_diag, double *__restrict__ gpart,
                                              const double *__restrict__ target, double *__restrict__ termU,
-                                             const int cp, const int nt, const int gN, const double dt, const double tf)
+                                             const int cp, const int nt, const int gN, const double dt, const double tf, const int cost)
 {
     constexpr int NPC = 64, XS = 68;
     __shared__ __attribute__((aligned(16))) double xs[NPC * XS];      // one plane of X_n at a time, then the right operands
@@ -1556,8 +1556,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         PSI_STAMP(3);
     }
     if (last) {
+        // cost 0 (:Infidelity): U = X_N target, lambda_N = (2/N_ess^2)(a + ib) U + h_N; :Tracking / :Norm: the terminal right-hand
+        // side is local, -(psi_N - target) / -psi_N (eval_grad_discrete_adjoint.jl:26-35): U = X_N rhs, lambda_N = U + h_N
         __syncthreads();
-        for (int e = threadIdx.x; e < NPC * 16; e += 256) bs[e] = target[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+        if (cost == 0) {
+            for (int e = threadIdx.x; e < NPC * 16; e += 256) bs[e] = target[(size_t)(e >> 4) * PWc + grp * 16 + (e & 15)];
+        } else {
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = wave * 16 + kk + 4 * r;
+                const double tv = (cost == 1) ? target[(size_t)row * PWc + grp * 16 + c16] : 0.0;
+                bs[row * 16 + c16] = tv - res[r];
+            }
+        }
         __syncthreads();
         d4 acc0 = (d4){0, 0, 0, 0}, acc1 = (d4){0, 0, 0, 0};
         #pragma unroll
@@ -2091,7 +2102,7 @@ int qgdk_psi(const qgdk_ctx *c)
     const bool guard = c->have_guard == 2;
     hipLaunchKernelGGL(k_psi, dim3(c->nt, c->cp / 8), dim3(256), 0, c->stream, c->LinvT, c->phist, c->psi0, c->hist, c->forcing, c->hforc,
                        guard ? c->guard_diag : (const double *)nullptr, guard ? c->gpart : (double *)nullptr,
-                       (c->have_target && c->cost_type == 0) ? c->target : (const double *)nullptr, c->termU, c->cp, c->nt, c->N, c->dt, c->tf);
+                       c->have_target ? c->target : (const double *)nullptr, c->termU, c->cp, c->nt, c->N, c->dt, c->tf, c->cost_type);
     return (int)hipGetLastError();
 }
 

@@ -135,8 +135,7 @@ def test_front_without_guard_many_columns(qgd, orc, monkeypatch):
 def test_front_eligibility_and_reuse(qgd, monkeypatch):
     """Which calls take the front, and what the other entry points see afterwards.  (1) qgd_eval_forward and
     qgd_discrete_adjoint do; history_precomputed with the same pcof reuses the front's forward sweep (terminal value formed by
-    the stand-alone terminal kernel).  (2) Another cost type, the 4-pivot panel inverse (QGD_PATHS=inv_panels), a windowed grid:
-    the general path.  (3) qgd_get_intermediate("P" / "Linv" / "L") after a front evaluation returns the TWO-POINT form's
+    the stand-alone terminal kernel).  (2) The 4-pivot panel inverse (QGD_PATHS=inv_panels), a windowed grid: the general path.  (3) qgd_get_intermediate("P" / "Linv" / "L") after a front evaluation returns the TWO-POINT form's
     matrices (the forward evaluation is redone on the general path), and the next evaluation takes the front again.
     (4) The forced gradient and eval_adjoint (general path) agree with the front's gradient / lambda."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=24, tf=24.0)
@@ -158,13 +157,13 @@ def test_front_eligibility_and_reuse(qgd, monkeypatch):
     assert not dp.front_path_taken() and np.abs(gf - g).max() <= 1e-11 * gs
     g3, _ = dp.discrete_adjoint(pcof)
     assert dp.front_path_taken() and np.array_equal(g3, g2)
-    # a stored front sweep is not reused across a change of cost type or target (its terminal value is :Infidelity's, with the
-    # target it was computed for): history_precomputed then redoes the sweep on the path that applies
+    # a stored front sweep is not reused across a change of cost type or target (k_psi formed its terminal value for the cost
+    # type and the target it was computed with): history_precomputed then redoes the sweep
     dp.set_cost_type("Tracking")
     gt, _ = dp.discrete_adjoint(pcof, history_precomputed=True)
-    assert not dp.front_path_taken()
+    assert dp.front_path_taken()
     gt2, _ = dp.discrete_adjoint(pcof)
-    assert np.abs(gt - gt2).max() <= 1e-13 * np.abs(gt2).max()
+    assert np.array_equal(gt, gt2) and np.abs(gt - g).max() > 1e-3 * gs
     dp.set_cost_type("Infidelity")
     dp.eval_forward(pcof)
     t2 = target[:, ::-1].copy()
@@ -225,3 +224,30 @@ def test_front_padded_problem(qgd, orc, monkeypatch):
     r = pp.evaluate_local(prob, Gp, Gq, off, pcof, target, order)
     assert np.abs(f["g"] - r["grad"]).max() <= 1e-11 * gs
     assert cases.oracle_pins(orc, prob, ctrl, pcof, target, order, r)
+
+
+@pytest.mark.parametrize("cost_type", ["Tracking", "Norm"])
+def test_front_cost_types(qgd, orc, monkeypatch, cost_type):
+    """:Tracking and :Norm (eval_grad_discrete_adjoint.jl:26-35: a terminal right-hand side that is local in the columns,
+    -(psi_N - target) or -psi_N): k_psi forms L_N^-H rhs for the terminal value.  Front against the general path, and the
+    general path's pin -- the oracle -- on the same inputs."""
+    prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=16, tf=16.0)
+    res = {}
+    for tag, paths in (("front", ""), ("general", "no_front")):
+        monkeypatch.setenv("QGD_PATHS", paths)
+        dp = qgd.DeviceProblem(prob, 8); dp.set_target(target); dp.set_controls(ctrl); dp.set_cost_type(cost_type)
+        lam = np.zeros(dp._hist_shape(), order="F")
+        g, o3 = dp.discrete_adjoint(pcof, lambda_history=lam)
+        res[tag] = (g, np.asarray(o3), lam, dp.front_path_taken())
+        dp.close()
+        monkeypatch.delenv("QGD_PATHS")
+    f, g = res["front"], res["general"]
+    assert f[3] and not g[3]
+    assert np.abs(f[0] - g[0]).max() <= 1e-12 * np.abs(g[0]).max() and np.abs(f[1] - g[1]).max() <= 1e-12
+    assert np.abs(f[2] - g[2]).max() <= 1e-12 * np.abs(g[2]).max()
+    orc.set_converged_terminal(True); orc.set_num_threads(8); orc.set_cost_type(cost_type)
+    try:
+        go = orc.discrete_adjoint(prob, ctrl, pcof, target, order=8)
+    finally:
+        orc.set_converged_terminal(False); orc.set_num_threads(0); orc.set_cost_type("Infidelity")
+    assert np.abs(f[0] - go).max() <= 1e-10 * np.abs(go).max()
