@@ -245,8 +245,8 @@ int qgd_set_small_path(qgd_handle h, int32_t on);
  * (1 value: whether the last forward evaluation took the fused front, below).  Returns the number of doubles the buffer needs
  * through *needed when out == NULL.
  *
- * The fused front (N = 64 with sparse operators, Hermite order <= 8, one rank, the grid resident, a diagonal guard projector or
- * none, pcof through the control basis): full evaluations of qgd_eval_forward / qgd_discrete_adjoint use the
+ * The fused front (N = 64 with sparse operators, Hermite order <= 8, 513 .. 704 time points, one rank, the grid resident, a
+ * diagonal guard projector or none, pcof through the control basis): full evaluations of qgd_eval_forward / qgd_discrete_adjoint use the
  * same-point step propagators S_n = R_n L_n^-1 (csrc/qgd_front.h); state history, lambda, forcing, scalars and gradient are the
  * same quantities as ever.  "L", "R", "Linv", "P" are always the two-point form's: asked for after such an evaluation they
  * make the library redo the forward evaluation on the general path first.

@@ -162,14 +162,21 @@ int upload_pcof(qgd_handle h, const double *pcof, int n_pcof)
 
 
 // Does this evaluation take the fused front (qgd_front.h)?  A full evaluation on one rank with the grid resident, the control
-// basis on the device and pcof small enough for the kernel arguments, a diagonal guard projector or none.
+// basis on the device and pcof small enough for the kernel arguments, a diagonal guard projector or none -- and a grid on which
+// it wins: 513 .. 704 time points, where k_front is one round of two to three workgroups per CU and the tail workgroups start
+// from pre-built panels (qgdk_front_pre_plan).  Measured (scripts/front_crossover.py, cnot3, us per evaluation front / general):
+// 100 steps 185 / 178, 256: 233 / 217, 400: 254 / 256, 512: 284 / 282, 550: 297 / 306, 700: 339 / 342, 800: 430 / 431,
+// 1100: 530 / 522 -- without the tail to balance, two launches with eight waves per half time point build faster than four
+// waves per time point do.  QGD_PATHS=front takes the front wherever it is supported (tests).
 static bool front_applies(qgd_handle h, const double *pcof, int n_pcof)
 {
     const qgdk_ctx &k = h->k;
-    return pcof && h->have_basis && n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy") &&
-           !qgd_path("no_front") && !qgd_path("inv_panels") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
-           !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) &&
-           (size_t)k.Np * 2 * k.cp < 32768 && k.phi0 && k.hforc && k.termU && k.n_ops > 0 && qgdk_front_supported(&k) != 0;
+    if (!(pcof && h->have_basis && n_pcof == k.n_pcof && n_pcof <= QGD_PCOF_KERNARG && h->graph_off && !qgd_path("pcof_copy") &&
+          !qgd_path("no_front") && !qgd_path("inv_panels") && h->chunks_eff == 1 && h->part_world == 1 && k.part_world == 1 && !h->comm && k.g_nt == 0 &&
+          !k.keep_scal && !k.grad_accumulate && k.nt >= 2 && (k.have_guard == 0 || k.have_guard == 2) &&
+          (size_t)k.Np * 2 * k.cp < 32768 && k.phi0 && k.hforc && k.termU && k.n_ops > 0 && qgdk_front_supported(&k) != 0)) return false;
+    int q2 = 0, q1 = 0;
+    return qgd_path("front") != nullptr || qgdk_front_pre_plan(&k, &q2, &q1) > 0;
 }
 
 

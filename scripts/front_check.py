@@ -12,7 +12,7 @@ def run(nsteps, order=8):
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
     m = order // 2
     out = {}
-    for tag, paths in (("front", ""), ("general", "no_front")):
+    for tag, paths in (("front", "front"), ("general", "no_front")):
         os.environ["QGD_PATHS"] = paths
         dp = qgd.DeviceProblem(prob, order); dp.set_target(target); dp.set_controls(ctrl)
         hist = np.zeros(dp._hist_shape(), order="F"); lam = np.zeros(dp._hist_shape(), order="F")

@@ -12,7 +12,7 @@ worst = 0.0
 for nt in (2, 3, 9, 255, 256, 257, 258, 511, 512, 513, 514, 551, 600, 703, 704, 705, 706, 767, 768, 769, 1001):
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nt - 1, tf=float(nt - 1))
     res = {}
-    for tag, paths in (("front", ""), ("general", "no_front")):
+    for tag, paths in (("front", "front"), ("general", "no_front")):
         os.environ["QGD_PATHS"] = paths
         dp = qgd.DeviceProblem(prob, 8); dp.set_target(target); dp.set_controls(ctrl)
         g, o = dp.discrete_adjoint(pcof); g2, o2 = dp.discrete_adjoint(pcof)

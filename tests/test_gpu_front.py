@@ -3,7 +3,8 @@ step propagator S_n = R_n L_n^-1 -- one workgroup per time point builds L_n^H, R
 sweep runs in phi = L psi, k_psi turns it into the state history, guard forcing and h = L^-H f; the adjoint sweep runs in lambda.
 Reference being reproduced: src/forward_evolution.jl:181-220 (forward step), :421-461 (adjoint step), checked here against the
 general path of the library (two-point propagators, QGD_PATHS=no_front), the numpy statements of tests/proto_propagator.py and the
-CPU oracle."""
+CPU oracle.  The library takes the front by itself on grids of 513 .. 704 time points (where it wins: qgd_host_eval.cpp,
+front_applies); QGD_PATHS=front takes it wherever it is supported, which is how the short grids here reach it."""
 import os
 
 import numpy as np
@@ -42,7 +43,7 @@ def test_front_equals_general_path(qgd, orc, monkeypatch, nsteps, order):
     lambda and guard forcing equal the general path's to rounding; on the short grids also the numpy statement of the local
     form and the oracle (1e-10)."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
-    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "", monkeypatch)
+    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "front", monkeypatch)
     g = _evaluate(qgd, prob, ctrl, pcof, target, order, "no_front", monkeypatch)
     assert f["front"] and not g["front"] and f["rep"] == 0
     gs = np.abs(g["g"]).max()
@@ -96,7 +97,7 @@ def test_front_pivot_stages(qgd, orc, monkeypatch, partner, noise, stage):
     ref = pp.evaluate_local(prob, Gp, Gq, off, pcof, target, order)
     if partner == 1 and noise > 0:
         assert cases.oracle_pins(orc, prob, ctrl, pcof, target, order, ref)
-    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "", monkeypatch, calls=2)      # (the second call starts with pivoting: same result)
+    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "front", monkeypatch, calls=2)      # (the second call starts with pivoting: same result)
     g = _evaluate(qgd, prob, ctrl, pcof, target, order, "no_front", monkeypatch)
     nt = prob.nsteps + 1
     assert f["front"] and not g["front"]
@@ -121,7 +122,7 @@ def test_front_without_guard_many_columns(qgd, orc, monkeypatch):
     rng = np.random.default_rng(3)
     pcof = (rng.random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
     target = rng.random((64, 64)) + 1j * rng.random((64, 64))
-    f = _evaluate(qgd, prob, ctrl, pcof, target, 8, "", monkeypatch)
+    f = _evaluate(qgd, prob, ctrl, pcof, target, 8, "front", monkeypatch)
     g = _evaluate(qgd, prob, ctrl, pcof, target, 8, "no_front", monkeypatch)
     assert f["front"] and not g["front"]
     gs = np.abs(g["g"]).max()
@@ -138,6 +139,14 @@ def test_front_eligibility_and_reuse(qgd, monkeypatch):
     the stand-alone terminal kernel).  (2) The 4-pivot panel inverse (QGD_PATHS=inv_panels), a windowed grid: the general path.  (3) qgd_get_intermediate("P" / "Linv" / "L") after a front evaluation returns the TWO-POINT form's
     matrices (the forward evaluation is redone on the general path), and the next evaluation takes the front again.
     (4) The forced gradient and eval_adjoint (general path) agree with the front's gradient / lambda."""
+    # the library's own choice: the front on 513 .. 704 time points, the general path on shorter and longer grids
+    for nsteps, want in ((300, False), (520, True), (800, False)):
+        p_, c_, x_, t_ = cases.cnot3_case(qgd, nsteps=nsteps, tf=float(nsteps))
+        d_ = qgd.DeviceProblem(p_, 8); d_.set_target(t_); d_.set_controls(c_)
+        d_.discrete_adjoint(x_)
+        assert d_.front_path_taken() == want, nsteps
+        d_.close()
+    monkeypatch.setenv("QGD_PATHS", "front")
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=24, tf=24.0)
     order = 8
     Gp, Gq, off = qgd.control_basis(ctrl, prob.nsteps, prob.tf, order // 2)
@@ -184,10 +193,11 @@ def test_front_eligibility_and_reuse(qgd, monkeypatch):
     dp.close()
 
 
-def test_front_non_finite_coefficients(qgd):
+def test_front_non_finite_coefficients(qgd, monkeypatch):
     """A coefficient vector with a NaN / an infinity in it: the evaluation ENDS with non-finite results, and the next
     evaluation of the same handle is bit for bit what it was before."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=40, tf=40.0)
+    monkeypatch.setenv("QGD_PATHS", "front")
     dp = qgd.DeviceProblem(prob, 8); dp.set_controls(ctrl); dp.set_target(target)
     g0, o0 = dp.discrete_adjoint(pcof)
     assert dp.front_path_taken()
@@ -214,7 +224,7 @@ def test_front_padded_problem(qgd, orc, monkeypatch):
     pcof = (rng.random(qgd.get_number_of_control_parameters(ctrl)) - 0.5) * 2 * np.pi * 0.005
     target = cases.rand_target(prob, 7)
     order = 6
-    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "", monkeypatch)
+    f = _evaluate(qgd, prob, ctrl, pcof, target, order, "front", monkeypatch)
     g = _evaluate(qgd, prob, ctrl, pcof, target, order, "no_front", monkeypatch)
     assert f["front"] and not g["front"]
     gs = np.abs(g["g"]).max()
@@ -233,7 +243,7 @@ def test_front_cost_types(qgd, orc, monkeypatch, cost_type):
     general path's pin -- the oracle -- on the same inputs."""
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=16, tf=16.0)
     res = {}
-    for tag, paths in (("front", ""), ("general", "no_front")):
+    for tag, paths in (("front", "front"), ("general", "no_front")):
         monkeypatch.setenv("QGD_PATHS", paths)
         dp = qgd.DeviceProblem(prob, 8); dp.set_target(target); dp.set_controls(ctrl); dp.set_cost_type(cost_type)
         lam = np.zeros(dp._hist_shape(), order="F")
