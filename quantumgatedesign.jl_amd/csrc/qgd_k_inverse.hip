@@ -1139,11 +1139,14 @@ int qgdk_front_supported(const qgdk_ctx *c)
 // EXPERIMENTS.md "Round 6": the tables launch grows by what the front kernel gains.)  QGD_PATHS=front_nopre: none (A/B).
 int qgdk_front_pre_plan(const qgdk_ctx *c, int *q2, int *q1)
 {
-    const int extra = qgd_path("front_nopre") ? 0 : front_extra(c->nt);
-    int a = extra;
-    if (extra + a > 192) a = 192 - extra;
-    *q2 = a > 0 ? a : 0; *q1 = 0;
-    return extra <= 192 ? extra : 0;
+    *q2 = 0; *q1 = 0;
+    if (qgd_path("front_nopre")) return 0;
+    const int nt = c->nt, extra = front_extra(nt);
+    if (extra > 192) return 0;
+    if (extra > 0) { *q2 = (2 * extra > 192) ? 192 - extra : extra; return extra; }
+    // (256 < nt <= 512 -- the CUs 0 .. nt-257 hold two workgroups, the rest one -- with the second workgroups pre-built: measured,
+    //  3-5 us slower than without at 281 .. 513 time points, and the general path is faster there either way)
+    return 0;
 }
 
 int qgdk_front(const qgdk_ctx *c)

@@ -9,11 +9,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge
 qgd = ge.import_package()
 import cases
-for ns in (20, 60, 100, 150, 200, 256, 300, 400, 512, 550, 700, 800, 1100):
+import sys as _s
+GRID = [int(a) for a in _s.argv[2:]] or (20, 60, 100, 150, 200, 256, 300, 400, 512, 550, 700, 800, 1100)
+FRONT = _s.argv[1] if len(_s.argv) > 1 else 'front'
+for ns in GRID:
     prob, ctrl, pcof, target = cases.cnot3_case(qgd, nsteps=ns, tf=float(ns))
     out = {}
     dps = {}
-    for tag, paths in (("front", "front"), ("general", "no_front")):
+    for tag, paths in (("front", FRONT), ("general", "no_front")):
         os.environ["QGD_PATHS"] = paths
         dp = qgd.DeviceProblem(prob, 8); dp.set_target(target); dp.set_controls(ctrl)
         for _ in range(30): dp.discrete_adjoint(pcof)
@@ -21,7 +24,7 @@ for ns in (20, 60, 100, 150, 200, 256, 300, 400, 512, 550, 700, 800, 1100):
     ts = {"front": [], "general": []}
     for rep in range(4):
         for tag in ("front", "general"):
-            os.environ["QGD_PATHS"] = "front" if tag == "front" else "no_front"
+            os.environ["QGD_PATHS"] = FRONT if tag == "front" else "no_front"
             dp = dps[tag]
             t0 = time.perf_counter()
             for _ in range(100): dp.discrete_adjoint(pcof)
