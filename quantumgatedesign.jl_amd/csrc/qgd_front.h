@@ -130,7 +130,8 @@ __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__r
 // of up to three workgroups per CU, workgroups b, b + 256, b + 512 on one CU: with nt = 512 + extra time points the CUs
 // 0 .. extra-1 hold three, and the launch ends with them.  Pre-built: every third workgroup (b >= 512), the second workgroups
 // b = 256 .. 256 + q2 - 1 and the first workgroups b = 0 .. q1 - 1 (q1 <= extra) -- they start with the elimination while the
-// rest of their CU builds.  (q2, q1) is the library's choice (qgdk_front_pre_plan: q2 = extra, q1 = 0), measured in EXPERIMENTS.md "Round 6".
+// rest of their CU builds.  (q2, q1) is the library's choice (qgdk_front_pre_plan: q2 = q1 = extra up to 192 workgroups), measured in
+// EXPERIMENTS.md "Round 6": the CUs that hold three then run three eliminations and no build, the others two and two.
 struct FrontPre { int extra, q2, q1; };
 __host__ __device__ static inline int front_extra(int nt) { const int e = nt - 512; return e < 0 ? 0 : (e > 256 ? 0 : e); }      // (beyond one round: no tail to balance)
 __host__ __device__ static inline int front_pre_count(const FrontPre p) { return p.extra + p.q2 + p.q1; }

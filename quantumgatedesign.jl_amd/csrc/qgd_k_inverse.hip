@@ -1133,8 +1133,9 @@ int qgdk_front_supported(const qgdk_ctx *c)
     return front_lds(c->m, c->ell_z) <= 53 * 1024 ? 1 : 0;      // three workgroups per CU
 }
 
-// Which workgroups of k_front start from step matrices the tables launch built (qgd_front.h: FrontPre): the third workgroup
-// and the second of every CU that holds three -- as long as they fit, one per CU, beside 64 table workgroups.  (More was
+// Which workgroups of k_front start from step matrices the tables launch built (qgd_front.h: FrontPre): all three workgroups
+// of every CU that holds three (the third and the second where that is more than 192) -- as long as they fit, one per CU,
+// beside 64 table workgroups.  (More was
 // measured, up to every second and third workgroup and the first ones of the CUs that hold three -- scripts/front_pre_sweep.py,
 // EXPERIMENTS.md "Round 6": the tables launch grows by what the front kernel gains.)  QGD_PATHS=front_nopre: none (A/B).
 int qgdk_front_pre_plan(const qgdk_ctx *c, int *q2, int *q1)
@@ -1143,7 +1144,11 @@ int qgdk_front_pre_plan(const qgdk_ctx *c, int *q2, int *q1)
     if (qgd_path("front_nopre")) return 0;
     const int nt = c->nt, extra = front_extra(nt);
     if (extra > 192) return 0;
-    if (extra > 0) { *q2 = (2 * extra > 192) ? 192 - extra : extra; return extra; }
+    if (extra > 0) {
+        *q2 = (2 * extra > 192) ? 192 - extra : extra;
+        if (3 * extra <= 192) *q1 = extra;      // (all three workgroups of the fullest CUs: 293.3 against 297.2-298.3 us per evaluation with two of three)
+        return extra;
+    }
     // (256 < nt <= 512 -- the CUs 0 .. nt-257 hold two workgroups, the rest one -- with the second workgroups pre-built: measured,
     //  3-5 us slower than without at 281 .. 513 time points, and the general path is faster there either way)
     return 0;
