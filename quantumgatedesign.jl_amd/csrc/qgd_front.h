@@ -120,8 +120,13 @@ __device__ __forceinline__ void front_build(double *smem_raw, const int32_t *__r
         #pragma unroll
         for (int c = 0; c < 4; c++) {
             const size_t o = (size_t)(c0 + c) * PW + ocol;
-            Eh[o] = Lacc[c].re; Eh[o + 8] = -Lacc[c].im;
-            Fh[o] = Racc[c].re; Fh[o + 8] = -Racc[c].im;
+            if (NTH == 1024) {      // (the pre-building launch: nobody reads the panels before the next kernel -- streamed past the L2)
+                __builtin_nontemporal_store(Lacc[c].re, Eh + o); __builtin_nontemporal_store(-Lacc[c].im, Eh + o + 8);
+                __builtin_nontemporal_store(Racc[c].re, Fh + o); __builtin_nontemporal_store(-Racc[c].im, Fh + o + 8);
+            } else {
+                Eh[o] = Lacc[c].re; Eh[o + 8] = -Lacc[c].im;
+                Fh[o] = Racc[c].re; Fh[o + 8] = -Racc[c].im;
+            }
         }
     }
 }
